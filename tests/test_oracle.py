@@ -1,0 +1,351 @@
+"""Pin the CPU oracle: (1) against fixtures captured from the reference's own
+Python (tests/golden/make_golden.py), (2) against independent formulations for
+the parts whose arithmetic lives in un-vendored third-party wheels (unpinned
+on the reference side -- SURVEY.md 8c)."""
+import io
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import oracle as O
+
+T = torch.from_numpy
+
+
+# ---------------------------------------------------------------- G1 losses --
+def test_losses_match_reference_fixtures(golden):
+    g = golden("g1_losses")
+    kinds = ["auc", "hinge_auc", "weighted_auc", "adaptive_auc", "weighted_hinge_auc",
+             "adaptive_hinge_auc", "log_rank", "info_nce"]
+    for c in range(int(g["num_cases"])):
+        k = int(g[f"c{c}_k"])
+        for kind in kinds:
+            for dt, tag, tol in ((torch.float32, "f32", 1e-6), (torch.float64, "f64", 1e-12)):
+                pos = T(g[f"c{c}_pos"]).to(dt).requires_grad_(True)
+                neg = T(g[f"c{c}_neg"]).to(dt).requires_grad_(True)
+                w = T(g[f"c{c}_w"]).to(dt)
+                out = O.LOSSES[kind](pos, neg, k, w)
+                out.backward()
+                np.testing.assert_allclose(out.item(), g[f"c{c}_{kind}_{tag}_loss"], rtol=tol)
+                np.testing.assert_allclose(pos.grad.numpy(), g[f"c{c}_{kind}_{tag}_gpos"], rtol=tol, atol=tol)
+                np.testing.assert_allclose(neg.grad.numpy(), g[f"c{c}_{kind}_{tag}_gneg"], rtol=tol, atol=tol)
+        pos = T(g[f"c{c}_pos"]).requires_grad_(True)
+        neg = T(g[f"c{c}_neg"]).requires_grad_(True)
+        out = O.LOSSES["ce"](pos, neg)
+        out.backward()
+        np.testing.assert_allclose(out.item(), g[f"c{c}_ce_f32_loss"], rtol=1e-6)
+        np.testing.assert_allclose(neg.grad.numpy(), g[f"c{c}_ce_f32_gneg"], rtol=1e-6, atol=1e-7)
+
+
+def test_loss_dispatch_fallback():
+    # model.py:107-126
+    assert O.select_loss("WeightedHingeAUC", True) == "weighted_hinge_auc"
+    assert O.select_loss("WeightedHingeAUC", False) == "auc"
+    assert O.select_loss("AdaAUC", False) == "auc"
+    assert O.select_loss("HingeAUC", False) == "hinge_auc"
+    assert O.select_loss("anything", True) == "auc"
+    assert O.select_loss("AUC", False) == "auc"
+
+
+# ---------------------------------------------------------------- G2 ---------
+def test_predictors_match_reference_fixtures(golden):
+    g = golden("g2_predictors")
+    for L in (1, 2, 3):
+        m = O.MLPPredictorRef(16, 16, 1, L, 0.0)
+        m.load_state_dict({k[len(f"mlp{L}_sd_"):]: T(g[k]) for k in g.files if k.startswith(f"mlp{L}_sd_")})
+        xi = T(g[f"mlp{L}_xi"]).requires_grad_(True)
+        xj = T(g[f"mlp{L}_xj"]).requires_grad_(True)
+        out = m(xi, xj)
+        out.sum().backward()
+        np.testing.assert_allclose(out.detach().numpy(), g[f"mlp{L}_out"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(xi.grad.numpy(), g[f"mlp{L}_gxi"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(xj.grad.numpy(), g[f"mlp{L}_gxj"], rtol=1e-6, atol=1e-7)
+        for k, p in m.named_parameters():
+            np.testing.assert_allclose(p.grad.numpy(), g[f"mlp{L}_grad_{k}"], rtol=1e-5, atol=1e-6)
+    d = O.DotPredictorRef()
+    xi = T(g["dot_xi"]).requires_grad_(True)
+    xj = T(g["dot_xj"]).requires_grad_(True)
+    out = d(xi, xj)
+    (out * torch.arange(1.0, 10.0)).sum().backward()
+    np.testing.assert_allclose(out.detach().numpy(), g["dot_out"], rtol=1e-6)
+    np.testing.assert_allclose(xi.grad.numpy(), g["dot_gxi"], rtol=1e-6)
+
+
+# ---------------------------------------------------------------- G3 ---------
+class _Affine(torch.nn.Module):
+    def __init__(self, a, b):
+        super().__init__()
+        self.a, self.b = a, b
+
+    def forward(self, x, adj, impl=None):
+        return x * self.a - self.b
+
+
+def test_gnn_control_flow_matches_reference(golden):
+    g = golden("g3_control_flow")
+    x = T(g["x"])
+    for L in (1, 2, 3):
+        net = O.GNNRef("SAGE", 5, 5, 5, L, 0.0)
+        net.convs = torch.nn.ModuleList([_Affine(1.5 - i, 0.3 * (i + 1)) for i in range(L)])
+        net.eval()
+        np.testing.assert_array_equal(net(x, None).numpy(), g[f"out_L{L}"])
+
+
+# ---------------------------------------------------------------- G4/G5 ------
+def test_local_sampler_bit_exact(golden):
+    g = golden("g4_g5_samplers")
+    torch.manual_seed(0)
+    out = O.local_neg_sample_ref(torch.tensor([[0, 1], [2, 3]]), 10, 3)
+    np.testing.assert_array_equal(out.numpy(), g["local_s0"])
+    assert out[..., 1].reshape(-1).tolist() == [4, 9, 3, 0, 3, 9]      # SURVEY 8c G4 probe
+    for seed in (11, 12, 13):
+        torch.manual_seed(seed)
+        out = O.local_neg_sample_ref(T(g[f"local_{seed}_pos"]), int(g[f"local_{seed}_N"]), int(g[f"local_{seed}_k"]))
+        assert out.dtype == torch.int64
+        np.testing.assert_array_equal(out.numpy(), g[f"local_{seed}_out"])
+
+
+def test_perm_copy_and_padding_bit_exact(golden):
+    g = golden("g4_g5_samplers")
+    ei = T(g["permcopy_in"])
+    torch.manual_seed(21)
+    np.testing.assert_array_equal(O.perm_copy_ref(ei, 8, 3).numpy(), g["permcopy_out_t8_c3"])
+    torch.manual_seed(22)
+    np.testing.assert_array_equal(O.perm_copy_ref(ei, 5, 2).numpy(), g["permcopy_out_t5_c2"])
+    torch.manual_seed(23)
+    src, dst = O.pad_negatives_ref(T(g["globalpad_short"]), 6)
+    out = torch.stack((src, dst), -1).reshape(-1, 2, 2)
+    np.testing.assert_array_equal(out.numpy(), g["globalpad_out"])
+    # what the reference hands to negative_sampling: edges + self loops, N, E*k
+    ei = g["globalcall_edge_index"]
+    assert ei.shape[1] == 3 + 3 and int(g["globalcall_n"]) == 10 and int(g["globalcall_m"]) == 4
+
+
+def test_structured_negative_sampling_properties():
+    rng = np.random.default_rng(0)
+    n = 60
+    lo, hi = np.triu_indices(n, 1)
+    pick = rng.choice(lo.size, 500, replace=False)
+    ei = torch.tensor(np.stack([np.r_[lo[pick], hi[pick]], np.r_[hi[pick], lo[pick]]]))
+    out = O.global_neg_sample_ref(ei, n, 500, 3, rng)
+    assert out.shape == (500, 3, 2) and out.dtype == torch.int64
+    flat = out.reshape(-1, 2)
+    assert (flat[:, 0] != flat[:, 1]).all()                     # no self loops
+    existing = set((ei[0] * n + ei[1]).tolist())
+    assert not existing.intersection((flat[:, 0] * n + flat[:, 1]).tolist())
+    assert len(set((flat[:, 0] * n + flat[:, 1]).tolist())) == flat.shape[0]   # distinct (no pad needed here)
+    assert int(flat.min()) >= 0 and int(flat.max()) < n
+
+
+# ---------------------------------------------------------------- G6 ---------
+def test_batch_permutation_bit_exact(golden):
+    g = golden("g6_dataloader")
+    for seed, n, B in [(123, 10, 4), (5, 1000, 64), (77, 65, 65), (8, 3, 10)]:
+        torch.manual_seed(seed)
+        batches = O.batch_permutation(n, B, True)
+        after = torch.randint(0, 1 << 30, (4,))
+        np.testing.assert_array_equal(torch.cat(batches).numpy(), g[f"s{seed}_n{n}_B{B}_perm"])
+        assert [b.numel() for b in batches] == g[f"s{seed}_n{n}_B{B}_sizes"].tolist()
+        np.testing.assert_array_equal(after.numpy(), g[f"s{seed}_n{n}_B{B}_after"])
+    torch.manual_seed(123)
+    assert [b.tolist() for b in O.batch_permutation(10, 4, True)] == [[8, 2, 6, 7], [0, 3, 9, 1], [5, 4]]
+    torch.manual_seed(9)
+    O.batch_permutation(10, 4, False)
+    np.testing.assert_array_equal(torch.randint(0, 1 << 30, (4,)).numpy(), g["noshuffle_after"])
+
+
+# ---------------------------------------------------------------- G7 ---------
+def test_pos_neg_edges_match_reference(golden):
+    g = golden("g7_pos_neg_edges")
+    se = {s: {k: T(g[f"cit_in_{s}_{k}"]) for k in ("source_node", "target_node", "target_node_neg")}
+          for s in ("train", "valid", "test")}
+    for s in ("valid", "test"):
+        pos, neg = O.pos_neg_edges_ref(s, se)
+        np.testing.assert_array_equal(pos.numpy(), g[f"cit_{s}_pos"])
+        np.testing.assert_array_equal(neg.numpy(), g[f"cit_{s}_neg"])
+    torch.manual_seed(71)
+    pos, neg = O.pos_neg_edges_ref("train", se, num_nodes=40, neg_sampler_name="local", num_neg=3)
+    np.testing.assert_array_equal(pos.numpy(), g["cit_train_pos"])
+    np.testing.assert_array_equal(neg.numpy(), g["cit_train_neg"])
+    se2 = {"train": {"edge": torch.zeros(1, 2, dtype=torch.long)},
+           "valid": {"edge": T(g["edge_in_valid_edge"]), "edge_neg": T(g["edge_in_valid_edge_neg"])}}
+    pos, neg = O.pos_neg_edges_ref("valid", se2)
+    np.testing.assert_array_equal(pos.numpy(), g["edge_valid_pos"])
+    np.testing.assert_array_equal(neg.numpy(), g["edge_valid_neg"])
+
+
+# ---------------------------------------------------------------- G8 ---------
+def _toy_adj(g):
+    N = int(g["N"])
+    lo, hi, w = T(g["lo"]), T(g["hi"]), T(g["w"])
+    row, col, val = torch.cat([lo, hi]), torch.cat([hi, lo]), torch.cat([w, w])
+    return N, lo, hi, w, O.CSR.from_coo(row, col, val, N)
+
+
+def build_trainer_from_g8(g, name, adj, N, encoder_factory=None, predictor_factory=None):
+    enc, pred, lossn, Lg, Lm, h, k, clip, weighted, B = g[f"{name}_cfg"].tolist()
+    Lg, Lm, h, k, B, clip, weighted = int(Lg), int(Lm), int(h), int(k), int(B), float(clip), bool(int(weighted))
+    encoder = (encoder_factory or (lambda: O.GNNRef(enc, h, h, h, Lg, 0.0)))()
+    predictor = (predictor_factory or (lambda: O.MLPPredictorRef(h, h, 1, Lm, 0.0) if pred == "MLP"
+                                       else O.DotPredictorRef()))()
+    emb = torch.nn.Embedding(N, h)
+    encoder.load_state_dict({key[len(f"{name}_init_enc."):]: T(g[key]) for key in g.files
+                             if key.startswith(f"{name}_init_enc.")})
+    predictor.load_state_dict({key[len(f"{name}_init_pred."):]: T(g[key]) for key in g.files
+                               if key.startswith(f"{name}_init_pred.")})
+    with torch.no_grad():
+        emb.weight.copy_(T(g[f"{name}_init_emb.weight"]))
+    return (encoder, predictor, emb), dict(enc=enc, loss=lossn, k=k, clip=clip, weighted=weighted, B=B)
+
+
+def test_train_trajectory_matches_reference(golden):
+    """The reference's BaseModel.train, run with the oracle convs in the PyG
+    slots, vs TrainerRef: identical index streams, loss accounting, clipping."""
+    g = golden("g8_train_trajectory")
+    N, lo, hi, w, adj = _toy_adj(g)
+    for name in g["config_names"].tolist():
+        (encoder, predictor, emb), c = build_trainer_from_g8(g, name, adj, N)
+        a = O.gcn_norm_csr(adj) if c["enc"] == "GCN" else adj
+        tr = O.TrainerRef(encoder, predictor, emb, a, loss_name=c["loss"], lr=0.01, clip_norm=c["clip"])
+        pos = torch.stack([lo, hi], 1)
+        weight = (w / w.max()).to(torch.float32) if c["weighted"] else None
+        torch.manual_seed(4242)
+        losses = []
+        for _ in range(3):
+            _, neg = O.pos_neg_edges_ref("train", {"train": {"edge": pos}}, num_nodes=N,
+                                         neg_sampler_name="local", num_neg=c["k"])
+            losses.append(tr.train_epoch(pos, neg, c["B"], c["k"], weight))
+        np.testing.assert_allclose(losses, g[f"{name}_losses"], rtol=2e-6, err_msg=name)
+        np.testing.assert_allclose(emb.weight.detach().numpy(), g[f"{name}_final_emb"], rtol=1e-4, atol=2e-6)
+        for key, v in encoder.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[f"{name}_final_enc.{key}"], rtol=1e-4, atol=2e-6)
+
+
+# ---------------------------------------------------------------- G9 ---------
+def test_adjust_lr_matches_reference(golden):
+    g = golden("g9_logger")
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=0.01)
+    lrs = [O.adjust_lr_ref(opt, r, 0.01) for r in (0.0, 0.25, 0.5, 0.99995, 1.0)]
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12)
+
+
+# ------------------------------------------- unpinned parts: cross-checks -----
+def _rand_graph(n, e, seed, weighted=True):
+    g = torch.Generator().manual_seed(seed)
+    r = torch.randint(0, n, (e,), generator=g)
+    c = torch.randint(0, n, (e,), generator=g)
+    v = torch.rand(e, generator=g) + 0.1 if weighted else None
+    return O.CSR.from_coo(r, c, v, n)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+@pytest.mark.parametrize("use_values", [True, False])
+def test_spmm_vs_dense_and_scipy(reduce, use_values):
+    adj = _rand_graph(50, 400, 1)       # has duplicates and empty rows
+    adj.rowptr[-1]
+    x = torch.randn(50, 7, dtype=torch.float64)
+    ref = O.spmm_dense_check(adj, x, reduce, use_values)
+    for impl in ("index_add", "sparse_csr"):
+        out = O.spmm(adj, x, reduce, use_values, impl=impl)
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-12, atol=1e-12)
+    v = adj.val.double().numpy() if use_values else np.ones(adj.col.numel())
+    S = sp.csr_matrix((v, adj.col.numpy(), adj.rowptr.numpy()), shape=(50, 50))
+    y = S @ x.numpy()
+    if reduce == "mean":
+        y = y / np.maximum(np.diff(adj.rowptr.numpy()), 1)[:, None]
+    np.testing.assert_allclose(ref.numpy(), y, rtol=1e-12, atol=1e-12)
+
+
+def test_spmm_backward_is_transpose():
+    adj = _rand_graph(40, 300, 2)
+    x = torch.randn(40, 5, dtype=torch.float64, requires_grad=True)
+    gout = torch.randn(40, 5, dtype=torch.float64)
+    for reduce in ("sum", "mean"):
+        for impl in ("index_add", "sparse_csr"):
+            x.grad = None
+            O.spmm(adj, x, reduce, True, impl=impl).backward(gout)
+            A = adj.to_dense()
+            if reduce == "mean":
+                A = A / adj.degree().clamp(min=1).double().unsqueeze(-1)
+            np.testing.assert_allclose(x.grad.numpy(), (A.t() @ gout).numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_sage_and_gcn_conv_dense_formulas():
+    adj = _rand_graph(30, 200, 3)
+    x = torch.randn(30, 6, dtype=torch.float64)
+    sage = O.SAGEConvRef(6, 4).double()
+    A = O.CSR(adj.rowptr, adj.col, None, 30).to_dense()
+    Dinv = 1.0 / adj.degree().clamp(min=1).double()
+    ref = (Dinv[:, None] * (A @ x)) @ sage.lin_l.weight.t() + sage.lin_l.bias + x @ sage.lin_r.weight.t()
+    np.testing.assert_allclose(sage(x, adj).detach().numpy(), ref.detach().numpy(), rtol=1e-10, atol=1e-12)
+    assert list(sage.state_dict().keys()) == ["lin_l.weight", "lin_l.bias", "lin_r.weight"]
+    gcn = O.GCNConvRef(6, 4).double()
+    with torch.no_grad():
+        gcn.bias.normal_()
+    ref = adj.to_dense() @ (x @ gcn.lin.weight.t()) + gcn.bias
+    np.testing.assert_allclose(gcn(x, adj).detach().numpy(), ref.detach().numpy(), rtol=1e-10, atol=1e-12)
+    assert list(gcn.state_dict().keys()) == ["bias", "lin.weight"]
+    assert float(O.GCNConvRef(6, 4).bias.abs().sum()) == 0.0
+
+
+def test_gcn_normalization_dense_formula():
+    adj = _rand_graph(25, 120, 4)
+    # symmetrise without duplicates, some self loops present
+    D = adj.to_dense()
+    D = ((D + D.t()) > 0).double()
+    r, c = D.nonzero(as_tuple=True)
+    a = O.CSR.from_coo(r, c, torch.ones(r.numel()), 25)
+    out = O.gcn_norm_csr(a).to_dense()
+    A = D.clone()
+    A.fill_diagonal_(1.0)
+    deg = A.sum(1)
+    dis = deg.pow(-0.5)
+    ref = dis[:, None] * A * dis[None, :]
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_hits_and_mrr_bruteforce():
+    g = torch.Generator().manual_seed(5)
+    pos = torch.randn(200, generator=g)
+    neg = torch.randn(500, generator=g)
+    for k in (20, 50, 100):
+        srt = sorted(neg.tolist(), reverse=True)
+        brute = sum(1 for p in pos.tolist() if p > srt[k - 1]) / 200.0
+        assert abs(O.hits_at_k(pos, neg, k) - brute) < 1e-12
+    assert O.hits_at_k(pos, neg[:10], 20) == 1.0
+    negm = torch.randn(200, 30, generator=g)
+    ranks = 1 + (negm > pos[:, None]).sum(1)
+    np.testing.assert_allclose(O.mrr_list(pos, negm).numpy(), (1.0 / ranks.float()).numpy())
+    r = O.evaluate_hits_ref(pos, neg, pos, neg)
+    assert set(r) == {"Hits@20", "Hits@50", "Hits@100"}
+
+
+def test_clip_grad_norm_matches_torch():
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    for c in (0.5, 100.0):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        want = [p.grad.clone() for p in ps]
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        for r, gr in zip(ref, want):
+            r.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, c)
+        O.clip_grad_norm_ref(ps, c)
+        for p, r in zip(ps, ref):
+            np.testing.assert_allclose(p.grad.numpy(), r.grad.numpy(), rtol=1e-6)
+
+
+def test_dropout_mask_statistics_and_determinism():
+    m1 = O.dropout_keep_mask(1234567890123, 512, 256, 0.3)
+    m2 = O.dropout_keep_mask(1234567890123, 512, 256, 0.3)
+    assert (m1 == m2).all()
+    assert abs(m1.mean() - 0.7) < 0.01
+    m3 = O.dropout_keep_mask(1234567890124, 512, 256, 0.3)
+    assert 0.35 < (m1 != m3).mean() < 0.5          # independent streams: 2*0.3*0.7 = 0.42
+    # row offset = same logical elements
+    m4 = O.dropout_keep_mask(1234567890123, 100, 256, 0.3, row0=50)
+    assert (m4 == m1[50:150]).all()
+    # column correlation sanity
+    assert abs(np.corrcoef(m1[:, 0], m1[:, 1])[0, 1]) < 0.15
