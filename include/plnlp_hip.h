@@ -1,0 +1,201 @@
+/* plnlp_hip.h -- C ABI of libplnlp_hip.so, the MI355X (gfx950) kernels behind the
+ * PLNLP training hot path.
+ *
+ * The reference (zhitao-wang/PLNLP) has no FFI layer: its hot path is Python
+ * calling un-vendored third-party kernels (torch_sparse SpMM, cuBLAS, ATen).
+ * Each entry point below replaces one of those call sites; the citation names
+ * the reference line whose work it does (paths relative to /root/reference).
+ *
+ * Contract (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer unless said otherwise;
+ *   - the caller owns every buffer, including workspaces; the library never
+ *     allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and is stream-ordered; entry points are re-entrant and
+ *     keep no global state (safe for one-process-per-GPU data parallelism);
+ *   - return value: 0 = enqueued; PLNLP_E_* (negative) = argument rejected,
+ *     nothing enqueued; positive = hipError_t reported by the launch;
+ *   - matrices are row-major fp32 with an explicit leading dimension (elements);
+ *   - graph indices are int32 (col) / int64 (rowptr), see Graph in
+ *     plnlp_amd/graph.py.
+ */
+#ifndef PLNLP_HIP_H
+#define PLNLP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLNLP_ABI_VERSION 1
+
+#define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
+#define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
+#define PLNLP_E_ALIGN     (-3)   /* pointer or leading dimension misaligned */
+#define PLNLP_E_UNSUPPORTED (-4) /* flag / size combination not implemented */
+#define PLNLP_E_WORKSPACE (-5)   /* workspace too small                     */
+
+int         plnlp_abi_version(void);
+const char* plnlp_error_string(int code);
+
+/* ---- epilogue flags shared by aggregate / linear -------------------------- */
+#define PLNLP_EPI_BIAS      1u   /* + bias[f]                                         */
+#define PLNLP_EPI_RELU      2u   /* max(.,0)                    layer.py:21,25,84     */
+#define PLNLP_EPI_DROPOUT   4u   /* counter-RNG dropout(p,seed) layer.py:22,26,85     */
+#define PLNLP_EPI_ACCUM     8u   /* out += result instead of out = result             */
+#define PLNLP_EPI_GATE     16u   /* result = gate[r,f] > 0 ? result*gate_scale : 0
+                                    (backward of relu+dropout given the forward output) */
+
+typedef struct plnlp_epilogue {
+    uint32_t     flags;
+    float        dropout_p;      /* PLNLP_EPI_DROPOUT                         */
+    uint64_t     dropout_seed;   /* PLNLP_EPI_DROPOUT: per-call 64-bit seed   */
+    const float* bias;           /* PLNLP_EPI_BIAS: [n_cols]                  */
+    const float* gate;           /* PLNLP_EPI_GATE: [n_rows, ld_gate]         */
+    int64_t      ld_gate;
+    float        gate_scale;
+} plnlp_epilogue;
+
+/* ---- K1/K2: CSR neighbour gather-and-reduce --------------------------------
+ * out[r, :] = EPI( red_{e in [rowptr[r], rowptr[r+1])} w_e * x[col[e], :] )
+ *   w_e = (val ? val[e] : 1) * (src_scale ? src_scale[col[e]] : 1)
+ *   reduce = PLNLP_REDUCE_SUM | PLNLP_REDUCE_MEAN (divide by max(rowlen,1))
+ * Replaces torch_sparse.matmul(adj_t, x, reduce) reached from SAGEConv /
+ * GCNConv (plnlp/layer.py:20,23,36,45) and, run on the transposed CSR, its
+ * autograd backward.  Atomic-free, deterministic.
+ * `x` and `out` must not alias.  feat % 4 == 0 and 16-byte aligned rows take
+ * the vector path; anything else takes a scalar path.
+ */
+#define PLNLP_REDUCE_SUM  0
+#define PLNLP_REDUCE_MEAN 1
+int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
+                            const float* val,        /* nullable: [nnz]      */
+                            const float* src_scale,  /* nullable: [n_src]    */
+                            const float* x, int64_t ldx,
+                            float* out, int64_t ldo,
+                            int64_t n_rows, int64_t feat, int reduce,
+                            const plnlp_epilogue* epi /* nullable, HOST ptr */,
+                            void* stream);
+
+/* ---- K4: dense fp32 linear on the f32-input MFMA ---------------------------
+ * C[M,N] = EPI( sum_s  op(A_s)[M,K_s] * op(B_s)[K_s,N] )     s = 0 .. n_seg-1 (<= 2)
+ *   a_trans = 0: A_s stored [M,K_s] (lda = row stride)   1: stored [K_s,M]
+ *   b_trans = 1: B_s stored [N,K_s] (nn.Linear weight)   0: stored [K_s,N]
+ * Replaces F.linear / addmm inside SAGEConv (lin_l(agg)+lin_r(x) as ONE
+ * concat-K product, n_seg = 2), GCNConv.lin and MLPPredictor.lins
+ * (plnlp/layer.py:36,45,83,86) and their autograd dgrad / wgrad GEMMs.
+ * split_k > 1: partial products go to `workspace` ([split_k, M, N] floats) and
+ * are reduced in fixed order by a second kernel (deterministic); the epilogue
+ * runs in that second kernel.
+ */
+typedef struct plnlp_gemm_operand {
+    const float* a; int64_t lda;
+    const float* b; int64_t ldb;
+    int64_t k;
+} plnlp_gemm_operand;
+
+int plnlp_gemm_f32(const plnlp_gemm_operand* segs /* HOST ptr */, int n_seg,
+                   int a_trans, int b_trans,
+                   float* c, int64_t ldc, int64_t m, int64_t n,
+                   const plnlp_epilogue* epi /* nullable, HOST ptr */,
+                   int split_k, float* workspace, int64_t workspace_floats,
+                   void* stream);
+
+/* column sums: out[f] = sum_r x[r,f] (bias gradients; mean row for eval,
+ * plnlp/model.py:193).  workspace: [n_blocks, feat] floats, n_blocks returned by
+ * plnlp_colsum_workspace_floats / feat. */
+int64_t plnlp_colsum_workspace_floats(int64_t n_rows, int64_t feat);
+int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t feat,
+                     float scale, float* out, float* workspace, int64_t workspace_floats,
+                     void* stream);
+
+/* ---- K3: edge endpoint gather + score --------------------------------------
+ * Replaces h[edge[0]], h[edge[1]] (plnlp/model.py:155-156,179-180) fused with
+ * DotPredictor.forward (layer.py:174-176) or the Hadamard product that opens
+ * MLPPredictor.forward (layer.py:81).  src/dst are int64 like the reference's
+ * edge tensors; h has n_rows rows and a negative index i addresses row n_rows + i
+ * (the reference appends a mean row so that -1 means "unseen node", model.py:191-194).
+ */
+int plnlp_edge_dot_fwd_f32(const float* h, int64_t ldh, int64_t n_rows,
+                           const int64_t* src, const int64_t* dst, int64_t n_edges,
+                           int64_t feat, float* out, void* stream);
+int plnlp_edge_hadamard_fwd_f32(const float* h, int64_t ldh, int64_t n_rows,
+                                const int64_t* src, const int64_t* dst, int64_t n_edges,
+                                int64_t feat, float* out, int64_t ldo, void* stream);
+/* backward of both: gh[src] += g (.) h[dst], gh[dst] += g (.) h[src]
+ * (index_put_(accumulate=True) in the reference's autograd).
+ *   g_is_vector = 0: g is [n_edges] (dot)   1: g is [n_edges, ldg] (hadamard)
+ * Scatter by fp32 atomics: summation order is not fixed. gh must
+ * be zero-initialised (or hold a gradient to accumulate into). */
+int plnlp_edge_scatter_bwd_f32(const float* h, int64_t ldh,
+                               const int64_t* src, const int64_t* dst, int64_t n_edges,
+                               int64_t feat, const float* g, int64_t ldg, int g_is_vector,
+                               float* gh, int64_t ldgh, void* stream);
+/* deterministic variant over a node-sorted incidence list built once per batch:
+ * for node slot s (seg_node[s] = node id, or s itself when seg_node is NULL), items
+ * [seg_ptr[s], seg_ptr[s+1]) each
+ * name an edge id and the OTHER endpoint:
+ *   gh[seg_node[s], :] = EPI( sum_items g[edge] (.) h[other, :] )   */
+int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh,
+                               const int64_t* seg_ptr, const int64_t* seg_node, int64_t n_seg,
+                               const int32_t* item_edge, const int32_t* item_other,
+                               int64_t feat, const float* g, int64_t ldg, int g_is_vector,
+                               float* gh, int64_t ldgh,
+                               const plnlp_epilogue* epi /* nullable: GATE only */,
+                               void* stream);
+
+/* ---- K5: pairwise ranking loss, forward + backward in one pass -------------
+ * d = pos[b] - neg[b*k + n];  loss = sum (or mean) over the [B,k] grid.
+ * Replaces plnlp/loss.py:5-48 + their autograd.  kind: PLNLP_LOSS_*.
+ * weight: [B] (weighted / adaptive kinds), nullable otherwise.
+ * Outputs: loss[1], gpos[B], gneg[B*k] (d loss / d input, already scaled by
+ * grad_scale).  workspace: plnlp_loss_workspace_floats(B) floats; reduction order
+ * is fixed (deterministic).
+ */
+#define PLNLP_LOSS_AUC                 0   /* loss.py:5-8   */
+#define PLNLP_LOSS_HINGE_AUC           1   /* loss.py:11-14 */
+#define PLNLP_LOSS_WEIGHTED_AUC        2   /* loss.py:17-21 */
+#define PLNLP_LOSS_ADAPTIVE_AUC        3   /* loss.py:24-28 */
+#define PLNLP_LOSS_WEIGHTED_HINGE_AUC  4   /* loss.py:31-35 */
+#define PLNLP_LOSS_ADAPTIVE_HINGE_AUC  5   /* loss.py:38-42 */
+#define PLNLP_LOSS_LOG_RANK            6   /* loss.py:45-48 (mean) */
+int64_t plnlp_loss_workspace_floats(int64_t batch);
+int plnlp_pairwise_loss_f32(int kind, const float* pos, const float* neg, const float* weight,
+                            int64_t batch, int64_t num_neg, float grad_scale,
+                            float* loss, float* gpos, float* gneg,
+                            float* workspace, int64_t workspace_floats, void* stream);
+
+/* ---- optimiser step (plnlp/model.py:163-167) -------------------------------
+ * sum of squares of a gradient tensor into partial[n_partial] (fixed order), so
+ * that clip_grad_norm_'s total norm over a parameter group is
+ * sqrt(sum over tensors and partials); then one fused Adam update with the clip
+ * coefficient read from DEVICE memory (no host sync):
+ *   coef = clip_coef ? min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) : 1
+ */
+int64_t plnlp_sqnorm_partials(int64_t n);
+int plnlp_sqnorm_f32(const float* g, int64_t n, float* partial, int64_t n_partial, void* stream);
+int plnlp_sum_partials_f32(const float* partial, int64_t n, float* out /* [1] */, int accumulate,
+                           void* stream);
+int plnlp_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                        int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int decoupled_wd, int64_t step,
+                        const float* sqnorm /* nullable DEVICE ptr */, float max_norm,
+                        float grad_scale, void* stream);
+/* grad *= min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) -- clip_grad_norm_ for callers that
+ * keep torch.optim as the optimiser */
+int plnlp_clip_scale_f32(float* grad, int64_t n, const float* sqnorm, float max_norm, void* stream);
+
+/* ---- small element-wise helpers -------------------------------------------- */
+/* y = gate>0 ? g*scale : 0  (relu+dropout backward as a stand-alone pass) */
+int plnlp_gate_f32(const float* g, const float* gate, float scale, float* y, int64_t n, void* stream);
+/* out[r, :] = dropout(x[r, :]) -- stand-alone counter-RNG dropout (tests) */
+int plnlp_dropout_f32(const float* x, float* y, int64_t n_rows, int64_t n_cols,
+                      float p, uint64_t seed, void* stream);
+int plnlp_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy,
+                        int64_t n_rows, int64_t n_cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLNLP_HIP_H */

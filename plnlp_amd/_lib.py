@@ -1,0 +1,148 @@
+"""ctypes binding of libplnlp_hip.so (the C ABI in include/plnlp_hip.h).
+
+No fallback: if the library cannot be loaded, every op raises.  PyTorch is used
+only to own device memory and streams; tensors cross the boundary as raw
+pointers + sizes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplnlp_hip.so")
+
+c_f32p = C.c_void_p   # device pointers travel as integers
+c_i64 = C.c_int64
+
+
+class Epilogue(C.Structure):
+    """mirror of plnlp_epilogue"""
+    _fields_ = [("flags", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
+                ("bias", C.c_void_p), ("gate", C.c_void_p), ("ld_gate", C.c_int64),
+                ("gate_scale", C.c_float)]
+
+
+class GemmOperand(C.Structure):
+    """mirror of plnlp_gemm_operand"""
+    _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64),
+                ("k", C.c_int64)]
+
+
+EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE = 1, 2, 4, 8, 16
+REDUCE_SUM, REDUCE_MEAN = 0, 1
+LOSS_KINDS = {"auc": 0, "hinge_auc": 1, "weighted_auc": 2, "adaptive_auc": 3,
+              "weighted_hinge_auc": 4, "adaptive_hinge_auc": 5, "log_rank": 6}
+
+# name -> (restype, argtypes); this table is also what tests check against the header
+SIGNATURES = {
+    "plnlp_abi_version": (C.c_int, []),
+    "plnlp_error_string": (C.c_char_p, [C.c_int]),
+    "plnlp_csr_aggregate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64,
+                                          C.c_void_p, c_i64, c_i64, c_i64, C.c_int, C.POINTER(Epilogue),
+                                          C.c_void_p]),
+    "plnlp_gemm_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
+                                 c_i64, C.POINTER(Epilogue), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_colsum_workspace_floats": (c_i64, [c_i64, c_i64]),
+    "plnlp_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_float, C.c_void_p, C.c_void_p, c_i64,
+                                   C.c_void_p]),
+    "plnlp_edge_dot_fwd_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, c_i64,
+                                         C.c_void_p, C.c_void_p]),
+    "plnlp_edge_hadamard_fwd_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, c_i64,
+                                              C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_edge_scatter_bwd_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, c_i64, c_i64,
+                                             C.c_void_p, c_i64, C.c_int, C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_edge_segment_bwd_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_void_p,
+                                             C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_int, C.c_void_p, c_i64,
+                                             C.POINTER(Epilogue), C.c_void_p]),
+    "plnlp_loss_workspace_floats": (c_i64, [c_i64]),
+    "plnlp_pairwise_loss_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_float,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_sqnorm_partials": (c_i64, [c_i64]),
+    "plnlp_sqnorm_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_sum_partials_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_int, C.c_void_p]),
+    "plnlp_adam_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_float,
+                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, c_i64, C.c_void_p,
+                                      C.c_float, C.c_float, C.c_void_p]),
+    "plnlp_clip_scale_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_void_p]),
+    "plnlp_gate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_dropout_f32": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_float, C.c_uint64, C.c_void_p]),
+    "plnlp_transpose_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class PlnlpHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library.  Raises if it is missing -- there is no
+    fallback path; build it with `python -m plnlp_amd.build`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PlnlpHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (python -m plnlp_amd.build); "
+            "plnlp_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.plnlp_abi_version() != 1:
+        raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().plnlp_error_string(rc).decode()
+        raise PlnlpHipError(f"{what}: {msg} (code {rc})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_device(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PlnlpHipError(
+                "plnlp_amd ops run only on an MI355X device tensor (got a CPU tensor); "
+                "there is no CPU path in the product -- the CPU oracle lives in oracle/ for tests")
+
+
+def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accumulate=False,
+                  gate=None, gate_scale=1.0) -> Optional[Epilogue]:
+    flags = 0
+    e = Epilogue()
+    if bias is not None:
+        flags |= EPI_BIAS
+        e.bias = bias.data_ptr()
+    if relu:
+        flags |= EPI_RELU
+    if dropout_p > 0.0:
+        flags |= EPI_DROPOUT
+        e.dropout_p = float(dropout_p)
+        e.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
+    if accumulate:
+        flags |= EPI_ACCUM
+    if gate is not None:
+        flags |= EPI_GATE
+        e.gate = gate.data_ptr()
+        e.ld_gate = gate.stride(0)
+        e.gate_scale = float(gate_scale)
+    if flags == 0:
+        return None
+    e.flags = flags
+    return e

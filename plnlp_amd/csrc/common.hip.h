@@ -1,0 +1,107 @@
+// Shared device helpers for libplnlp_hip.so (gfx950 only; wave64 hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/plnlp_hip.h"
+
+#define PLNLP_WAVE 64
+
+namespace plnlp {
+
+// ---- counter-based dropout mask ---------------------------------------------
+// keep(element) for logical element index idx = row * n_cols + col under a 64-bit
+// per-call seed.  oracle/reference_path.py::dropout_keep_mask restates this in
+// numpy; the two must stay bit-identical.
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t idx, uint32_t seed_lo, uint32_t seed_hi,
+                                             uint32_t thresh) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t h = lowbias32(lo ^ seed_lo);
+    h = lowbias32(h + hi * 0x9E3779B9u + seed_hi);
+    return h >= thresh;
+}
+__host__ __device__ inline uint32_t dropout_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0.0) t = 0.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+// ---- epilogue, device-side copy of plnlp_epilogue ------------------------------
+struct Epi {
+    uint32_t     flags;
+    uint32_t     thresh;        // dropout threshold
+    uint32_t     seed_lo, seed_hi;
+    float        keep_scale;    // 1/(1-p)
+    float        gate_scale;
+    const float* bias;
+    const float* gate;
+    int64_t      ld_gate;
+};
+
+inline int make_epi(const plnlp_epilogue* e, Epi* out) {
+    Epi d{};
+    d.keep_scale = 1.f;
+    d.gate_scale = 1.f;
+    if (e) {
+        d.flags = e->flags;
+        if (d.flags & PLNLP_EPI_BIAS) { if (!e->bias) return PLNLP_E_NULL; d.bias = e->bias; }
+        if (d.flags & PLNLP_EPI_GATE) {
+            if (!e->gate) return PLNLP_E_NULL;
+            d.gate = e->gate; d.ld_gate = e->ld_gate; d.gate_scale = e->gate_scale;
+        }
+        if (d.flags & PLNLP_EPI_DROPOUT) {
+            if (!(e->dropout_p >= 0.f) || e->dropout_p >= 1.f) return PLNLP_E_SHAPE;
+            if (e->dropout_p == 0.f) d.flags &= ~PLNLP_EPI_DROPOUT;
+            d.thresh = dropout_thresh(e->dropout_p);
+            d.seed_lo = (uint32_t)e->dropout_seed;
+            d.seed_hi = (uint32_t)(e->dropout_seed >> 32);
+            d.keep_scale = 1.f / (1.f - e->dropout_p);
+        }
+    }
+    *out = d;
+    return 0;
+}
+
+// apply to one value at (row r, column f) of an [*, n_cols] result
+__device__ __forceinline__ float epi_apply(const Epi& e, float v, int64_t r, int64_t f,
+                                           int64_t n_cols, float prev) {
+    if (e.flags & PLNLP_EPI_BIAS) v += e.bias[f];
+    if (e.flags & PLNLP_EPI_RELU) v = fmaxf(v, 0.f);
+    if (e.flags & PLNLP_EPI_DROPOUT)
+        v = dropout_keep((uint64_t)r * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh)
+                ? v * e.keep_scale : 0.f;
+    if (e.flags & PLNLP_EPI_GATE) v = e.gate[r * e.ld_gate + f] > 0.f ? v * e.gate_scale : 0.f;
+    if (e.flags & PLNLP_EPI_ACCUM) v += prev;
+    return v;
+}
+
+__device__ __forceinline__ float4 epi_apply4(const Epi& e, float4 v, int64_t r, int64_t f,
+                                             int64_t n_cols, const float* out_row) {
+    if (e.flags == 0) return v;
+    float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.flags & PLNLP_EPI_ACCUM) prev = *reinterpret_cast<const float4*>(out_row + f);
+    v.x = epi_apply(e, v.x, r, f + 0, n_cols, prev.x);
+    v.y = epi_apply(e, v.y, r, f + 1, n_cols, prev.y);
+    v.z = epi_apply(e, v.z, r, f + 2, n_cols, prev.z);
+    v.w = epi_apply(e, v.w, r, f + 3, n_cols, prev.w);
+    return v;
+}
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace plnlp

@@ -1,0 +1,265 @@
+// K1/K2 -- CSR neighbour gather-and-reduce for gfx950 (MI355X).
+//
+//   out[r,:] = EPI( red_{e in row r} w_e * x[col[e], :] )
+//
+// HBM/L2-bound: 0.5 FLOP per byte, so the design is about bytes in flight, not
+// math.  One wave64 owns one output row.  A feature row is read with 16 B per
+// lane (1 KiB per wave-instruction); the row's column indices arrive 64 at a
+// time through ONE coalesced load and are broadcast lane->SGPR with
+// v_readlane, so every feature-row address is scalar-base + lane offset.  Up
+// to 8 independent row loads are in flight per wave before the first FMA
+// (>= 8 KiB per wave, 16 waves per CU -> >= 128 KiB per CU against the ~32 KiB
+// per CU that saturates HBM).  No atomics: the reduction order inside a row is
+// the CSR order, so results are bit-reproducible run to run.
+//
+// Narrow feature rows (feat <= 128) pack 2/4/8 neighbours into one wave
+// instruction (LPR lanes per row) and fold the partial sums with DPP/bpermute
+// shuffles at the end.
+#include "common.hip.h"
+
+namespace plnlp {
+
+template <int LPR>  // lanes per feature row: 64, 32, 16, 8
+struct AggGeom {
+    static constexpr int NG = 64 / LPR;  // neighbours per wave instruction
+};
+
+// gather up to CH neighbour rows (m of them valid, wave-uniform) then accumulate.
+template <int VPL, int LPR, int CH, bool WEIGHTED>
+__device__ __forceinline__ void agg_chunk(float4 (&acc)[VPL], const float* __restrict__ x, int64_t ldx,
+                                          int cvec, float wvec, int j0, int m, int sub, int grp,
+                                          int nslots) {
+    constexpr int NG = 64 / LPR;
+    float4 v[CH][VPL];
+    float  w[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        if (u < m) {  // wave-uniform
+            int src_lane = j0 + u * NG + grp;
+            int idx;
+            if constexpr (NG == 1) {
+                idx = __builtin_amdgcn_readlane(cvec, j0 + u);
+                if constexpr (WEIGHTED) w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wvec), j0 + u));
+            } else {
+                idx = __shfl(cvec, src_lane, 64);
+                if constexpr (WEIGHTED) w[u] = __shfl(wvec, src_lane, 64);
+            }
+            const float4* p = reinterpret_cast<const float4*>(x + (int64_t)idx * ldx);
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                int s = sub + k * LPR;
+                v[u][k] = (s < nslots) ? p[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        if (u < m) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                if constexpr (WEIGHTED) {
+                    acc[k].x = fmaf(w[u], v[u][k].x, acc[k].x);
+                    acc[k].y = fmaf(w[u], v[u][k].y, acc[k].y);
+                    acc[k].z = fmaf(w[u], v[u][k].z, acc[k].z);
+                    acc[k].w = fmaf(w[u], v[u][k].w, acc[k].w);
+                } else {
+                    acc[k].x += v[u][k].x; acc[k].y += v[u][k].y;
+                    acc[k].z += v[u][k].z; acc[k].w += v[u][k].w;
+                }
+            }
+        }
+    }
+}
+
+template <int VPL, int LPR, bool WEIGHTED>
+__global__ __launch_bounds__(256) void csr_agg_vec_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, const float* __restrict__ src_scale,
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+    int64_t n_rows, int feat, int mean, Epi epi) {
+    constexpr int NG = 64 / LPR;
+    constexpr int CH = (VPL >= 4) ? 4 : 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= n_rows) return;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int nslots = feat >> 2;
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+
+    float4 acc[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int64_t e0 = beg; e0 < end; e0 += 64) {
+        const int n = (int)((end - e0) < 64 ? (end - e0) : 64);
+        int cvec = 0;
+        float wvec = 0.f;
+        if (lane < n) {
+            cvec = col[e0 + lane];
+            if constexpr (WEIGHTED) {
+                wvec = val ? val[e0 + lane] : 1.f;
+                if (src_scale) wvec *= src_scale[cvec];
+            }
+        }
+        // groups of NG neighbours; neighbours past n have cvec = 0 (a valid row) and weight 0,
+        // but are never accumulated: the chunk count m covers whole groups only for the
+        // full part and the ragged tail is handled group-lane-wise below.
+        const int ngroups = (n + NG - 1) / NG;  // wave instructions needed
+        for (int j = 0; j < ngroups; j += CH) {
+            const int m = (ngroups - j) < CH ? (ngroups - j) : CH;
+            if constexpr (NG == 1) {
+                agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j, m, sub, grp, nslots);
+            } else {
+                // a lane group whose neighbour index runs past n must contribute nothing
+                // (not even 0*x: x may hold inf).  Mask by zeroing through a select.
+                float4 part[VPL];
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int full = (n / NG);  // groups j < full are complete for every grp
+                if (j + m <= full) {
+                    agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j * NG, m, sub, grp, nslots);
+                } else {
+                    // last, ragged chunk: do complete groups, then the partial one under a lane mask
+                    const int mfull = full - j > 0 ? full - j : 0;
+                    if (mfull > 0)
+                        agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j * NG, mfull, sub, grp, nslots);
+                    const int jl = (j + mfull) * NG;  // first neighbour of the ragged group
+                    if (jl < n) {
+                        agg_chunk<VPL, LPR, 1, WEIGHTED>(part, x, ldx, cvec, wvec, jl, 1, sub, grp, nslots);
+                        const bool ok = (jl + grp) < n;
+#pragma unroll
+                        for (int k = 0; k < VPL; ++k) {
+                            acc[k].x += ok ? part[k].x : 0.f; acc[k].y += ok ? part[k].y : 0.f;
+                            acc[k].z += ok ? part[k].z : 0.f; acc[k].w += ok ? part[k].w : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if constexpr (NG > 1) {  // fold the NG partial sums into group 0
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                acc[k].x += __shfl_xor(acc[k].x, o, 64); acc[k].y += __shfl_xor(acc[k].y, o, 64);
+                acc[k].z += __shfl_xor(acc[k].z, o, 64); acc[k].w += __shfl_xor(acc[k].w, o, 64);
+            }
+        }
+        if (grp != 0) return;
+    }
+
+    if (mean) {
+        const float d = (float)((end - beg) > 0 ? (end - beg) : 1);
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) { acc[k].x /= d; acc[k].y /= d; acc[k].z /= d; acc[k].w /= d; }
+    }
+    float* orow = out + r * ldo;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        int s = sub + k * LPR;
+        if (s < nslots) {
+            float4 y = epi_apply4(epi, acc[k], r, (int64_t)s * 4, feat, orow);
+            *reinterpret_cast<float4*>(orow + s * 4) = y;
+        }
+    }
+}
+
+// scalar path: any feat / alignment.  Lane l owns columns l, l+64, ...
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, const float* __restrict__ src_scale,
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+    int64_t n_rows, int feat, int mean, Epi epi) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= n_rows) return;
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    for (int f0 = 0; f0 < feat; f0 += 64 * 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t e = beg; e < end; ++e) {
+            const int c = col[e];
+            float w = 1.f;
+            if constexpr (WEIGHTED) {
+                w = val ? val[e] : 1.f;
+                if (src_scale) w *= src_scale[c];
+            }
+            const float* p = x + (int64_t)c * ldx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int f = f0 + lane + 64 * k;
+                if (f < feat) acc[k] = WEIGHTED ? fmaf(w, p[f], acc[k]) : acc[k] + p[f];
+            }
+        }
+        const float d = (float)((end - beg) > 0 ? (end - beg) : 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int f = f0 + lane + 64 * k;
+            if (f < feat) {
+                float v = mean ? acc[k] / d : acc[k];
+                float prev = (epi.flags & PLNLP_EPI_ACCUM) ? out[r * ldo + f] : 0.f;
+                out[r * ldo + f] = epi_apply(epi, v, r, f, feat, prev);
+            }
+        }
+    }
+}
+
+template <int VPL, int LPR>
+static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* rowptr, const int32_t* col,
+                      const float* val, const float* src_scale, const float* x, int64_t ldx, float* out,
+                      int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e) {
+    if (weighted)
+        hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true>), grid, dim3(256), 0, s, rowptr, col, val,
+                           src_scale, x, ldx, out, ldo, n_rows, feat, mean, e);
+    else
+        hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false>), grid, dim3(256), 0, s, rowptr, col, val,
+                           src_scale, x, ldx, out, ldo, n_rows, feat, mean, e);
+    return launch_status();
+}
+
+}  // namespace plnlp
+
+extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                                       const float* src_scale, const float* x, int64_t ldx, float* out,
+                                       int64_t ldo, int64_t n_rows, int64_t feat, int reduce,
+                                       const plnlp_epilogue* epi, void* stream) {
+    using namespace plnlp;
+    if (!rowptr || !x || !out) return PLNLP_E_NULL;
+    if (n_rows < 0 || feat <= 0 || ldx < feat || ldo < feat || feat > (1 << 20)) return PLNLP_E_SHAPE;
+    if (reduce != PLNLP_REDUCE_SUM && reduce != PLNLP_REDUCE_MEAN) return PLNLP_E_UNSUPPORTED;
+    if (n_rows == 0) return 0;
+    if (!col) return PLNLP_E_NULL;
+    Epi e;
+    if (int rc = make_epi(epi, &e)) return rc;
+    if (n_rows > (int64_t)4 * 0x7FFFFFFF) return PLNLP_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((n_rows + 3) / 4));
+    const bool weighted = (val != nullptr) || (src_scale != nullptr);
+    const int mean = reduce == PLNLP_REDUCE_MEAN;
+    const bool vec_ok = (feat % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) &&
+                        ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) && feat <= 1024 &&
+                        (!(e.flags & PLNLP_EPI_GATE) || true);
+    if (!vec_ok) {
+        if (weighted)
+            hipLaunchKernelGGL((csr_agg_scalar_kernel<true>), grid, dim3(256), 0, s, rowptr, col, val, src_scale,
+                               x, ldx, out, ldo, n_rows, (int)feat, mean, e);
+        else
+            hipLaunchKernelGGL((csr_agg_scalar_kernel<false>), grid, dim3(256), 0, s, rowptr, col, val, src_scale,
+                               x, ldx, out, ldo, n_rows, (int)feat, mean, e);
+        return launch_status();
+    }
+    const int nslots = (int)(feat / 4);
+#define PLNLP_AGG(VPL, LPR) \
+    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e)
+    if (nslots <= 8) PLNLP_AGG(1, 8);
+    if (nslots <= 16) PLNLP_AGG(1, 16);
+    if (nslots <= 32) PLNLP_AGG(1, 32);
+    if (nslots <= 64) PLNLP_AGG(1, 64);
+    if (nslots <= 128) PLNLP_AGG(2, 64);
+    PLNLP_AGG(4, 64);
+#undef PLNLP_AGG
+}

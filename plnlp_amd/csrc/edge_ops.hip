@@ -1,0 +1,311 @@
+// K3 -- edge endpoint gather + score, forward and backward (gfx950).
+//
+// Forward: the reference materialises h[src], h[dst] ([E,F] each) and then
+// multiplies (plnlp/model.py:155-156 -> layer.py:81,175).  Here the two gathers
+// and the product / dot are one pass: LPR lanes own one edge, 16 B per lane per
+// endpoint row, both endpoint rows in flight together.
+//
+// Backward: index_put_(accumulate=True) in the reference.  Two forms:
+//   * plnlp_edge_scatter_bwd_f32  -- hardware fp32 atomics (order not fixed);
+//   * plnlp_edge_segment_bwd_f32  -- atomic-free gather-reduce over a node-sorted
+//     incidence list (deterministic); also overwrites untouched rows with 0 so no
+//     memset of gh is needed.
+#include "common.hip.h"
+
+namespace plnlp {
+
+__device__ __forceinline__ int64_t wrap_index(int64_t i, int64_t n_rows) { return i < 0 ? i + n_rows : i; }
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------- forward: dot ---------------------------------------------------
+template <int LPR, bool VEC>
+__global__ __launch_bounds__(256) void edge_dot_fwd_kernel(const float* __restrict__ h, int64_t ldh, int64_t n_rows,
+                                                           const int64_t* __restrict__ src,
+                                                           const int64_t* __restrict__ dst, int64_t n_edges,
+                                                           int feat, float* __restrict__ out) {
+    constexpr int GPB = 256 / LPR;  // edges per block iteration
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    for (int64_t e = (int64_t)blockIdx.x * GPB + grp; e < n_edges; e += (int64_t)gridDim.x * GPB) {
+        const float* a = h + wrap_index(src[e], n_rows) * ldh;
+        const float* b = h + wrap_index(dst[e], n_rows) * ldh;
+        float acc = 0.f;
+        if constexpr (VEC) {
+            const int nslots = feat >> 2;
+            for (int s = sub; s < nslots; s += LPR) {
+                const float4 u = reinterpret_cast<const float4*>(a)[s];
+                const float4 v = reinterpret_cast<const float4*>(b)[s];
+                acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc);
+                acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
+            }
+        } else {
+            for (int f = sub; f < feat; f += LPR) acc = fmaf(a[f], b[f], acc);
+        }
+        acc = group_sum<LPR>(acc);
+        if (sub == 0) out[e] = acc;
+    }
+}
+
+// ---------------- forward: hadamard ----------------------------------------------
+template <int LPR, bool VEC>
+__global__ __launch_bounds__(256) void edge_hadamard_fwd_kernel(const float* __restrict__ h, int64_t ldh,
+                                                                int64_t n_rows, const int64_t* __restrict__ src,
+                                                                const int64_t* __restrict__ dst, int64_t n_edges,
+                                                                int feat, float* __restrict__ out, int64_t ldo) {
+    constexpr int GPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    for (int64_t e = (int64_t)blockIdx.x * GPB + grp; e < n_edges; e += (int64_t)gridDim.x * GPB) {
+        const float* a = h + wrap_index(src[e], n_rows) * ldh;
+        const float* b = h + wrap_index(dst[e], n_rows) * ldh;
+        float* o = out + e * ldo;
+        if constexpr (VEC) {
+            const int nslots = feat >> 2;
+            for (int s = sub; s < nslots; s += LPR) {
+                const float4 u = reinterpret_cast<const float4*>(a)[s];
+                const float4 v = reinterpret_cast<const float4*>(b)[s];
+                reinterpret_cast<float4*>(o)[s] = make_float4(u.x * v.x, u.y * v.y, u.z * v.z, u.w * v.w);
+            }
+        } else {
+            for (int f = sub; f < feat; f += LPR) o[f] = a[f] * b[f];
+        }
+    }
+}
+
+// ---------------- backward: atomic scatter -----------------------------------------
+template <int LPR, bool GVEC>
+__global__ __launch_bounds__(256) void edge_scatter_bwd_kernel(const float* __restrict__ h, int64_t ldh,
+                                                               const int64_t* __restrict__ src,
+                                                               const int64_t* __restrict__ dst, int64_t n_edges,
+                                                               int feat, const float* __restrict__ g, int64_t ldg,
+                                                               float* __restrict__ gh, int64_t ldgh) {
+    constexpr int GPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    for (int64_t e = (int64_t)blockIdx.x * GPB + grp; e < n_edges; e += (int64_t)gridDim.x * GPB) {
+        const int64_t si = src[e], di = dst[e];
+        const float* a = h + si * ldh;
+        const float* b = h + di * ldh;
+        float* ga = gh + si * ldgh;
+        float* gb = gh + di * ldgh;
+        const float gs = GVEC ? 0.f : g[e];
+        for (int f = sub; f < feat; f += LPR) {
+            const float gv = GVEC ? g[e * ldg + f] : gs;
+            unsafeAtomicAdd(ga + f, gv * b[f]);
+            unsafeAtomicAdd(gb + f, gv * a[f]);
+        }
+    }
+}
+
+// ---------------- backward: deterministic segmented gather-reduce -----------------
+// one wave per node slot; items are (edge id, other endpoint).
+template <bool GVEC, bool VEC>
+__global__ __launch_bounds__(256) void edge_segment_bwd_kernel(
+    const float* __restrict__ h, int64_t ldh, const int64_t* __restrict__ seg_ptr,
+    const int64_t* __restrict__ seg_node, int64_t n_seg, const int32_t* __restrict__ item_edge,
+    const int32_t* __restrict__ item_other, int feat, const float* __restrict__ g, int64_t ldg,
+    float* __restrict__ gh, int64_t ldgh, Epi epi) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+    if (s >= n_seg) return;
+    const int64_t node = seg_node ? seg_node[s] : s;
+    const int64_t beg = seg_ptr[s], end = seg_ptr[s + 1];
+    float* orow = gh + node * ldgh;
+    if constexpr (VEC) {
+        const int nslots = feat >> 2;
+        for (int s0 = 0; s0 < nslots; s0 += 128) {
+            float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            for (int64_t i0 = beg; i0 < end; i0 += 64) {
+                const int n = (int)((end - i0) < 64 ? (end - i0) : 64);
+                int ev = 0, ov = 0;
+                float gv = 0.f;
+                if (lane < n) {
+                    ev = item_edge[i0 + lane];
+                    ov = item_other[i0 + lane];
+                    if constexpr (!GVEC) gv = g[ev];
+                }
+                for (int j = 0; j < n; j += 4) {
+                    float4 x[4][2], gg[4][2];
+                    float w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j + u < n) {
+                            const int o = __builtin_amdgcn_readlane(ov, j + u);
+                            const float4* p = reinterpret_cast<const float4*>(h + (int64_t)o * ldh);
+                            if constexpr (GVEC) {
+                                const int ed = __builtin_amdgcn_readlane(ev, j + u);
+                                const float4* q = reinterpret_cast<const float4*>(g + (int64_t)ed * ldg);
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    const int sl = s0 + lane + 64 * k;
+                                    gg[u][k] = sl < nslots ? q[sl] : make_float4(0.f, 0.f, 0.f, 0.f);
+                                }
+                            } else {
+                                w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), j + u));
+                            }
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const int sl = s0 + lane + 64 * k;
+                                x[u][k] = sl < nslots ? p[sl] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j + u < n) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                if constexpr (GVEC) {
+                                    acc[k].x = fmaf(gg[u][k].x, x[u][k].x, acc[k].x);
+                                    acc[k].y = fmaf(gg[u][k].y, x[u][k].y, acc[k].y);
+                                    acc[k].z = fmaf(gg[u][k].z, x[u][k].z, acc[k].z);
+                                    acc[k].w = fmaf(gg[u][k].w, x[u][k].w, acc[k].w);
+                                } else {
+                                    acc[k].x = fmaf(w[u], x[u][k].x, acc[k].x);
+                                    acc[k].y = fmaf(w[u], x[u][k].y, acc[k].y);
+                                    acc[k].z = fmaf(w[u], x[u][k].z, acc[k].z);
+                                    acc[k].w = fmaf(w[u], x[u][k].w, acc[k].w);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int sl = s0 + lane + 64 * k;
+                if (sl < nslots) {
+                    const float4 y = epi_apply4(epi, acc[k], node, (int64_t)sl * 4, feat, orow);
+                    reinterpret_cast<float4*>(orow)[sl] = y;
+                }
+            }
+        }
+    } else {
+        for (int f = lane; f < feat; f += 64) {
+            float acc = 0.f;
+            for (int64_t i = beg; i < end; ++i) {
+                const int ed = item_edge[i], o = item_other[i];
+                const float gv = GVEC ? g[(int64_t)ed * ldg + f] : g[ed];
+                acc = fmaf(gv, h[(int64_t)o * ldh + f], acc);
+            }
+            const float prev = (epi.flags & PLNLP_EPI_ACCUM) ? orow[f] : 0.f;
+            orow[f] = epi_apply(epi, acc, node, f, feat, prev);
+        }
+    }
+}
+
+static inline int pick_lpr(int64_t feat, bool vec) {
+    const int64_t units = vec ? feat / 4 : feat;
+    if (units <= 8) return 8;
+    if (units <= 16) return 16;
+    if (units <= 32) return 32;
+    return 64;
+}
+static inline unsigned edge_grid(int64_t n_edges, int lpr) {
+    const int64_t gpb = 256 / lpr;
+    int64_t b = (n_edges + gpb - 1) / gpb;
+    const int64_t cap = 256 * 16;
+    return (unsigned)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+}  // namespace plnlp
+
+#define PLNLP_DISPATCH_LPR(lpr, MACRO) \
+    switch (lpr) { case 8: MACRO(8); break; case 16: MACRO(16); break; case 32: MACRO(32); break; default: MACRO(64); }
+
+extern "C" int plnlp_edge_dot_fwd_f32(const float* h, int64_t ldh, int64_t n_rows, const int64_t* src,
+                                      const int64_t* dst, int64_t n_edges, int64_t feat, float* out,
+                                      void* stream) {
+    using namespace plnlp;
+    if (!h || !out) return PLNLP_E_NULL;
+    if (n_edges < 0 || feat <= 0 || ldh < feat || n_rows <= 0 || feat > (1 << 20)) return PLNLP_E_SHAPE;
+    if (n_edges == 0) return 0;
+    if (!src || !dst) return PLNLP_E_NULL;
+    const bool vec = feat % 4 == 0 && ldh % 4 == 0 && (uintptr_t)h % 16 == 0;
+    const int lpr = pick_lpr(feat, vec);
+    dim3 grid(edge_grid(n_edges, lpr));
+    hipStream_t s = (hipStream_t)stream;
+#define M(L)                                                                                                   \
+    if (vec) hipLaunchKernelGGL((edge_dot_fwd_kernel<L, true>), grid, dim3(256), 0, s, h, ldh, n_rows, src, dst, \
+                                n_edges, (int)feat, out);                                                      \
+    else hipLaunchKernelGGL((edge_dot_fwd_kernel<L, false>), grid, dim3(256), 0, s, h, ldh, n_rows, src, dst,   \
+                            n_edges, (int)feat, out)
+    PLNLP_DISPATCH_LPR(lpr, M)
+#undef M
+    return launch_status();
+}
+
+extern "C" int plnlp_edge_hadamard_fwd_f32(const float* h, int64_t ldh, int64_t n_rows, const int64_t* src,
+                                           const int64_t* dst, int64_t n_edges, int64_t feat, float* out,
+                                           int64_t ldo, void* stream) {
+    using namespace plnlp;
+    if (!h || !out) return PLNLP_E_NULL;
+    if (n_edges < 0 || feat <= 0 || ldh < feat || ldo < feat || n_rows <= 0 || feat > (1 << 20)) return PLNLP_E_SHAPE;
+    if (n_edges == 0) return 0;
+    if (!src || !dst) return PLNLP_E_NULL;
+    const bool vec = feat % 4 == 0 && ldh % 4 == 0 && ldo % 4 == 0 && (uintptr_t)h % 16 == 0 &&
+                     (uintptr_t)out % 16 == 0;
+    const int lpr = pick_lpr(feat, vec);
+    dim3 grid(edge_grid(n_edges, lpr));
+    hipStream_t s = (hipStream_t)stream;
+#define M(L)                                                                                                     \
+    if (vec) hipLaunchKernelGGL((edge_hadamard_fwd_kernel<L, true>), grid, dim3(256), 0, s, h, ldh, n_rows, src,  \
+                                dst, n_edges, (int)feat, out, ldo);                                              \
+    else hipLaunchKernelGGL((edge_hadamard_fwd_kernel<L, false>), grid, dim3(256), 0, s, h, ldh, n_rows, src,     \
+                            dst, n_edges, (int)feat, out, ldo)
+    PLNLP_DISPATCH_LPR(lpr, M)
+#undef M
+    return launch_status();
+}
+
+extern "C" int plnlp_edge_scatter_bwd_f32(const float* h, int64_t ldh, const int64_t* src, const int64_t* dst,
+                                          int64_t n_edges, int64_t feat, const float* g, int64_t ldg,
+                                          int g_is_vector, float* gh, int64_t ldgh, void* stream) {
+    using namespace plnlp;
+    if (!h || !g || !gh) return PLNLP_E_NULL;
+    if (n_edges < 0 || feat <= 0 || ldh < feat || ldgh < feat || (g_is_vector && ldg < feat)) return PLNLP_E_SHAPE;
+    if (n_edges == 0) return 0;
+    if (!src || !dst) return PLNLP_E_NULL;
+    const int lpr = pick_lpr(feat, false);
+    dim3 grid(edge_grid(n_edges, lpr));
+    hipStream_t s = (hipStream_t)stream;
+#define M(L)                                                                                                    \
+    if (g_is_vector) hipLaunchKernelGGL((edge_scatter_bwd_kernel<L, true>), grid, dim3(256), 0, s, h, ldh, src,  \
+                                        dst, n_edges, (int)feat, g, ldg, gh, ldgh);                              \
+    else hipLaunchKernelGGL((edge_scatter_bwd_kernel<L, false>), grid, dim3(256), 0, s, h, ldh, src, dst,        \
+                            n_edges, (int)feat, g, ldg, gh, ldgh)
+    PLNLP_DISPATCH_LPR(lpr, M)
+#undef M
+    return launch_status();
+}
+
+extern "C" int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh, const int64_t* seg_ptr,
+                                          const int64_t* seg_node, int64_t n_seg, const int32_t* item_edge,
+                                          const int32_t* item_other, int64_t feat, const float* g, int64_t ldg,
+                                          int g_is_vector, float* gh, int64_t ldgh, const plnlp_epilogue* epi,
+                                          void* stream) {
+    using namespace plnlp;
+    if (!h || !g || !gh || !seg_ptr) return PLNLP_E_NULL;
+    if (n_seg < 0 || feat <= 0 || ldh < feat || ldgh < feat || (g_is_vector && ldg < feat) || feat > (1 << 20))
+        return PLNLP_E_SHAPE;
+    if (n_seg == 0) return 0;
+    if (!item_edge || !item_other) return PLNLP_E_NULL;
+    Epi e;
+    if (int rc = make_epi(epi, &e)) return rc;
+    const bool vec = feat % 4 == 0 && ldh % 4 == 0 && ldgh % 4 == 0 && (uintptr_t)h % 16 == 0 &&
+                     (uintptr_t)gh % 16 == 0 && (!g_is_vector || (ldg % 4 == 0 && (uintptr_t)g % 16 == 0)) &&
+                     (!(e.flags & PLNLP_EPI_GATE) || true);
+    dim3 grid((unsigned)((n_seg + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+#define L(GV, V)                                                                                                  \
+    hipLaunchKernelGGL((edge_segment_bwd_kernel<GV, V>), grid, dim3(256), 0, s, h, ldh, seg_ptr, seg_node, n_seg, \
+                       item_edge, item_other, (int)feat, g, ldg, gh, ldgh, e)
+    if (g_is_vector) { if (vec) L(true, true); else L(true, false); }
+    else             { if (vec) L(false, true); else L(false, false); }
+#undef L
+    return launch_status();
+}

@@ -1,0 +1,298 @@
+// K4 -- fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+//   C[M,N] = EPI( sum_s op(A_s) * op(B_s) )          up to 2 K-segments (concat-K)
+//
+// Exact f32: the MFMA is bit-for-bit an fmaf chain (no TF32/xf32 on gfx950), so
+// results stay inside fp32 round-off of the reference's sgemm.  Peak for this
+// instruction is the fp32 vector peak, 157.3 TFLOP/s.
+//
+// Block = 256 threads = 4 waves (2x2), block tile 128x128, K-tile 32, wave tile
+// 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulator registers).  Global -> register
+// -> LDS staging with the next K-tile's global loads in flight during the MFMAs,
+// two LDS buffers, one barrier per K-tile.
+//
+// Operand layouts are kept as stored -- no transposes are materialised:
+//   "K-contiguous" operand (reduction index fastest: A of x@W^T, W itself):
+//       LDS tile [128][32+4]; a lane fetches 4 consecutive k with one
+//       ds_read_b128 and feeds them to 4 successive MFMAs.  The MFMA's k slot
+//       (lane>>5) is re-labelled -- half h owns k = 8q+4h+{0..3} -- which is
+//       legal because A and B use the same labelling and the sum over k is
+//       order-free across the two halves.  Row stride 36 floats makes the 16
+//       rows of a ds_read_b128 lane group start on 16 distinct bank quads.
+//   "row-contiguous" operand (reduction index slowest: dY and X in wgrad, W in
+//       dgrad): LDS tile [32][128]; lanes read consecutive floats (ds_read_b32),
+//       conflict-free.
+// Split-K (wgrad reduces over hundreds of thousands of rows into a 256x256
+// result): grid.z slices write raw partial tiles to a workspace and a second
+// kernel adds them in slice order -- deterministic, no atomics.
+#include "common.hip.h"
+
+namespace plnlp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDK = BK + 4;   // K-contiguous tile row stride (floats)
+constexpr int LDR = 128;      // row-contiguous tile row stride (floats)
+constexpr int TILE_FLOATS = 128 * LDK;  // >= 32*128
+
+struct Seg {
+    const float* a; int64_t lda;
+    const float* b; int64_t ldb;
+    int k;
+    int a_vec, b_vec;  // 16-byte path usable
+};
+
+struct GemmArgs {
+    Seg seg[2];
+    int nseg;
+    int tiles0;       // K-tiles in segment 0
+    int tiles_total;
+    float* c; int64_t ldc;
+    int64_t m; int n;
+    int split_k;
+    int64_t ws_stride;  // floats per split slice (m*n)
+};
+
+// ---- global -> registers ------------------------------------------------------
+// K-contiguous operand: rows [row0, row0+128) x k [k0, k0+32); thread t loads
+// float4 at (row0 + (t>>3) + 32p, k0 + 4*(t&7)), p = 0..3.
+__device__ __forceinline__ void load_kc(float4 (&r)[4], const float* __restrict__ base, int64_t ld,
+                                        int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
+    const int kq = (t & 7) * 4 + k0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t row = row0 + (t >> 3) + 32 * p;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nrows) {
+            const float* q = base + row * ld + kq;
+            if (vec && kq + 3 < kdim) {
+                v = *reinterpret_cast<const float4*>(q);
+            } else {
+                if (kq + 0 < kdim) v.x = q[0];
+                if (kq + 1 < kdim) v.y = q[1];
+                if (kq + 2 < kdim) v.z = q[2];
+                if (kq + 3 < kdim) v.w = q[3];
+            }
+        }
+        r[p] = v;
+    }
+}
+// row-contiguous operand stored [kdim][nrows]: k [k0,k0+32) x rows [row0,row0+128);
+// thread t loads float4 at (k0 + (t>>5) + 8p, row0 + 4*(t&31)).
+__device__ __forceinline__ void load_rc(float4 (&r)[4], const float* __restrict__ base, int64_t ld,
+                                        int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
+    const int64_t rq = row0 + (t & 31) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int k = k0 + (t >> 5) + 8 * p;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < kdim) {
+            const float* q = base + (int64_t)k * ld + rq;
+            if (vec && rq + 3 < nrows) {
+                v = *reinterpret_cast<const float4*>(q);
+            } else {
+                if (rq + 0 < nrows) v.x = q[0];
+                if (rq + 1 < nrows) v.y = q[1];
+                if (rq + 2 < nrows) v.z = q[2];
+                if (rq + 3 < nrows) v.w = q[3];
+            }
+        }
+        r[p] = v;
+    }
+}
+__device__ __forceinline__ void store_kc(float* __restrict__ tile, const float4 (&r)[4], int t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        *reinterpret_cast<float4*>(tile + ((t >> 3) + 32 * p) * LDK + (t & 7) * 4) = r[p];
+}
+__device__ __forceinline__ void store_rc(float* __restrict__ tile, const float4 (&r)[4], int t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        *reinterpret_cast<float4*>(tile + ((t >> 5) + 8 * p) * LDR + (t & 31) * 4) = r[p];
+}
+
+template <bool A_T, bool B_T>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // K-tile range of this split slice
+    const int z = blockIdx.z;
+    const int per = (g.tiles_total + g.split_k - 1) / g.split_k;
+    const int tb = z * per;
+    const int te = (tb + per) < g.tiles_total ? (tb + per) : g.tiles_total;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    float4 ra[4], rb[4];
+    auto gload = [&](int tile) {
+        const int sidx = (tile >= g.tiles0 && g.nseg > 1) ? 1 : 0;
+        const Seg& s = g.seg[sidx];
+        const int k0 = (tile - (sidx ? g.tiles0 : 0)) * BK;
+        if constexpr (A_T) load_rc(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
+        else               load_kc(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
+        if constexpr (B_T) load_kc(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
+        else               load_rc(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
+    };
+
+    if (tb < te) gload(tb);
+    for (int tile = tb; tile < te; ++tile) {
+        const int buf = (tile - tb) & 1;
+        float* at = lds + buf * TILE_FLOATS;
+        float* bt = lds + (2 + buf) * TILE_FLOATS;
+        if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
+        if constexpr (B_T) store_kc(bt, rb, t); else store_rc(bt, rb, t);
+        __syncthreads();
+        if (tile + 1 < te) gload(tile + 1);
+
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + l31;
+                if constexpr (A_T) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) a[i][s] = at[(8 * q + 4 * h + s) * LDR + row];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(at + row * LDK + 8 * q + 4 * h);
+                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + l31;
+                if constexpr (B_T) {
+                    const float4 v = *reinterpret_cast<const float4*>(bt + row * LDK + 8 * q + 4 * h);
+                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b[j][s] = bt[(8 * q + 4 * h + s) * LDR + row];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- write back: C/D map of the 32x32 MFMA: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+    float* cbase = g.c;
+    int64_t ldc = g.ldc;
+    const bool raw = g.split_k > 1;
+    if (raw) { cbase = g.c + (int64_t)z * g.ws_stride; ldc = g.n; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            if (col >= g.n) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t row = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (row >= g.m) continue;
+                float v = acc[i][j][q];
+                float* p = cbase + row * ldc + col;
+                if (!raw && epi.flags) {
+                    const float prev = (epi.flags & PLNLP_EPI_ACCUM) ? *p : 0.f;
+                    v = epi_apply(epi, v, row, col, g.n, prev);
+                }
+                *p = v;
+            }
+        }
+    }
+}
+
+// sum split-K slices in slice order, apply the epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split_k,
+                                                            int64_t stride, float* __restrict__ c, int64_t ldc,
+                                                            int64_t m, int n, Epi epi) {
+    const int64_t total = m * (int64_t)n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int zz = 0; zz < split_k; ++zz) v += ws[(int64_t)zz * stride + i];
+        const int64_t row = i / n;
+        const int col = (int)(i - row * n);
+        float* p = c + row * ldc + col;
+        if (epi.flags) {
+            const float prev = (epi.flags & PLNLP_EPI_ACCUM) ? *p : 0.f;
+            v = epi_apply(epi, v, row, col, n, prev);
+        }
+        *p = v;
+    }
+}
+
+}  // namespace plnlp
+
+extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c,
+                              int64_t ldc, int64_t m, int64_t n, const plnlp_epilogue* epi, int split_k,
+                              float* workspace, int64_t workspace_floats, void* stream) {
+    using namespace plnlp;
+    if (!segs || !c) return PLNLP_E_NULL;
+    if (n_seg < 1 || n_seg > 2 || m < 0 || n < 0 || ldc < n || n > 0x7FFFFFF0) return PLNLP_E_SHAPE;
+    if (m == 0 || n == 0) return 0;
+    if (split_k < 1) split_k = 1;
+    GemmArgs g{};
+    g.nseg = n_seg;
+    int tiles[2] = {0, 0};
+    for (int s = 0; s < n_seg; ++s) {
+        const plnlp_gemm_operand& o = segs[s];
+        if (!o.a || !o.b) return PLNLP_E_NULL;
+        if (o.k <= 0 || o.k > 0x7FFFFF00) return PLNLP_E_SHAPE;
+        const int64_t a_inner = a_trans ? m : o.k, b_inner = b_trans ? o.k : n;
+        if (o.lda < a_inner || o.ldb < b_inner) return PLNLP_E_SHAPE;
+        Seg& d = g.seg[s];
+        d.a = o.a; d.lda = o.lda; d.b = o.b; d.ldb = o.ldb; d.k = (int)o.k;
+        d.a_vec = ((uintptr_t)o.a % 16 == 0) && (o.lda % 4 == 0);
+        d.b_vec = ((uintptr_t)o.b % 16 == 0) && (o.ldb % 4 == 0);
+        tiles[s] = (int)((o.k + BK - 1) / BK);
+    }
+    g.tiles0 = tiles[0];
+    g.tiles_total = tiles[0] + tiles[1];
+    if (split_k > g.tiles_total) split_k = g.tiles_total;
+    g.m = m; g.n = (int)n; g.split_k = split_k; g.ws_stride = m * n;
+    Epi e;
+    if (int rc = make_epi(epi, &e)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t gm = (m + BM - 1) / BM, gn = (n + BN - 1) / BN;
+    if (gm > 0x7FFFFFFF || gn > 65535 || split_k > 65535) return PLNLP_E_SHAPE;
+    if (split_k > 1) {
+        if (!workspace) return PLNLP_E_NULL;
+        if (workspace_floats < (int64_t)split_k * m * n) return PLNLP_E_WORKSPACE;
+        g.c = workspace; g.ldc = n;
+    } else {
+        g.c = c; g.ldc = ldc;
+    }
+    dim3 grid((unsigned)gm, (unsigned)gn, (unsigned)split_k);
+#define PLNLP_GEMM(AT, BT) hipLaunchKernelGGL((gemm_f32_kernel<AT, BT>), grid, dim3(256), 0, s, g, e)
+    if (a_trans) { if (b_trans) PLNLP_GEMM(true, true); else PLNLP_GEMM(true, false); }
+    else         { if (b_trans) PLNLP_GEMM(false, true); else PLNLP_GEMM(false, false); }
+#undef PLNLP_GEMM
+    if (int rc = launch_status()) return rc;
+    if (split_k > 1) {
+        const int64_t total = m * n;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, split_k,
+                           g.ws_stride, c, ldc, m, (int)n, e);
+        return launch_status();
+    }
+    return 0;
+}

@@ -1,0 +1,322 @@
+// K5 pairwise loss (forward+backward fused), optimiser step, column sums and the
+// small element-wise helpers.  All reductions are two-stage with a fixed order
+// (block partials, then one block adds the partials in index order) so a step is
+// bit-reproducible; nothing here syncs with the host.
+#include "common.hip.h"
+
+namespace plnlp {
+
+// block-wide sum in a fixed order: wave shuffle tree, then wave 0 adds the 4 wave sums.
+__device__ __forceinline__ float block_sum_256(float v, float* smem4) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) smem4[wave] = v;
+    __syncthreads();
+    float r = smem4[0] + smem4[1] + smem4[2] + smem4[3];
+    __syncthreads();
+    return r;
+}
+
+// ---------------- pairwise loss ---------------------------------------------------
+__device__ __forceinline__ void pair_term(int kind, float d, float w, float& l, float& dl) {
+    // returns loss term l and dl/dd
+    switch (kind) {
+        case PLNLP_LOSS_AUC: { float t = 1.f - d; l = t * t; dl = -2.f * t; } break;
+        case PLNLP_LOSS_HINGE_AUC: { float t = fmaxf(1.f - d, 0.f); l = t * t; dl = -2.f * t; } break;
+        case PLNLP_LOSS_WEIGHTED_AUC: { float t = 1.f - d; l = w * (t * t); dl = -2.f * w * t; } break;
+        case PLNLP_LOSS_ADAPTIVE_AUC: { float t = w - d; l = t * t; dl = -2.f * t; } break;
+        case PLNLP_LOSS_WEIGHTED_HINGE_AUC: { float t = fmaxf(w - d, 0.f); l = w * (t * t); dl = -2.f * w * t; } break;
+        case PLNLP_LOSS_ADAPTIVE_HINGE_AUC: { float t = fmaxf(w - d, 0.f); l = t * t; dl = -2.f * t; } break;
+        default: {  // LOG_RANK: -log(sigmoid(d) + 1e-15)
+            float s = 1.f / (1.f + expf(-d));
+            l = -logf(s + 1e-15f);
+            dl = -(s * (1.f - s)) / (s + 1e-15f);
+        } break;
+    }
+}
+
+__global__ __launch_bounds__(256) void pairwise_loss_kernel(int kind, const float* __restrict__ pos,
+                                                            const float* __restrict__ neg,
+                                                            const float* __restrict__ weight, int64_t batch,
+                                                            int num_neg, float term_scale, float grad_scale,
+                                                            float* __restrict__ gpos, float* __restrict__ gneg,
+                                                            float* __restrict__ partial) {
+    __shared__ float sm[4];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float lsum = 0.f;
+    if (b < batch) {
+        const float p = pos[b];
+        const float w = weight ? weight[b] : 1.f;
+        float gp = 0.f;
+        for (int n = 0; n < num_neg; ++n) {
+            const float q = neg[b * num_neg + n];
+            float l, dl;
+            pair_term(kind, p - q, w, l, dl);
+            lsum += l;
+            gp += dl;
+            gneg[b * num_neg + n] = -dl * term_scale * grad_scale;
+        }
+        gpos[b] = gp * term_scale * grad_scale;
+    }
+    const float tot = block_sum_256(lsum, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot * term_scale;
+}
+
+// one block: out = (accumulate ? out : 0) + sum_i partial[i], fixed order
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int64_t n,
+                                                           float* __restrict__ out, int accumulate) {
+    __shared__ float sm[4];
+    float v = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) v += partial[i];
+    const float tot = block_sum_256(v, sm);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + tot : tot;
+}
+
+// ---------------- sum of squares --------------------------------------------------
+constexpr int64_t SQ_CHUNK = 256 * 4 * 16;  // elements per block
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n,
+                                                     float* __restrict__ partial) {
+    __shared__ float sm[4];
+    const int64_t beg = (int64_t)blockIdx.x * SQ_CHUNK;
+    const int64_t end = beg + SQ_CHUNK < n ? beg + SQ_CHUNK : n;
+    float v = 0.f;
+    if (((uintptr_t)g % 16) == 0) {
+        int64_t i = beg + (int64_t)threadIdx.x * 4;
+        for (; i + 3 < end; i += 1024) {
+            const float4 x = *reinterpret_cast<const float4*>(g + i);
+            v = fmaf(x.x, x.x, v); v = fmaf(x.y, x.y, v); v = fmaf(x.z, x.z, v); v = fmaf(x.w, x.w, v);
+        }
+        for (; i < end; ++i) { if (i < end) v = fmaf(g[i], g[i], v); }
+    } else {
+        for (int64_t i = beg + threadIdx.x; i < end; i += 256) v = fmaf(g[i], g[i], v);
+    }
+    const float tot = block_sum_256(v, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// ---------------- Adam -------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float lr, float b1, float b2, float eps, float wd,
+                                                   int decoupled, float bc1, float bc2_sqrt,
+                                                   const float* __restrict__ sqnorm, float max_norm,
+                                                   float grad_scale) {
+    float coef = grad_scale;
+    if (sqnorm) {
+        const float c = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
+        coef *= c < 1.f ? c : 1.f;
+    }
+    const float step = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] * coef;
+        float pi = p[i];
+        if (wd != 0.f) { if (decoupled) pi *= (1.f - lr * wd); else gi = fmaf(wd, pi, gi); }
+        float mi = m[i], vi = v[i];
+        mi = mi + (1.f - b1) * (gi - mi);            // lerp, as torch.optim.Adam
+        vi = fmaf(1.f - b2, gi * gi, b2 * vi);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+// scale a gradient in place by the clip coefficient (used when the optimiser is not ours)
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, int64_t n,
+                                                         const float* __restrict__ sqnorm, float max_norm) {
+    const float c = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
+    const float coef = c < 1.f ? c : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) g[i] *= coef;
+}
+
+// ---------------- column sums -------------------------------------------------------
+constexpr int CS_ROWS = 256;  // rows per block
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx,
+                                                             int64_t n_rows, int feat,
+                                                             float* __restrict__ partial) {
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
+    const int64_t r1 = r0 + CS_ROWS < n_rows ? r0 + CS_ROWS : n_rows;
+    for (int f = threadIdx.x; f < feat; f += 256) {
+        float acc = 0.f;
+        for (int64_t r = r0; r < r1; ++r) acc += x[r * ldx + f];
+        partial[(int64_t)blockIdx.x * feat + f] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int64_t n_blocks,
+                                                           int feat, float scale, float* __restrict__ out) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= feat) return;
+    float acc = 0.f;
+    for (int64_t b = 0; b < n_blocks; ++b) acc += partial[b * feat + f];
+    out[f] = acc * scale;
+}
+
+// ---------------- element-wise ------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ g, const float* __restrict__ gate,
+                                                   float scale, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = gate[i] > 0.f ? g[i] * scale : 0.f;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      int64_t n, uint32_t thresh, uint32_t seed_lo,
+                                                      uint32_t seed_hi, float keep_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = dropout_keep((uint64_t)i, seed_lo, seed_hi, thresh) ? x[i] * keep_scale : 0.f;
+}
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        float* __restrict__ y, int64_t ldy, int64_t n_rows,
+                                                        int64_t n_cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < n_rows && c0 + tx < n_cols) tile[i][tx] = x[(r0 + i) * ldx + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < n_cols && r0 + tx < n_rows) y[(c0 + i) * ldy + r0 + tx] = tile[tx][i];
+}
+
+static inline unsigned ew_grid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (unsigned)(b < 2048 ? (b > 0 ? b : 1) : 2048);
+}
+
+}  // namespace plnlp
+
+extern "C" int64_t plnlp_loss_workspace_floats(int64_t batch) { return (batch + 255) / 256 + 1; }
+
+extern "C" int plnlp_pairwise_loss_f32(int kind, const float* pos, const float* neg, const float* weight,
+                                       int64_t batch, int64_t num_neg, float grad_scale, float* loss,
+                                       float* gpos, float* gneg, float* workspace, int64_t workspace_floats,
+                                       void* stream) {
+    using namespace plnlp;
+    if (!pos || !neg || !loss || !gpos || !gneg || !workspace) return PLNLP_E_NULL;
+    if (batch <= 0 || num_neg <= 0 || num_neg > 1 << 20) return PLNLP_E_SHAPE;
+    if (kind < PLNLP_LOSS_AUC || kind > PLNLP_LOSS_LOG_RANK) return PLNLP_E_UNSUPPORTED;
+    const bool needs_w = kind == PLNLP_LOSS_WEIGHTED_AUC || kind == PLNLP_LOSS_ADAPTIVE_AUC ||
+                         kind == PLNLP_LOSS_WEIGHTED_HINGE_AUC || kind == PLNLP_LOSS_ADAPTIVE_HINGE_AUC;
+    if (needs_w && !weight) return PLNLP_E_NULL;
+    const int64_t blocks = (batch + 255) / 256;
+    if (workspace_floats < blocks) return PLNLP_E_WORKSPACE;
+    const float term_scale = kind == PLNLP_LOSS_LOG_RANK ? 1.f / (float)(batch * num_neg) : 1.f;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pairwise_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, s, kind, pos, neg,
+                       needs_w ? weight : nullptr, batch, (int)num_neg, term_scale, grad_scale, gpos, gneg,
+                       workspace);
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, workspace, blocks, loss, 0);
+    return launch_status();
+}
+
+extern "C" int64_t plnlp_sqnorm_partials(int64_t n) { return n <= 0 ? 0 : (n + plnlp::SQ_CHUNK - 1) / plnlp::SQ_CHUNK; }
+
+extern "C" int plnlp_sqnorm_f32(const float* g, int64_t n, float* partial, int64_t n_partial, void* stream) {
+    using namespace plnlp;
+    if (n < 0) return PLNLP_E_SHAPE;
+    if (n == 0) return 0;
+    if (!g || !partial) return PLNLP_E_NULL;
+    const int64_t blocks = plnlp_sqnorm_partials(n);
+    if (n_partial < blocks) return PLNLP_E_WORKSPACE;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, partial);
+    return launch_status();
+}
+
+extern "C" int plnlp_sum_partials_f32(const float* partial, int64_t n, float* out, int accumulate, void* stream) {
+    using namespace plnlp;
+    if (!out || (n > 0 && !partial)) return PLNLP_E_NULL;
+    if (n < 0) return PLNLP_E_SHAPE;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, out, accumulate);
+    return launch_status();
+}
+
+extern "C" int plnlp_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   float lr, float beta1, float beta2, float eps, float weight_decay,
+                                   int decoupled_wd, int64_t step, const float* sqnorm, float max_norm,
+                                   float grad_scale, void* stream) {
+    using namespace plnlp;
+    if (n < 0 || step < 1) return PLNLP_E_SHAPE;
+    if (n == 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return PLNLP_E_NULL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, (float)bc1,
+                       (float)sqrt(bc2), sqnorm, max_norm, grad_scale);
+    return launch_status();
+}
+
+extern "C" int plnlp_clip_scale_f32(float* grad, int64_t n, const float* sqnorm, float max_norm, void* stream) {
+    using namespace plnlp;
+    if (n < 0) return PLNLP_E_SHAPE;
+    if (n == 0) return 0;
+    if (!grad || !sqnorm) return PLNLP_E_NULL;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, grad, n, sqnorm,
+                       max_norm);
+    return launch_status();
+}
+
+extern "C" int64_t plnlp_colsum_workspace_floats(int64_t n_rows, int64_t feat) {
+    return ((n_rows + plnlp::CS_ROWS - 1) / plnlp::CS_ROWS) * feat;
+}
+
+extern "C" int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t feat, float scale, float* out,
+                                float* workspace, int64_t workspace_floats, void* stream) {
+    using namespace plnlp;
+    if (!x || !out || !workspace) return PLNLP_E_NULL;
+    if (n_rows <= 0 || feat <= 0 || ldx < feat || feat > (1 << 24)) return PLNLP_E_SHAPE;
+    const int64_t blocks = (n_rows + CS_ROWS - 1) / CS_ROWS;
+    if (workspace_floats < blocks * feat) return PLNLP_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, n_rows, (int)feat,
+                       workspace);
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((feat + 255) / 256)), dim3(256), 0, s, workspace, blocks,
+                       (int)feat, scale, out);
+    return launch_status();
+}
+
+extern "C" int plnlp_gate_f32(const float* g, const float* gate, float scale, float* y, int64_t n, void* stream) {
+    using namespace plnlp;
+    if (n < 0) return PLNLP_E_SHAPE;
+    if (n == 0) return 0;
+    if (!g || !gate || !y) return PLNLP_E_NULL;
+    hipLaunchKernelGGL(gate_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, g, gate, scale, y, n);
+    return launch_status();
+}
+
+extern "C" int plnlp_dropout_f32(const float* x, float* y, int64_t n_rows, int64_t n_cols, float p, uint64_t seed,
+                                 void* stream) {
+    using namespace plnlp;
+    if (n_rows < 0 || n_cols < 0 || !(p >= 0.f) || p >= 1.f) return PLNLP_E_SHAPE;
+    const int64_t n = n_rows * n_cols;
+    if (n == 0) return 0;
+    if (!x || !y) return PLNLP_E_NULL;
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n,
+                       dropout_thresh(p), (uint32_t)seed, (uint32_t)(seed >> 32), 1.f / (1.f - p));
+    return launch_status();
+}
+
+extern "C" int plnlp_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows,
+                                   int64_t n_cols, void* stream) {
+    using namespace plnlp;
+    if (n_rows < 0 || n_cols < 0 || ldx < n_cols || ldy < n_rows) return PLNLP_E_SHAPE;
+    if (n_rows == 0 || n_cols == 0) return 0;
+    if (!x || !y) return PLNLP_E_NULL;
+    dim3 grid((unsigned)((n_cols + 31) / 32), (unsigned)((n_rows + 31) / 32));
+    if (grid.y > 65535) return PLNLP_E_SHAPE;
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, n_rows, n_cols);
+    return launch_status();
+}
+
+extern "C" int plnlp_abi_version(void) { return PLNLP_ABI_VERSION; }
+
+extern "C" const char* plnlp_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case PLNLP_E_NULL: return "plnlp: required pointer is NULL";
+        case PLNLP_E_SHAPE: return "plnlp: invalid or inconsistent size";
+        case PLNLP_E_ALIGN: return "plnlp: misaligned pointer or leading dimension";
+        case PLNLP_E_UNSUPPORTED: return "plnlp: unsupported flag or size";
+        case PLNLP_E_WORKSPACE: return "plnlp: workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "plnlp: unknown error";
+    }
+}

@@ -1,0 +1,174 @@
+"""Graph -- the adjacency object of the MI355X path.
+
+It stands where `torch_sparse.SparseTensor` stands in the reference
+(`data.adj_t`: main.py:81-83,110,124,136,186; utils.py:83-97) and exposes the
+members those call sites touch (`coo`, `size`, `sum(dim=1)`, `set_diag`,
+`set_value`, `to_symmetric`, `to`, `t`).  Layout in HBM, fixed for the whole
+run (the graph is static across training steps):
+
+    rowptr  int64 [n_rows+1]      row i lists the SOURCES j of messages into i
+    col     int32 [nnz]           sorted by (row, col); duplicates kept
+    val     fp32  [nnz] | None
+
+plus, built once on first use, the transposed CSR (`t()`), which the backward
+pass of the aggregation kernel walks -- so backward is a gather too and needs
+no atomics -- and `inv_deg = 1/max(rowlen,1)`.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+
+class Graph:
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor],
+                 n_rows: int, n_cols: int):
+        assert rowptr.dtype == torch.int64 and col.dtype == torch.int32
+        assert rowptr.numel() == n_rows + 1
+        self.rowptr, self.col, self.val = rowptr.contiguous(), col.contiguous(), val
+        if val is not None:
+            assert val.dtype == torch.float32 and val.numel() == col.numel()
+            self.val = val.contiguous()
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self._t: Optional["Graph"] = None
+        self._inv_deg: Optional[torch.Tensor] = None
+
+    # ---- construction ---------------------------------------------------------
+    @classmethod
+    def from_coo(cls, row: torch.Tensor, col: torch.Tensor, value: Optional[torch.Tensor] = None,
+                 num_rows: Optional[int] = None, num_cols: Optional[int] = None) -> "Graph":
+        """SparseTensor(row=, col=, value=): entries ordered by (row, col)."""
+        row, col = row.to(torch.int64), col.to(torch.int64)
+        n_rows = int(row.max()) + 1 if num_rows is None else int(num_rows)
+        n_cols = n_rows if num_cols is None else int(num_cols)
+        if col.numel() and int(col.max()) >= 2 ** 31:
+            raise ValueError("column ids must fit int32")
+        order = torch.argsort(row * n_cols + col, stable=True)
+        row, col = row[order], col[order]
+        val = None if value is None else value[order].to(torch.float32)
+        rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=row.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(row, minlength=n_rows), 0)
+        return cls(rowptr, col.to(torch.int32), val, n_rows, n_cols)
+
+    @classmethod
+    def from_edge_index(cls, edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor] = None,
+                        num_nodes: Optional[int] = None) -> "Graph":
+        """T.ToSparseTensor() (main.py:81): adj_t = transposed adjacency, i.e. row =
+        edge_index[1] (target), col = edge_index[0] (source)."""
+        n = int(edge_index.max()) + 1 if num_nodes is None else int(num_nodes)
+        return cls.from_coo(edge_index[1], edge_index[0], edge_weight, n, n)
+
+    # ---- SparseTensor-like surface -----------------------------------------------
+    @property
+    def nnz(self) -> int:
+        return self.col.numel()
+
+    @property
+    def device(self):
+        return self.col.device
+
+    def size(self, dim: int) -> int:
+        return (self.n_rows, self.n_cols)[dim]
+
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self.n_rows, self.n_cols
+
+    def row_index(self) -> torch.Tensor:
+        deg = self.rowptr[1:] - self.rowptr[:-1]
+        return torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), deg)
+
+    def coo(self):
+        return self.row_index(), self.col.to(torch.int64), self.val
+
+    def degree(self) -> torch.Tensor:
+        return self.rowptr[1:] - self.rowptr[:-1]
+
+    def inv_degree(self) -> torch.Tensor:
+        """1 / max(rowlen, 1), fp32 -- the per-row factor of `mean` aggregation."""
+        if self._inv_deg is None:
+            self._inv_deg = 1.0 / self.degree().clamp(min=1).to(torch.float32)
+        return self._inv_deg
+
+    def sum(self, dim: int = 1) -> torch.Tensor:
+        """adj_t.sum(dim=1) (main.py:146, utils.py:85,93)."""
+        assert dim == 1
+        if self.val is None:
+            return self.degree().to(torch.float32)
+        out = torch.zeros(self.n_rows, dtype=torch.float32, device=self.device)
+        return out.index_add_(0, self.row_index(), self.val)
+
+    def set_value(self, value: Optional[torch.Tensor]) -> "Graph":
+        g = Graph(self.rowptr, self.col, value, self.n_rows, self.n_cols)
+        return g
+
+    def set_diag(self) -> "Graph":
+        """diagonal := 1 (existing diagonal entries replaced) -- utils.py:84."""
+        r, c, v = self.coo()
+        v = torch.ones(c.numel(), device=self.device) if v is None else v
+        off = r != c
+        n = min(self.n_rows, self.n_cols)
+        ar = torch.arange(n, device=self.device)
+        return Graph.from_coo(torch.cat([r[off], ar]), torch.cat([c[off], ar]),
+                              torch.cat([v[off], torch.ones(n, device=self.device)]),
+                              self.n_rows, self.n_cols)
+
+    def scale(self, row_scale: Optional[torch.Tensor], col_scale: Optional[torch.Tensor]) -> "Graph":
+        """dense[N,1] * adj_t * dense[1,N] (utils.py:88,96)."""
+        r, c, v = self.coo()
+        v = torch.ones(c.numel(), device=self.device) if v is None else v
+        if row_scale is not None:
+            v = row_scale[r] * v
+        if col_scale is not None:
+            v = v * col_scale[c]
+        return Graph(self.rowptr, self.col, v.to(torch.float32), self.n_rows, self.n_cols)
+
+    def to_symmetric(self) -> "Graph":
+        """[3P] SparseTensor.to_symmetric (main.py:110): union of A and A^T,
+        duplicates summed when valued."""
+        r, c, v = self.coo()
+        rr, cc = torch.cat([r, c]), torch.cat([c, r])
+        n = max(self.n_rows, self.n_cols)
+        key = rr * n + cc
+        uniq, inverse = torch.unique(key, return_inverse=True)
+        val = None
+        if v is not None:
+            val = torch.zeros(uniq.numel(), device=self.device).index_add_(0, inverse, torch.cat([v, v]))
+        return Graph.from_coo(uniq // n, uniq % n, val, n, n)
+
+    def to(self, device) -> "Graph":
+        g = Graph(self.rowptr.to(device), self.col.to(device),
+                  None if self.val is None else self.val.to(device), self.n_rows, self.n_cols)
+        return g
+
+    def cuda(self):
+        return self.to("cuda")
+
+    # ---- transposed view (backward pass) --------------------------------------------
+    def t(self) -> "Graph":
+        if self._t is None:
+            r, c, v = self.coo()
+            self._t = Graph.from_coo(c, r, v, self.n_cols, self.n_rows)
+            self._t._t = self
+        return self._t
+
+    def __repr__(self):
+        return (f"Graph(n_rows={self.n_rows}, n_cols={self.n_cols}, nnz={self.nnz}, "
+                f"valued={self.val is not None}, device={self.device})")
+
+
+def gcn_normalization(adj_t: Graph) -> Graph:
+    """plnlp/utils.py:83-89: D^-1/2 (A with diag := 1) D^-1/2, inf -> 0."""
+    a = adj_t.set_diag()
+    deg = a.sum(dim=1).to(torch.float)
+    dis = deg.pow(-0.5)
+    dis[dis == float("inf")] = 0
+    return a.scale(dis, dis)
+
+
+def adj_normalization(adj_t: Graph) -> Graph:
+    """plnlp/utils.py:92-97: D^-1 A."""
+    deg = adj_t.sum(dim=1).to(torch.float)
+    inv = deg.pow(-1)
+    inv[inv == float("inf")] = 0
+    return adj_t.scale(inv, None)

@@ -1,0 +1,269 @@
+"""Encoders and edge predictors with the surface of the reference's
+plnlp/layer.py (same class names, constructor arguments, `forward` arguments,
+`reset_parameters`, attribute and state_dict names) over the HIP kernels.
+
+What differs from the reference is only *where* work happens:
+  * a conv and the relu/dropout that BaseGNN applies after it are one fused call
+    (GEMM / aggregation epilogues) -- `BaseGNN.forward` hands the activation to
+    the conv instead of running separate element-wise passes;
+  * predictors additionally expose `score_edges(h, src, dst)`, which fuses the
+    endpoint gathers of plnlp/model.py:155-156 into the scoring kernel; the
+    reference-style `forward(x_i, x_j)` is kept for callers that gather first.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .graph import Graph
+from .ops import _Act
+
+
+def _require_graph(adj_t) -> Graph:
+    if not isinstance(adj_t, Graph):
+        raise TypeError("adj_t must be a plnlp_amd.Graph (the MI355X stand-in for torch_sparse.SparseTensor); "
+                        f"got {type(adj_t).__name__}")
+    return adj_t
+
+
+# ------------------------------------------------------------------ convs ------
+class SAGEConv(torch.nn.Module):
+    """PyG 2.0.1 SAGEConv(in, out) defaults as used at layer.py:36: mean
+    aggregation (edge values ignored), root weight, bias on lin_l only.
+    Parameters: lin_l.weight, lin_l.bias, lin_r.weight."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = torch.nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = torch.nn.Linear(in_channels, out_channels, bias=False)
+
+    def reset_parameters(self):
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
+
+    def forward(self, x, adj_t, act: _Act = None):
+        act = act if act is not None else _Act(False, 0.0, False)
+        return ops.SAGEConvFn.apply(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight,
+                                    _require_graph(adj_t), act)
+
+
+class GCNConv(torch.nn.Module):
+    """PyG 2.0.1 GCNConv(in, out, normalize=False) as used at layer.py:45:
+    glorot `lin` without bias, then aggregation with the stored (pre-normalised,
+    main.py:177-179) edge values, then `bias` (zeros at reset)."""
+
+    def __init__(self, in_channels: int, out_channels: int, normalize: bool = False):
+        super().__init__()
+        if normalize:
+            raise NotImplementedError("the reference always passes normalize=False (layer.py:45)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.bias = torch.nn.Parameter(torch.zeros(out_channels))
+        self.lin = torch.nn.Linear(in_channels, out_channels, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        torch.nn.init.xavier_uniform_(self.lin.weight)
+        torch.nn.init.zeros_(self.bias)
+
+    def forward(self, x, adj_t, act: _Act = None):
+        act = act if act is not None else _Act(False, 0.0, False)
+        return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act)
+
+
+# --------------------------------------------------------------- encoders ------
+class BaseGNN(torch.nn.Module):
+    """layer.py:7-27.  relu+dropout follow every conv but the last; a 1-layer
+    encoder gets them after its only conv too (layer.py:24-26)."""
+
+    def __init__(self, dropout, num_layers):
+        super().__init__()
+        self.convs = torch.nn.ModuleList()
+        self.dropout = dropout
+        self.num_layers = num_layers
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+
+    def forward(self, x, adj_t):
+        last = len(self.convs) - 1
+        for i, conv in enumerate(self.convs):
+            activated = i < last or self.num_layers == 1
+            if isinstance(conv, (SAGEConv, GCNConv)):
+                x = conv(x, adj_t, _Act(True, self.dropout, self.training) if activated else None)
+            else:  # foreign conv module: un-fused reference order
+                x = conv(x, adj_t)
+                if activated:
+                    x = F.dropout(F.relu(x), p=self.dropout, training=self.training)
+        return x
+
+
+def _stack(conv_cls, in_channels, hidden_channels, out_channels, num_layers):
+    widths = [in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels]
+    return [conv_cls(widths[i], widths[i + 1]) for i in range(num_layers)]
+
+
+class SAGE(BaseGNN):
+    """layer.py:30-36"""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout):
+        super().__init__(dropout, num_layers)
+        self.convs.extend(_stack(SAGEConv, in_channels, hidden_channels, out_channels, num_layers))
+
+
+class GCN(BaseGNN):
+    """layer.py:39-45"""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout):
+        super().__init__(dropout, num_layers)
+        self.convs.extend(_stack(GCNConv, in_channels, hidden_channels, out_channels, num_layers))
+
+
+class _OutOfScopeEncoder(BaseGNN):
+    _what = ""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout):
+        raise NotImplementedError(
+            f"{type(self).__name__} ({self._what}) is outside the hot path this package accelerates "
+            "(SURVEY.md 2.1 #1: no README recipe uses it); use SAGE or GCN")
+
+
+class WSAGE(_OutOfScopeEncoder):
+    """layer.py:48-54 (GraphConv) -- constructible name only."""
+    _what = "PyG GraphConv"
+
+
+class Transformer(_OutOfScopeEncoder):
+    """layer.py:57-63 (TransformerConv) -- constructible name only."""
+    _what = "PyG TransformerConv"
+
+
+# -------------------------------------------------------------- predictors ------
+def _mlp(lins, x, dropout, training):
+    """Linear -> relu -> dropout ... -> Linear, every Linear on the MFMA GEMM with
+    the activation fused into its epilogue (layer.py:82-86)."""
+    last = len(lins) - 1
+    for i, lin in enumerate(lins):
+        act = _Act(True, dropout, training) if i < last else _Act(False, 0.0, False)
+        x = ops.LinearFn.apply(x, lin.weight, lin.bias, act)
+    return x
+
+
+def _hidden_stack(lins, x, dropout, training):
+    """every Linear followed by relu+dropout (MLPDot/MLPBil towers, layer.py:130-136)."""
+    for lin in lins:
+        x = ops.LinearFn.apply(x, lin.weight, lin.bias, _Act(True, dropout, training))
+    return x
+
+
+def _linear_list(widths):
+    return torch.nn.ModuleList(torch.nn.Linear(widths[i], widths[i + 1]) for i in range(len(widths) - 1))
+
+
+class _LinsPredictor(torch.nn.Module):
+    def reset_parameters(self):
+        for lin in self.lins:
+            lin.reset_parameters()
+
+    def score_edges(self, h, src, dst):
+        """gather-first fallback for the predictors that have no fused kernel"""
+        return self.forward(h[src], h[dst])
+
+
+class MLPPredictor(_LinsPredictor):
+    """layer.py:66-87: Hadamard product of the endpoint rows, then an MLP -> [E, out]."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout):
+        super().__init__()
+        self.lins = _linear_list([in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels])
+        self.dropout = dropout
+
+    def forward(self, x_i, x_j):
+        return _mlp(self.lins, x_i * x_j, self.dropout, self.training)
+
+    def score_edges(self, h, src, dst):
+        return _mlp(self.lins, ops.EdgeHadamardFn.apply(h, src, dst), self.dropout, self.training)
+
+
+class MLPCatPredictor(_LinsPredictor):
+    """layer.py:90-116: symmetrised MLP over [x_i|x_j] and [x_j|x_i]."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout):
+        super().__init__()
+        self.lins = _linear_list([2 * in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels])
+        self.dropout = dropout
+
+    def forward(self, x_i, x_j):
+        a = _mlp(self.lins, torch.cat([x_i, x_j], dim=-1), self.dropout, self.training)
+        b = _mlp(self.lins, torch.cat([x_j, x_i], dim=-1), self.dropout, self.training)
+        return (a + b) / 2
+
+
+class MLPDotPredictor(_LinsPredictor):
+    """layer.py:119-139: shared tower on both endpoints, then dot."""
+
+    def __init__(self, in_channels, hidden_channels, num_layers, dropout):
+        super().__init__()
+        self.lins = _linear_list([in_channels] + [hidden_channels] * num_layers)
+        self.dropout = dropout
+
+    def forward(self, x_i, x_j):
+        x_i = _hidden_stack(self.lins, x_i, self.dropout, self.training)
+        x_j = _hidden_stack(self.lins, x_j, self.dropout, self.training)
+        return torch.sum(x_i * x_j, dim=-1)
+
+
+class MLPBilPredictor(_LinsPredictor):
+    """layer.py:142-164: shared tower, then bilinear form."""
+
+    def __init__(self, in_channels, hidden_channels, num_layers, dropout):
+        super().__init__()
+        self.lins = _linear_list([in_channels] + [hidden_channels] * num_layers)
+        self.bilin = torch.nn.Linear(hidden_channels, hidden_channels, bias=False)
+        self.dropout = dropout
+
+    def reset_parameters(self):
+        super().reset_parameters()
+        self.bilin.reset_parameters()
+
+    def forward(self, x_i, x_j):
+        x_i = _hidden_stack(self.lins, x_i, self.dropout, self.training)
+        x_j = _hidden_stack(self.lins, x_j, self.dropout, self.training)
+        bx = ops.LinearFn.apply(x_i, self.bilin.weight, None, _Act(False, 0.0, False))
+        return torch.sum(bx * x_j, dim=-1)
+
+
+class DotPredictor(torch.nn.Module):
+    """layer.py:167-176: <x_i, x_j> -> [E]; no parameters."""
+
+    def __init__(self):
+        super().__init__()
+
+    def reset_parameters(self):
+        return
+
+    def forward(self, x_i, x_j):
+        return torch.sum(x_i * x_j, dim=-1)
+
+    def score_edges(self, h, src, dst):
+        return ops.EdgeDotFn.apply(h, src, dst)
+
+
+class BilinearPredictor(torch.nn.Module):
+    """layer.py:179-189"""
+
+    def __init__(self, hidden_channels):
+        super().__init__()
+        self.bilin = torch.nn.Linear(hidden_channels, hidden_channels, bias=False)
+
+    def reset_parameters(self):
+        self.bilin.reset_parameters()
+
+    def forward(self, x_i, x_j):
+        bx = ops.LinearFn.apply(x_i, self.bilin.weight, None, _Act(False, 0.0, False))
+        return torch.sum(bx * x_j, dim=-1)
+
+    def score_edges(self, h, src, dst):
+        return self.forward(h[src], h[dst])

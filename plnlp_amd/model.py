@@ -1,0 +1,298 @@
+"""Trainer and factories -- the caller side of the hot path, with the surface of
+the reference's plnlp/model.py (BaseModel, create_input_layer,
+create_gnn_layer, create_predictor_layer, adjust_lr) so a main.py-style driver
+swaps this package in.
+
+What this BaseModel does differently from the reference's, at equal results:
+  * positives and negatives of a step are scored by ONE fused gather+score call
+    (one backward scatter), not two predictor calls;
+  * the batch permutation and the epoch's edge tensors live on the device for
+    the whole epoch; the per-step `loss.item()` host sync (model.py:170) is
+    replaced by a device accumulator read once per epoch;
+  * clipping (per group, model.py:163-165) + Adam run as fused HIP kernels;
+  * optional edge-batch data parallelism: one process per GPU, every rank holds a
+    replica, takes its slice of each step's batch, and gradients are SUM-reduced
+    over RCCL before clipping (the loss is a sum over pairs, so the reduced
+    gradient equals the single-GPU gradient of the whole batch).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import loss as loss_mod
+from .layer import (GCN, SAGE, WSAGE, BilinearPredictor, DotPredictor, MLPBilPredictor, MLPCatPredictor,
+                    MLPDotPredictor, MLPPredictor, Transformer)
+from .optim import FusedAdam, group_sqnorm
+from .utils import batch_permutation, evaluate_hits, evaluate_mrr, get_pos_neg_edges
+
+
+class BaseModel(object):
+    """plnlp/model.py:9-226.  Constructor arguments as the reference; keyword-only
+    extras: `modules=(encoder, predictor)` to inject pre-built modules,
+    `process_group` / `dp_scaling` for data parallelism."""
+
+    def __init__(self, lr, dropout, grad_clip_norm, gnn_num_layers, mlp_num_layers, emb_hidden_channels,
+                 gnn_hidden_channels, mlp_hidden_channels, num_nodes, num_node_feats, gnn_encoder_name,
+                 predictor_name, loss_func, optimizer_name, device, use_node_feats, train_node_emb,
+                 pretrain_emb=None, *, modules=None, process_group=None, dp_scaling="weak"):
+        self.loss_func_name = loss_func
+        self.num_nodes = num_nodes
+        self.num_node_feats = num_node_feats
+        self.use_node_feats = use_node_feats
+        self.train_node_emb = train_node_emb
+        self.clip_norm = grad_clip_norm
+        self.device = torch.device(device)
+        self.process_group = process_group
+        self.dp_scaling = dp_scaling
+
+        self.input_channels, self.emb = create_input_layer(
+            num_nodes=num_nodes, num_node_feats=num_node_feats, hidden_channels=emb_hidden_channels,
+            use_node_feats=use_node_feats, train_node_emb=train_node_emb, pretrain_emb=pretrain_emb)
+        if self.emb is not None:
+            self.emb = self.emb.to(self.device)
+
+        if modules is not None:
+            self.encoder, self.predictor = modules[0].to(self.device), modules[1].to(self.device)
+        else:
+            self.encoder = create_gnn_layer(input_channels=self.input_channels,
+                                            hidden_channels=gnn_hidden_channels, num_layers=gnn_num_layers,
+                                            dropout=dropout, encoder_name=gnn_encoder_name).to(self.device)
+            self.predictor = create_predictor_layer(hidden_channels=mlp_hidden_channels,
+                                                    num_layers=mlp_num_layers, dropout=dropout,
+                                                    predictor_name=predictor_name).to(self.device)
+
+        self.para_list = list(self.encoder.parameters()) + list(self.predictor.parameters())
+        if self.emb is not None:
+            self.para_list += list(self.emb.parameters())
+
+        self._fused_step = self.device.type == "cuda" and optimizer_name != 'SGD'
+        if self._fused_step:
+            self.optimizer = FusedAdam(self.para_list, lr=lr, decoupled=(optimizer_name == 'AdamW'),
+                                       weight_decay=0.01 if optimizer_name == 'AdamW' else 0.0)
+        elif optimizer_name == 'AdamW':
+            self.optimizer = torch.optim.AdamW(self.para_list, lr=lr)
+        elif optimizer_name == 'SGD':
+            self.optimizer = torch.optim.SGD(self.para_list, lr=lr, momentum=0.9, weight_decay=1e-5,
+                                             nesterov=True)
+        else:
+            self.optimizer = torch.optim.Adam(self.para_list, lr=lr)
+
+    # ------------------------------------------------------------------ setup ---
+    def param_init(self):
+        """model.py:92-96"""
+        self.encoder.reset_parameters()
+        self.predictor.reset_parameters()
+        if self.emb is not None:
+            torch.nn.init.xavier_uniform_(self.emb.weight)
+        if self.process_group is not None:       # replicas must start identical
+            for p in self.para_list:
+                torch.distributed.broadcast(p.data, 0, group=self.process_group)
+
+    def create_input_feat(self, data):
+        """model.py:98-105"""
+        if not self.use_node_feats:
+            return self.emb.weight
+        feat = data.x.to(self.device)
+        if self.train_node_emb:
+            feat = torch.cat([self.emb.weight, feat], dim=-1)
+        return feat
+
+    def calculate_loss(self, pos_out, neg_out, num_neg, margin=None):
+        """model.py:107-126: names that need a per-edge weight silently become
+        plain auc_loss when the split has none; unknown names are auc_loss too."""
+        fn, weighted = loss_mod.BY_NAME.get(self.loss_func_name, (loss_mod.auc_loss, False))
+        if self.loss_func_name == 'CE':
+            return fn(pos_out, neg_out)
+        if weighted:
+            if margin is None:
+                return loss_mod.auc_loss(pos_out, neg_out, num_neg)
+            return fn(pos_out, neg_out, num_neg, margin)
+        return fn(pos_out, neg_out, num_neg)
+
+    # ------------------------------------------------------------- DP helpers ---
+    def _world(self):
+        if self.process_group is None:
+            return 0, 1
+        return (torch.distributed.get_rank(self.process_group),
+                torch.distributed.get_world_size(self.process_group))
+
+    def _allreduce_grads(self):
+        """SUM over ranks, issued before clipping so clipping sees the global gradient."""
+        if self.process_group is None:
+            return
+        works = []
+        for p in self.para_list:
+            if p.grad is None:      # a rank whose slice was empty contributes zeros
+                p.grad = torch.zeros_like(p)
+            works.append(torch.distributed.all_reduce(p.grad, group=self.process_group, async_op=True))
+        for w in works:
+            w.wait()
+
+    def _clip_and_step(self):
+        """model.py:163-167: encoder and predictor clipped as separate groups, the
+        embedding not at all; then the optimiser."""
+        if self._fused_step:
+            clip = {}
+            if self.clip_norm >= 0:
+                for group in (list(self.encoder.parameters()), list(self.predictor.parameters())):
+                    sq = group_sqnorm(group)
+                    if sq is not None:
+                        clip.update({id(p): (sq, float(self.clip_norm)) for p in group})
+            self.optimizer.step(clip=clip)
+            return
+        if self.clip_norm >= 0:
+            for module in (self.encoder, self.predictor):
+                params = [p for p in module.parameters()]
+                if params:
+                    torch.nn.utils.clip_grad_norm_(params, self.clip_norm)
+        self.optimizer.step()
+
+    def _score(self, h, src, dst):
+        if hasattr(self.predictor, "score_edges"):
+            return self.predictor.score_edges(h, src, dst)
+        return self.predictor(h[src], h[dst])
+
+    def train_step(self, data, pos_edge, neg_edge, num_neg, weight_margin=None):
+        """One iteration of the hot loop, model.py:148-167, on this rank's slice:
+        pos_edge [b,2], neg_edge [b,k,2] (device).  Returns the detached local loss."""
+        self.optimizer.zero_grad(set_to_none=True)
+        h = self.encoder(self.create_input_feat(data), data.adj_t)
+        local = pos_edge.size(0)
+        if local > 0:
+            neg_flat = neg_edge.reshape(-1, 2)
+            src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
+            dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
+            out = self._score(h, src, dst)
+            loss = self.calculate_loss(out[:local], out[local:], num_neg, margin=weight_margin)
+        else:                                    # empty slice: still take part in the reduction
+            loss = h.sum() * 0.0
+        loss.backward()
+        self._allreduce_grads()
+        self._clip_and_step()
+        return loss.detach().reshape(())
+
+    # ------------------------------------------------------------------ train ---
+    def train(self, data, split_edge, batch_size, neg_sampler_name, num_neg):
+        """model.py:128-173: one epoch; returns sum(loss_b * B_b) / sum(B_b).
+
+        With a process group, `batch_size` is the per-rank batch when
+        dp_scaling == 'weak' (global batch = world * batch_size) and the global
+        batch when 'strong'; either way each global batch is cut into `world`
+        contiguous slices."""
+        self.encoder.train()
+        self.predictor.train()
+        rank, world = self._world()
+
+        pos_train_edge, neg_train_edge = get_pos_neg_edges(
+            'train', split_edge, edge_index=data.edge_index, num_nodes=self.num_nodes,
+            neg_sampler_name=neg_sampler_name, num_neg=num_neg)
+        pos_train_edge, neg_train_edge = pos_train_edge.to(self.device), neg_train_edge.to(self.device)
+        edge_weight_margin = None
+        if 'weight' in split_edge['train']:
+            edge_weight_margin = split_edge['train']['weight'].to(self.device)
+
+        global_batch = batch_size * world if (world > 1 and self.dp_scaling == "weak") else batch_size
+        batches = batch_permutation(pos_train_edge.size(0), global_batch, True)
+        order = torch.cat(batches).to(self.device) if batches else None
+
+        loss_acc = torch.zeros((), dtype=torch.float32, device=self.device)
+        total_examples = 0
+        start = 0
+        for b in batches:
+            n_b = b.numel()
+            perm_all = order[start:start + n_b]
+            start += n_b
+            if world > 1:
+                per = (n_b + world - 1) // world
+                perm = perm_all[rank * per:(rank + 1) * per]
+            else:
+                perm = perm_all
+            weight_margin = edge_weight_margin[perm] if edge_weight_margin is not None else None
+            loss = self.train_step(data, pos_train_edge[perm], neg_train_edge[perm], num_neg, weight_margin)
+            loss_acc += loss * n_b
+            total_examples += n_b
+
+        if world > 1:
+            torch.distributed.all_reduce(loss_acc, group=self.process_group)
+        return loss_acc.item() / max(total_examples, 1)
+
+    # ------------------------------------------------------------------- eval ---
+    @torch.no_grad()
+    def batch_predict(self, h, edges, batch_size):
+        """model.py:175-182, predictions kept on the device until the end"""
+        preds = []
+        for perm in batch_permutation(edges.size(0), batch_size, False):
+            edge = edges[perm.to(edges.device)]
+            preds.append(self._score(h, edge[:, 0], edge[:, 1]).reshape(-1))
+        return torch.cat(preds, dim=0).cpu()
+
+    @torch.no_grad()
+    def test(self, data, split_edge, batch_size, evaluator, eval_metric):
+        """model.py:184-226.  The reference recomputes the (deterministic,
+        eval-mode) encoder output a second time before the test split
+        (model.py:204-206); that pass is redundant and is not repeated."""
+        self.encoder.eval()
+        self.predictor.eval()
+
+        h = self.encoder(self.create_input_feat(data), data.adj_t)
+        # index -1 = unseen node = mean of all seen representations (model.py:191-194)
+        h = torch.cat([h, torch.mean(h, dim=0, keepdim=True)], dim=0)
+
+        preds = {}
+        for split in ('valid', 'test'):
+            pos_edge, neg_edge = get_pos_neg_edges(split, split_edge)
+            preds[split] = (self.batch_predict(h, pos_edge.to(self.device), batch_size),
+                            self.batch_predict(h, neg_edge.to(self.device), batch_size))
+        # batch_predict consumed base-seed draws as the reference's loaders do (4 loaders)
+        fn = evaluate_hits if eval_metric == 'hits' else evaluate_mrr
+        return fn(evaluator, preds['valid'][0], preds['valid'][1], preds['test'][0], preds['test'][1])
+
+
+# -------------------------------------------------------------------- factories --
+def create_input_layer(num_nodes, num_node_feats, hidden_channels, use_node_feats=True,
+                       train_node_emb=False, pretrain_emb=None):
+    """model.py:229-249 -> (input width of the encoder, embedding or None)"""
+    have_pretrained = pretrain_emb is not None and pretrain_emb != ''
+    emb = None
+    input_dim = num_node_feats if use_node_feats else 0
+    if train_node_emb and use_node_feats or (not use_node_feats and not have_pretrained):
+        emb = torch.nn.Embedding(num_nodes, hidden_channels)
+        input_dim += hidden_channels
+    elif have_pretrained:
+        emb = torch.nn.Embedding.from_pretrained(torch.load(pretrain_emb))
+        input_dim += emb.weight.size(1)
+    return input_dim, emb
+
+
+_ENCODERS = {'GCN': GCN, 'WSAGE': WSAGE, 'TRANSFORMER': Transformer}
+_PREDICTORS = {
+    'DOT': lambda h, n, p: DotPredictor(),
+    'BIL': lambda h, n, p: BilinearPredictor(h),
+    'MLP': lambda h, n, p: MLPPredictor(h, h, 1, n, p),
+    'MLPDOT': lambda h, n, p: MLPDotPredictor(h, 1, n, p),
+    'MLPBIL': lambda h, n, p: MLPBilPredictor(h, 1, n, p),
+    'MLPCAT': lambda h, n, p: MLPCatPredictor(h, h, 1, n, p),
+}
+
+
+def create_gnn_layer(input_channels, hidden_channels, num_layers, dropout=0, encoder_name='SAGE'):
+    """model.py:252-260: name matched case-insensitively, anything unknown is SAGE"""
+    cls = _ENCODERS.get(encoder_name.upper(), SAGE)
+    return cls(input_channels, hidden_channels, hidden_channels, num_layers, dropout)
+
+
+def create_predictor_layer(hidden_channels, num_layers, dropout=0, predictor_name='MLP'):
+    """model.py:263-276: unknown names give None, as the reference does"""
+    make = _PREDICTORS.get(predictor_name.upper())
+    return None if make is None else make(hidden_channels, num_layers, dropout)
+
+
+def adjust_lr(optimizer, decay_ratio, lr):
+    """model.py:279-286: linear decay, floor at 1e-4 * lr"""
+    new_lr = max(lr * (1 - decay_ratio), lr * 0.0001)
+    for group in optimizer.param_groups:
+        group['lr'] = new_lr
+    return new_lr

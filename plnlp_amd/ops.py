@@ -1,0 +1,502 @@
+"""Host-side operators of the MI355X path: thin Python over the C ABI
+(include/plnlp_hip.h) plus the torch.autograd.Function wrappers that make the
+HIP kernels differentiable, so `loss.backward()` in a reference-style training
+loop (plnlp/model.py:161) runs the hand-written backward kernels.
+
+Every function here requires device tensors; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from .graph import Graph
+
+# ------------------------------------------------------------------ seeds ------
+_seed_state = {"base": 0x5DEECE66D, "counter": 0}
+
+
+def manual_seed(seed: int) -> None:
+    """Seed the counter-based dropout stream (independent of torch's generators;
+    identical on every data-parallel rank so replicated encoder passes agree)."""
+    _seed_state["base"] = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _seed_state["counter"] = 0
+
+
+def next_seed() -> int:
+    """splitmix64(base + counter * golden): one fresh 64-bit seed per dropout call."""
+    _seed_state["counter"] += 1
+    z = (_seed_state["base"] + _seed_state["counter"] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """fp32, unit stride along the last dim (leading dimension = stride(0))."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() == 2 and (t.stride(1) != 1 or t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    elif t.dim() == 1 and t.stride(0) != 1:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+# ------------------------------------------------------------- raw kernels ------
+def csr_aggregate(graph: Graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
+                  src_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  epilogue: Optional[L.Epilogue] = None) -> torch.Tensor:
+    """out[r] = red_{e in row r} w_e x[col[e]]  (plnlp_csr_aggregate_f32)."""
+    lib = L.load()
+    L.require_device(x, graph.col)
+    x = _f32c(x)
+    assert x.shape[0] == graph.n_cols, (x.shape, graph)
+    feat = x.shape[1]
+    if out is None:
+        out = torch.empty(graph.n_rows, feat, dtype=torch.float32, device=x.device)
+    val = graph.val if use_values else None
+    rc = lib.plnlp_csr_aggregate_f32(
+        graph.rowptr.data_ptr(), graph.col.data_ptr(), L.ptr(val), L.ptr(src_scale),
+        x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), graph.n_rows, feat,
+        L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM,
+        C.byref(epilogue) if epilogue is not None else None, L.stream_ptr())
+    L.check(rc, "plnlp_csr_aggregate_f32")
+    return out
+
+
+def _pick_split_k(m: int, n: int, ktiles: int) -> int:
+    blocks = ((m + 127) // 128) * ((n + 127) // 128)
+    if blocks >= 256 or ktiles <= 1:
+        return 1
+    return max(1, min(ktiles, (768 + blocks - 1) // blocks, 512))
+
+
+def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_trans: bool,
+         out: Optional[torch.Tensor] = None, epilogue: Optional[L.Epilogue] = None,
+         split_k: Optional[int] = None) -> torch.Tensor:
+    """C = EPI(sum_s op(A_s) op(B_s))  (plnlp_gemm_f32).  A_s: [M,K] or [K,M] if
+    a_trans; B_s: [N,K] if b_trans (nn.Linear weight layout) else [K,N]."""
+    lib = L.load()
+    ops = (L.GemmOperand * len(segs))()
+    m = n = None
+    ktiles = 0
+    keep = []
+    for i, (a, b) in enumerate(segs):
+        L.require_device(a, b)
+        a, b = _f32c(a), _f32c(b)
+        keep += [a, b]
+        ma, ka = (a.shape[1], a.shape[0]) if a_trans else a.shape
+        nb, kb = b.shape if b_trans else (b.shape[1], b.shape[0])
+        assert ka == kb, f"segment {i}: K mismatch {a.shape} {b.shape}"
+        assert m in (None, ma) and n in (None, nb)
+        m, n = ma, nb
+        ops[i].a, ops[i].lda, ops[i].b, ops[i].ldb, ops[i].k = a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), ka
+        ktiles += (ka + 31) // 32
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=keep[0].device)
+    if split_k is None:
+        split_k = _pick_split_k(m, n, ktiles)
+    split_k = max(1, min(split_k, ktiles))
+    ws = None
+    if split_k > 1:
+        ws = torch.empty(split_k * m * n, dtype=torch.float32, device=out.device)
+    rc = lib.plnlp_gemm_f32(ops, len(segs), int(a_trans), int(b_trans), out.data_ptr(), _ld(out), m, n,
+                            C.byref(epilogue) if epilogue is not None else None, split_k,
+                            L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr())
+    L.check(rc, "plnlp_gemm_f32")
+    return out
+
+
+def colsum(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    lib = L.load()
+    L.require_device(x)
+    x = _f32c(x)
+    n, f = x.shape
+    out = torch.empty(f, dtype=torch.float32, device=x.device)
+    nws = lib.plnlp_colsum_workspace_floats(n, f)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    L.check(lib.plnlp_colsum_f32(x.data_ptr(), _ld(x), n, f, scale, out.data_ptr(), ws.data_ptr(), nws,
+                                 L.stream_ptr()), "plnlp_colsum_f32")
+    return out
+
+
+def gate(g: torch.Tensor, y: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """relu+dropout backward: g * scale where the forward output y > 0, else 0."""
+    lib = L.load()
+    L.require_device(g, y)
+    g, y = g.contiguous(), y.contiguous()
+    if out is None:
+        out = torch.empty_like(g)
+    L.check(lib.plnlp_gate_f32(g.data_ptr(), y.data_ptr(), scale, out.data_ptr(), g.numel(), L.stream_ptr()),
+            "plnlp_gate_f32")
+    return out
+
+
+def dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    lib = L.load()
+    L.require_device(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(lib.plnlp_dropout_f32(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], p,
+                                  seed & 0xFFFFFFFFFFFFFFFF, L.stream_ptr()), "plnlp_dropout_f32")
+    return y
+
+
+def _edge_idx(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.int64:
+        t = t.to(torch.int64)
+    return t.contiguous()
+
+
+def edge_dot_fwd(h: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    lib = L.load()
+    L.require_device(h, src, dst)
+    h, src, dst = _f32c(h), _edge_idx(src), _edge_idx(dst)
+    out = torch.empty(src.numel(), dtype=torch.float32, device=h.device)
+    L.check(lib.plnlp_edge_dot_fwd_f32(h.data_ptr(), _ld(h), h.shape[0], src.data_ptr(), dst.data_ptr(),
+                                       src.numel(), h.shape[1], out.data_ptr(), L.stream_ptr()),
+            "plnlp_edge_dot_fwd_f32")
+    return out
+
+
+def edge_hadamard_fwd(h: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    lib = L.load()
+    L.require_device(h, src, dst)
+    h, src, dst = _f32c(h), _edge_idx(src), _edge_idx(dst)
+    out = torch.empty(src.numel(), h.shape[1], dtype=torch.float32, device=h.device)
+    L.check(lib.plnlp_edge_hadamard_fwd_f32(h.data_ptr(), _ld(h), h.shape[0], src.data_ptr(), dst.data_ptr(),
+                                            src.numel(), h.shape[1], out.data_ptr(), _ld(out), L.stream_ptr()),
+            "plnlp_edge_hadamard_fwd_f32")
+    return out
+
+
+class Incidence:
+    """Node-sorted incidence list of one edge batch: for every node, the batch
+    edges touching it and, per item, the OTHER endpoint.  Built with a stable
+    device sort so the reduction order (hence every bit of gh) is reproducible."""
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, n_nodes: int):
+        src, dst = _edge_idx(src), _edge_idx(dst)
+        e = src.numel()
+        if e >= 2 ** 31:
+            raise ValueError("edge batch too large for int32 item ids")
+        ends = torch.cat([src, dst])
+        if n_nodes <= 0:
+            raise ValueError("n_nodes")
+        ends = torch.where(ends < 0, ends + n_nodes, ends)
+        order = torch.argsort(ends, stable=True)
+        eid = torch.arange(e, dtype=torch.int32, device=src.device).repeat(2)
+        other = torch.cat([dst, src])
+        other = torch.where(other < 0, other + n_nodes, other).to(torch.int32)
+        self.item_edge = eid[order].contiguous()
+        self.item_other = other[order].contiguous()
+        self.seg_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=src.device)
+        self.seg_ptr[1:] = torch.cumsum(torch.bincount(ends, minlength=n_nodes), 0)
+        self.n_nodes = n_nodes
+
+
+def edge_segment_bwd(h: torch.Tensor, inc: Incidence, g: torch.Tensor,
+                     out: Optional[torch.Tensor] = None,
+                     epilogue: Optional[L.Epilogue] = None) -> torch.Tensor:
+    """gh[n] = sum_{items of n} g[edge] (.) h[other]   (deterministic)."""
+    lib = L.load()
+    L.require_device(h, g)
+    h, g = _f32c(h), _f32c(g)
+    is_vec = g.dim() == 2
+    if out is None:
+        out = torch.empty(inc.n_nodes, h.shape[1], dtype=torch.float32, device=h.device)
+    L.check(lib.plnlp_edge_segment_bwd_f32(
+        h.data_ptr(), _ld(h), inc.seg_ptr.data_ptr(), None, inc.n_nodes, inc.item_edge.data_ptr(),
+        inc.item_other.data_ptr(), h.shape[1], g.data_ptr(), _ld(g) if is_vec else 0, int(is_vec),
+        out.data_ptr(), _ld(out), C.byref(epilogue) if epilogue is not None else None, L.stream_ptr()),
+        "plnlp_edge_segment_bwd_f32")
+    return out
+
+
+def edge_scatter_bwd(h: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, g: torch.Tensor,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """atomic form (summation order not fixed)."""
+    lib = L.load()
+    L.require_device(h, g, src, dst)
+    h, g, src, dst = _f32c(h), _f32c(g), _edge_idx(src), _edge_idx(dst)
+    is_vec = g.dim() == 2
+    if out is None:
+        out = torch.zeros_like(h)
+    L.check(lib.plnlp_edge_scatter_bwd_f32(h.data_ptr(), _ld(h), src.data_ptr(), dst.data_ptr(), src.numel(),
+                                           h.shape[1], g.data_ptr(), _ld(g) if is_vec else 0, int(is_vec),
+                                           out.data_ptr(), _ld(out), L.stream_ptr()),
+            "plnlp_edge_scatter_bwd_f32")
+    return out
+
+
+def pairwise_loss(kind: str, pos: torch.Tensor, neg: torch.Tensor, num_neg: int,
+                  weight: Optional[torch.Tensor] = None, grad_scale: float = 1.0):
+    """returns (loss[1], gpos[B], gneg[B*k])"""
+    lib = L.load()
+    L.require_device(pos, neg, weight)
+    pos = _f32c(pos.reshape(-1))
+    neg = _f32c(neg.reshape(-1))
+    b = pos.numel()
+    assert neg.numel() == b * num_neg, (pos.shape, neg.shape, num_neg)
+    if weight is not None:
+        weight = _f32c(weight.reshape(-1))
+        assert weight.numel() == b
+    loss = torch.empty(1, dtype=torch.float32, device=pos.device)
+    gpos = torch.empty(b, dtype=torch.float32, device=pos.device)
+    gneg = torch.empty(b * num_neg, dtype=torch.float32, device=pos.device)
+    nws = lib.plnlp_loss_workspace_floats(b)
+    ws = torch.empty(nws, dtype=torch.float32, device=pos.device)
+    L.check(lib.plnlp_pairwise_loss_f32(L.LOSS_KINDS[kind], pos.data_ptr(), neg.data_ptr(), L.ptr(weight), b,
+                                        num_neg, grad_scale, loss.data_ptr(), gpos.data_ptr(), gneg.data_ptr(),
+                                        ws.data_ptr(), nws, L.stream_ptr()), "plnlp_pairwise_loss_f32")
+    return loss, gpos, gneg
+
+
+def sqnorm_into(tensors: Sequence[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
+    """out[0] = sum_t ||t||^2 (fixed order) -- the squared total norm of a parameter group."""
+    lib = L.load()
+    counts = [lib.plnlp_sqnorm_partials(t.numel()) for t in tensors]
+    total = sum(counts)
+    part = torch.empty(max(total, 1), dtype=torch.float32, device=out.device)
+    off = 0
+    s = L.stream_ptr()
+    for t, c in zip(tensors, counts):
+        L.require_device(t)
+        assert t.is_contiguous() and t.dtype == torch.float32
+        if c:
+            L.check(lib.plnlp_sqnorm_f32(t.data_ptr(), t.numel(), part.data_ptr() + 4 * off, c, s),
+                    "plnlp_sqnorm_f32")
+        off += c
+    L.check(lib.plnlp_sum_partials_f32(part.data_ptr(), total, out.data_ptr(), 0, s), "plnlp_sum_partials_f32")
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+              decoupled=False, step=1, sqnorm=None, max_norm=0.0, grad_scale=1.0) -> None:
+    lib = L.load()
+    L.require_device(param, grad, exp_avg, exp_avg_sq)
+    assert param.is_contiguous() and grad.is_contiguous()
+    L.check(lib.plnlp_adam_step_f32(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                    param.numel(), lr, beta1, beta2, eps, weight_decay, int(decoupled), step,
+                                    L.ptr(sqnorm), max_norm, grad_scale, L.stream_ptr()), "plnlp_adam_step_f32")
+
+
+def clip_scale_(grad: torch.Tensor, sqnorm: torch.Tensor, max_norm: float) -> None:
+    lib = L.load()
+    L.require_device(grad, sqnorm)
+    assert grad.is_contiguous()
+    L.check(lib.plnlp_clip_scale_f32(grad.data_ptr(), grad.numel(), sqnorm.data_ptr(), max_norm, L.stream_ptr()),
+            "plnlp_clip_scale_f32")
+
+
+# ---------------------------------------------------------- autograd wrappers ----
+class _Act:
+    """relu + dropout description of one layer call"""
+    __slots__ = ("relu", "p", "seed")
+
+    def __init__(self, relu: bool, p: float, training: bool):
+        self.relu = bool(relu)
+        self.p = float(p) if training else 0.0
+        self.seed = next_seed() if self.p > 0.0 else 0
+
+    @property
+    def active(self):
+        return self.relu or self.p > 0.0
+
+    @property
+    def scale(self):
+        return 1.0 / (1.0 - self.p) if self.p > 0.0 else 1.0
+
+
+def _act_backward(gy: torch.Tensor, y: torch.Tensor, act: _Act) -> torch.Tensor:
+    """dz from dy for y = dropout(relu(z)): the kept, positive entries are exactly
+    y > 0, so dz = dy * 1/(1-p) there and 0 elsewhere.  The reference never applies
+    dropout without a preceding relu (layer.py:21-22,25-26,84-85); asserted."""
+    if not act.active:
+        return gy
+    assert act.relu, "dropout without relu is not used by the reference path"
+    return gate(gy, y, act.scale)
+
+
+class AggregateFn(torch.autograd.Function):
+    """torch_sparse.matmul(adj_t, x, reduce) with its autograd (Appendix A.3)."""
+
+    @staticmethod
+    def forward(ctx, x, graph: Graph, reduce: str, use_values: bool):
+        ctx.graph, ctx.reduce, ctx.use_values = graph, reduce, use_values
+        return csr_aggregate(graph, x, reduce, use_values)
+
+    @staticmethod
+    def backward(ctx, g):
+        graph = ctx.graph
+        gt = graph.t()
+        gx = csr_aggregate(gt, g.contiguous(), "sum", ctx.use_values,
+                           src_scale=graph.inv_degree() if ctx.reduce == "mean" else None)
+        return gx, None, None, None
+
+
+class SAGEConvFn(torch.autograd.Function):
+    """One SAGEConv (+ optional relu/dropout of BaseGNN.forward, layer.py:20-26):
+        y = act( mean_agg(x) @ Wl^T + bl + x @ Wr^T )
+    forward : K1 aggregate, then ONE concat-K MFMA GEMM with fused bias/relu/dropout.
+    backward: gate, 2 wgrad (split-K), colsum, 2 dgrad, K2 aggregate over the
+              transposed CSR accumulating into the root-weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w_l, b_l, w_r, graph: Graph, act: _Act):
+        x = _f32c(x)
+        agg = csr_aggregate(graph, x, "mean", use_values=False)
+        epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+        y = gemm([(agg, w_l), (x, w_r)], False, True, epilogue=epi)
+        ctx.graph, ctx.act = graph, act
+        ctx.save_for_backward(x, agg, w_l, w_r, y if act.active else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, agg, w_l, w_r, y = ctx.saved_tensors
+        graph, act = ctx.graph, ctx.act
+        dz = _act_backward(gy.contiguous(), y, act)
+        need = ctx.needs_input_grad
+        gx = gwl = gbl = gwr = None
+        if need[1]:
+            gwl = gemm([(dz, agg)], True, False)           # [out, in] = dz^T @ agg
+        if need[2]:
+            gbl = colsum(dz)
+        if need[3]:
+            gwr = gemm([(dz, x)], True, False)
+        if need[0]:
+            gx = gemm([(dz, w_r)], False, False)            # root path: dz @ Wr
+            gagg = gemm([(dz, w_l)], False, False)          # dz @ Wl
+            csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(),
+                          out=gx, epilogue=L.make_epilogue(accumulate=True))
+        return gx, gwl, gbl, gwr, None, None
+
+
+class GCNConvFn(torch.autograd.Function):
+    """One GCNConv(normalize=False) (+ relu/dropout):  y = act( A_hat (x W^T) + b )
+    forward : MFMA GEMM, then K1 weighted aggregate with fused bias/relu/dropout."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, graph: Graph, act: _Act):
+        x = _f32c(x)
+        xw = gemm([(x, w)], False, True)
+        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+        y = csr_aggregate(graph, xw, "sum", use_values=True, epilogue=epi)
+        ctx.graph, ctx.act = graph, act
+        ctx.save_for_backward(x, w, y if act.active else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        graph, act = ctx.graph, ctx.act
+        dz = _act_backward(gy.contiguous(), y, act)
+        need = ctx.needs_input_grad
+        gx = gw = gb = None
+        if need[2]:
+            gb = colsum(dz)
+        if need[0] or need[1]:
+            gxw = csr_aggregate(graph.t(), dz, "sum", use_values=True)
+            if need[1]:
+                gw = gemm([(gxw, x)], True, False)
+            if need[0]:
+                gx = gemm([(gxw, w)], False, False)
+        return gx, gw, gb, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) on the MFMA GEMM (MLPPredictor.lins, layer.py:83-86)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act: _Act):
+        x = _f32c(x)
+        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+        y = gemm([(x, w)], False, True, epilogue=epi)
+        ctx.act = act
+        ctx.save_for_backward(x, w, y if act.active else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        dz = _act_backward(gy.contiguous(), y, ctx.act)
+        need = ctx.needs_input_grad
+        gx = gw = gb = None
+        if need[0]:
+            gx = gemm([(dz, w)], False, False)
+        if need[1]:
+            gw = gemm([(dz, x)], True, False)
+        if need[2]:
+            gb = colsum(dz)
+        return gx, gw, gb, None
+
+
+# backward of the edge gathers: "segment" (deterministic gather-reduce) or "atomic"
+EDGE_BACKWARD = {"mode": "segment"}
+
+
+class EdgeDotFn(torch.autograd.Function):
+    """DotPredictor over gathered endpoints: out[e] = <h[src[e]], h[dst[e]]>
+    (model.py:155-156 + layer.py:174-176 in one pass)."""
+
+    @staticmethod
+    def forward(ctx, h, src, dst):
+        h = _f32c(h)
+        ctx.save_for_backward(h, src, dst)
+        return edge_dot_fwd(h, src, dst)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, src, dst = ctx.saved_tensors
+        g = g.contiguous()
+        if EDGE_BACKWARD["mode"] == "segment":
+            gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g)
+        else:
+            gh = edge_scatter_bwd(h, src, dst, g)
+        return gh, None, None
+
+
+class EdgeHadamardFn(torch.autograd.Function):
+    """x[e,:] = h[src[e],:] * h[dst[e],:]  (model.py:155-156 + layer.py:81)."""
+
+    @staticmethod
+    def forward(ctx, h, src, dst):
+        h = _f32c(h)
+        ctx.save_for_backward(h, src, dst)
+        return edge_hadamard_fwd(h, src, dst)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, src, dst = ctx.saved_tensors
+        g = _f32c(g)
+        if EDGE_BACKWARD["mode"] == "segment":
+            gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g)
+        else:
+            gh = edge_scatter_bwd(h, src, dst, g)
+        return gh, None, None
+
+
+class PairwiseLossFn(torch.autograd.Function):
+    """loss.py:5-48 forward and backward in one kernel; backward just scales."""
+
+    @staticmethod
+    def forward(ctx, pos, neg, weight, kind: str, num_neg: int):
+        loss, gpos, gneg = pairwise_loss(kind, pos, neg, num_neg, weight)
+        ctx.save_for_backward(gpos, gneg)
+        ctx.shapes = (pos.shape, neg.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        gpos, gneg = ctx.saved_tensors
+        ps, ns = ctx.shapes
+        return (gpos * g).reshape(ps), (gneg * g).reshape(ns), None, None, None

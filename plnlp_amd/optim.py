@@ -1,0 +1,49 @@
+"""Optimiser step of the hot loop (plnlp/model.py:163-167) as HIP kernels:
+per-group gradient-norm clipping folded into one fused Adam/AdamW update per
+tensor.  The clip coefficient is computed on the device from the squared norm
+(no host synchronisation, unlike clip_grad_norm_ + optimizer.step())."""
+from typing import Dict, Iterable, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam / AdamW (amsgrad=False) semantics; `param_groups` is kept
+    so `adjust_lr` (model.py:279-286) works unchanged."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      decoupled=decoupled))
+
+    @torch.no_grad()
+    def step(self, clip: Optional[Dict[int, Tuple[torch.Tensor, float]]] = None, grad_scale: float = 1.0):
+        """clip: id(param) -> (squared-norm device scalar of the param's clip group, max_norm)"""
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                sq, max_norm = (clip or {}).get(id(p), (None, 0.0))
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], lr=group["lr"], beta1=b1, beta2=b2,
+                              eps=group["eps"], weight_decay=group["weight_decay"],
+                              decoupled=group["decoupled"], step=st["step"], sqnorm=sq, max_norm=max_norm,
+                              grad_scale=grad_scale)
+
+
+def group_sqnorm(params: Sequence[torch.nn.Parameter]) -> Optional[torch.Tensor]:
+    """squared total gradient norm of a clip group as a device scalar"""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return None
+    grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
+    out = torch.empty(1, dtype=torch.float32, device=grads[0].device)
+    return ops.sqnorm_into(grads, out)

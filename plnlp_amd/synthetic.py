@@ -1,0 +1,94 @@
+"""Synthetic OGB-shaped inputs.  No dataset files exist on the GPU
+box and there is no network, so benchmarks and parity runs use seeded graphs
+with the node / edge counts and degree skew of the OGB datasets the reference's
+recipes name (README.md:24,31,35,40).  Pure torch; runs on CPU or GPU."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from .graph import Graph
+
+SHAPES = {
+    # name: nodes, undirected train edges, skew exponent of the Chung-Lu weights
+    "ddi": dict(num_nodes=4267, num_edges=1_067_911, skew=0.5),
+    "collab": dict(num_nodes=235_868, num_edges=1_179_052, skew=0.9),
+    "citation2": dict(num_nodes=2_927_963, num_edges=30_387_995, skew=0.8),
+}
+
+
+@dataclass
+class SyntheticData:
+    """duck-type of the `data` object main.py hands to BaseModel.train/test"""
+    adj_t: Graph
+    edge_index: torch.Tensor          # [2, nnz] int64, CPU (negative sampler input)
+    num_nodes: int
+    x: Optional[torch.Tensor] = None
+
+
+def _chung_lu_edges(n: int, m: int, skew: float, gen: torch.Generator, device) -> torch.Tensor:
+    """~m distinct undirected non-loop edges with P(node i) ~ (i+1)^-skew"""
+    w = torch.arange(1, n + 1, dtype=torch.float64, device=device).pow(-skew)
+    cdf = torch.cumsum(w / w.sum(), 0).to(torch.float32)
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    want = m
+    for _ in range(8):
+        need = int((want - keys.numel()) * 1.15) + 1024
+        u = torch.rand(2, need, generator=gen, device=device)
+        e = torch.searchsorted(cdf, u).clamp_(max=n - 1)
+        a, b = torch.minimum(e[0], e[1]), torch.maximum(e[0], e[1])
+        k = (a * n + b)[a != b]
+        keys = torch.unique(torch.cat([keys, k]))
+        if keys.numel() >= want:
+            break
+    if keys.numel() > want:       # drop a random subset, keep determinism under the generator
+        pick = torch.randperm(keys.numel(), generator=gen, device=device)[:want]
+        keys = keys[pick.sort().values]
+    return torch.stack([keys // n, keys % n])
+
+
+def make_graph(shape: str = "collab", seed: int = 0, device="cpu", scale: float = 1.0,
+               weighted: bool = False, num_nodes: Optional[int] = None,
+               num_edges: Optional[int] = None) -> Dict:
+    """returns dict(edges=[2,m] undirected pairs (lo,hi), adj_t=Graph (symmetric), weight, data)"""
+    cfg = dict(SHAPES[shape])
+    n = int(num_nodes if num_nodes is not None else max(16, round(cfg["num_nodes"] * scale)))
+    m = int(num_edges if num_edges is not None else max(16, round(cfg["num_edges"] * scale)))
+    m = min(m, n * (n - 1) // 2)
+    gen = torch.Generator(device=device).manual_seed(20240101 + seed)
+    # shuffle node ids so that degree is not monotone in the id
+    e = _chung_lu_edges(n, m, cfg["skew"], gen, device)
+    relabel = torch.randperm(n, generator=gen, device=device)
+    e = relabel[e]
+    lo, hi = torch.minimum(e[0], e[1]), torch.maximum(e[0], e[1])
+    w = None
+    if weighted:
+        w = torch.randint(1, 6, (lo.numel(),), generator=gen, device=device).to(torch.float32)
+    row, col = torch.cat([lo, hi]), torch.cat([hi, lo])
+    adj = Graph.from_coo(row, col, None if w is None else torch.cat([w, w]), n, n)
+    r, c, _ = adj.coo()
+    data = SyntheticData(adj_t=adj, edge_index=torch.stack([c, r]).cpu(), num_nodes=n)
+    return dict(edges=torch.stack([lo, hi], 1), weight=w, adj_t=adj, data=data, num_nodes=n)
+
+
+def random_walk_pairs(adj: Graph, start: torch.Tensor, walk_length: int, gen: torch.Generator):
+    """main.py:241-253 with torch_cluster.random_walk semantics (uniform neighbour,
+    stay put on isolated nodes): pairs (start, j-th hop) with weight 1/(j+1),
+    self pairs removed."""
+    rowptr, col = adj.rowptr, adj.col.to(torch.int64)
+    deg = (rowptr[1:] - rowptr[:-1])
+    cur = start
+    pairs, weights = [], []
+    for j in range(walk_length):
+        d = deg[cur]
+        u = torch.rand(cur.numel(), generator=gen, device=cur.device)
+        off = (u * d.to(torch.float32)).to(torch.int64).clamp_(max=(d - 1).clamp(min=0))
+        nxt = torch.where(d > 0, col[(rowptr[cur] + off).clamp_(max=col.numel() - 1)], cur)
+        pairs.append(torch.stack([start, nxt], 1))
+        weights.append(torch.full((start.numel(),), 1.0 / (j + 1), device=start.device))
+        cur = nxt
+    pairs, weights = torch.cat(pairs), torch.cat(weights)
+    keep = pairs[:, 0] != pairs[:, 1]
+    return pairs[keep], weights[keep]

@@ -1,0 +1,441 @@
+"""GPU parity: every HIP kernel, the fused layers and a whole training trajectory
+against the CPU oracle on the same seeded inputs.  fp32 tolerance: 1e-5
+relative (BASELINE.json north_star), with an absolute floor scaled to the data
+(sums of O(10^2) unit-variance terms); integer / index outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def P():
+    import plnlp_amd
+    from plnlp_amd import _lib
+    _lib.load()                      # no library -> the GPU suite must fail, not skip
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return plnlp_amd
+
+
+def dev(t):
+    return t.cuda() if t is not None else None
+
+
+def to_graph(P, csr: O.CSR):
+    return P.Graph(csr.rowptr.clone(), csr.col.to(torch.int32), None if csr.val is None else csr.val.float(),
+                   csr.n_rows, csr.n_cols).to("cuda")
+
+
+def rand_csr(n, e, seed, weighted=True, n_cols=None, hub=None):
+    g = torch.Generator().manual_seed(seed)
+    n_cols = n if n_cols is None else n_cols
+    r = torch.randint(0, n, (e,), generator=g)
+    c = torch.randint(0, n_cols, (e,), generator=g)
+    if hub is not None:       # one very long row and one empty row
+        r = torch.cat([r, torch.full((hub,), 3)])
+        c = torch.cat([c, torch.randint(0, n_cols, (hub,), generator=g)])
+        keep = r != 5
+        r, c = r[keep], c[keep]
+    v = torch.rand(r.numel(), generator=g) + 0.1 if weighted else None
+    return O.CSR.from_coo(r, c, v, n, n_cols)
+
+
+def close(a, b, rtol=RTOL, atol=None, msg=""):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    if atol is None:
+        atol = rtol * max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
+
+
+# --------------------------------------------------------------- aggregation ----
+@pytest.mark.parametrize("feat", [4, 32, 64, 100, 128, 200, 256, 512, 1024, 178, 7])
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_csr_aggregate_matches_oracle(P, feat, reduce):
+    csr = rand_csr(300, 3000, feat, weighted=True, hub=700)
+    x = torch.randn(300, feat, generator=torch.Generator().manual_seed(1))
+    g = to_graph(P, csr)
+    for use_values in (True, False):
+        ref = O.spmm(csr, x.double(), reduce, use_values)
+        out = P.ops.csr_aggregate(g, dev(x), reduce, use_values)
+        close(out, ref, msg=f"feat={feat} {reduce} values={use_values}")
+    # deterministic: bit-identical on a second run
+    a = P.ops.csr_aggregate(g, dev(x), reduce, True)
+    b = P.ops.csr_aggregate(g, dev(x), reduce, True)
+    assert torch.equal(a, b)
+
+
+def test_csr_aggregate_edge_cases(P):
+    # empty graph rows, rectangular, single row, nnz = 0
+    csr = O.CSR.from_coo(torch.tensor([], dtype=torch.long), torch.tensor([], dtype=torch.long), None, 5, 9)
+    x = torch.randn(9, 64)
+    out = P.ops.csr_aggregate(to_graph(P, csr), dev(x), "mean", False)
+    assert out.shape == (5, 64) and float(out.abs().max()) == 0.0
+    csr = rand_csr(1, 130, 3, weighted=True, n_cols=40)
+    x = torch.randn(40, 256)
+    close(P.ops.csr_aggregate(to_graph(P, csr), dev(x), "sum", True), O.spmm(csr, x.double(), "sum", True))
+    # src_scale + accumulate epilogue (the SAGE backward form)
+    csr = rand_csr(64, 500, 4, weighted=False)
+    x = torch.randn(64, 128)
+    s = torch.rand(64) + 0.5
+    base = torch.randn(64, 128)
+    out = dev(base.clone())
+    from plnlp_amd import _lib
+    P.ops.csr_aggregate(to_graph(P, csr), dev(x), "sum", False, src_scale=dev(s), out=out,
+                        epilogue=_lib.make_epilogue(accumulate=True))
+    ref = base.double() + O.spmm(csr, (x * s[:, None]).double(), "sum", False)
+    close(out, ref)
+    # strided input (column slice of a wider matrix)
+    wide = torch.randn(64, 256)
+    out = P.ops.csr_aggregate(to_graph(P, csr), dev(wide)[:, 128:], "mean", False)
+    close(out, O.spmm(csr, wide[:, 128:].double(), "mean", False))
+
+
+def test_csr_aggregate_epilogue_bias_relu_dropout(P):
+    from plnlp_amd import _lib
+    csr = rand_csr(200, 1500, 5, weighted=True)
+    x = torch.randn(200, 200)
+    bias = torch.randn(200)
+    seed, p = 0x1234567890ABCDEF, 0.3
+    epi = _lib.make_epilogue(bias=dev(bias), relu=True, dropout_p=p, dropout_seed=seed)
+    out = P.ops.csr_aggregate(to_graph(P, csr), dev(x), "sum", True, epilogue=epi)
+    z = torch.relu(O.spmm(csr, x, "sum", True) + bias)
+    ref = O.counter_dropout(z, p, seed)
+    close(out, ref)
+    keep_gpu = (out.cpu() != 0) | (z == 0)
+    keep_ref = torch.from_numpy(O.dropout_keep_mask(seed, 200, 200, p)) | (z == 0)
+    assert torch.equal(keep_gpu, keep_ref)            # mask bit-exact
+
+
+def test_dropout_mask_bit_exact(P):
+    x = torch.ones(513, 257)
+    for seed, p in ((1, 0.5), (0xFFFFFFFFFFFFFFFF, 0.3), (1 << 40, 0.9)):
+        y = P.ops.dropout(dev(x), p, seed).cpu()
+        keep = torch.from_numpy(O.dropout_keep_mask(seed, 513, 257, p))
+        assert torch.equal(y != 0, keep)
+        close(y[keep], torch.full((int(keep.sum()),), 1.0 / (1.0 - p)))
+
+
+# ----------------------------------------------------------------------- GEMM ----
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 256, 256), (257, 200, 178), (1000, 1, 512),
+                                   (65, 130, 50), (4267, 512, 512), (33, 7, 5)])
+def test_gemm_nt_matches_fp64(P, m, n, k):
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g)
+    ref = a.double() @ w.double().t()
+    out = P.ops.gemm([(dev(a), dev(w))], False, True)
+    close(out, ref, atol=2e-5 * np.sqrt(k))
+    out2 = P.ops.gemm([(dev(a), dev(w))], False, True, split_k=3)
+    close(out2, ref, atol=2e-5 * np.sqrt(k))
+
+
+def test_gemm_layout_variants_and_segments(P):
+    g = torch.Generator().manual_seed(7)
+    m, n, k1, k2 = 500, 192, 96, 50
+    a1, a2 = torch.randn(m, k1, generator=g), torch.randn(m, k2, generator=g)
+    w1, w2 = torch.randn(n, k1, generator=g), torch.randn(n, k2, generator=g)
+    bias = torch.randn(n, generator=g)
+    from plnlp_amd import _lib
+    out = P.ops.gemm([(dev(a1), dev(w1)), (dev(a2), dev(w2))], False, True,
+                     epilogue=_lib.make_epilogue(bias=dev(bias), relu=True))
+    ref = torch.relu(a1.double() @ w1.double().t() + a2.double() @ w2.double().t() + bias.double())
+    close(out, ref, atol=1e-4)
+    # dgrad form: dY[M,N] @ W[N,K]
+    dy = torch.randn(m, n, generator=g)
+    close(P.ops.gemm([(dev(dy), dev(w1))], False, False), dy.double() @ w1.double(), atol=1e-4)
+    # wgrad form: dY^T[N,M] @ X[M,K], reduction over 500 rows, forced split-K and auto
+    for sk in (None, 1, 4):
+        close(P.ops.gemm([(dev(dy), dev(a1))], True, False, split_k=sk), dy.double().t() @ a1.double(), atol=2e-4)
+    # both transposed: A stored [K,M], B stored [N,K]
+    wt = torch.randn(k1, n, generator=g)          # plays B stored [N'=k1, K'=n]
+    close(P.ops.gemm([(dev(dy.t().contiguous()), dev(wt))], True, True),
+          dy.double() @ wt.double().t(), atol=1e-4)
+    # accumulate epilogue
+    base = torch.randn(m, k1, generator=g)
+    out = dev(base.clone())
+    P.ops.gemm([(dev(dy), dev(w1))], False, False, out=out, epilogue=_lib.make_epilogue(accumulate=True))
+    close(out, base.double() + dy.double() @ w1.double(), atol=1e-4)
+
+
+def test_gemm_is_exact_fma_chain_determinism(P):
+    a = torch.randn(777, 300)
+    w = torch.randn(130, 300)
+    x = P.ops.gemm([(dev(a), dev(w))], False, True)
+    y = P.ops.gemm([(dev(a), dev(w))], False, True)
+    assert torch.equal(x, y)
+    s1 = P.ops.gemm([(dev(a), dev(w))], False, True, split_k=5)
+    s2 = P.ops.gemm([(dev(a), dev(w))], False, True, split_k=5)
+    assert torch.equal(s1, s2)
+
+
+def test_colsum_and_gate(P):
+    x = torch.randn(1000, 200)
+    close(P.ops.colsum(dev(x)), x.double().sum(0), atol=1e-4)
+    close(P.ops.colsum(dev(x), 1.0 / 1000), x.double().mean(0), atol=1e-6)
+    y = torch.randn(1000, 200)
+    gg = P.ops.gate(dev(x), dev(y), 1.25)
+    close(gg, torch.where(y > 0, x * 1.25, torch.zeros_like(x)))
+
+
+# ----------------------------------------------------------------- edge scoring ----
+@pytest.mark.parametrize("feat", [256, 512, 200, 64, 16, 30])
+def test_edge_dot_and_hadamard_forward(P, feat):
+    g = torch.Generator().manual_seed(feat)
+    h = torch.randn(500, feat, generator=g)
+    src = torch.randint(0, 500, (3001,), generator=g)
+    dst = torch.randint(0, 500, (3001,), generator=g)
+    close(P.ops.edge_dot_fwd(dev(h), dev(src), dev(dst)), (h[src].double() * h[dst].double()).sum(-1))
+    close(P.ops.edge_hadamard_fwd(dev(h), dev(src), dev(dst)), h[src] * h[dst], rtol=1e-6)
+    # -1 addresses the appended last row (model.py:191-194)
+    s2 = src.clone()
+    s2[::7] = -1
+    close(P.ops.edge_dot_fwd(dev(h), dev(s2), dev(dst)), (h[s2].double() * h[dst].double()).sum(-1))
+
+
+@pytest.mark.parametrize("feat,vec", [(256, False), (512, True), (200, True), (30, False)])
+def test_edge_backward_segment_and_atomic(P, feat, vec):
+    g = torch.Generator().manual_seed(feat + 1)
+    n, e = 400, 5000
+    h = torch.randn(n, feat, generator=g)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    src[:50] = 7          # a hot node
+    go = torch.randn(e, feat, generator=g) if vec else torch.randn(e, generator=g)
+    hd = h.double().requires_grad_(True)
+    if vec:
+        (hd[src] * hd[dst] * go.double()).sum().backward()
+    else:
+        ((hd[src] * hd[dst]).sum(-1) * go.double()).sum().backward()
+    inc = P.ops.Incidence(dev(src), dev(dst), n)
+    a = P.ops.edge_segment_bwd(dev(h), inc, dev(go))
+    b = P.ops.edge_segment_bwd(dev(h), inc, dev(go))
+    assert torch.equal(a, b)                           # deterministic
+    close(a, hd.grad, atol=2e-4)
+    close(P.ops.edge_scatter_bwd(dev(h), dev(src), dev(dst), dev(go)), hd.grad, atol=2e-4)
+
+
+# ------------------------------------------------------------------------ loss ----
+def test_pairwise_losses_match_golden_fixtures(P, golden):
+    g = golden("g1_losses")
+    kinds = ["auc", "hinge_auc", "weighted_auc", "adaptive_auc", "weighted_hinge_auc", "adaptive_hinge_auc",
+             "log_rank"]
+    for c in range(int(g["num_cases"])):
+        k = int(g[f"c{c}_k"])
+        pos, neg, w = (torch.from_numpy(g[f"c{c}_{n}"]) for n in ("pos", "neg", "w"))
+        for kind in kinds:
+            loss, gpos, gneg = P.ops.pairwise_loss(kind, dev(pos), dev(neg), k, dev(w))
+            close(loss.reshape(()), g[f"c{c}_{kind}_f64_loss"], rtol=2e-6)
+            close(gpos.reshape(-1, 1), g[f"c{c}_{kind}_f64_gpos"], rtol=1e-5, atol=2e-6)
+            close(gneg.reshape(-1, 1), g[f"c{c}_{kind}_f64_gneg"], rtol=1e-5, atol=2e-6)
+
+
+def test_loss_functions_autograd_surface(P):
+    pos = torch.randn(70000, 1).cuda().requires_grad_(True)
+    neg = torch.randn(210000, 1).cuda().requires_grad_(True)
+    w = (torch.rand(70000) + 0.2).cuda()
+    out = P.loss.weighted_hinge_auc_loss(pos, neg, 3, w)
+    assert out.dim() == 0
+    (out * 2.0).backward()
+    pc = pos.detach().cpu().double().requires_grad_(True)
+    nc = neg.detach().cpu().double().requires_grad_(True)
+    ref = O.LOSSES["weighted_hinge_auc"](pc, nc, 3, w.cpu().double())
+    (ref * 2.0).backward()
+    close(out, ref, rtol=1e-5)
+    close(pos.grad, pc.grad, atol=1e-5)
+    close(neg.grad, nc.grad, atol=1e-5)
+    out2 = P.loss.weighted_hinge_auc_loss(pos, neg, 3, w)
+    assert torch.equal(out.detach(), out2.detach())        # fixed-order reduction
+
+
+# ----------------------------------------------------------------- fused layers ----
+def _copy_params(dst_mod, src_mod):
+    dst_mod.load_state_dict({k: v.clone() for k, v in src_mod.state_dict().items()})
+
+
+@pytest.mark.parametrize("kind,layers,feat", [("SAGE", 1, 64), ("SAGE", 2, 128), ("GCN", 2, 200), ("SAGE", 3, 32)])
+def test_encoder_forward_backward_matches_oracle(P, kind, layers, feat):
+    torch.manual_seed(11)
+    n = 500
+    csr = rand_csr(n, 6000, 21, weighted=True)
+    if kind == "GCN":
+        csr = O.gcn_norm_csr(csr)
+    ref = O.GNNRef(kind, feat, feat, feat, layers, 0.0).double()
+    enc = getattr(P, kind)(feat, feat, feat, layers, 0.0)
+    _copy_params(enc, ref.float())
+    ref = ref.double()
+    enc = enc.cuda()
+    assert list(enc.state_dict().keys()) == list(ref.state_dict().keys())
+    x = torch.randn(n, feat)
+    xd = x.double().requires_grad_(True)
+    xg = x.cuda().requires_grad_(True)
+    go = torch.randn(n, feat)
+    ref(xd, csr).backward(go.double())
+    out = enc(xg, to_graph(P, csr))
+    out.backward(go.cuda())
+    close(out, ref(xd, csr), atol=2e-5 * np.sqrt(feat))
+    close(xg.grad, xd.grad, atol=1e-4)
+    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad, rtol=1e-4, atol=2e-4 * max(1.0, float(q.grad.abs().max())), msg=k)
+
+
+def test_encoder_dropout_matches_oracle_with_same_counter_mask(P):
+    """training-mode dropout: the oracle is handed the same counter-RNG seeds"""
+    n, feat = 300, 64
+    csr = rand_csr(n, 3000, 5, weighted=False)
+    ref = O.GNNRef("SAGE", feat, feat, feat, 2, 0.3)
+    enc = P.SAGE(feat, feat, feat, 2, 0.3)
+    _copy_params(enc, ref)
+    enc = enc.cuda().train()
+    ref.train()
+    P.manual_seed(99)
+    seeds = []
+    P.manual_seed(99)
+    seeds.append(P.ops.next_seed())
+    P.manual_seed(99)
+    ref.dropout_fn = lambda x, i: O.counter_dropout(x, 0.3, seeds[i])
+    x = torch.randn(n, feat)
+    xg = x.cuda().requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    out = enc(xg, to_graph(P, csr))
+    want = ref(xc, csr)
+    close(out, want, atol=1e-4)
+    go = torch.randn(n, feat)
+    out.backward(go.cuda())
+    want.backward(go)
+    close(xg.grad, xc.grad, atol=1e-4)
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_mlp_predictor_matches_golden_fixture(P, golden, L):
+    g = golden("g2_predictors")
+    m = P.MLPPredictor(16, 16, 1, L, 0.0)
+    m.load_state_dict({k[len(f"mlp{L}_sd_"):]: torch.from_numpy(g[k]) for k in g.files
+                       if k.startswith(f"mlp{L}_sd_")})
+    m = m.cuda()
+    xi = torch.from_numpy(g[f"mlp{L}_xi"]).cuda().requires_grad_(True)
+    xj = torch.from_numpy(g[f"mlp{L}_xj"]).cuda().requires_grad_(True)
+    out = m(xi, xj)
+    out.sum().backward()
+    close(out, g[f"mlp{L}_out"], atol=1e-5)
+    close(xi.grad, g[f"mlp{L}_gxi"], atol=1e-5)
+    for k, p in m.named_parameters():
+        close(p.grad, g[f"mlp{L}_grad_{k}"], atol=2e-5, msg=k)
+    # fused gather path gives the same scores
+    h = torch.cat([xi.detach(), xj.detach()])
+    idx = torch.arange(9).cuda()
+    close(m.score_edges(h, idx, idx + 9), g[f"mlp{L}_out"], atol=1e-5)
+
+
+def test_dot_predictor_score_edges_backward(P, golden):
+    g = golden("g2_predictors")
+    xi, xj = torch.from_numpy(g["dot_xi"]), torch.from_numpy(g["dot_xj"])
+    h = torch.cat([xi, xj]).cuda().requires_grad_(True)
+    idx = torch.arange(9).cuda()
+    out = P.DotPredictor().score_edges(h, idx, idx + 9)
+    (out * torch.arange(1.0, 10.0).cuda()).sum().backward()
+    close(out, g["dot_out"])
+    close(h.grad[:9], g["dot_gxi"])
+    close(h.grad[9:], g["dot_gxj"])
+
+
+# --------------------------------------------------------- whole training path ----
+def test_training_trajectory_matches_reference_fixture(P, golden):
+    """plnlp_amd.BaseModel.train on the GPU vs the trajectory the REFERENCE's
+    BaseModel.train produced (fixture G8): same seeds -> same negatives, same
+    batches, same losses and final weights within fp32 tolerance."""
+    from tests.test_oracle import _toy_adj
+    g = golden("g8_train_trajectory")
+    N, lo, hi, w, adj = _toy_adj(g)
+
+    class Data:
+        pass
+
+    for name in g["config_names"].tolist():
+        enc, pred, lossn, Lg, Lm, h, k, clip, weighted, B = g[f"{name}_cfg"].tolist()
+        Lg, Lm, h, k, B, clip, weighted = int(Lg), int(Lm), int(h), int(k), int(B), float(clip), bool(int(weighted))
+        m = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=clip, gnn_num_layers=Lg, mlp_num_layers=Lm,
+                        emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=N,
+                        num_node_feats=0, gnn_encoder_name=enc, predictor_name=pred, loss_func=lossn,
+                        optimizer_name="Adam", device="cuda", use_node_feats=False, train_node_emb=True)
+        m.encoder.load_state_dict({key[len(f"{name}_init_enc."):]: torch.from_numpy(g[key]) for key in g.files
+                                   if key.startswith(f"{name}_init_enc.")})
+        m.predictor.load_state_dict({key[len(f"{name}_init_pred."):]: torch.from_numpy(g[key]) for key in g.files
+                                     if key.startswith(f"{name}_init_pred.")})
+        with torch.no_grad():
+            m.emb.weight.copy_(torch.from_numpy(g[f"{name}_init_emb.weight"]))
+        data = Data()
+        a = O.gcn_norm_csr(adj) if enc == "GCN" else adj
+        data.adj_t = to_graph(P, a)
+        data.edge_index = torch.stack([torch.cat([hi, lo]), torch.cat([lo, hi])])
+        split = {"train": {"edge": torch.stack([lo, hi], 1)}}
+        if weighted:
+            split["train"]["weight"] = (w / w.max()).to(torch.float32)
+        torch.manual_seed(4242)
+        losses = [m.train(data, split, B, "local", k) for _ in range(3)]
+        close(losses, g[f"{name}_losses"], rtol=2e-5, msg=name)
+        close(m.emb.weight, g[f"{name}_final_emb"], rtol=1e-3, atol=2e-5, msg=name)
+        for key, v in m.encoder.state_dict().items():
+            close(v, g[f"{name}_final_enc.{key}"], rtol=1e-3, atol=2e-5, msg=f"{name} {key}")
+
+
+def test_eval_path_hits_parity(P):
+    """test(): encoder in eval mode, appended mean row, -1 = unseen node, Hits@K
+    identical between the GPU path and the oracle on the same weights/data."""
+    torch.manual_seed(5)
+    N, h = 400, 64
+    csr = rand_csr(N, 5000, 77, weighted=False)
+    m = P.BaseModel(lr=0.01, dropout=0.3, grad_clip_norm=1.0, gnn_num_layers=1, mlp_num_layers=2,
+                    emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=N,
+                    num_node_feats=0, gnn_encoder_name="SAGE", predictor_name="DOT", loss_func="AUC",
+                    optimizer_name="Adam", device="cuda", use_node_feats=False, train_node_emb=True)
+    m.param_init()
+    g = torch.Generator().manual_seed(3)
+    split = {"train": {"edge": torch.randint(0, N, (50, 2), generator=g)}}
+    for s in ("valid", "test"):
+        e = torch.randint(0, N, (300, 2), generator=g)
+        e[::11, 1] = -1
+        split[s] = {"edge": e, "edge_neg": torch.randint(0, N, (2000, 2), generator=g)}
+
+    class Data:
+        pass
+    data = Data()
+    data.adj_t = to_graph(P, csr)
+    res = m.test(data, split, 128, P.utils.Evaluator("ogbl-collab"), "hits")
+    ref_enc = O.GNNRef("SAGE", h, h, h, 1, 0.3)
+    ref_enc.load_state_dict({k: v.cpu() for k, v in m.encoder.state_dict().items()})
+    emb = torch.nn.Embedding(N, h)
+    emb.weight.data.copy_(m.emb.weight.detach().cpu())
+    tr = O.TrainerRef(ref_enc, O.DotPredictorRef(), emb, csr)
+    hh = tr.embed_for_eval()
+    preds = {s: (tr.score(hh, split[s]["edge"], 128), tr.score(hh, split[s]["edge_neg"], 128)) for s in ("valid", "test")}
+    ref = O.evaluate_hits_ref(preds["valid"][0], preds["valid"][1], preds["test"][0], preds["test"][1])
+    for key in ref:
+        assert abs(res[key][0] - ref[key][0]) <= 0.003 + 1e-9 and abs(res[key][1] - ref[key][1]) <= 0.003 + 1e-9, \
+            (key, res[key], ref[key])                      # +-0.3 Hits@K points
+
+
+def test_fused_adam_and_clip_match_torch(P):
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(1000, 37)), torch.nn.Parameter(torch.randn(513))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ps = [torch.nn.Parameter(p.detach().cuda()) for p in ps]
+    from plnlp_amd.optim import FusedAdam, group_sqnorm
+    opt = FusedAdam(ps, lr=0.01)
+    ropt = torch.optim.Adam(ref, lr=0.01)
+    for it in range(5):
+        for p, r in zip(ps, ref):
+            gr = torch.randn_like(r) * (10.0 if it % 2 else 0.01)
+            r.grad = gr.clone()
+            p.grad = gr.cuda()
+        torch.nn.utils.clip_grad_norm_(ref, 2.0)
+        ropt.step()
+        sq = group_sqnorm(ps)
+        opt.step(clip={id(p): (sq, 2.0) for p in ps})
+    for p, r in zip(ps, ref):
+        close(p, r, rtol=1e-5, atol=1e-6)
