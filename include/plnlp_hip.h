@@ -66,7 +66,26 @@ typedef struct plnlp_epilogue {
  * autograd backward.  Atomic-free, deterministic.
  * `x` and `out` must not alias.  feat % 4 == 0 and 16-byte aligned rows take
  * the vector path; anything else takes a scalar path.
+ *
+ * Long rows (hubs of a power-law graph) would serialise on one wave; an optional
+ * plnlp_row_split moves every row longer than `threshold` out of the main pass:
+ * each such row is cut into chunks of `threshold` edges, one wave per chunk writes
+ * a partial sum to the workspace, and one wave per long row adds the partials in
+ * chunk order (fixed order -> still deterministic).  The tables are built by the
+ * caller (once per static graph; per batch, with upper-bound sizes and -1 padding,
+ * for the per-step incidence lists): see plnlp_amd/graph.py::RowSplit.
  */
+typedef struct plnlp_row_split {
+    int64_t        threshold;        /* >= 64                                           */
+    int64_t        n_long;           /* entries in long_rows (slots holding -1 are idle) */
+    const int64_t* long_rows;        /* [n_long] row ids                                 */
+    const int64_t* chunk_ptr;        /* [n_long+1] first chunk of each long row          */
+    int64_t        n_chunks;         /* entries in chunk_long (>= chunk_ptr[n_long])     */
+    const int32_t* chunk_long;       /* [n_chunks] slot in long_rows owning the chunk    */
+    float*         workspace;        /* [n_chunks, feat], 16-byte aligned                */
+    int64_t        workspace_floats;
+} plnlp_row_split;
+
 #define PLNLP_REDUCE_SUM  0
 #define PLNLP_REDUCE_MEAN 1
 int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
@@ -76,6 +95,7 @@ int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                             float* out, int64_t ldo,
                             int64_t n_rows, int64_t feat, int reduce,
                             const plnlp_epilogue* epi /* nullable, HOST ptr */,
+                            const plnlp_row_split* split /* nullable, HOST ptr */,
                             void* stream);
 
 /* ---- K4: dense fp32 linear on the f32-input MFMA ---------------------------

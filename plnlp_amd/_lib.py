@@ -26,6 +26,13 @@ class Epilogue(C.Structure):
                 ("gate_scale", C.c_float)]
 
 
+class RowSplit(C.Structure):
+    """mirror of plnlp_row_split"""
+    _fields_ = [("threshold", C.c_int64), ("n_long", C.c_int64), ("long_rows", C.c_void_p),
+                ("chunk_ptr", C.c_void_p), ("n_chunks", C.c_int64), ("chunk_long", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
+
+
 class GemmOperand(C.Structure):
     """mirror of plnlp_gemm_operand"""
     _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64),
@@ -43,7 +50,7 @@ SIGNATURES = {
     "plnlp_error_string": (C.c_char_p, [C.c_int]),
     "plnlp_csr_aggregate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64,
                                           C.c_void_p, c_i64, c_i64, c_i64, C.c_int, C.POINTER(Epilogue),
-                                          C.c_void_p]),
+                                          C.POINTER(RowSplit), C.c_void_p]),
     "plnlp_gemm_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
                                  c_i64, C.POINTER(Epilogue), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
     "plnlp_colsum_workspace_floats": (c_i64, [c_i64, c_i64]),
@@ -145,4 +152,5 @@ def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accum
     if flags == 0:
         return None
     e.flags = flags
+    e._keepalive = (bias, gate)      # the struct holds raw pointers; keep the tensors alive with it
     return e

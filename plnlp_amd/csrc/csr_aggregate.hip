@@ -71,26 +71,14 @@ __device__ __forceinline__ void agg_chunk(float4 (&acc)[VPL], const float* __res
     }
 }
 
+// accumulate edges [beg, end) of one row into acc (wave-cooperative)
 template <int VPL, int LPR, bool WEIGHTED>
-__global__ __launch_bounds__(256) void csr_agg_vec_kernel(
-    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const float* __restrict__ val, const float* __restrict__ src_scale,
-    const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
-    int64_t n_rows, int feat, int mean, Epi epi) {
+__device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64_t end,
+                                          const int32_t* __restrict__ col, const float* __restrict__ val,
+                                          const float* __restrict__ src_scale, const float* __restrict__ x,
+                                          int64_t ldx, int lane, int sub, int grp, int nslots) {
     constexpr int NG = 64 / LPR;
     constexpr int CH = (VPL >= 4) ? 4 : 8;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
-    if (r >= n_rows) return;
-    const int sub = lane % LPR, grp = lane / LPR;
-    const int nslots = feat >> 2;
-    const int64_t beg = rowptr[r], end = rowptr[r + 1];
-
-    float4 acc[VPL];
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-
     for (int64_t e0 = beg; e0 < end; e0 += 64) {
         const int n = (int)((end - e0) < 64 ? (end - e0) : 64);
         int cvec = 0;
@@ -102,9 +90,6 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
                 if (src_scale) wvec *= src_scale[cvec];
             }
         }
-        // groups of NG neighbours; neighbours past n have cvec = 0 (a valid row) and weight 0,
-        // but are never accumulated: the chunk count m covers whole groups only for the
-        // full part and the ragged tail is handled group-lane-wise below.
         const int ngroups = (n + NG - 1) / NG;  // wave instructions needed
         for (int j = 0; j < ngroups; j += CH) {
             const int m = (ngroups - j) < CH ? (ngroups - j) : CH;
@@ -112,20 +97,19 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
                 agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j, m, sub, grp, nslots);
             } else {
                 // a lane group whose neighbour index runs past n must contribute nothing
-                // (not even 0*x: x may hold inf).  Mask by zeroing through a select.
-                float4 part[VPL];
-#pragma unroll
-                for (int k = 0; k < VPL; ++k) part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int full = (n / NG);  // groups j < full are complete for every grp
+                // (not even 0*x: x may hold inf): complete groups first, the ragged one under a select.
+                const int full = (n / NG);
                 if (j + m <= full) {
                     agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j * NG, m, sub, grp, nslots);
                 } else {
-                    // last, ragged chunk: do complete groups, then the partial one under a lane mask
                     const int mfull = full - j > 0 ? full - j : 0;
                     if (mfull > 0)
                         agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j * NG, mfull, sub, grp, nslots);
                     const int jl = (j + mfull) * NG;  // first neighbour of the ragged group
                     if (jl < n) {
+                        float4 part[VPL];
+#pragma unroll
+                        for (int k = 0; k < VPL; ++k) part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                         agg_chunk<VPL, LPR, 1, WEIGHTED>(part, x, ldx, cvec, wvec, jl, 1, sub, grp, nslots);
                         const bool ok = (jl + grp) < n;
 #pragma unroll
@@ -138,8 +122,11 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
             }
         }
     }
+}
 
-    if constexpr (NG > 1) {  // fold the NG partial sums into group 0
+template <int VPL, int LPR>
+__device__ __forceinline__ void fold_groups(float4 (&acc)[VPL]) {
+    if constexpr (LPR < 64) {
 #pragma unroll
         for (int o = LPR; o < 64; o <<= 1) {
 #pragma unroll
@@ -148,11 +135,15 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
                 acc[k].z += __shfl_xor(acc[k].z, o, 64); acc[k].w += __shfl_xor(acc[k].w, o, 64);
             }
         }
-        if (grp != 0) return;
     }
+}
 
+template <int VPL, int LPR>
+__device__ __forceinline__ void finish_row(float4 (&acc)[VPL], int64_t r, int64_t deg, int mean, int feat,
+                                           int nslots, int sub, float* __restrict__ out, int64_t ldo,
+                                           const Epi& epi) {
     if (mean) {
-        const float d = (float)((end - beg) > 0 ? (end - beg) : 1);
+        const float d = (float)(deg > 0 ? deg : 1);
 #pragma unroll
         for (int k = 0; k < VPL; ++k) { acc[k].x /= d; acc[k].y /= d; acc[k].z /= d; acc[k].w /= d; }
     }
@@ -164,6 +155,103 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
             float4 y = epi_apply4(epi, acc[k], r, (int64_t)s * 4, feat, orow);
             *reinterpret_cast<float4*>(orow + s * 4) = y;
         }
+    }
+}
+
+// main pass: one wave per row; rows longer than skip_above (> 0) are left to the split passes
+template <int VPL, int LPR, bool WEIGHTED>
+__global__ __launch_bounds__(256) void csr_agg_vec_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, const float* __restrict__ src_scale,
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= n_rows) return;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int nslots = feat >> 2;
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    if (skip_above > 0 && end - beg > skip_above) return;
+
+    float4 acc[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, src_scale, x, ldx, lane, sub, grp, nslots);
+    fold_groups<VPL, LPR>(acc);
+    if (LPR < 64 && grp != 0) return;
+    finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi);
+}
+
+// split pass 1: one wave per chunk (<= threshold edges) of a long row; raw weighted sums to the workspace
+struct SplitArgs {
+    int64_t threshold;
+    int64_t n_long;
+    const int64_t* long_rows;
+    const int64_t* chunk_ptr;
+    int64_t n_chunks;
+    const int32_t* chunk_long;
+    float* ws;
+};
+
+template <int VPL, int LPR, bool WEIGHTED>
+__global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, const float* __restrict__ src_scale,
+    const float* __restrict__ x, int64_t ldx, int feat, SplitArgs sp) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+    if (c >= sp.n_chunks || c >= sp.chunk_ptr[sp.n_long]) return;
+    const int l = sp.chunk_long[c];
+    const int64_t r = sp.long_rows[l];
+    if (r < 0) return;
+    const int64_t j = c - sp.chunk_ptr[l];
+    const int64_t rb = rowptr[r], re = rowptr[r + 1];
+    const int64_t beg = rb + j * sp.threshold;
+    const int64_t end = (beg + sp.threshold) < re ? (beg + sp.threshold) : re;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int nslots = feat >> 2;
+    float4 acc[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, src_scale, x, ldx, lane, sub, grp, nslots);
+    fold_groups<VPL, LPR>(acc);
+    if (LPR < 64 && grp != 0) return;
+    float* w = sp.ws + c * (int64_t)feat;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        int s = sub + k * LPR;
+        if (s < nslots) *reinterpret_cast<float4*>(w + s * 4) = acc[k];
+    }
+}
+
+// split pass 2: one wave per long row adds its chunk sums in chunk order, then mean / epilogue / store
+__global__ __launch_bounds__(256) void csr_agg_finalize_kernel(const int64_t* __restrict__ rowptr, int feat,
+                                                               int mean, SplitArgs sp, float* __restrict__ out,
+                                                               int64_t ldo, Epi epi) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t l = (int64_t)blockIdx.x * 4 + wave;
+    if (l >= sp.n_long) return;
+    const int64_t r = sp.long_rows[l];
+    if (r < 0) return;
+    const int64_t c0 = sp.chunk_ptr[l], c1 = sp.chunk_ptr[l + 1];
+    const int64_t deg = rowptr[r + 1] - rowptr[r];
+    const int nslots = feat >> 2;
+    for (int s = lane; s < nslots; s += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t c = c0; c < c1; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(sp.ws + c * (int64_t)feat + s * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (mean) {
+            const float d = (float)(deg > 0 ? deg : 1);
+            acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d;
+        }
+        float* orow = out + r * ldo;
+        const float4 y = epi_apply4(epi, acc, r, (int64_t)s * 4, feat, orow);
+        *reinterpret_cast<float4*>(orow + s * 4) = y;
     }
 }
 
@@ -211,13 +299,26 @@ __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
 template <int VPL, int LPR>
 static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* rowptr, const int32_t* col,
                       const float* val, const float* src_scale, const float* x, int64_t ldx, float* out,
-                      int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e) {
+                      int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e, const SplitArgs* sp) {
+    const int64_t skip = sp ? sp->threshold : 0;
     if (weighted)
         hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true>), grid, dim3(256), 0, s, rowptr, col, val,
-                           src_scale, x, ldx, out, ldo, n_rows, feat, mean, e);
+                           src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
     else
         hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false>), grid, dim3(256), 0, s, rowptr, col, val,
-                           src_scale, x, ldx, out, ldo, n_rows, feat, mean, e);
+                           src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
+    if (int rc = launch_status()) return rc;
+    if (!sp || sp->n_long == 0 || sp->n_chunks == 0) return 0;
+    dim3 cgrid((unsigned)((sp->n_chunks + 3) / 4));
+    if (weighted)
+        hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, true>), cgrid, dim3(256), 0, s, rowptr, col, val,
+                           src_scale, x, ldx, feat, *sp);
+    else
+        hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, false>), cgrid, dim3(256), 0, s, rowptr, col, val,
+                           src_scale, x, ldx, feat, *sp);
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)((sp->n_long + 3) / 4)), dim3(256), 0, s, rowptr,
+                       feat, mean, *sp, out, ldo, e);
     return launch_status();
 }
 
@@ -226,7 +327,7 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
 extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                                        const float* src_scale, const float* x, int64_t ldx, float* out,
                                        int64_t ldo, int64_t n_rows, int64_t feat, int reduce,
-                                       const plnlp_epilogue* epi, void* stream) {
+                                       const plnlp_epilogue* epi, const plnlp_row_split* split, void* stream) {
     using namespace plnlp;
     if (!rowptr || !x || !out) return PLNLP_E_NULL;
     if (n_rows < 0 || feat <= 0 || ldx < feat || ldo < feat || feat > (1 << 20)) return PLNLP_E_SHAPE;
@@ -241,8 +342,20 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
     const bool weighted = (val != nullptr) || (src_scale != nullptr);
     const int mean = reduce == PLNLP_REDUCE_MEAN;
     const bool vec_ok = (feat % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) &&
-                        ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) && feat <= 1024 &&
-                        (!(e.flags & PLNLP_EPI_GATE) || true);
+                        ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) && feat <= 1024;
+    SplitArgs sa{};
+    const SplitArgs* sp = nullptr;
+    if (split && split->n_long > 0 && split->n_chunks > 0) {
+        if (!vec_ok) return PLNLP_E_UNSUPPORTED;   // long-row splitting is implemented on the vector path
+        if (split->threshold < 64 || !split->long_rows || !split->chunk_ptr || !split->chunk_long ||
+            !split->workspace) return PLNLP_E_NULL;
+        if (split->workspace_floats < split->n_chunks * feat) return PLNLP_E_WORKSPACE;
+        if ((uintptr_t)split->workspace % 16 != 0) return PLNLP_E_ALIGN;
+        sa.threshold = split->threshold; sa.n_long = split->n_long; sa.long_rows = split->long_rows;
+        sa.chunk_ptr = split->chunk_ptr; sa.n_chunks = split->n_chunks; sa.chunk_long = split->chunk_long;
+        sa.ws = split->workspace;
+        sp = &sa;
+    }
     if (!vec_ok) {
         if (weighted)
             hipLaunchKernelGGL((csr_agg_scalar_kernel<true>), grid, dim3(256), 0, s, rowptr, col, val, src_scale,
@@ -254,7 +367,7 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
     }
     const int nslots = (int)(feat / 4);
 #define PLNLP_AGG(VPL, LPR) \
-    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e)
+    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp)
     if (nslots <= 8) PLNLP_AGG(1, 8);
     if (nslots <= 16) PLNLP_AGG(1, 16);
     if (nslots <= 32) PLNLP_AGG(1, 32);

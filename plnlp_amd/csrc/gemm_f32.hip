@@ -57,9 +57,16 @@ struct GemmArgs {
 // ---- global -> registers ------------------------------------------------------
 // K-contiguous operand: rows [row0, row0+128) x k [k0, k0+32); thread t loads
 // float4 at (row0 + (t>>3) + 32p, k0 + 4*(t&7)), p = 0..3.
+template <bool FULL>
 __device__ __forceinline__ void load_kc(float4 (&r)[4], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
     const int kq = (t & 7) * 4 + k0;
+    if constexpr (FULL) {  // interior tile: 4 independent 16-byte loads, no guards, no waits between them
+        const float* q = base + (row0 + (t >> 3)) * ld + kq;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const float4*>(q + (int64_t)(32 * p) * ld);
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int64_t row = row0 + (t >> 3) + 32 * p;
@@ -80,9 +87,16 @@ __device__ __forceinline__ void load_kc(float4 (&r)[4], const float* __restrict_
 }
 // row-contiguous operand stored [kdim][nrows]: k [k0,k0+32) x rows [row0,row0+128);
 // thread t loads float4 at (k0 + (t>>5) + 8p, row0 + 4*(t&31)).
+template <bool FULL>
 __device__ __forceinline__ void load_rc(float4 (&r)[4], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
     const int64_t rq = row0 + (t & 31) * 4;
+    if constexpr (FULL) {
+        const float* q = base + (int64_t)(k0 + (t >> 5)) * ld + rq;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const float4*>(q + (int64_t)(8 * p) * ld);
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int k = k0 + (t >> 5) + 8 * p;
@@ -142,10 +156,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
         const int sidx = (tile >= g.tiles0 && g.nseg > 1) ? 1 : 0;
         const Seg& s = g.seg[sidx];
         const int k0 = (tile - (sidx ? g.tiles0 : 0)) * BK;
-        if constexpr (A_T) load_rc(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
-        else               load_kc(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
-        if constexpr (B_T) load_kc(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
-        else               load_rc(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
+        const bool kfull = k0 + BK <= s.k;
+        const bool afull = kfull && s.a_vec && (m0 + BM <= g.m);      // block-uniform
+        const bool bfull = kfull && s.b_vec && (n0 + BN <= g.n);
+        if (afull) {
+            if constexpr (A_T) load_rc<true>(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
+            else               load_kc<true>(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
+        } else {
+            if constexpr (A_T) load_rc<false>(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
+            else               load_kc<false>(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
+        }
+        if (bfull) {
+            if constexpr (B_T) load_kc<true>(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
+            else               load_rc<true>(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
+        } else {
+            if constexpr (B_T) load_kc<false>(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
+            else               load_rc<false>(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
+        }
     };
 
     if (tb < te) gload(tb);

@@ -129,25 +129,27 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, 
 }
 
 // ---------------- column sums -------------------------------------------------------
-constexpr int CS_ROWS = 256;  // rows per block
+// stage 1: CS_BLOCKS blocks stride over the rows, thread = column (coalesced row reads);
+// stage 2: one wave per column adds the block partials (shuffle tree: fixed order).
+constexpr int CS_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx,
                                                              int64_t n_rows, int feat,
                                                              float* __restrict__ partial) {
-    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
-    const int64_t r1 = r0 + CS_ROWS < n_rows ? r0 + CS_ROWS : n_rows;
     for (int f = threadIdx.x; f < feat; f += 256) {
         float acc = 0.f;
-        for (int64_t r = r0; r < r1; ++r) acc += x[r * ldx + f];
+        for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) acc += x[r * ldx + f];
         partial[(int64_t)blockIdx.x * feat + f] = acc;
     }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int64_t n_blocks,
                                                            int feat, float scale, float* __restrict__ out) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= feat) return;
     float acc = 0.f;
-    for (int64_t b = 0; b < n_blocks; ++b) acc += partial[b * feat + f];
-    out[f] = acc * scale;
+    for (int64_t b = lane; b < n_blocks; b += 64) acc += partial[b * feat + f];
+    acc = wave_sum(acc);
+    if (lane == 0) out[f] = acc * scale;
 }
 
 // ---------------- element-wise ------------------------------------------------------
@@ -254,8 +256,11 @@ extern "C" int plnlp_clip_scale_f32(float* grad, int64_t n, const float* sqnorm,
     return launch_status();
 }
 
+static inline int64_t colsum_blocks(int64_t n_rows) {
+    return n_rows < plnlp::CS_BLOCKS ? (n_rows > 0 ? n_rows : 1) : plnlp::CS_BLOCKS;
+}
 extern "C" int64_t plnlp_colsum_workspace_floats(int64_t n_rows, int64_t feat) {
-    return ((n_rows + plnlp::CS_ROWS - 1) / plnlp::CS_ROWS) * feat;
+    return colsum_blocks(n_rows) * feat;
 }
 
 extern "C" int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t feat, float scale, float* out,
@@ -263,13 +268,13 @@ extern "C" int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int
     using namespace plnlp;
     if (!x || !out || !workspace) return PLNLP_E_NULL;
     if (n_rows <= 0 || feat <= 0 || ldx < feat || feat > (1 << 24)) return PLNLP_E_SHAPE;
-    const int64_t blocks = (n_rows + CS_ROWS - 1) / CS_ROWS;
+    const int64_t blocks = colsum_blocks(n_rows);
     if (workspace_floats < blocks * feat) return PLNLP_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, n_rows, (int)feat,
                        workspace);
     if (int rc = launch_status()) return rc;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((feat + 255) / 256)), dim3(256), 0, s, workspace, blocks,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((feat + 3) / 4)), dim3(256), 0, s, workspace, blocks,
                        (int)feat, scale, out);
     return launch_status();
 }

@@ -21,6 +21,58 @@ from typing import Optional, Tuple
 import torch
 
 
+class RowSplit:
+    """Tables for plnlp_row_split (include/plnlp_hip.h): which rows are longer than
+    `threshold` edges and how they are cut into chunks.
+
+    `static`  -- exact sizes (one host sync; done once per graph, which never changes);
+    `dynamic` -- no host sync: sizes are the upper bounds nnz/threshold (long rows) and
+                 2*nnz/threshold (chunks), unused slots hold -1 / are never reached.  Used
+                 for the per-batch incidence lists of the edge-gather backward."""
+
+    def __init__(self, rowptr: torch.Tensor, threshold: int = 256, dynamic: bool = False):
+        self.threshold = int(threshold)
+        dev = rowptr.device
+        deg = rowptr[1:] - rowptr[:-1]
+        n_rows = deg.numel()
+        if not dynamic:
+            long_rows = torch.nonzero(deg > threshold).reshape(-1)
+            self.n_long = int(long_rows.numel())
+            nch = (deg[long_rows] + threshold - 1) // threshold
+            self.long_rows = long_rows.contiguous()
+            self.chunk_ptr = torch.zeros(self.n_long + 1, dtype=torch.int64, device=dev)
+            self.chunk_ptr[1:] = torch.cumsum(nch, 0)
+            self.n_chunks = int(self.chunk_ptr[-1]) if self.n_long else 0
+            self.chunk_long = torch.repeat_interleave(
+                torch.arange(self.n_long, dtype=torch.int32, device=dev), nch).contiguous()
+        else:
+            raise ValueError("use RowSplit.dynamic(rowptr, nnz, threshold)")
+
+    @classmethod
+    def dynamic(cls, rowptr: torch.Tensor, nnz: int, threshold: int = 256) -> "RowSplit":
+        self = cls.__new__(cls)
+        self.threshold = int(threshold)
+        dev = rowptr.device
+        deg = rowptr[1:] - rowptr[:-1]
+        n_rows = deg.numel()
+        self.n_long = max(1, min(n_rows, nnz // threshold))
+        self.n_chunks = nnz // threshold + self.n_long
+        top, idx = torch.topk(deg, self.n_long)
+        is_long = top > threshold
+        self.long_rows = torch.where(is_long, idx, torch.full_like(idx, -1)).contiguous()
+        nch = torch.where(is_long, (top + threshold - 1) // threshold, torch.zeros_like(top))
+        self.chunk_ptr = torch.zeros(self.n_long + 1, dtype=torch.int64, device=dev)
+        self.chunk_ptr[1:] = torch.cumsum(nch, 0)
+        slots = torch.arange(self.n_chunks, dtype=torch.int64, device=dev)
+        self.chunk_long = torch.searchsorted(self.chunk_ptr[1:].contiguous(), slots, right=True) \
+            .clamp_(max=self.n_long - 1).to(torch.int32).contiguous()
+        return self
+
+    @property
+    def active(self) -> bool:
+        return self.n_long > 0 and self.n_chunks > 0
+
+
 class Graph:
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor],
                  n_rows: int, n_cols: int):
@@ -33,6 +85,13 @@ class Graph:
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self._t: Optional["Graph"] = None
         self._inv_deg: Optional[torch.Tensor] = None
+        self._split: Optional[RowSplit] = None
+
+    def row_split(self, threshold: int = 256) -> RowSplit:
+        """long-row tables of this (static) graph, built once"""
+        if self._split is None or self._split.threshold != threshold:
+            self._split = RowSplit(self.rowptr, threshold)
+        return self._split
 
     # ---- construction ---------------------------------------------------------
     @classmethod

@@ -51,10 +51,19 @@ def _ld(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------- raw kernels ------
-def csr_aggregate(graph: Graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
+SPLIT_THRESHOLD = 256   # rows longer than this are cut into chunks (one wave each)
+
+
+def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
+    return (feat % 4 == 0 and feat <= 1024 and _ld(x) % 4 == 0 and _ld(out) % 4 == 0
+            and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0)
+
+
+def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
                   src_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                  epilogue: Optional[L.Epilogue] = None) -> torch.Tensor:
-    """out[r] = red_{e in row r} w_e x[col[e]]  (plnlp_csr_aggregate_f32)."""
+                  epilogue: Optional[L.Epilogue] = None, split="auto") -> torch.Tensor:
+    """out[r] = red_{e in row r} w_e x[col[e]]  (plnlp_csr_aggregate_f32).
+    `graph` needs rowptr/col/val/n_rows/n_cols (+ row_split() when split == 'auto')."""
     lib = L.load()
     L.require_device(x, graph.col)
     x = _f32c(x)
@@ -63,11 +72,19 @@ def csr_aggregate(graph: Graph, x: torch.Tensor, reduce: str = "sum", use_values
     if out is None:
         out = torch.empty(graph.n_rows, feat, dtype=torch.float32, device=x.device)
     val = graph.val if use_values else None
+    sp = None
+    if split == "auto":
+        split = graph.row_split(SPLIT_THRESHOLD) if _vector_path(x, out, feat) else None
+    if split is not None and split.active and _vector_path(x, out, feat):
+        ws = torch.empty(split.n_chunks * feat, dtype=torch.float32, device=x.device)
+        sp = L.RowSplit(split.threshold, split.n_long, split.long_rows.data_ptr(), split.chunk_ptr.data_ptr(),
+                        split.n_chunks, split.chunk_long.data_ptr(), ws.data_ptr(), ws.numel())
     rc = lib.plnlp_csr_aggregate_f32(
-        graph.rowptr.data_ptr(), graph.col.data_ptr(), L.ptr(val), L.ptr(src_scale),
+        graph.rowptr.data_ptr(), graph.col.data_ptr() or graph.rowptr.data_ptr(), L.ptr(val), L.ptr(src_scale),
         x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), graph.n_rows, feat,
         L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM,
-        C.byref(epilogue) if epilogue is not None else None, L.stream_ptr())
+        C.byref(epilogue) if epilogue is not None else None,
+        C.byref(sp) if sp is not None else None, L.stream_ptr())
     L.check(rc, "plnlp_csr_aggregate_f32")
     return out
 
@@ -201,6 +218,17 @@ class Incidence:
         self.seg_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=src.device)
         self.seg_ptr[1:] = torch.cumsum(torch.bincount(ends, minlength=n_nodes), 0)
         self.n_nodes = n_nodes
+        # graph-like view so the aggregation kernel can walk it: row = node, col = other endpoint
+        self.rowptr, self.col, self.val = self.seg_ptr, self.item_other, None
+        self.n_rows = self.n_cols = n_nodes
+        self._split = None
+
+    def row_split(self, threshold: int):
+        """hot nodes of the batch (built without a host sync: upper-bound sizes)"""
+        if self._split is None:
+            from .graph import RowSplit
+            self._split = RowSplit.dynamic(self.seg_ptr, self.item_edge.numel(), threshold)
+        return self._split
 
 
 def edge_segment_bwd(h: torch.Tensor, inc: Incidence, g: torch.Tensor,
@@ -213,6 +241,14 @@ def edge_segment_bwd(h: torch.Tensor, inc: Incidence, g: torch.Tensor,
     is_vec = g.dim() == 2
     if out is None:
         out = torch.empty(inc.n_nodes, h.shape[1], dtype=torch.float32, device=h.device)
+    if not is_vec:
+        # scalar per-edge gradient (DOT): gh = S h with S[n, other] = g[edge] -- exactly the
+        # weighted CSR aggregation, so it runs on K1 (incl. hot-node splitting)
+        inc.val = g[inc.item_edge.to(torch.int64)]
+        try:
+            return csr_aggregate(inc, h, "sum", True, out=out, epilogue=epilogue)
+        finally:
+            inc.val = None
     L.check(lib.plnlp_edge_segment_bwd_f32(
         h.data_ptr(), _ld(h), inc.seg_ptr.data_ptr(), None, inc.n_nodes, inc.item_edge.data_ptr(),
         inc.item_other.data_ptr(), h.shape[1], g.data_ptr(), _ld(g) if is_vec else 0, int(is_vec),

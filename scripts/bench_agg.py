@@ -1,0 +1,48 @@
+"""Micro-benchmark of the CSR aggregation kernel (K1) against the HBM roofline.
+python scripts/bench_agg.py [--cases collab,uniform,citation2] [--feat 256,512]"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import plnlp_amd as P
+from plnlp_amd import synthetic
+from bench import agg_bytes, time_kernel
+
+
+def uniform_graph(n, m, device, seed=0):
+    g = torch.Generator(device=device).manual_seed(seed)
+    a = torch.randint(0, n, (m,), generator=g, device=device)
+    b = torch.randint(0, n, (m,), generator=g, device=device)
+    return P.Graph.from_coo(torch.cat([a, b]), torch.cat([b, a]), None, n, n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default="collab,uniform,ddi")
+    ap.add_argument("--feat", default="256,512")
+    ap.add_argument("--weighted", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    for case in args.cases.split(","):
+        if case == "uniform":
+            g = uniform_graph(235868, 1179052, dev)
+        elif case == "uniform_big":
+            g = uniform_graph(2927963, 30387995, dev)
+        else:
+            g = synthetic.make_graph(case, seed=2, device=dev, weighted=args.weighted)["adj_t"]
+        deg = g.degree()
+        for feat in [int(f) for f in args.feat.split(",")]:
+            x = torch.randn(g.n_cols, feat, device=dev)
+            out = torch.empty(g.n_rows, feat, device=dev)
+            t = time_kernel(lambda: P.ops.csr_aggregate(g, x, "mean", args.weighted, out=out), iters=10)
+            by = agg_bytes(g.nnz, g.n_rows, feat, args.weighted)
+            print(json.dumps({"case": case, "N": g.n_rows, "nnz": g.nnz, "max_deg": int(deg.max()), "feat": feat,
+                              "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
+                              "frac_of_8TBps": round(by / t / 8e12, 4),
+                              "source_MiB": round(g.n_cols * feat * 4 / 2 ** 20, 1)}), flush=True)
+            del x, out
+        del g
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -345,10 +345,48 @@ def test_dot_predictor_score_edges_backward(P, golden):
 
 
 # --------------------------------------------------------- whole training path ----
+def _g8_model(P, g, name, N):
+    enc, pred, lossn, Lg, Lm, h, k, clip, weighted, B = g[f"{name}_cfg"].tolist()
+    Lg, Lm, h, k, B, clip, weighted = int(Lg), int(Lm), int(h), int(k), int(B), float(clip), bool(int(weighted))
+    m = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=clip, gnn_num_layers=Lg, mlp_num_layers=Lm,
+                    emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=N,
+                    num_node_feats=0, gnn_encoder_name=enc, predictor_name=pred, loss_func=lossn,
+                    optimizer_name="Adam", device="cuda", use_node_feats=False, train_node_emb=True)
+    m.encoder.load_state_dict({key[len(f"{name}_init_enc."):]: torch.from_numpy(g[key]) for key in g.files
+                               if key.startswith(f"{name}_init_enc.")})
+    m.predictor.load_state_dict({key[len(f"{name}_init_pred."):]: torch.from_numpy(g[key]) for key in g.files
+                                 if key.startswith(f"{name}_init_pred.")})
+    with torch.no_grad():
+        m.emb.weight.copy_(torch.from_numpy(g[f"{name}_init_emb.weight"]))
+    return m, dict(enc=enc, k=k, B=B, weighted=weighted, clip=clip, loss=lossn)
+
+
+def _oracle_f64_losses(g, name, adj, N, lo, hi, w, epochs=3):
+    from tests.test_oracle import build_trainer_from_g8
+    (enc, pred, emb), c = build_trainer_from_g8(g, name, adj, N)
+    a = O.gcn_norm_csr(adj) if c["enc"] == "GCN" else adj
+    a = O.CSR(a.rowptr, a.col, None if a.val is None else a.val.double(), a.n_cols)
+    tr = O.TrainerRef(enc.double(), pred.double(), emb.double(), a, loss_name=c["loss"], lr=0.01,
+                      clip_norm=c["clip"])
+    pos = torch.stack([lo, hi], 1)
+    weight = (w / w.max()).double() if c["weighted"] else None
+    torch.manual_seed(4242)
+    out = []
+    for _ in range(epochs):
+        _, neg = O.pos_neg_edges_ref("train", {"train": {"edge": pos}}, num_nodes=N, neg_sampler_name="local",
+                                     num_neg=c["k"])
+        out.append(tr.train_epoch(pos, neg, c["B"], c["k"], weight))
+    return np.array(out)
+
+
 def test_training_trajectory_matches_reference_fixture(P, golden):
-    """plnlp_amd.BaseModel.train on the GPU vs the trajectory the REFERENCE's
-    BaseModel.train produced (fixture G8): same seeds -> same negatives, same
-    batches, same losses and final weights within fp32 tolerance."""
+    """plnlp_amd.BaseModel.train on the GPU vs the trajectory the REFERENCE's own
+    BaseModel.train produced on CPU (fixture G8): same seeds -> same negatives and
+    batches.  Epoch 1 must agree to fp32 round-off.  Later epochs are compared
+    through the float64 oracle: Adam divides by sqrt(v), which amplifies
+    round-off in near-zero gradients, so the reference's own fp32 run drifts from
+    exact arithmetic by ~1e-3 after a few steps -- the GPU run must stay within a
+    small multiple of THAT drift (it is a different, equally valid fp32 rounding)."""
     from tests.test_oracle import _toy_adj
     g = golden("g8_train_trajectory")
     N, lo, hi, w, adj = _toy_adj(g)
@@ -357,31 +395,80 @@ def test_training_trajectory_matches_reference_fixture(P, golden):
         pass
 
     for name in g["config_names"].tolist():
-        enc, pred, lossn, Lg, Lm, h, k, clip, weighted, B = g[f"{name}_cfg"].tolist()
-        Lg, Lm, h, k, B, clip, weighted = int(Lg), int(Lm), int(h), int(k), int(B), float(clip), bool(int(weighted))
-        m = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=clip, gnn_num_layers=Lg, mlp_num_layers=Lm,
-                        emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=N,
-                        num_node_feats=0, gnn_encoder_name=enc, predictor_name=pred, loss_func=lossn,
-                        optimizer_name="Adam", device="cuda", use_node_feats=False, train_node_emb=True)
-        m.encoder.load_state_dict({key[len(f"{name}_init_enc."):]: torch.from_numpy(g[key]) for key in g.files
-                                   if key.startswith(f"{name}_init_enc.")})
-        m.predictor.load_state_dict({key[len(f"{name}_init_pred."):]: torch.from_numpy(g[key]) for key in g.files
-                                     if key.startswith(f"{name}_init_pred.")})
-        with torch.no_grad():
-            m.emb.weight.copy_(torch.from_numpy(g[f"{name}_init_emb.weight"]))
+        m, c = _g8_model(P, g, name, N)
         data = Data()
-        a = O.gcn_norm_csr(adj) if enc == "GCN" else adj
-        data.adj_t = to_graph(P, a)
+        data.adj_t = to_graph(P, O.gcn_norm_csr(adj) if c["enc"] == "GCN" else adj)
         data.edge_index = torch.stack([torch.cat([hi, lo]), torch.cat([lo, hi])])
         split = {"train": {"edge": torch.stack([lo, hi], 1)}}
-        if weighted:
+        if c["weighted"]:
             split["train"]["weight"] = (w / w.max()).to(torch.float32)
         torch.manual_seed(4242)
-        losses = [m.train(data, split, B, "local", k) for _ in range(3)]
-        close(losses, g[f"{name}_losses"], rtol=2e-5, msg=name)
-        close(m.emb.weight, g[f"{name}_final_emb"], rtol=1e-3, atol=2e-5, msg=name)
-        for key, v in m.encoder.state_dict().items():
-            close(v, g[f"{name}_final_enc.{key}"], rtol=1e-3, atol=2e-5, msg=f"{name} {key}")
+        losses = np.array([m.train(data, split, c["B"], "local", c["k"]) for _ in range(3)])
+        ref32 = g[f"{name}_losses"]
+        ref64 = _oracle_f64_losses(g, name, adj, N, lo, hi, w)
+        close(losses[0], ref32[0], rtol=2e-5, msg=name)
+        drift = np.abs(ref32 - ref64)
+        assert (np.abs(losses - ref64) <= 4 * drift + 2e-5 * np.abs(ref64)).all(), (name, losses, ref32, ref64)
+
+
+def test_single_step_gradients_match_oracle(P, golden):
+    """one hot-loop iteration from identical weights: loss and EVERY gradient
+    (before clipping / Adam) against the float64 oracle"""
+    from tests.test_oracle import _toy_adj, build_trainer_from_g8
+    g = golden("g8_train_trajectory")
+    N, lo, hi, w, adj = _toy_adj(g)
+
+    class Data:
+        pass
+
+    for name in g["config_names"].tolist():
+        m, c = _g8_model(P, g, name, N)
+        (enc, pred, emb), _ = build_trainer_from_g8(g, name, adj, N)
+        a = O.gcn_norm_csr(adj) if c["enc"] == "GCN" else adj
+        data = Data()
+        data.adj_t = to_graph(P, a)
+        a64 = O.CSR(a.rowptr, a.col, None if a.val is None else a.val.double(), a.n_cols)
+        enc, pred, emb = enc.double(), pred.double(), emb.double()
+        pos = torch.stack([lo, hi], 1)[: c["B"]]
+        torch.manual_seed(1)
+        neg = O.local_neg_sample_ref(pos, N, c["k"])
+        weight = (w / w.max())[: c["B"]] if c["weighted"] else None
+        # oracle
+        hh = enc(emb.weight, a64)
+        ne = neg.reshape(-1, 2)
+        po, no = pred(hh[pos[:, 0]], hh[pos[:, 1]]), pred(hh[ne[:, 0]], hh[ne[:, 1]])
+        kind = O.select_loss(c["loss"], weight is not None)
+        lref = O.LOSSES[kind](po, no, c["k"], None if weight is None else weight.double())
+        lref.backward()
+        # GPU: forward/backward only
+        m.encoder.train()
+        m.predictor.train()
+        h = m.encoder(m.create_input_feat(data), data.adj_t)
+        src = torch.cat([pos[:, 0], ne[:, 0]]).cuda()
+        dst = torch.cat([pos[:, 1], ne[:, 1]]).cuda()
+        out = m._score(h, src, dst)
+        n = pos.size(0)
+        loss = m.calculate_loss(out[:n], out[n:], c["k"], margin=None if weight is None else weight.cuda())
+        loss.backward()
+        close(loss, lref, rtol=1e-5, msg=name)
+        close(out[:n].reshape(-1), po.reshape(-1), atol=1e-5, msg=name)
+        # the reference's own fp32 arithmetic (CPU oracle in float32) sets the yardstick: several
+        # gradients are exact zeros by symmetry that fp32 only reaches as cancellation noise
+        (enc32, pred32, emb32), _ = build_trainer_from_g8(g, name, adj, N)
+        h32 = enc32(emb32.weight, a)
+        l32 = O.LOSSES[kind](pred32(h32[pos[:, 0]], h32[pos[:, 1]]), pred32(h32[ne[:, 0]], h32[ne[:, 1]]),
+                             c["k"], weight)
+        l32.backward()
+        triples = [("emb", m.emb.weight, emb32.weight, emb.weight)]
+        gp = list(m.encoder.named_parameters()) + list(m.predictor.named_parameters())
+        p32 = list(enc32.parameters()) + list(pred32.parameters())
+        p64 = list(enc.parameters()) + list(pred.parameters())
+        triples += [(key, p, q32, q64) for (key, p), q32, q64 in zip(gp, p32, p64)]
+        for key, p, q32, q64 in triples:
+            err = float((p.grad.cpu().double() - q64.grad).abs().max())
+            yard = float((q32.grad.double() - q64.grad).abs().max())
+            scale = max(1.0, float(q64.grad.abs().max()))
+            assert err <= 4 * yard + 2e-6 * scale, (name, key, err, yard, scale)
 
 
 def test_eval_path_hits_parity(P):
@@ -439,3 +526,55 @@ def test_fused_adam_and_clip_match_torch(P):
         opt.step(clip={id(p): (sq, 2.0) for p in ps})
     for p, r in zip(ps, ref):
         close(p, r, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------- long rows / hot nodes ----
+@pytest.mark.parametrize("feat", [64, 256, 512])
+def test_row_split_hub_rows_match_oracle_and_unsplit(P, feat):
+    """rows far longer than the split threshold: chunked path == oracle, and the
+    dynamic (no-sync, upper-bound sized) tables give the same bits as the static ones"""
+    from plnlp_amd.graph import RowSplit
+    g = torch.Generator().manual_seed(feat)
+    n = 700
+    r = torch.cat([torch.randint(0, n, (4000,), generator=g), torch.full((3000,), 11), torch.full((257,), 12),
+                   torch.full((256,), 13), torch.full((1025,), 699)])
+    c = torch.randint(0, n, (r.numel(),), generator=g)
+    v = torch.rand(r.numel(), generator=g) + 0.1
+    csr = O.CSR.from_coo(r, c, v, n)
+    gr = to_graph(P, csr)
+    x = torch.randn(n, feat, generator=g)
+    sp = gr.row_split(256)
+    assert sp.n_long == 3 and sp.n_chunks >= 12 + 2 + 5
+    for reduce in ("sum", "mean"):
+        for use_values in (True, False):
+            ref = O.spmm(csr, x.double(), reduce, use_values)
+            a = P.ops.csr_aggregate(gr, dev(x), reduce, use_values)                 # static split
+            b = P.ops.csr_aggregate(gr, dev(x), reduce, use_values, split=None)     # no split
+            d = P.ops.csr_aggregate(gr, dev(x), reduce, use_values,
+                                    split=RowSplit.dynamic(gr.rowptr, gr.nnz, 256))  # dynamic tables
+            close(a, ref, atol=2e-4)
+            close(b, ref, atol=2e-4)
+            assert torch.equal(a, d)
+    # epilogue on split rows too
+    from plnlp_amd import _lib
+    bias = dev(torch.randn(feat))
+    a = P.ops.csr_aggregate(gr, dev(x), "sum", True, epilogue=_lib.make_epilogue(bias=bias, relu=True))
+    close(a, torch.relu(O.spmm(csr, x.double(), "sum", True) + bias.cpu().double()), atol=2e-4)
+
+
+def test_edge_backward_hot_node_dot(P):
+    """a node that appears in thousands of batch edges (random-walk pairs pile up on hubs)"""
+    g = torch.Generator().manual_seed(3)
+    n, e, feat = 1000, 20000, 256
+    h = torch.randn(n, feat, generator=g)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    src[:6000] = 5
+    dst[6000:7000] = 5
+    go = torch.randn(e, generator=g)
+    hd = h.double().requires_grad_(True)
+    ((hd[src] * hd[dst]).sum(-1) * go.double()).sum().backward()
+    inc = P.ops.Incidence(dev(src), dev(dst), n)
+    a = P.ops.edge_segment_bwd(dev(h), inc, dev(go))
+    close(a, hd.grad, atol=1e-3)
+    assert torch.equal(a, P.ops.edge_segment_bwd(dev(h), P.ops.Incidence(dev(src), dev(dst), n), dev(go)))
