@@ -52,6 +52,7 @@ struct GemmArgs {
     int64_t m; int n;
     int split_k;
     int64_t ws_stride;  // floats per split slice (m*n)
+    int64_t gm; int gn; // tile grid
 };
 
 // ---- global -> registers ------------------------------------------------------
@@ -134,8 +135,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // block -> tile: the gn column tiles of one row panel run back to back on ONE XCD (blocks
+    // are dealt to XCDs round-robin), so the A panel they share is fetched from HBM once
+    // and served from that XCD's L2 afterwards.  Pure performance: any mapping is correct.
+    int64_t mt; int nt;
+    {
+        const int64_t id = blockIdx.x, gn = g.gn, total = g.gm * gn;
+        const int64_t per_xcd = (total / (8 * gn)) * gn;     // whole row panels per XCD
+        const int64_t body = per_xcd * 8;
+        if (id < body) {
+            const int64_t xcd = id & 7, local = id >> 3;
+            const int64_t t = xcd * per_xcd + local;
+            mt = t / gn; nt = (int)(t % gn);
+        } else {
+            mt = id / gn; nt = (int)(id % gn);
+        }
+    }
+    const int64_t m0 = mt * BM;
+    const int n0 = nt * BN;
 
     // K-tile range of this split slice
     const int z = blockIdx.z;
@@ -231,15 +248,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + l31;
             if (col >= g.n) continue;
+            Epi e2 = epi;                       // bias is per column: fetch it once, not per element
+            float bcol = 0.f;
+            if (!raw && (epi.flags & PLNLP_EPI_BIAS)) { bcol = epi.bias[col]; e2.flags &= ~PLNLP_EPI_BIAS; }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int64_t row = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (row >= g.m) continue;
-                float v = acc[i][j][q];
+                float v = acc[i][j][q] + bcol;
                 float* p = cbase + row * ldc + col;
-                if (!raw && epi.flags) {
-                    const float prev = (epi.flags & PLNLP_EPI_ACCUM) ? *p : 0.f;
-                    v = epi_apply(epi, v, row, col, g.n, prev);
+                if (!raw && e2.flags) {
+                    const float prev = (e2.flags & PLNLP_EPI_ACCUM) ? *p : 0.f;
+                    v = epi_apply(e2, v, row, col, g.n, prev);
                 }
                 *p = v;
             }
@@ -307,7 +327,9 @@ extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_t
     } else {
         g.c = c; g.ldc = ldc;
     }
-    dim3 grid((unsigned)gm, (unsigned)gn, (unsigned)split_k);
+    if (gm * gn > 0x7FFFFFFF) return PLNLP_E_SHAPE;
+    g.gm = gm; g.gn = (int)gn;
+    dim3 grid((unsigned)(gm * gn), 1, (unsigned)split_k);
 #define PLNLP_GEMM(AT, BT) hipLaunchKernelGGL((gemm_f32_kernel<AT, BT>), grid, dim3(256), 0, s, g, e)
     if (a_trans) { if (b_trans) PLNLP_GEMM(true, true); else PLNLP_GEMM(true, false); }
     else         { if (b_trans) PLNLP_GEMM(false, true); else PLNLP_GEMM(false, false); }

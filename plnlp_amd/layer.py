@@ -87,16 +87,26 @@ class BaseGNN(torch.nn.Module):
         for conv in self.convs:
             conv.reset_parameters()
 
-    def forward(self, x, adj_t):
+    def forward(self, x, adj_t, fuse_output_gate: bool = False):
+        """fuse_output_gate (only meaningful for a 1-layer encoder, whose output IS a
+        relu+dropout result): returns (h, gate_scale) and leaves the derivative of that
+        final activation to the consumer's backward (EdgeDotFn), see ops._Act."""
         last = len(self.convs) - 1
+        out_act = None
         for i, conv in enumerate(self.convs):
             activated = i < last or self.num_layers == 1
             if isinstance(conv, (SAGEConv, GCNConv)):
-                x = conv(x, adj_t, _Act(True, self.dropout, self.training) if activated else None)
+                act = _Act(True, self.dropout, self.training) if activated else None
+                if fuse_output_gate and i == last and act is not None:
+                    act.gate_in_consumer = True
+                    out_act = act
+                x = conv(x, adj_t, act)
             else:  # foreign conv module: un-fused reference order
                 x = conv(x, adj_t)
                 if activated:
                     x = F.dropout(F.relu(x), p=self.dropout, training=self.training)
+        if fuse_output_gate:
+            return x, (out_act.scale if out_act is not None else 0.0)
         return x
 
 
@@ -247,8 +257,8 @@ class DotPredictor(torch.nn.Module):
     def forward(self, x_i, x_j):
         return torch.sum(x_i * x_j, dim=-1)
 
-    def score_edges(self, h, src, dst):
-        return ops.EdgeDotFn.apply(h, src, dst)
+    def score_edges(self, h, src, dst, gate_scale: float = 0.0):
+        return ops.EdgeDotFn.apply(h, src, dst, gate_scale)
 
 
 class BilinearPredictor(torch.nn.Module):

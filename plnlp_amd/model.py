@@ -23,7 +23,7 @@ from typing import Optional
 import torch
 
 from . import loss as loss_mod
-from .layer import (GCN, SAGE, WSAGE, BilinearPredictor, DotPredictor, MLPBilPredictor, MLPCatPredictor,
+from .layer import (GCN, SAGE, WSAGE, BaseGNN, BilinearPredictor, DotPredictor, MLPBilPredictor, MLPCatPredictor,
                     MLPDotPredictor, MLPPredictor, Transformer)
 from .optim import FusedAdam, group_sqnorm
 from .utils import batch_permutation, evaluate_hits, evaluate_mrr, get_pos_neg_edges
@@ -159,13 +159,22 @@ class BaseModel(object):
         """One iteration of the hot loop, model.py:148-167, on this rank's slice:
         pos_edge [b,2], neg_edge [b,k,2] (device).  Returns the detached local loss."""
         self.optimizer.zero_grad(set_to_none=True)
-        h = self.encoder(self.create_input_feat(data), data.adj_t)
         local = pos_edge.size(0)
+        # a 1-layer encoder ends in relu+dropout (layer.py:24-26); with the fused DOT scorer
+        # as the only consumer of h, that activation's backward rides in the scorer's
+        # gather-reduce epilogue instead of a separate pass over [N, h]
+        fuse_gate = (local > 0 and isinstance(self.encoder, BaseGNN) and self.encoder.num_layers == 1
+                     and isinstance(self.predictor, DotPredictor))
+        if fuse_gate:
+            h, gate_scale = self.encoder(self.create_input_feat(data), data.adj_t, fuse_output_gate=True)
+        else:
+            h, gate_scale = self.encoder(self.create_input_feat(data), data.adj_t), 0.0
         if local > 0:
             neg_flat = neg_edge.reshape(-1, 2)
             src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
             dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
-            out = self._score(h, src, dst)
+            out = (self.predictor.score_edges(h, src, dst, gate_scale) if fuse_gate
+                   else self._score(h, src, dst))
             loss = self.calculate_loss(out[:local], out[local:], num_neg, margin=weight_margin)
         else:                                    # empty slice: still take part in the reduction
             loss = h.sum() * 0.0

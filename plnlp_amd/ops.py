@@ -209,14 +209,15 @@ class Incidence:
         if n_nodes <= 0:
             raise ValueError("n_nodes")
         ends = torch.where(ends < 0, ends + n_nodes, ends)
-        order = torch.argsort(ends, stable=True)
+        sorted_ends, order = torch.sort(ends, stable=True)
         eid = torch.arange(e, dtype=torch.int32, device=src.device).repeat(2)
         other = torch.cat([dst, src])
         other = torch.where(other < 0, other + n_nodes, other).to(torch.int32)
         self.item_edge = eid[order].contiguous()
         self.item_other = other[order].contiguous()
-        self.seg_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=src.device)
-        self.seg_ptr[1:] = torch.cumsum(torch.bincount(ends, minlength=n_nodes), 0)
+        # seg_ptr[n] = first item of node n: binary search of the node ids in the sorted endpoints
+        self.seg_ptr = torch.searchsorted(
+            sorted_ends, torch.arange(n_nodes + 1, dtype=torch.int64, device=src.device)).contiguous()
         self.n_nodes = n_nodes
         # graph-like view so the aggregation kernel can walk it: row = node, col = other endpoint
         self.rowptr, self.col, self.val = self.seg_ptr, self.item_other, None
@@ -336,12 +337,16 @@ def clip_scale_(grad: torch.Tensor, sqnorm: torch.Tensor, max_norm: float) -> No
 # ---------------------------------------------------------- autograd wrappers ----
 class _Act:
     """relu + dropout description of one layer call"""
-    __slots__ = ("relu", "p", "seed")
+    __slots__ = ("relu", "p", "seed", "gate_in_consumer")
 
     def __init__(self, relu: bool, p: float, training: bool):
         self.relu = bool(relu)
         self.p = float(p) if training else 0.0
         self.seed = next_seed() if self.p > 0.0 else 0
+        # True when the op that consumes this layer's output folds the relu/dropout
+        # derivative into its own backward (EdgeDotFn with gate_scale): the incoming
+        # gradient is then already d/dz and this layer must not gate it again
+        self.gate_in_consumer = False
 
     @property
     def active(self):
@@ -356,7 +361,7 @@ def _act_backward(gy: torch.Tensor, y: torch.Tensor, act: _Act) -> torch.Tensor:
     """dz from dy for y = dropout(relu(z)): the kept, positive entries are exactly
     y > 0, so dz = dy * 1/(1-p) there and 0 elsewhere.  The reference never applies
     dropout without a preceding relu (layer.py:21-22,25-26,84-85); asserted."""
-    if not act.active:
+    if not act.active or act.gate_in_consumer:
         return gy
     assert act.relu, "dropout without relu is not used by the reference path"
     return gate(gy, y, act.scale)
@@ -410,10 +415,14 @@ class SAGEConvFn(torch.autograd.Function):
         if need[3]:
             gwr = gemm([(dz, x)], True, False)
         if need[0]:
-            gx = gemm([(dz, w_r)], False, False)            # root path: dz @ Wr
-            gagg = gemm([(dz, w_l)], False, False)          # dz @ Wl
+            # both data gradients in ONE GEMM: [gx | gagg] = dz @ [Wr | Wl]  (dz read once)
+            cin = w_r.shape[1]
+            both = gemm([(dz, torch.cat([w_r, w_l], dim=1))], False, False)
+            gx, gagg = both[:, :cin], both[:, cin:]
             csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(),
                           out=gx, epilogue=L.make_epilogue(accumulate=True))
+            if gx.stride(0) != cin:
+                gx = gx.contiguous()
         return gx, gwl, gbl, gwr, None, None
 
 
@@ -485,20 +494,28 @@ class EdgeDotFn(torch.autograd.Function):
     (model.py:155-156 + layer.py:174-176 in one pass)."""
 
     @staticmethod
-    def forward(ctx, h, src, dst):
+    def forward(ctx, h, src, dst, gate_scale=0.0):
+        """gate_scale > 0: h is the output of relu(+dropout, scale = 1/(1-p)) and the returned
+        gradient is taken w.r.t. the pre-activation (h > 0 ? g * gate_scale : 0), folding the
+        activation backward into the gather-reduce epilogue (no separate pass over [N, F])."""
         h = _f32c(h)
         ctx.save_for_backward(h, src, dst)
+        ctx.gate_scale = float(gate_scale)
         return edge_dot_fwd(h, src, dst)
 
     @staticmethod
     def backward(ctx, g):
         h, src, dst = ctx.saved_tensors
         g = g.contiguous()
+        gs = ctx.gate_scale
         if EDGE_BACKWARD["mode"] == "segment":
-            gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g)
+            epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
+            gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g, epilogue=epi)
         else:
             gh = edge_scatter_bwd(h, src, dst, g)
-        return gh, None, None
+            if gs > 0.0:
+                gh = gate(gh, h, gs)
+        return gh, None, None, None
 
 
 class EdgeHadamardFn(torch.autograd.Function):

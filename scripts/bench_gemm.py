@@ -1,0 +1,45 @@
+"""Micro-benchmark of the f32-MFMA GEMM (K4) on the shapes of the hot path."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import plnlp_amd as P
+from plnlp_amd import _lib
+from bench import time_kernel
+
+SHAPES = {
+    # name: (M, N, K-segments, a_trans, b_trans, epilogue)
+    "collab_fwd": (235868, 256, [256, 256], False, True, True),
+    "collab_dgrad": (235868, 256, [256], False, False, False),
+    "collab_wgrad": (256, 256, [235868], True, False, False),
+    "ddi_pred_fwd": (262144, 512, [512], False, True, True),
+    "ddi_pred_wgrad": (512, 512, [262144], True, False, False),
+    "ddi_enc_fwd": (4267, 512, [512, 512], False, True, True),
+    "square4k": (4096, 4096, [4096], False, True, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    for name in args.shapes.split(","):
+        m, n, ks, at, bt, epi = SHAPES[name]
+        segs = []
+        for k in ks:
+            a = torch.randn((k, m) if at else (m, k), device=dev)
+            b = torch.randn((n, k) if bt else (k, n), device=dev)
+            segs.append((a, b))
+        bias = torch.randn(n, device=dev)
+        e = _lib.make_epilogue(bias=bias, relu=True, dropout_p=0.3, dropout_seed=1) if epi else None
+        out = torch.empty(m, n, device=dev)
+        t = time_kernel(lambda: P.ops.gemm(segs, at, bt, out=out, epilogue=e), iters=args.iters)
+        flop = 2.0 * m * n * sum(ks)
+        print(json.dumps({"shape": name, "M": m, "N": n, "K": ks, "ms": round(t * 1e3, 4),
+                          "TFLOPs": round(flop / t / 1e12, 2), "frac_of_157": round(flop / t / 157.3e12, 3)}), flush=True)
+        del segs, out
+
+
+if __name__ == "__main__":
+    main()
