@@ -31,7 +31,7 @@ from .utils import batch_permutation, evaluate_hits, evaluate_mrr, get_pos_neg_e
 
 class BaseModel(object):
     """plnlp/model.py:9-226.  Constructor arguments as the reference; keyword-only
-    extras: `modules=(encoder, predictor)` to inject pre-built modules,
+    extras: `modules=(encoder, predictor[, loss_fn])` to inject pre-built modules,
     `process_group` / `dp_scaling` for data parallelism."""
 
     def __init__(self, lr, dropout, grad_clip_norm, gnn_num_layers, mlp_num_layers, emb_hidden_channels,
@@ -54,8 +54,11 @@ class BaseModel(object):
         if self.emb is not None:
             self.emb = self.emb.to(self.device)
 
+        self._loss_override = None
         if modules is not None:
             self.encoder, self.predictor = modules[0].to(self.device), modules[1].to(self.device)
+            if len(modules) > 2:          # (pos_out, neg_out, num_neg, margin) -> 0-d loss
+                self._loss_override = modules[2]
         else:
             self.encoder = create_gnn_layer(input_channels=self.input_channels,
                                             hidden_channels=gnn_hidden_channels, num_layers=gnn_num_layers,
@@ -103,6 +106,8 @@ class BaseModel(object):
     def calculate_loss(self, pos_out, neg_out, num_neg, margin=None):
         """model.py:107-126: names that need a per-edge weight silently become
         plain auc_loss when the split has none; unknown names are auc_loss too."""
+        if self._loss_override is not None:
+            return self._loss_override(pos_out, neg_out, num_neg, margin)
         fn, weighted = loss_mod.BY_NAME.get(self.loss_func_name, (loss_mod.auc_loss, False))
         if self.loss_func_name == 'CE':
             return fn(pos_out, neg_out)
@@ -207,7 +212,7 @@ class BaseModel(object):
         batches = batch_permutation(pos_train_edge.size(0), global_batch, True)
         order = torch.cat(batches).to(self.device) if batches else None
 
-        loss_acc = torch.zeros((), dtype=torch.float32, device=self.device)
+        loss_acc = torch.zeros((), dtype=torch.float64, device=self.device)   # Python-float accumulation in the reference
         total_examples = 0
         start = 0
         for b in batches:
@@ -221,7 +226,7 @@ class BaseModel(object):
                 perm = perm_all
             weight_margin = edge_weight_margin[perm] if edge_weight_margin is not None else None
             loss = self.train_step(data, pos_train_edge[perm], neg_train_edge[perm], num_neg, weight_margin)
-            loss_acc += loss * n_b
+            loss_acc += loss.double() * n_b
             total_examples += n_b
 
         if world > 1:
