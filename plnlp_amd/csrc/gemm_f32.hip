@@ -30,6 +30,9 @@
 namespace plnlp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// staging registers use the native vector type: HIP's float4 struct is copied with memcpy, which
+// kept the staged tile in scratch memory instead of VGPRs
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDK = BK + 4;   // K-contiguous tile row stride (floats)
@@ -52,30 +55,31 @@ struct GemmArgs {
     int64_t m; int n;
     int split_k;
     int64_t ws_stride;  // floats per split slice (m*n)
-    int64_t gm; int gn; // tile grid
+    int64_t gm; int gn; // tile grid of this launch (a rectangular region of the full tile grid)
+    int64_t mt0; int nt0; // first row / column tile of the region
 };
 
 // ---- global -> registers ------------------------------------------------------
 // K-contiguous operand: rows [row0, row0+128) x k [k0, k0+32); thread t loads
 // float4 at (row0 + (t>>3) + 32p, k0 + 4*(t&7)), p = 0..3.
 template <bool FULL>
-__device__ __forceinline__ void load_kc(float4 (&r)[4], const float* __restrict__ base, int64_t ld,
+__device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
     const int kq = (t & 7) * 4 + k0;
     if constexpr (FULL) {  // interior tile: 4 independent 16-byte loads, no guards, no waits between them
         const float* q = base + (row0 + (t >> 3)) * ld + kq;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const float4*>(q + (int64_t)(32 * p) * ld);
+        for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const f32x4*>(q + (int64_t)(32 * p) * ld);
         return;
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int64_t row = row0 + (t >> 3) + 32 * p;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row < nrows) {
             const float* q = base + row * ld + kq;
             if (vec && kq + 3 < kdim) {
-                v = *reinterpret_cast<const float4*>(q);
+                v = *reinterpret_cast<const f32x4*>(q);
             } else {
                 if (kq + 0 < kdim) v.x = q[0];
                 if (kq + 1 < kdim) v.y = q[1];
@@ -89,23 +93,23 @@ __device__ __forceinline__ void load_kc(float4 (&r)[4], const float* __restrict_
 // row-contiguous operand stored [kdim][nrows]: k [k0,k0+32) x rows [row0,row0+128);
 // thread t loads float4 at (k0 + (t>>5) + 8p, row0 + 4*(t&31)).
 template <bool FULL>
-__device__ __forceinline__ void load_rc(float4 (&r)[4], const float* __restrict__ base, int64_t ld,
+__device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
     const int64_t rq = row0 + (t & 31) * 4;
     if constexpr (FULL) {
         const float* q = base + (int64_t)(k0 + (t >> 5)) * ld + rq;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const float4*>(q + (int64_t)(8 * p) * ld);
+        for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const f32x4*>(q + (int64_t)(8 * p) * ld);
         return;
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int k = k0 + (t >> 5) + 8 * p;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (k < kdim) {
             const float* q = base + (int64_t)k * ld + rq;
             if (vec && rq + 3 < nrows) {
-                v = *reinterpret_cast<const float4*>(q);
+                v = *reinterpret_cast<const f32x4*>(q);
             } else {
                 if (rq + 0 < nrows) v.x = q[0];
                 if (rq + 1 < nrows) v.y = q[1];
@@ -116,18 +120,93 @@ __device__ __forceinline__ void load_rc(float4 (&r)[4], const float* __restrict_
         r[p] = v;
     }
 }
-__device__ __forceinline__ void store_kc(float* __restrict__ tile, const float4 (&r)[4], int t) {
+__device__ __forceinline__ void store_kc(float* __restrict__ tile, const f32x4 (&r)[4], int t) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
-        *reinterpret_cast<float4*>(tile + ((t >> 3) + 32 * p) * LDK + (t & 7) * 4) = r[p];
+        *reinterpret_cast<f32x4*>(tile + ((t >> 3) + 32 * p) * LDK + (t & 7) * 4) = r[p];
 }
-__device__ __forceinline__ void store_rc(float* __restrict__ tile, const float4 (&r)[4], int t) {
+__device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (&r)[4], int t) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
-        *reinterpret_cast<float4*>(tile + ((t >> 5) + 8 * p) * LDR + (t & 31) * 4) = r[p];
+        *reinterpret_cast<f32x4*>(tile + ((t >> 5) + 8 * p) * LDR + (t & 31) * 4) = r[p];
 }
 
-template <bool A_T, bool B_T>
+// one K-tile of both operands, global -> registers.  The segment is picked with selects (no
+// runtime-indexed struct access: that sent the staging registers to scratch).
+template <bool A_T, bool B_T, bool FAST>
+__device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[4], f32x4 (&rb)[4],
+                                          int64_t m0, int n0, int t) {
+    const bool s1 = (g.nseg > 1) && (tile >= g.tiles0);
+    const float* a = s1 ? g.seg[1].a : g.seg[0].a;
+    const float* b = s1 ? g.seg[1].b : g.seg[0].b;
+    const int64_t lda = s1 ? g.seg[1].lda : g.seg[0].lda;
+    const int64_t ldb = s1 ? g.seg[1].ldb : g.seg[0].ldb;
+    const int kdim = s1 ? g.seg[1].k : g.seg[0].k;
+    const int avec = s1 ? g.seg[1].a_vec : g.seg[0].a_vec;
+    const int bvec = s1 ? g.seg[1].b_vec : g.seg[0].b_vec;
+    const int k0 = (tile - (s1 ? g.tiles0 : 0)) * BK;
+    if constexpr (A_T) load_rc<FAST>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+    else               load_kc<FAST>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+    if constexpr (B_T) load_kc<FAST>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
+    else               load_rc<FAST>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
+}
+
+template <bool A_T, bool B_T, bool FAST>
+__device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
+                                       int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
+                                       int h) {
+    f32x4 ra[4], rb[4];
+    if (tb < te) load_tile<A_T, B_T, FAST>(g, tb, ra, rb, m0, n0, t);
+    for (int tile = tb; tile < te; ++tile) {
+        const int buf = (tile - tb) & 1;
+        float* at = lds + buf * TILE_FLOATS;
+        float* bt = lds + (2 + buf) * TILE_FLOATS;
+        if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
+        if constexpr (B_T) store_kc(bt, rb, t); else store_rc(bt, rb, t);
+        __syncthreads();
+        if (tile + 1 < te) load_tile<A_T, B_T, FAST>(g, tile + 1, ra, rb, m0, n0, t);
+
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + l31;
+                if constexpr (A_T) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) a[i][s] = at[(8 * q + 4 * h + s) * LDR + row];
+                } else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(at + row * LDK + 8 * q + 4 * h);
+                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + l31;
+                if constexpr (B_T) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(bt + row * LDK + 8 * q + 4 * h);
+                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b[j][s] = bt[(8 * q + 4 * h + s) * LDR + row];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+// FAST = every tile of the launch is interior and 16-byte loadable (pure dwordx4 loads, nothing
+// between their issue and the MFMAs); the guarded form covers edge strips, ragged K, unaligned
+// operands.  They are separate kernels on purpose: as two paths of one kernel the compiler merged
+// the MFMA bodies and passed the staged tile through scratch, waiting on every load first.
+template <bool A_T, bool B_T, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
 
@@ -151,8 +230,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
             mt = id / gn; nt = (int)(id % gn);
         }
     }
-    const int64_t m0 = mt * BM;
-    const int n0 = nt * BN;
+    const int64_t m0 = (mt + g.mt0) * BM;
+    const int n0 = (nt + g.nt0) * BN;
 
     // K-tile range of this split slice
     const int z = blockIdx.z;
@@ -168,74 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    float4 ra[4], rb[4];
-    auto gload = [&](int tile) {
-        const int sidx = (tile >= g.tiles0 && g.nseg > 1) ? 1 : 0;
-        const Seg& s = g.seg[sidx];
-        const int k0 = (tile - (sidx ? g.tiles0 : 0)) * BK;
-        const bool kfull = k0 + BK <= s.k;
-        const bool afull = kfull && s.a_vec && (m0 + BM <= g.m);      // block-uniform
-        const bool bfull = kfull && s.b_vec && (n0 + BN <= g.n);
-        if (afull) {
-            if constexpr (A_T) load_rc<true>(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
-            else               load_kc<true>(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
-        } else {
-            if constexpr (A_T) load_rc<false>(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
-            else               load_kc<false>(ra, s.a, s.lda, m0, g.m, k0, s.k, s.a_vec, t);
-        }
-        if (bfull) {
-            if constexpr (B_T) load_kc<true>(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
-            else               load_rc<true>(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
-        } else {
-            if constexpr (B_T) load_kc<false>(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
-            else               load_rc<false>(rb, s.b, s.ldb, n0, g.n, k0, s.k, s.b_vec, t);
-        }
-    };
-
-    if (tb < te) gload(tb);
-    for (int tile = tb; tile < te; ++tile) {
-        const int buf = (tile - tb) & 1;
-        float* at = lds + buf * TILE_FLOATS;
-        float* bt = lds + (2 + buf) * TILE_FLOATS;
-        if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
-        if constexpr (B_T) store_kc(bt, rb, t); else store_rc(bt, rb, t);
-        __syncthreads();
-        if (tile + 1 < te) gload(tile + 1);
-
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float a[2][4], b[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wm * 64 + i * 32 + l31;
-                if constexpr (A_T) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) a[i][s] = at[(8 * q + 4 * h + s) * LDR + row];
-                } else {
-                    const float4 v = *reinterpret_cast<const float4*>(at + row * LDK + 8 * q + 4 * h);
-                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wn * 64 + j * 32 + l31;
-                if constexpr (B_T) {
-                    const float4 v = *reinterpret_cast<const float4*>(bt + row * LDK + 8 * q + 4 * h);
-                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) b[j][s] = bt[(8 * q + 4 * h + s) * LDR + row];
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-        }
-    }
+    k_loop<A_T, B_T, FAST>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
 
     // ---- write back: C/D map of the 32x32 MFMA: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
     float* cbase = g.c;
@@ -328,13 +340,27 @@ extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_t
         g.c = c; g.ldc = ldc;
     }
     if (gm * gn > 0x7FFFFFFF) return PLNLP_E_SHAPE;
-    g.gm = gm; g.gn = (int)gn;
-    dim3 grid((unsigned)(gm * gn), 1, (unsigned)split_k);
-#define PLNLP_GEMM(AT, BT) hipLaunchKernelGGL((gemm_f32_kernel<AT, BT>), grid, dim3(256), 0, s, g, e)
-    if (a_trans) { if (b_trans) PLNLP_GEMM(true, true); else PLNLP_GEMM(true, false); }
-    else         { if (b_trans) PLNLP_GEMM(false, true); else PLNLP_GEMM(false, false); }
+    bool can_fast = true;
+    for (int si = 0; si < n_seg; ++si)
+        can_fast = can_fast && g.seg[si].a_vec && g.seg[si].b_vec && (g.seg[si].k % BK == 0);
+    const int64_t m_full = can_fast ? m / BM : 0;
+    const int64_t n_full = can_fast ? n / BN : 0;
+    auto launch = [&](bool fast, int64_t mt0, int64_t nt0, int64_t rm, int64_t rn) -> int {
+        if (rm <= 0 || rn <= 0) return 0;
+        GemmArgs r = g;
+        r.mt0 = mt0; r.nt0 = (int)nt0; r.gm = rm; r.gn = (int)rn;
+        dim3 grid((unsigned)(rm * rn), 1, (unsigned)split_k);
+#define PLNLP_GEMM(AT, BT)                                                                             \
+        if (fast) hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, true>), grid, dim3(256), 0, s, r, e);    \
+        else      hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, false>), grid, dim3(256), 0, s, r, e)
+        if (a_trans) { if (b_trans) { PLNLP_GEMM(true, true); } else { PLNLP_GEMM(true, false); } }
+        else         { if (b_trans) { PLNLP_GEMM(false, true); } else { PLNLP_GEMM(false, false); } }
 #undef PLNLP_GEMM
-    if (int rc = launch_status()) return rc;
+        return launch_status();
+    };
+    if (int rc = launch(true, 0, 0, m_full, n_full)) return rc;                     // interior
+    if (int rc = launch(false, m_full, 0, gm - m_full, gn)) return rc;             // bottom strip
+    if (int rc = launch(false, 0, n_full, m_full, gn - n_full)) return rc;         // right strip
     if (split_k > 1) {
         const int64_t total = m * n;
         int64_t blocks = (total + 255) / 256;

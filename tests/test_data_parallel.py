@@ -47,6 +47,7 @@ def _run(rank, world, port, batch, scaling, loss_name, predictor, out_q):
     if world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         pg = dist.group.WORLD
+    torch.set_num_threads(1)
     torch.manual_seed(100)                       # same init + same index streams on every rank
     adj, pos, w = _problem()
     # float64 compute modules: the equivalence under test is exact in real arithmetic; in fp32 the
@@ -74,6 +75,8 @@ def _run(rank, world, port, batch, scaling, loss_name, predictor, out_q):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        torch.set_num_threads(os.cpu_count() or 1)      # do not leak the setting into other tests
     return losses, flat
 
 
@@ -94,7 +97,6 @@ def _spawn(world, batch, scaling, loss_name, predictor):
 
 @pytest.mark.parametrize("scaling,loss_name,predictor", [("strong", "AUC", "MLP"), ("weak", "WeightedHingeAUC", "DOT")])
 def test_two_ranks_equal_one_process(scaling, loss_name, predictor):
-    torch.set_num_threads(1)
     B = 64
     single_batch = B if scaling == "strong" else 2 * B       # weak: global batch = world * B
     ref_losses, ref_flat = _run(0, 1, 0, single_batch, scaling, loss_name, predictor, None)
@@ -108,7 +110,6 @@ def test_two_ranks_equal_one_process(scaling, loss_name, predictor):
 def test_uneven_last_batch_and_empty_slice():
     """a last global batch smaller than the world size leaves a rank with no edges;
     it must still join the reduction"""
-    torch.set_num_threads(1)
     adj, pos, w = _problem()
     n = pos.size(0)
     B = n - 1                      # second global batch has exactly 1 edge -> rank 1 gets none
