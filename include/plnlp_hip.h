@@ -105,9 +105,10 @@ int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
  * Replaces F.linear / addmm inside SAGEConv (lin_l(agg)+lin_r(x) as ONE
  * concat-K product, n_seg = 2), GCNConv.lin and MLPPredictor.lins
  * (plnlp/layer.py:36,45,83,86) and their autograd dgrad / wgrad GEMMs.
- * split_k > 1: partial products go to `workspace` ([split_k, M, N] floats) and
- * are reduced in fixed order by a second kernel (deterministic); the epilogue
- * runs in that second kernel.
+ * split_k > 1: partial products go to `workspace` ([split_k, M, N] floats; pass
+ * [split_k + 1, M, N] to let a ragged K tail run as its own slice) and are reduced
+ * in fixed order by a second kernel (deterministic); the epilogue runs in that
+ * second kernel.
  */
 typedef struct plnlp_gemm_operand {
     const float* a; int64_t lda;

@@ -57,6 +57,7 @@ struct GemmArgs {
     int64_t ws_stride;  // floats per split slice (m*n)
     int64_t gm; int gn; // tile grid of this launch (a rectangular region of the full tile grid)
     int64_t mt0; int nt0; // first row / column tile of the region
+    int z0;               // first split-K slice this launch writes
 };
 
 // ---- global -> registers ------------------------------------------------------
@@ -133,7 +134,9 @@ __device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (
 
 // one K-tile of both operands, global -> registers.  The segment is picked with selects (no
 // runtime-indexed struct access: that sent the staging registers to scratch).
-template <bool A_T, bool B_T, bool FAST>
+// MODE 0: guarded loads everywhere (unaligned operands); 1: fast loads, every K-tile full;
+// 2: fast loads, except a ragged last K-tile of a segment which takes the guarded (zero-filling) form
+template <bool A_T, bool B_T, int MODE>
 __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[4], f32x4 (&rb)[4],
                                           int64_t m0, int n0, int t) {
     const bool s1 = (g.nseg > 1) && (tile >= g.tiles0);
@@ -145,18 +148,26 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
     const int avec = s1 ? g.seg[1].a_vec : g.seg[0].a_vec;
     const int bvec = s1 ? g.seg[1].b_vec : g.seg[0].b_vec;
     const int k0 = (tile - (s1 ? g.tiles0 : 0)) * BK;
-    if constexpr (A_T) load_rc<FAST>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-    else               load_kc<FAST>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-    if constexpr (B_T) load_kc<FAST>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
-    else               load_rc<FAST>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
+    const bool full = (MODE == 1) || (MODE == 2 && k0 + BK <= kdim);
+    if (MODE != 0 && full) {
+        if constexpr (A_T) load_rc<true>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+        else               load_kc<true>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+        if constexpr (B_T) load_kc<true>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
+        else               load_rc<true>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
+    } else {
+        if constexpr (A_T) load_rc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+        else               load_kc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+        if constexpr (B_T) load_kc<false>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
+        else               load_rc<false>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
+    }
 }
 
-template <bool A_T, bool B_T, bool FAST>
+template <bool A_T, bool B_T, int MODE>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
                                        int h) {
     f32x4 ra[4], rb[4];
-    if (tb < te) load_tile<A_T, B_T, FAST>(g, tb, ra, rb, m0, n0, t);
+    if (tb < te) load_tile<A_T, B_T, MODE>(g, tb, ra, rb, m0, n0, t);
     for (int tile = tb; tile < te; ++tile) {
         const int buf = (tile - tb) & 1;
         float* at = lds + buf * TILE_FLOATS;
@@ -164,7 +175,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
         if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
         if constexpr (B_T) store_kc(bt, rb, t); else store_rc(bt, rb, t);
         __syncthreads();
-        if (tile + 1 < te) load_tile<A_T, B_T, FAST>(g, tile + 1, ra, rb, m0, n0, t);
+        if (tile + 1 < te) load_tile<A_T, B_T, MODE>(g, tile + 1, ra, rb, m0, n0, t);
 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -202,11 +213,9 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
     }
 }
 
-// FAST = every tile of the launch is interior and 16-byte loadable (pure dwordx4 loads, nothing
-// between their issue and the MFMAs); the guarded form covers edge strips, ragged K, unaligned
-// operands.  They are separate kernels on purpose: as two paths of one kernel the compiler merged
-// the MFMA bodies and passed the staged tile through scratch, waiting on every load first.
-template <bool A_T, bool B_T, bool FAST>
+// MODE (see load_tile): separate kernels so the hot loop of the aligned case carries no guarded
+// code at all (pure dwordx4 loads, nothing between their issue and the MFMAs).
+template <bool A_T, bool B_T, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
 
@@ -247,13 +256,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    k_loop<A_T, B_T, FAST>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
+    k_loop<A_T, B_T, MODE>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
 
     // ---- write back: C/D map of the 32x32 MFMA: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
     float* cbase = g.c;
     int64_t ldc = g.ldc;
     const bool raw = g.split_k > 1;
-    if (raw) { cbase = g.c + (int64_t)z * g.ws_stride; ldc = g.n; }
+    if (raw) { cbase = g.c + (int64_t)(z + g.z0) * g.ws_stride; ldc = g.n; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -340,32 +349,61 @@ extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_t
         g.c = c; g.ldc = ldc;
     }
     if (gm * gn > 0x7FFFFFFF) return PLNLP_E_SHAPE;
-    bool can_fast = true;
-    for (int si = 0; si < n_seg; ++si)
-        can_fast = can_fast && g.seg[si].a_vec && g.seg[si].b_vec && (g.seg[si].k % BK == 0);
-    const int64_t m_full = can_fast ? m / BM : 0;
-    const int64_t n_full = can_fast ? n / BN : 0;
-    auto launch = [&](bool fast, int64_t mt0, int64_t nt0, int64_t rm, int64_t rn) -> int {
-        if (rm <= 0 || rn <= 0) return 0;
-        GemmArgs r = g;
-        r.mt0 = mt0; r.nt0 = (int)nt0; r.gm = rm; r.gn = (int)rn;
-        dim3 grid((unsigned)(rm * rn), 1, (unsigned)split_k);
-#define PLNLP_GEMM(AT, BT)                                                                             \
-        if (fast) hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, true>), grid, dim3(256), 0, s, r, e);    \
-        else      hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, false>), grid, dim3(256), 0, s, r, e)
-        if (a_trans) { if (b_trans) { PLNLP_GEMM(true, true); } else { PLNLP_GEMM(true, false); } }
-        else         { if (b_trans) { PLNLP_GEMM(false, true); } else { PLNLP_GEMM(false, false); } }
-#undef PLNLP_GEMM
+    // aligned operands take the fast loaders (edge rows clamped).  A ragged K tail is one guarded tile
+    // (MODE 2); under split-K it is peeled into its own extra slice so the hot slices stay MODE 1.
+    bool aligned = true, ragged = false;
+    for (int si = 0; si < n_seg; ++si) {
+        aligned = aligned && g.seg[si].a_vec && g.seg[si].b_vec;
+        ragged = ragged || (g.seg[si].k % BK != 0);
+    }
+    if (a_trans) aligned = aligned && (m % 4 == 0) && m >= 4;    // row-contiguous operands move 4 rows per load
+    if (!b_trans) aligned = aligned && (n % 4 == 0) && n >= 4;
+    int mode = !aligned ? 0 : (ragged ? 2 : 1);
+    int reduce_slices = split_k;
+    GemmArgs tail{};
+    bool peel = false;
+    if (mode == 2 && split_k > 1 && n_seg == 1 && g.seg[0].k >= 2 * BK &&
+        workspace_floats >= (int64_t)(split_k + 1) * m * n) {
+        const int kfull = (g.seg[0].k / BK) * BK;
+        tail = g;
+        tail.seg[0].a = a_trans ? g.seg[0].a + (int64_t)kfull * g.seg[0].lda : g.seg[0].a + kfull;
+        tail.seg[0].b = b_trans ? g.seg[0].b + kfull : g.seg[0].b + (int64_t)kfull * g.seg[0].ldb;
+        tail.seg[0].k = g.seg[0].k - kfull;
+        tail.seg[0].a_vec = tail.seg[0].b_vec = 0;
+        tail.tiles0 = tail.tiles_total = 1;
+        tail.split_k = split_k + 1;     // > 1: raw write into the workspace
+        tail.z0 = split_k;
+        g.seg[0].k = kfull;
+        g.tiles0 = g.tiles_total = kfull / BK;
+        if (split_k > g.tiles_total) split_k = g.tiles_total;
+        g.split_k = split_k;
+        reduce_slices = split_k + 1;
+        tail.z0 = split_k;
+        mode = 1;
+        peel = true;
+    }
+    g.mt0 = 0; g.nt0 = 0; g.gm = gm; g.gn = (int)gn; g.z0 = 0;
+    tail.mt0 = 0; tail.nt0 = 0; tail.gm = gm; tail.gn = (int)gn;
+    auto launch = [&](const GemmArgs& ga, int md, int slices) -> int {
+        dim3 grid((unsigned)(gm * gn), 1, (unsigned)slices);
+#define PLNLP_GEMM_M(AT, BT)                                                                              \
+        switch (md) {                                                                                    \
+            case 1: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 1>), grid, dim3(256), 0, s, ga, e); break;   \
+            case 2: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 2>), grid, dim3(256), 0, s, ga, e); break;   \
+            default: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 0>), grid, dim3(256), 0, s, ga, e); break;  \
+        }
+        if (a_trans) { if (b_trans) { PLNLP_GEMM_M(true, true) } else { PLNLP_GEMM_M(true, false) } }
+        else         { if (b_trans) { PLNLP_GEMM_M(false, true) } else { PLNLP_GEMM_M(false, false) } }
+#undef PLNLP_GEMM_M
         return launch_status();
     };
-    if (int rc = launch(true, 0, 0, m_full, n_full)) return rc;                     // interior
-    if (int rc = launch(false, m_full, 0, gm - m_full, gn)) return rc;             // bottom strip
-    if (int rc = launch(false, 0, n_full, m_full, gn - n_full)) return rc;         // right strip
+    if (int rc = launch(g, mode, split_k)) return rc;
+    if (peel) { if (int rc = launch(tail, 0, 1)) return rc; }
     if (split_k > 1) {
         const int64_t total = m * n;
         int64_t blocks = (total + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, split_k,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, reduce_slices,
                            g.ws_stride, c, ldc, m, (int)n, e);
         return launch_status();
     }

@@ -124,7 +124,7 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     split_k = max(1, min(split_k, ktiles))
     ws = None
     if split_k > 1:
-        ws = torch.empty(split_k * m * n, dtype=torch.float32, device=out.device)
+        ws = torch.empty((split_k + 1) * m * n, dtype=torch.float32, device=out.device)   # +1: ragged-K tail slice
     rc = lib.plnlp_gemm_f32(ops, len(segs), int(a_trans), int(b_trans), out.data_ptr(), _ld(out), m, n,
                             C.byref(epilogue) if epilogue is not None else None, split_k,
                             L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr())
