@@ -59,7 +59,7 @@ typedef struct plnlp_epilogue {
 
 /* ---- K1/K2: CSR neighbour gather-and-reduce --------------------------------
  * out[r, :] = EPI( red_{e in [rowptr[r], rowptr[r+1])} w_e * x[col[e], :] )
- *   w_e = (val ? val[e] : 1) * (src_scale ? src_scale[col[e]] : 1)
+ *   w_e = (val ? val[val_index ? val_index[e] : e] : 1) * (src_scale ? src_scale[col[e]] : 1)
  *   reduce = PLNLP_REDUCE_SUM | PLNLP_REDUCE_MEAN (divide by max(rowlen,1))
  * Replaces torch_sparse.matmul(adj_t, x, reduce) reached from SAGEConv /
  * GCNConv (plnlp/layer.py:20,23,36,45) and, run on the transposed CSR, its
@@ -76,20 +76,30 @@ typedef struct plnlp_epilogue {
  * for the per-step incidence lists): see plnlp_amd/graph.py::RowSplit.
  */
 typedef struct plnlp_row_split {
-    int64_t        threshold;        /* >= 64                                           */
-    int64_t        n_long;           /* entries in long_rows (slots holding -1 are idle) */
-    const int64_t* long_rows;        /* [n_long] row ids                                 */
-    const int64_t* chunk_ptr;        /* [n_long+1] first chunk of each long row          */
-    int64_t        n_chunks;         /* entries in chunk_long (>= chunk_ptr[n_long])     */
-    const int32_t* chunk_long;       /* [n_chunks] slot in long_rows owning the chunk    */
-    float*         workspace;        /* [n_chunks, feat], 16-byte aligned                */
+    int64_t        threshold;        /* >= 64                                            */
+    int64_t        n_long;           /* entries in long_rows (slots holding -1 are idle)  */
+    const int64_t* long_rows;        /* [n_long] row ids                                  */
+    const int64_t* chunk_beg;        /* [n_long] first chunk id of each long row          */
+    const int32_t* chunk_cnt;        /* [n_long] chunks of each long row                  */
+    int64_t        n_chunks;         /* entries in chunk_long                             */
+    const int32_t* chunk_long;       /* [n_chunks] slot in long_rows owning the chunk, -1 = idle */
+    float*         workspace;        /* [n_chunks, feat], 16-byte aligned                 */
     int64_t        workspace_floats;
 } plnlp_row_split;
+
+/* Build the tables above on the device (no host sync): capacities are upper bounds
+ * (a CSR with nnz entries has at most nnz/threshold long rows and nnz/threshold + that
+ * many chunks); counters[0..2] receive {long rows, chunks, overflow flag}. */
+int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int64_t threshold,
+                          int64_t n_long_cap, int64_t n_chunks_cap,
+                          int64_t* long_rows, int64_t* chunk_beg, int32_t* chunk_cnt,
+                          int32_t* chunk_long, int64_t* counters /* [4] */, void* stream);
 
 #define PLNLP_REDUCE_SUM  0
 #define PLNLP_REDUCE_MEAN 1
 int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
-                            const float* val,        /* nullable: [nnz]      */
+                            const float* val,        /* nullable: [nnz], or indexed through val_index */
+                            const int32_t* val_index,/* nullable: [nnz]; weight of entry e = val[val_index[e]] */
                             const float* src_scale,  /* nullable: [n_src]    */
                             const float* x, int64_t ldx,
                             float* out, int64_t ldo,
@@ -153,6 +163,14 @@ int plnlp_edge_scatter_bwd_f32(const float* h, int64_t ldh,
                                const int64_t* src, const int64_t* dst, int64_t n_edges,
                                int64_t feat, const float* g, int64_t ldg, int g_is_vector,
                                float* gh, int64_t ldgh, void* stream);
+/* node-sorted incidence list of an edge batch, built on the device without a host sync
+ * (keys-only radix sort of unique (node, item) keys -> a fully determined order):
+ *   seg_ptr[n_nodes+1], and per sorted item the batch edge id and the OTHER endpoint.
+ * keys_a / keys_b: [2*n_edges] uint64 scratch; temp: plnlp_incidence_temp_bytes(n_edges) bytes. */
+int64_t plnlp_incidence_temp_bytes(int64_t n_edges);
+int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
+                          uint64_t* keys_a, uint64_t* keys_b, void* temp, int64_t temp_bytes,
+                          int32_t* item_edge, int32_t* item_other, int64_t* seg_ptr, void* stream);
 /* deterministic variant over a node-sorted incidence list built once per batch:
  * for node slot s (seg_node[s] = node id, or s itself when seg_node is NULL), items
  * [seg_ptr[s], seg_ptr[s+1]) each

@@ -29,8 +29,8 @@ class Epilogue(C.Structure):
 class RowSplit(C.Structure):
     """mirror of plnlp_row_split"""
     _fields_ = [("threshold", C.c_int64), ("n_long", C.c_int64), ("long_rows", C.c_void_p),
-                ("chunk_ptr", C.c_void_p), ("n_chunks", C.c_int64), ("chunk_long", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
+                ("chunk_beg", C.c_void_p), ("chunk_cnt", C.c_void_p), ("n_chunks", C.c_int64),
+                ("chunk_long", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
 
 
 class GemmOperand(C.Structure):
@@ -48,7 +48,12 @@ LOSS_KINDS = {"auc": 0, "hinge_auc": 1, "weighted_auc": 2, "adaptive_auc": 3,
 SIGNATURES = {
     "plnlp_abi_version": (C.c_int, []),
     "plnlp_error_string": (C.c_char_p, [C.c_int]),
-    "plnlp_csr_aggregate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64,
+    "plnlp_row_split_build": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plnlp_incidence_temp_bytes": (c_i64, [c_i64]),
+    "plnlp_incidence_build": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plnlp_csr_aggregate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64,
                                           C.c_void_p, c_i64, c_i64, c_i64, C.c_int, C.POINTER(Epilogue),
                                           C.POINTER(RowSplit), C.c_void_p]),
     "plnlp_gemm_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,

@@ -75,6 +75,7 @@ __device__ __forceinline__ void agg_chunk(float4 (&acc)[VPL], const float* __res
 template <int VPL, int LPR, bool WEIGHTED>
 __device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64_t end,
                                           const int32_t* __restrict__ col, const float* __restrict__ val,
+                                          const int32_t* __restrict__ val_index,
                                           const float* __restrict__ src_scale, const float* __restrict__ x,
                                           int64_t ldx, int lane, int sub, int grp, int nslots) {
     constexpr int NG = 64 / LPR;
@@ -86,7 +87,7 @@ __device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64
         if (lane < n) {
             cvec = col[e0 + lane];
             if constexpr (WEIGHTED) {
-                wvec = val ? val[e0 + lane] : 1.f;
+                wvec = val ? val[val_index ? (int64_t)val_index[e0 + lane] : e0 + lane] : 1.f;
                 if (src_scale) wvec *= src_scale[cvec];
             }
         }
@@ -162,7 +163,8 @@ __device__ __forceinline__ void finish_row(float4 (&acc)[VPL], int64_t r, int64_
 template <int VPL, int LPR, bool WEIGHTED>
 __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const float* __restrict__ val, const float* __restrict__ src_scale,
+    const float* __restrict__ val, const int32_t* __restrict__ val_index,
+    const float* __restrict__ src_scale,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
     int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi) {
     const int lane = threadIdx.x & 63;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     float4 acc[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, src_scale, x, ldx, lane, sub, grp, nslots);
+    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
     finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi);
@@ -188,7 +190,8 @@ struct SplitArgs {
     int64_t threshold;
     int64_t n_long;
     const int64_t* long_rows;
-    const int64_t* chunk_ptr;
+    const int64_t* chunk_beg;
+    const int32_t* chunk_cnt;
     int64_t n_chunks;
     const int32_t* chunk_long;
     float* ws;
@@ -197,16 +200,18 @@ struct SplitArgs {
 template <int VPL, int LPR, bool WEIGHTED>
 __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const float* __restrict__ val, const float* __restrict__ src_scale,
+    const float* __restrict__ val, const int32_t* __restrict__ val_index,
+    const float* __restrict__ src_scale,
     const float* __restrict__ x, int64_t ldx, int feat, SplitArgs sp) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t c = (int64_t)blockIdx.x * 4 + wave;
-    if (c >= sp.n_chunks || c >= sp.chunk_ptr[sp.n_long]) return;
+    if (c >= sp.n_chunks) return;
     const int l = sp.chunk_long[c];
+    if (l < 0) return;                 // idle chunk slot
     const int64_t r = sp.long_rows[l];
     if (r < 0) return;
-    const int64_t j = c - sp.chunk_ptr[l];
+    const int64_t j = c - sp.chunk_beg[l];
     const int64_t rb = rowptr[r], re = rowptr[r + 1];
     const int64_t beg = rb + j * sp.threshold;
     const int64_t end = (beg + sp.threshold) < re ? (beg + sp.threshold) : re;
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     float4 acc[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, src_scale, x, ldx, lane, sub, grp, nslots);
+    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
     float* w = sp.ws + c * (int64_t)feat;
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void csr_agg_finalize_kernel(const int64_t* __
     if (l >= sp.n_long) return;
     const int64_t r = sp.long_rows[l];
     if (r < 0) return;
-    const int64_t c0 = sp.chunk_ptr[l], c1 = sp.chunk_ptr[l + 1];
+    const int64_t c0 = sp.chunk_beg[l], c1 = c0 + sp.chunk_cnt[l];
     const int64_t deg = rowptr[r + 1] - rowptr[r];
     const int nslots = feat >> 2;
     for (int s = lane; s < nslots; s += 64) {
@@ -259,7 +264,8 @@ __global__ __launch_bounds__(256) void csr_agg_finalize_kernel(const int64_t* __
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const float* __restrict__ val, const float* __restrict__ src_scale,
+    const float* __restrict__ val, const int32_t* __restrict__ val_index,
+    const float* __restrict__ src_scale,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
     int64_t n_rows, int feat, int mean, Epi epi) {
     const int lane = threadIdx.x & 63;
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
             const int c = col[e];
             float w = 1.f;
             if constexpr (WEIGHTED) {
-                w = val ? val[e] : 1.f;
+                w = val ? val[val_index ? (int64_t)val_index[e] : e] : 1.f;
                 if (src_scale) w *= src_scale[c];
             }
             const float* p = x + (int64_t)c * ldx;
@@ -298,24 +304,25 @@ __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
 
 template <int VPL, int LPR>
 static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* rowptr, const int32_t* col,
-                      const float* val, const float* src_scale, const float* x, int64_t ldx, float* out,
+                      const float* val, const int32_t* val_index, const float* src_scale, const float* x,
+                      int64_t ldx, float* out,
                       int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e, const SplitArgs* sp) {
     const int64_t skip = sp ? sp->threshold : 0;
     if (weighted)
         hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true>), grid, dim3(256), 0, s, rowptr, col, val,
-                           src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
+                           val_index, src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
     else
         hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false>), grid, dim3(256), 0, s, rowptr, col, val,
-                           src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
+                           val_index, src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
     if (int rc = launch_status()) return rc;
     if (!sp || sp->n_long == 0 || sp->n_chunks == 0) return 0;
     dim3 cgrid((unsigned)((sp->n_chunks + 3) / 4));
     if (weighted)
         hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, true>), cgrid, dim3(256), 0, s, rowptr, col, val,
-                           src_scale, x, ldx, feat, *sp);
+                           val_index, src_scale, x, ldx, feat, *sp);
     else
         hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, false>), cgrid, dim3(256), 0, s, rowptr, col, val,
-                           src_scale, x, ldx, feat, *sp);
+                           val_index, src_scale, x, ldx, feat, *sp);
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)((sp->n_long + 3) / 4)), dim3(256), 0, s, rowptr,
                        feat, mean, *sp, out, ldo, e);
@@ -325,7 +332,8 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
 }  // namespace plnlp
 
 extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col, const float* val,
-                                       const float* src_scale, const float* x, int64_t ldx, float* out,
+                                       const int32_t* val_index, const float* src_scale, const float* x,
+                                       int64_t ldx, float* out,
                                        int64_t ldo, int64_t n_rows, int64_t feat, int reduce,
                                        const plnlp_epilogue* epi, const plnlp_row_split* split, void* stream) {
     using namespace plnlp;
@@ -347,27 +355,29 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
     const SplitArgs* sp = nullptr;
     if (split && split->n_long > 0 && split->n_chunks > 0) {
         if (!vec_ok) return PLNLP_E_UNSUPPORTED;   // long-row splitting is implemented on the vector path
-        if (split->threshold < 64 || !split->long_rows || !split->chunk_ptr || !split->chunk_long ||
+        if (split->threshold < 64) return PLNLP_E_SHAPE;
+        if (!split->long_rows || !split->chunk_beg || !split->chunk_cnt || !split->chunk_long ||
             !split->workspace) return PLNLP_E_NULL;
         if (split->workspace_floats < split->n_chunks * feat) return PLNLP_E_WORKSPACE;
         if ((uintptr_t)split->workspace % 16 != 0) return PLNLP_E_ALIGN;
         sa.threshold = split->threshold; sa.n_long = split->n_long; sa.long_rows = split->long_rows;
-        sa.chunk_ptr = split->chunk_ptr; sa.n_chunks = split->n_chunks; sa.chunk_long = split->chunk_long;
+        sa.chunk_beg = split->chunk_beg; sa.chunk_cnt = split->chunk_cnt; sa.n_chunks = split->n_chunks;
+        sa.chunk_long = split->chunk_long;
         sa.ws = split->workspace;
         sp = &sa;
     }
     if (!vec_ok) {
         if (weighted)
-            hipLaunchKernelGGL((csr_agg_scalar_kernel<true>), grid, dim3(256), 0, s, rowptr, col, val, src_scale,
-                               x, ldx, out, ldo, n_rows, (int)feat, mean, e);
+            hipLaunchKernelGGL((csr_agg_scalar_kernel<true>), grid, dim3(256), 0, s, rowptr, col, val, val_index,
+                               src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e);
         else
-            hipLaunchKernelGGL((csr_agg_scalar_kernel<false>), grid, dim3(256), 0, s, rowptr, col, val, src_scale,
-                               x, ldx, out, ldo, n_rows, (int)feat, mean, e);
+            hipLaunchKernelGGL((csr_agg_scalar_kernel<false>), grid, dim3(256), 0, s, rowptr, col, val, val_index,
+                               src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e);
         return launch_status();
     }
     const int nslots = (int)(feat / 4);
 #define PLNLP_AGG(VPL, LPR) \
-    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp)
+    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp)
     if (nslots <= 8) PLNLP_AGG(1, 8);
     if (nslots <= 16) PLNLP_AGG(1, 16);
     if (nslots <= 32) PLNLP_AGG(1, 32);

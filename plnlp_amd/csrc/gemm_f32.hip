@@ -174,8 +174,12 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
         float* bt = lds + (2 + buf) * TILE_FLOATS;
         if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
         if constexpr (B_T) store_kc(bt, rb, t); else store_rc(bt, rb, t);
+#ifndef ABL_NOBARRIER
         __syncthreads();
+#endif
+#ifndef ABL_NOGLOAD
         if (tile + 1 < te) load_tile<A_T, B_T, MODE>(g, tile + 1, ra, rb, m0, n0, t);
+#endif
 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -282,6 +286,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
                     const float prev = (e2.flags & PLNLP_EPI_ACCUM) ? *p : 0.f;
                     v = epi_apply(e2, v, row, col, g.n, prev);
                 }
+#ifdef ABL_NOSTORE
+                if (v == 123.456f)
+#endif
                 *p = v;
             }
         }

@@ -1,0 +1,143 @@
+// Per-batch index structures for the backward of the edge gathers, built on the device with no
+// host synchronisation:
+//   plnlp_incidence_build  -- node-sorted incidence list of an edge batch (which batch edges touch
+//                             each node, and the OTHER endpoint of each), via one keys-only radix sort
+//                             of (node << shift | item) -- unique keys, so the order is fully
+//                             determined and every later reduction is bit-reproducible;
+//   plnlp_row_split_build  -- the long-row tables of plnlp_row_split for any CSR rowptr.
+// The sort itself is rocPRIM's device radix sort (a ROCm library primitive, used as plumbing).
+#include "common.hip.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace plnlp {
+
+__device__ __forceinline__ int64_t wrap_node(int64_t i, int64_t n) { return i < 0 ? i + n : i; }
+
+__global__ __launch_bounds__(256) void incidence_keys_kernel(const int64_t* __restrict__ src,
+                                                             const int64_t* __restrict__ dst, int64_t n_edges,
+                                                             int64_t n_nodes, int shift,
+                                                             uint64_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * n_edges) return;
+    const int64_t node = wrap_node(i < n_edges ? src[i] : dst[i - n_edges], n_nodes);
+    keys[i] = ((uint64_t)node << shift) | (uint64_t)i;
+}
+
+// sorted keys -> items (edge id, other endpoint) and the node segment pointers
+__global__ __launch_bounds__(256) void incidence_items_kernel(const uint64_t* __restrict__ keys,
+                                                              const int64_t* __restrict__ src,
+                                                              const int64_t* __restrict__ dst, int64_t n_edges,
+                                                              int64_t n_nodes, int shift,
+                                                              int32_t* __restrict__ item_edge,
+                                                              int32_t* __restrict__ item_other,
+                                                              int64_t* __restrict__ seg_ptr) {
+    const int64_t n_items = 2 * n_edges;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_items) return;
+    const uint64_t key = keys[p];
+    const int64_t node = (int64_t)(key >> shift);
+    const int64_t i = (int64_t)(key & ((1ull << shift) - 1));
+    const int64_t e = i < n_edges ? i : i - n_edges;
+    item_edge[p] = (int32_t)e;
+    item_other[p] = (int32_t)wrap_node(i < n_edges ? dst[e] : src[e], n_nodes);
+    // seg_ptr[n] = first sorted position whose node >= n
+    const int64_t prev = p == 0 ? -1 : (int64_t)(keys[p - 1] >> shift);
+    for (int64_t n = prev + 1; n <= node; ++n) seg_ptr[n] = p;
+    if (p == n_items - 1)
+        for (int64_t n = node + 1; n <= n_nodes; ++n) seg_ptr[n] = n_items;
+}
+
+__global__ __launch_bounds__(256) void fill_i64_kernel(int64_t* __restrict__ p, int64_t n, int64_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+
+// rows longer than `threshold` get a slot (atomic compaction: slot ORDER is arbitrary, which is
+// harmless -- each long row's chunks are still reduced in chunk order) and a run of chunk ids
+__global__ __launch_bounds__(256) void row_split_build_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows,
+                                                              int64_t threshold, int64_t n_long_cap,
+                                                              int64_t n_chunks_cap,
+                                                              int64_t* __restrict__ long_rows,
+                                                              int64_t* __restrict__ chunk_beg,
+                                                              int32_t* __restrict__ chunk_cnt,
+                                                              int32_t* __restrict__ chunk_long,
+                                                              unsigned long long* __restrict__ counters) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t deg = rowptr[r + 1] - rowptr[r];
+    if (deg <= threshold) return;
+    const int64_t nch = (deg + threshold - 1) / threshold;
+    const int64_t slot = (int64_t)atomicAdd(&counters[0], 1ull);
+    const int64_t cb = (int64_t)atomicAdd(&counters[1], (unsigned long long)nch);
+    if (slot >= n_long_cap || cb + nch > n_chunks_cap) { atomicAdd(&counters[2], 1ull); return; }  // overflow flag
+    long_rows[slot] = r;
+    chunk_beg[slot] = cb;
+    chunk_cnt[slot] = (int32_t)nch;
+    for (int64_t j = 0; j < nch; ++j) chunk_long[cb + j] = (int32_t)slot;
+}
+
+static inline int bits_for(int64_t n) {  // smallest b with (1 << b) >= n
+    int b = 0;
+    while (((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+}  // namespace plnlp
+
+extern "C" int64_t plnlp_incidence_temp_bytes(int64_t n_edges) {
+    size_t bytes = 0;
+    uint64_t* k = nullptr;
+    if (n_edges <= 0) return 0;
+    rocprim::radix_sort_keys(nullptr, bytes, k, k, (size_t)(2 * n_edges), 0, 64, (hipStream_t)0);
+    return (int64_t)bytes + 256;
+}
+
+extern "C" int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
+                                     uint64_t* keys_a, uint64_t* keys_b, void* temp, int64_t temp_bytes,
+                                     int32_t* item_edge, int32_t* item_other, int64_t* seg_ptr, void* stream) {
+    using namespace plnlp;
+    if (n_edges < 0 || n_nodes <= 0 || n_edges >= (1ll << 30)) return PLNLP_E_SHAPE;
+    if (!seg_ptr) return PLNLP_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_edges == 0) {
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(64), dim3(256), 0, s, seg_ptr, n_nodes + 1, (int64_t)0);
+        return launch_status();
+    }
+    if (!src || !dst || !keys_a || !keys_b || !temp || !item_edge || !item_other) return PLNLP_E_NULL;
+    const int64_t n_items = 2 * n_edges;
+    const int shift = bits_for(n_items);
+    const int node_bits = bits_for(n_nodes);
+    if (shift + node_bits > 64) return PLNLP_E_SHAPE;
+    size_t need = 0;
+    rocprim::radix_sort_keys(nullptr, need, keys_a, keys_b, (size_t)n_items, 0, (unsigned)(shift + node_bits), s);
+    if ((int64_t)need > temp_bytes) return PLNLP_E_WORKSPACE;
+    const unsigned blocks = (unsigned)((n_items + 255) / 256);
+    hipLaunchKernelGGL(incidence_keys_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n_edges, n_nodes, shift, keys_a);
+    if (int rc = launch_status()) return rc;
+    size_t tb = (size_t)temp_bytes;
+    hipError_t err = rocprim::radix_sort_keys(temp, tb, keys_a, keys_b, (size_t)n_items, 0,
+                                              (unsigned)(shift + node_bits), s);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(incidence_items_kernel, dim3(blocks), dim3(256), 0, s, keys_b, src, dst, n_edges, n_nodes,
+                       shift, item_edge, item_other, seg_ptr);
+    return launch_status();
+}
+
+extern "C" int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int64_t threshold, int64_t n_long_cap,
+                                     int64_t n_chunks_cap, int64_t* long_rows, int64_t* chunk_beg,
+                                     int32_t* chunk_cnt, int32_t* chunk_long, int64_t* counters, void* stream) {
+    using namespace plnlp;
+    if (!rowptr || !long_rows || !chunk_beg || !chunk_cnt || !chunk_long || !counters) return PLNLP_E_NULL;
+    if (n_rows < 0 || threshold < 64 || n_long_cap <= 0 || n_chunks_cap <= 0) return PLNLP_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(long_rows, 0xFF, sizeof(int64_t) * n_long_cap, s);   // -1: idle slot
+    if (e == hipSuccess) e = hipMemsetAsync(chunk_long, 0xFF, sizeof(int32_t) * n_chunks_cap, s);
+    if (e == hipSuccess) e = hipMemsetAsync(chunk_cnt, 0, sizeof(int32_t) * n_long_cap, s);
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, sizeof(int64_t) * 4, s);
+    if (e != hipSuccess) return (int)e;
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(row_split_build_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, rowptr,
+                       n_rows, threshold, n_long_cap, n_chunks_cap, long_rows, chunk_beg, chunk_cnt, chunk_long,
+                       reinterpret_cast<unsigned long long*>(counters));
+    return launch_status();
+}

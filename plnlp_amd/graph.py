@@ -23,50 +23,34 @@ import torch
 
 class RowSplit:
     """Tables for plnlp_row_split (include/plnlp_hip.h): which rows are longer than
-    `threshold` edges and how they are cut into chunks.
+    `threshold` edges and how they are cut into chunks.  Built on the device by
+    plnlp_row_split_build with capacities that are upper bounds (a CSR with nnz
+    entries has at most nnz/threshold long rows), so no host sync is needed; idle
+    slots hold -1.  `exact=True` (static graphs, built once) reads the counters back
+    once to shrink the launch grids to the used sizes."""
 
-    `static`  -- exact sizes (one host sync; done once per graph, which never changes);
-    `dynamic` -- no host sync: sizes are the upper bounds nnz/threshold (long rows) and
-                 2*nnz/threshold (chunks), unused slots hold -1 / are never reached.  Used
-                 for the per-batch incidence lists of the edge-gather backward."""
-
-    def __init__(self, rowptr: torch.Tensor, threshold: int = 256, dynamic: bool = False):
+    def __init__(self, rowptr: torch.Tensor, nnz: int, threshold: int = 256, exact: bool = False):
+        from . import _lib as L
+        lib = L.load()
+        L.require_device(rowptr)
         self.threshold = int(threshold)
         dev = rowptr.device
-        deg = rowptr[1:] - rowptr[:-1]
-        n_rows = deg.numel()
-        if not dynamic:
-            long_rows = torch.nonzero(deg > threshold).reshape(-1)
-            self.n_long = int(long_rows.numel())
-            nch = (deg[long_rows] + threshold - 1) // threshold
-            self.long_rows = long_rows.contiguous()
-            self.chunk_ptr = torch.zeros(self.n_long + 1, dtype=torch.int64, device=dev)
-            self.chunk_ptr[1:] = torch.cumsum(nch, 0)
-            self.n_chunks = int(self.chunk_ptr[-1]) if self.n_long else 0
-            self.chunk_long = torch.repeat_interleave(
-                torch.arange(self.n_long, dtype=torch.int32, device=dev), nch).contiguous()
-        else:
-            raise ValueError("use RowSplit.dynamic(rowptr, nnz, threshold)")
-
-    @classmethod
-    def dynamic(cls, rowptr: torch.Tensor, nnz: int, threshold: int = 256) -> "RowSplit":
-        self = cls.__new__(cls)
-        self.threshold = int(threshold)
-        dev = rowptr.device
-        deg = rowptr[1:] - rowptr[:-1]
-        n_rows = deg.numel()
+        n_rows = rowptr.numel() - 1
         self.n_long = max(1, min(n_rows, nnz // threshold))
-        self.n_chunks = nnz // threshold + self.n_long
-        top, idx = torch.topk(deg, self.n_long)
-        is_long = top > threshold
-        self.long_rows = torch.where(is_long, idx, torch.full_like(idx, -1)).contiguous()
-        nch = torch.where(is_long, (top + threshold - 1) // threshold, torch.zeros_like(top))
-        self.chunk_ptr = torch.zeros(self.n_long + 1, dtype=torch.int64, device=dev)
-        self.chunk_ptr[1:] = torch.cumsum(nch, 0)
-        slots = torch.arange(self.n_chunks, dtype=torch.int64, device=dev)
-        self.chunk_long = torch.searchsorted(self.chunk_ptr[1:].contiguous(), slots, right=True) \
-            .clamp_(max=self.n_long - 1).to(torch.int32).contiguous()
-        return self
+        self.n_chunks = max(1, nnz // threshold + self.n_long)
+        self.long_rows = torch.empty(self.n_long, dtype=torch.int64, device=dev)
+        self.chunk_beg = torch.empty(self.n_long, dtype=torch.int64, device=dev)
+        self.chunk_cnt = torch.empty(self.n_long, dtype=torch.int32, device=dev)
+        self.chunk_long = torch.empty(self.n_chunks, dtype=torch.int32, device=dev)
+        self.counters = torch.empty(4, dtype=torch.int64, device=dev)
+        L.check(lib.plnlp_row_split_build(rowptr.data_ptr(), n_rows, self.threshold, self.n_long, self.n_chunks,
+                                          self.long_rows.data_ptr(), self.chunk_beg.data_ptr(),
+                                          self.chunk_cnt.data_ptr(), self.chunk_long.data_ptr(),
+                                          self.counters.data_ptr(), L.stream_ptr()), "plnlp_row_split_build")
+        if exact:
+            used_long, used_chunks, overflow = (int(v) for v in self.counters[:3].tolist())
+            assert overflow == 0
+            self.n_long, self.n_chunks = used_long, used_chunks     # arrays keep their capacity; grids shrink
 
     @property
     def active(self) -> bool:
@@ -90,7 +74,7 @@ class Graph:
     def row_split(self, threshold: int = 256) -> RowSplit:
         """long-row tables of this (static) graph, built once"""
         if self._split is None or self._split.threshold != threshold:
-            self._split = RowSplit(self.rowptr, threshold)
+            self._split = RowSplit(self.rowptr, self.nnz, threshold, exact=True)
         return self._split
 
     # ---- construction ---------------------------------------------------------

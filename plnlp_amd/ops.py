@@ -72,15 +72,18 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
     if out is None:
         out = torch.empty(graph.n_rows, feat, dtype=torch.float32, device=x.device)
     val = graph.val if use_values else None
+    val_index = getattr(graph, "val_index", None) if use_values else None
     sp = None
     if split == "auto":
         split = graph.row_split(SPLIT_THRESHOLD) if _vector_path(x, out, feat) else None
     if split is not None and split.active and _vector_path(x, out, feat):
         ws = torch.empty(split.n_chunks * feat, dtype=torch.float32, device=x.device)
-        sp = L.RowSplit(split.threshold, split.n_long, split.long_rows.data_ptr(), split.chunk_ptr.data_ptr(),
-                        split.n_chunks, split.chunk_long.data_ptr(), ws.data_ptr(), ws.numel())
+        sp = L.RowSplit(split.threshold, split.n_long, split.long_rows.data_ptr(), split.chunk_beg.data_ptr(),
+                        split.chunk_cnt.data_ptr(), split.n_chunks, split.chunk_long.data_ptr(), ws.data_ptr(),
+                        ws.numel())
     rc = lib.plnlp_csr_aggregate_f32(
-        graph.rowptr.data_ptr(), graph.col.data_ptr() or graph.rowptr.data_ptr(), L.ptr(val), L.ptr(src_scale),
+        graph.rowptr.data_ptr(), graph.col.data_ptr() or graph.rowptr.data_ptr(), L.ptr(val), L.ptr(val_index),
+        L.ptr(src_scale),
         x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), graph.n_rows, feat,
         L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM,
         C.byref(epilogue) if epilogue is not None else None,
@@ -196,39 +199,39 @@ def edge_hadamard_fwd(h: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> 
 
 
 class Incidence:
-    """Node-sorted incidence list of one edge batch: for every node, the batch
-    edges touching it and, per item, the OTHER endpoint.  Built with a stable
-    device sort so the reduction order (hence every bit of gh) is reproducible."""
+    """Node-sorted incidence list of one edge batch: for every node, the batch edges
+    touching it and, per item, the OTHER endpoint (plnlp_incidence_build: one keys-only
+    radix sort of unique (node, item) keys on the device, no host sync; the order -- hence
+    every bit of the reduced gradient -- is reproducible).  Doubles as the CSR the
+    aggregation kernel walks: row = node, col = other endpoint, weight = g[edge]."""
 
     def __init__(self, src: torch.Tensor, dst: torch.Tensor, n_nodes: int):
+        lib = L.load()
+        L.require_device(src, dst)
         src, dst = _edge_idx(src), _edge_idx(dst)
         e = src.numel()
-        if e >= 2 ** 31:
-            raise ValueError("edge batch too large for int32 item ids")
-        ends = torch.cat([src, dst])
-        if n_nodes <= 0:
-            raise ValueError("n_nodes")
-        ends = torch.where(ends < 0, ends + n_nodes, ends)
-        sorted_ends, order = torch.sort(ends, stable=True)
-        eid = torch.arange(e, dtype=torch.int32, device=src.device).repeat(2)
-        other = torch.cat([dst, src])
-        other = torch.where(other < 0, other + n_nodes, other).to(torch.int32)
-        self.item_edge = eid[order].contiguous()
-        self.item_other = other[order].contiguous()
-        # seg_ptr[n] = first item of node n: binary search of the node ids in the sorted endpoints
-        self.seg_ptr = torch.searchsorted(
-            sorted_ends, torch.arange(n_nodes + 1, dtype=torch.int64, device=src.device)).contiguous()
-        self.n_nodes = n_nodes
-        # graph-like view so the aggregation kernel can walk it: row = node, col = other endpoint
-        self.rowptr, self.col, self.val = self.seg_ptr, self.item_other, None
-        self.n_rows = self.n_cols = n_nodes
+        dev = src.device
+        self.n_nodes = self.n_rows = self.n_cols = int(n_nodes)
+        self.item_edge = torch.empty(2 * e, dtype=torch.int32, device=dev)
+        self.item_other = torch.empty(2 * e, dtype=torch.int32, device=dev)
+        self.seg_ptr = torch.empty(n_nodes + 1, dtype=torch.int64, device=dev)
+        keys = torch.empty(2, max(2 * e, 1), dtype=torch.int64, device=dev)
+        tbytes = lib.plnlp_incidence_temp_bytes(e)
+        temp = torch.empty(max(tbytes, 8), dtype=torch.uint8, device=dev)
+        L.check(lib.plnlp_incidence_build(src.data_ptr(), dst.data_ptr(), e, n_nodes, keys[0].data_ptr(),
+                                          keys[1].data_ptr(), temp.data_ptr(), temp.numel(),
+                                          self.item_edge.data_ptr(), self.item_other.data_ptr(),
+                                          self.seg_ptr.data_ptr(), L.stream_ptr()), "plnlp_incidence_build")
+        self.rowptr, self.col = self.seg_ptr, self.item_other
+        self.val = None            # set to the per-edge gradient g; indexed through val_index
+        self.val_index = self.item_edge
         self._split = None
 
     def row_split(self, threshold: int):
-        """hot nodes of the batch (built without a host sync: upper-bound sizes)"""
+        """hot nodes of the batch (tables built on the device, upper-bound sizes)"""
         if self._split is None:
             from .graph import RowSplit
-            self._split = RowSplit.dynamic(self.seg_ptr, self.item_edge.numel(), threshold)
+            self._split = RowSplit(self.seg_ptr, self.item_edge.numel(), threshold)
         return self._split
 
 
@@ -245,7 +248,7 @@ def edge_segment_bwd(h: torch.Tensor, inc: Incidence, g: torch.Tensor,
     if not is_vec:
         # scalar per-edge gradient (DOT): gh = S h with S[n, other] = g[edge] -- exactly the
         # weighted CSR aggregation, so it runs on K1 (incl. hot-node splitting)
-        inc.val = g[inc.item_edge.to(torch.int64)]
+        inc.val = g                       # weight of item = g[item_edge[item]] (val_index)
         try:
             return csr_aggregate(inc, h, "sum", True, out=out, epilogue=epilogue)
         finally:

@@ -552,7 +552,7 @@ def test_row_split_hub_rows_match_oracle_and_unsplit(P, feat):
             a = P.ops.csr_aggregate(gr, dev(x), reduce, use_values)                 # static split
             b = P.ops.csr_aggregate(gr, dev(x), reduce, use_values, split=None)     # no split
             d = P.ops.csr_aggregate(gr, dev(x), reduce, use_values,
-                                    split=RowSplit.dynamic(gr.rowptr, gr.nnz, 256))  # dynamic tables
+                                    split=RowSplit(gr.rowptr, gr.nnz, 256))      # upper-bound sized tables
             close(a, ref, atol=2e-4)
             close(b, ref, atol=3e-3)      # unsplit: one sequential fp32 chain over 3000 terms
             assert torch.equal(a, d)
