@@ -133,6 +133,15 @@ int plnlp_gemm_f32(const plnlp_gemm_operand* segs /* HOST ptr */, int n_seg,
                    int split_k, float* workspace, int64_t workspace_floats,
                    void* stream);
 
+/* same product with the result columns split between two buffers: columns [0, n_split) go to
+ * c, columns [n_split, n) to c2 -- one pass over A yields both data gradients of SAGEConv
+ * ([gx | gagg] = dz @ [Wr | Wl]) without a strided view to re-pack.  No epilogue, no split-K. */
+int plnlp_gemm_split_out_f32(const plnlp_gemm_operand* segs /* HOST ptr */, int n_seg,
+                             int a_trans, int b_trans,
+                             float* c, int64_t ldc, float* c2, int64_t ldc2, int64_t n_split,
+                             int64_t m, int64_t n, const plnlp_epilogue* epi /* must be NULL / empty */,
+                             void* stream);
+
 /* column sums: out[f] = sum_r x[r,f] (bias gradients; mean row for eval,
  * plnlp/model.py:193).  workspace: [n_blocks, feat] floats, n_blocks returned by
  * plnlp_colsum_workspace_floats / feat. */

@@ -58,6 +58,9 @@ SIGNATURES = {
                                           C.POINTER(RowSplit), C.c_void_p]),
     "plnlp_gemm_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
                                  c_i64, C.POINTER(Epilogue), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_gemm_split_out_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64,
+                                           C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.POINTER(Epilogue),
+                                           C.c_void_p]),
     "plnlp_colsum_workspace_floats": (c_i64, [c_i64, c_i64]),
     "plnlp_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_float, C.c_void_p, C.c_void_p, c_i64,
                                    C.c_void_p]),

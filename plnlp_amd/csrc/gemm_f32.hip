@@ -58,6 +58,7 @@ struct GemmArgs {
     int64_t gm; int gn; // tile grid of this launch (a rectangular region of the full tile grid)
     int64_t mt0; int nt0; // first row / column tile of the region
     int z0;               // first split-K slice this launch writes
+    float* c2; int64_t ldc2; int n_split;   // columns >= n_split go to c2[:, col - n_split] (n_split = n: unused)
 };
 
 // ---- global -> registers ------------------------------------------------------
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
                 const int64_t row = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (row >= g.m) continue;
                 float v = acc[i][j][q] + bcol;
-                float* p = cbase + row * ldc + col;
+                float* p = (!raw && col >= g.n_split) ? g.c2 + row * g.ldc2 + (col - g.n_split)
+                                                      : cbase + row * ldc + col;
                 if (!raw && e2.flags) {
                     const float prev = (e2.flags & PLNLP_EPI_ACCUM) ? *p : 0.f;
                     v = epi_apply(e2, v, row, col, g.n, prev);
@@ -316,12 +318,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace plnlp
 
+static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c, int64_t ldc,
+                     int64_t m, int64_t n, float* c2, int64_t ldc2, int64_t n_split, const plnlp_epilogue* epi,
+                     int split_k, float* workspace, int64_t workspace_floats, void* stream);
+
 extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c,
                               int64_t ldc, int64_t m, int64_t n, const plnlp_epilogue* epi, int split_k,
                               float* workspace, int64_t workspace_floats, void* stream) {
+    if (ldc < n) return PLNLP_E_SHAPE;
+    return gemm_impl(segs, n_seg, a_trans, b_trans, c, ldc, m, n, nullptr, 0, n, epi, split_k, workspace,
+                     workspace_floats, stream);
+}
+
+extern "C" int plnlp_gemm_split_out_f32(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans,
+                                        float* c, int64_t ldc, float* c2, int64_t ldc2, int64_t n_split,
+                                        int64_t m, int64_t n, const plnlp_epilogue* epi, void* stream) {
+    if (!c2) return PLNLP_E_NULL;
+    if (n_split <= 0 || n_split >= n || ldc < n_split || ldc2 < n - n_split) return PLNLP_E_SHAPE;
+    if (epi && epi->flags) return PLNLP_E_UNSUPPORTED;     // plain product only
+    return gemm_impl(segs, n_seg, a_trans, b_trans, c, ldc, m, n, c2, ldc2, n_split, nullptr, 1, nullptr, 0, stream);
+}
+
+static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c, int64_t ldc,
+                     int64_t m, int64_t n, float* c2, int64_t ldc2, int64_t n_split, const plnlp_epilogue* epi,
+                     int split_k, float* workspace, int64_t workspace_floats, void* stream) {
     using namespace plnlp;
     if (!segs || !c) return PLNLP_E_NULL;
-    if (n_seg < 1 || n_seg > 2 || m < 0 || n < 0 || ldc < n || n > 0x7FFFFFF0) return PLNLP_E_SHAPE;
+    if (n_seg < 1 || n_seg > 2 || m < 0 || n < 0 || n > 0x7FFFFFF0) return PLNLP_E_SHAPE;
     if (m == 0 || n == 0) return 0;
     if (split_k < 1) split_k = 1;
     GemmArgs g{};
@@ -343,6 +366,7 @@ extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_t
     g.tiles_total = tiles[0] + tiles[1];
     if (split_k > g.tiles_total) split_k = g.tiles_total;
     g.m = m; g.n = (int)n; g.split_k = split_k; g.ws_stride = m * n;
+    g.c2 = c2; g.ldc2 = ldc2; g.n_split = (int)n_split;
     Epi e;
     if (int rc = make_epi(epi, &e)) return rc;
     hipStream_t s = (hipStream_t)stream;

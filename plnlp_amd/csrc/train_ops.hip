@@ -141,6 +141,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         partial[(int64_t)blockIdx.x * feat + f] = acc;
     }
 }
+// 16-byte variant (feat % 4 == 0, feat <= 1024, aligned): a row is covered by feat/4 lanes, so a
+// 256-thread block streams 256/(feat/4) rows per step with dwordx4 loads; the row lanes are then
+// folded through LDS in a fixed order.
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                 int64_t n_rows, int feat,
+                                                                 float* __restrict__ partial) {
+    __shared__ float4 sm[256];
+    const int q = feat >> 2;              // float4 per row
+    const int lanes = 256 / q;            // rows per step (host guarantees q divides 256)
+    const int c4 = threadIdx.x % q, rl = threadIdx.x / q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < n_rows; r += (int64_t)gridDim.x * lanes) {
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < lanes; ++k) {
+            const float4 v = sm[k * q + c4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * feat + c4 * 4) = acc;
+    }
+}
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int64_t n_blocks,
                                                            int feat, float scale, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -271,8 +296,15 @@ extern "C" int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int
     const int64_t blocks = colsum_blocks(n_rows);
     if (workspace_floats < blocks * feat) return PLNLP_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, n_rows, (int)feat,
-                       workspace);
+    const int64_t q = feat / 4;
+    const bool vec = feat % 4 == 0 && q <= 256 && 256 % q == 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0 &&
+                     (uintptr_t)workspace % 16 == 0;
+    if (vec)
+        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, n_rows,
+                           (int)feat, workspace);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, n_rows,
+                           (int)feat, workspace);
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((feat + 3) / 4)), dim3(256), 0, s, workspace, blocks,
                        (int)feat, scale, out);

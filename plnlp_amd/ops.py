@@ -135,6 +135,23 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     return out
 
 
+def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool = False):
+    """(a @ op(b)) with the result columns split into two contiguous tensors
+    (plnlp_gemm_split_out_f32): returns (out[:, :n_split], out[:, n_split:])."""
+    lib = L.load()
+    L.require_device(a, b)
+    a, b = _f32c(a), _f32c(b)
+    m, k = a.shape
+    n = b.shape[0] if b_trans else b.shape[1]
+    ops = (L.GemmOperand * 1)()
+    ops[0].a, ops[0].lda, ops[0].b, ops[0].ldb, ops[0].k = a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), k
+    c1 = torch.empty(m, n_split, dtype=torch.float32, device=a.device)
+    c2 = torch.empty(m, n - n_split, dtype=torch.float32, device=a.device)
+    L.check(lib.plnlp_gemm_split_out_f32(ops, 1, 0, int(b_trans), c1.data_ptr(), _ld(c1), c2.data_ptr(), _ld(c2),
+                                         n_split, m, n, None, L.stream_ptr()), "plnlp_gemm_split_out_f32")
+    return c1, c2
+
+
 def colsum(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     lib = L.load()
     L.require_device(x)
@@ -420,12 +437,9 @@ class SAGEConvFn(torch.autograd.Function):
         if need[0]:
             # both data gradients in ONE GEMM: [gx | gagg] = dz @ [Wr | Wl]  (dz read once)
             cin = w_r.shape[1]
-            both = gemm([(dz, torch.cat([w_r, w_l], dim=1))], False, False)
-            gx, gagg = both[:, :cin], both[:, cin:]
+            gx, gagg = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin)
             csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(),
                           out=gx, epilogue=L.make_epilogue(accumulate=True))
-            if gx.stride(0) != cin:
-                gx = gx.contiguous()
         return gx, gwl, gbl, gwr, None, None
 
 

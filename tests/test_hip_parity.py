@@ -579,3 +579,17 @@ def test_edge_backward_hot_node_dot(P):
     a = P.ops.edge_segment_bwd(dev(h), inc, dev(go))
     close(a, hd.grad, atol=1e-3)
     assert torch.equal(a, P.ops.edge_segment_bwd(dev(h), P.ops.Incidence(dev(src), dev(dst), n), dev(go)))
+
+
+def test_gemm_split_out_and_colsum_shapes(P):
+    g = torch.Generator().manual_seed(12)
+    a = torch.randn(1000, 96, generator=g)
+    b = torch.randn(96, 320, generator=g)
+    c1, c2 = P.ops.gemm_split_out(dev(a), dev(b), 128)
+    ref = a.double() @ b.double()
+    assert c1.shape == (1000, 128) and c2.shape == (1000, 192) and c1.is_contiguous() and c2.is_contiguous()
+    close(c1, ref[:, :128], atol=1e-4)
+    close(c2, ref[:, 128:], atol=1e-4)
+    for feat in (256, 512, 200, 64, 12, 7):
+        x = torch.randn(5000, feat, generator=g)
+        close(P.ops.colsum(dev(x)), x.double().sum(0), atol=2e-4)
