@@ -45,7 +45,8 @@ const char* plnlp_error_string(int code);
 #define PLNLP_EPI_DROPOUT   4u   /* counter-RNG dropout(p,seed) layer.py:22,26,85     */
 #define PLNLP_EPI_ACCUM     8u   /* out += result instead of out = result             */
 #define PLNLP_EPI_GATE     16u   /* result = gate[r,f] > 0 ? result*gate_scale : 0
-                                    (backward of relu+dropout given the forward output) */
+                                    (backward of relu+dropout given the forward output);
+                                    applied LAST, i.e. after PLNLP_EPI_ACCUM */
 
 typedef struct plnlp_epilogue {
     uint32_t     flags;
@@ -147,8 +148,21 @@ int plnlp_gemm_split_out_f32(const plnlp_gemm_operand* segs /* HOST ptr */, int 
  * plnlp_colsum_workspace_floats / feat. */
 int64_t plnlp_colsum_workspace_floats(int64_t n_rows, int64_t feat);
 int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t feat,
+                     const float* row_weight /* nullable: out[f] = sum_r row_weight[r]*x[r,f] */,
                      float scale, float* out, float* workspace, int64_t workspace_floats,
                      void* stream);
+
+/* ---- single-output linear head (MLPPredictor's last layer, plnlp/layer.py:86, out_channels = 1) --
+ * forward : out[r] = <x[r,:], w> + (bias ? *bias : 0)                 (a GEMM with N = 1 would waste
+ *           127/128 of every MFMA tile; this is a bandwidth-bound row reduction)
+ * backward: dx[r,:] = EPI( g[r] * w[:] )   (EPI: gate by the previous layer's output)
+ *           dw[k]   = sum_r g[r] * x[r,k]  -> plnlp_colsum_f32 with row_weight = g */
+int plnlp_matvec_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t feat,
+                     const float* w, const float* bias /* nullable, DEVICE scalar */,
+                     float* out, void* stream);
+int plnlp_outer_f32(const float* g, const float* w, int64_t n_rows, int64_t feat,
+                    float* dx, int64_t lddx, const plnlp_epilogue* epi /* nullable: GATE */,
+                    void* stream);
 
 /* ---- K3: edge endpoint gather + score --------------------------------------
  * Replaces h[edge[0]], h[edge[1]] (plnlp/model.py:155-156,179-180) fused with

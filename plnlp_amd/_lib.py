@@ -62,8 +62,12 @@ SIGNATURES = {
                                            C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.POINTER(Epilogue),
                                            C.c_void_p]),
     "plnlp_colsum_workspace_floats": (c_i64, [c_i64, c_i64]),
-    "plnlp_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_float, C.c_void_p, C.c_void_p, c_i64,
+    "plnlp_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                   c_i64, C.c_void_p]),
+    "plnlp_matvec_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "plnlp_outer_f32": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, c_i64, C.POINTER(Epilogue),
+                                  C.c_void_p]),
     "plnlp_edge_dot_fwd_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, c_i64,
                                          C.c_void_p, C.c_void_p]),
     "plnlp_edge_hadamard_fwd_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, c_i64,

@@ -76,8 +76,8 @@ __device__ __forceinline__ float epi_apply(const Epi& e, float v, int64_t r, int
     if (e.flags & PLNLP_EPI_DROPOUT)
         v = dropout_keep((uint64_t)r * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh)
                 ? v * e.keep_scale : 0.f;
-    if (e.flags & PLNLP_EPI_GATE) v = e.gate[r * e.ld_gate + f] > 0.f ? v * e.gate_scale : 0.f;
     if (e.flags & PLNLP_EPI_ACCUM) v += prev;
+    if (e.flags & PLNLP_EPI_GATE) v = e.gate[r * e.ld_gate + f] > 0.f ? v * e.gate_scale : 0.f;
     return v;
 }
 

@@ -134,10 +134,12 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, 
 constexpr int CS_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx,
                                                              int64_t n_rows, int feat,
+                                                             const float* __restrict__ rw,
                                                              float* __restrict__ partial) {
     for (int f = threadIdx.x; f < feat; f += 256) {
         float acc = 0.f;
-        for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) acc += x[r * ldx + f];
+        for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x)
+            acc = rw ? fmaf(rw[r], x[r * ldx + f], acc) : acc + x[r * ldx + f];
         partial[(int64_t)blockIdx.x * feat + f] = acc;
     }
 }
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // folded through LDS in a fixed order.
 __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* __restrict__ x, int64_t ldx,
                                                                  int64_t n_rows, int feat,
+                                                                 const float* __restrict__ rw,
                                                                  float* __restrict__ partial) {
     __shared__ float4 sm[256];
     const int q = feat >> 2;              // float4 per row
@@ -154,7 +157,9 @@ __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* __
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < n_rows; r += (int64_t)gridDim.x * lanes) {
         const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        const float w = rw ? rw[r] : 1.f;
+        acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
+        acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
     }
     sm[threadIdx.x] = acc;
     __syncthreads();
@@ -200,6 +205,46 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     __syncthreads();
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < n_cols && r0 + tx < n_rows) y[(c0 + i) * ldy + r0 + tx] = tile[tx][i];
+}
+
+// ---------------- single-output linear head ----------------------------------------------
+// one wave per row, 16 B per lane (float4) when aligned, shuffle tree reduction (fixed order)
+template <bool VEC>
+__global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows,
+                                                     int feat, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const float b = bias ? bias[0] : 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_rows; r += (int64_t)gridDim.x * 4) {
+        const float* row = x + r * ldx;
+        float acc = 0.f;
+        if constexpr (VEC) {
+            for (int s = lane; s < (feat >> 2); s += 64) {
+                const float4 v = reinterpret_cast<const float4*>(row)[s];
+                const float4 u = reinterpret_cast<const float4*>(w)[s];
+                acc = fmaf(v.x, u.x, acc); acc = fmaf(v.y, u.y, acc);
+                acc = fmaf(v.z, u.z, acc); acc = fmaf(v.w, u.w, acc);
+            }
+        } else {
+            for (int f = lane; f < feat; f += 64) acc = fmaf(row[f], w[f], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[r] = acc + b;
+    }
+}
+
+__global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                    int64_t n_rows, int feat, float* __restrict__ dx,
+                                                    int64_t lddx, Epi epi) {
+    const int64_t total = n_rows * (int64_t)feat;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / feat;
+        const int f = (int)(i - r * feat);
+        float* p = dx + r * lddx + f;
+        float v = g[r] * w[f];
+        if (epi.flags) v = epi_apply(epi, v, r, f, feat, (epi.flags & PLNLP_EPI_ACCUM) ? *p : 0.f);
+        *p = v;
+    }
 }
 
 static inline unsigned ew_grid(int64_t n) {
@@ -288,8 +333,9 @@ extern "C" int64_t plnlp_colsum_workspace_floats(int64_t n_rows, int64_t feat) {
     return colsum_blocks(n_rows) * feat;
 }
 
-extern "C" int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t feat, float scale, float* out,
-                                float* workspace, int64_t workspace_floats, void* stream) {
+extern "C" int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t feat,
+                                const float* row_weight, float scale, float* out, float* workspace,
+                                int64_t workspace_floats, void* stream) {
     using namespace plnlp;
     if (!x || !out || !workspace) return PLNLP_E_NULL;
     if (n_rows <= 0 || feat <= 0 || ldx < feat || feat > (1 << 24)) return PLNLP_E_SHAPE;
@@ -301,13 +347,44 @@ extern "C" int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int
                      (uintptr_t)workspace % 16 == 0;
     if (vec)
         hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, n_rows,
-                           (int)feat, workspace);
+                           (int)feat, row_weight, workspace);
     else
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, n_rows,
-                           (int)feat, workspace);
+                           (int)feat, row_weight, workspace);
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((feat + 3) / 4)), dim3(256), 0, s, workspace, blocks,
                        (int)feat, scale, out);
+    return launch_status();
+}
+
+extern "C" int plnlp_matvec_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t feat, const float* w,
+                                const float* bias, float* out, void* stream) {
+    using namespace plnlp;
+    if (n_rows < 0 || feat <= 0 || ldx < feat || feat > (1 << 24)) return PLNLP_E_SHAPE;
+    if (n_rows == 0) return 0;
+    if (!x || !w || !out) return PLNLP_E_NULL;
+    int64_t blocks = (n_rows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const bool vec = feat % 4 == 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0;
+    if (vec)
+        hipLaunchKernelGGL(matvec_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                           n_rows, (int)feat, w, bias, out);
+    else
+        hipLaunchKernelGGL(matvec_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                           n_rows, (int)feat, w, bias, out);
+    return launch_status();
+}
+
+extern "C" int plnlp_outer_f32(const float* g, const float* w, int64_t n_rows, int64_t feat, float* dx,
+                               int64_t lddx, const plnlp_epilogue* epi, void* stream) {
+    using namespace plnlp;
+    if (n_rows < 0 || feat <= 0 || lddx < feat || feat > (1 << 24)) return PLNLP_E_SHAPE;
+    if (n_rows == 0) return 0;
+    if (!g || !w || !dx) return PLNLP_E_NULL;
+    Epi e;
+    if (int rc = make_epi(epi, &e)) return rc;
+    hipLaunchKernelGGL(outer_kernel, dim3(ew_grid(n_rows * feat)), dim3(256), 0, (hipStream_t)stream, g, w, n_rows,
+                       (int)feat, dx, lddx, e);
     return launch_status();
 }
 

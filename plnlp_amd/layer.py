@@ -43,10 +43,10 @@ class SAGEConv(torch.nn.Module):
         self.lin_l.reset_parameters()
         self.lin_r.reset_parameters()
 
-    def forward(self, x, adj_t, act: _Act = None):
+    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None):
         act = act if act is not None else _Act(False, 0.0, False)
         return ops.SAGEConvFn.apply(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight,
-                                    _require_graph(adj_t), act)
+                                    _require_graph(adj_t), act, in_act)
 
 
 class GCNConv(torch.nn.Module):
@@ -67,9 +67,9 @@ class GCNConv(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.lin.weight)
         torch.nn.init.zeros_(self.bias)
 
-    def forward(self, x, adj_t, act: _Act = None):
+    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None):
         act = act if act is not None else _Act(False, 0.0, False)
-        return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act)
+        return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act, in_act)
 
 
 # --------------------------------------------------------------- encoders ------
@@ -93,6 +93,7 @@ class BaseGNN(torch.nn.Module):
         final activation to the consumer's backward (EdgeDotFn), see ops._Act."""
         last = len(self.convs) - 1
         out_act = None
+        prev_act = None        # activation that produced the current x (native convs only)
         for i, conv in enumerate(self.convs):
             activated = i < last or self.num_layers == 1
             if isinstance(conv, (SAGEConv, GCNConv)):
@@ -100,11 +101,14 @@ class BaseGNN(torch.nn.Module):
                 if fuse_output_gate and i == last and act is not None:
                     act.gate_in_consumer = True
                     out_act = act
-                x = conv(x, adj_t, act)
+                # the conv's backward folds the derivative of the activation that produced its input
+                x = conv(x, adj_t, act, prev_act if torch.is_grad_enabled() else None)
+                prev_act = act
             else:  # foreign conv module: un-fused reference order
                 x = conv(x, adj_t)
                 if activated:
                     x = F.dropout(F.relu(x), p=self.dropout, training=self.training)
+                prev_act = None
         if fuse_output_gate:
             return x, (out_act.scale if out_act is not None else 0.0)
         return x
@@ -190,11 +194,17 @@ class MLPPredictor(_LinsPredictor):
         self.lins = _linear_list([in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels])
         self.dropout = dropout
 
+    def _stack(self, x):
+        params = []
+        for lin in self.lins:
+            params += [lin.weight, lin.bias]
+        return ops.MLPStackFn.apply(x, float(self.dropout), self.training, *params)
+
     def forward(self, x_i, x_j):
-        return _mlp(self.lins, x_i * x_j, self.dropout, self.training)
+        return self._stack(x_i * x_j)
 
     def score_edges(self, h, src, dst):
-        return _mlp(self.lins, ops.EdgeHadamardFn.apply(h, src, dst), self.dropout, self.training)
+        return self._stack(ops.EdgeHadamardFn.apply(h, src, dst))
 
 
 class MLPCatPredictor(_LinsPredictor):

@@ -152,17 +152,44 @@ def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool
     return c1, c2
 
 
-def colsum(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+def colsum(x: torch.Tensor, scale: float = 1.0, row_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[f] = scale * sum_r (row_weight[r] *) x[r, f]"""
     lib = L.load()
-    L.require_device(x)
+    L.require_device(x, row_weight)
     x = _f32c(x)
     n, f = x.shape
+    if row_weight is not None:
+        row_weight = _f32c(row_weight.reshape(-1))
+        assert row_weight.numel() == n
     out = torch.empty(f, dtype=torch.float32, device=x.device)
     nws = lib.plnlp_colsum_workspace_floats(n, f)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-    L.check(lib.plnlp_colsum_f32(x.data_ptr(), _ld(x), n, f, scale, out.data_ptr(), ws.data_ptr(), nws,
-                                 L.stream_ptr()), "plnlp_colsum_f32")
+    L.check(lib.plnlp_colsum_f32(x.data_ptr(), _ld(x), n, f, L.ptr(row_weight), scale, out.data_ptr(),
+                                 ws.data_ptr(), nws, L.stream_ptr()), "plnlp_colsum_f32")
     return out
+
+
+def matvec(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r] = <x[r,:], w> + bias  (plnlp_matvec_f32)"""
+    lib = L.load()
+    L.require_device(x, w, bias)
+    x, w = _f32c(x), _f32c(w.reshape(-1))
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    L.check(lib.plnlp_matvec_f32(x.data_ptr(), _ld(x), x.shape[0], x.shape[1], w.data_ptr(), L.ptr(bias),
+                                 out.data_ptr(), L.stream_ptr()), "plnlp_matvec_f32")
+    return out
+
+
+def outer(g: torch.Tensor, w: torch.Tensor, epilogue: Optional[L.Epilogue] = None) -> torch.Tensor:
+    """dx[r,:] = EPI(g[r] * w[:])  (plnlp_outer_f32)"""
+    lib = L.load()
+    L.require_device(g, w)
+    g, w = _f32c(g.reshape(-1)), _f32c(w.reshape(-1))
+    dx = torch.empty(g.numel(), w.numel(), dtype=torch.float32, device=g.device)
+    L.check(lib.plnlp_outer_f32(g.data_ptr(), w.data_ptr(), g.numel(), w.numel(), dx.data_ptr(), _ld(dx),
+                                C.byref(epilogue) if epilogue is not None else None, L.stream_ptr()),
+            "plnlp_outer_f32")
+    return dx
 
 
 def gate(g: torch.Tensor, y: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -412,12 +439,18 @@ class SAGEConvFn(torch.autograd.Function):
               transposed CSR accumulating into the root-weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w_l, b_l, w_r, graph: Graph, act: _Act):
+    def forward(ctx, x, w_l, b_l, w_r, graph: Graph, act: _Act, in_act: Optional[_Act] = None):
+        """in_act: the relu/dropout that PRODUCED x (previous layer).  When given, backward
+        returns the gradient w.r.t. that layer's pre-activation (its derivative rides in the
+        epilogue of the last kernel that touches gx) and in_act.gate_in_consumer is set."""
         x = _f32c(x)
         agg = csr_aggregate(graph, x, "mean", use_values=False)
         epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
         y = gemm([(agg, w_l), (x, w_r)], False, True, epilogue=epi)
         ctx.graph, ctx.act = graph, act
+        ctx.in_act = in_act if (in_act is not None and in_act.active) else None
+        if ctx.in_act is not None:
+            ctx.in_act.gate_in_consumer = True
         ctx.save_for_backward(x, agg, w_l, w_r, y if act.active else None)
         return y
 
@@ -438,9 +471,11 @@ class SAGEConvFn(torch.autograd.Function):
             # both data gradients in ONE GEMM: [gx | gagg] = dz @ [Wr | Wl]  (dz read once)
             cin = w_r.shape[1]
             gx, gagg = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin)
-            csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(),
-                          out=gx, epilogue=L.make_epilogue(accumulate=True))
-        return gx, gwl, gbl, gwr, None, None
+            ia = ctx.in_act
+            csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(), out=gx,
+                          epilogue=L.make_epilogue(accumulate=True, gate=x if ia is not None else None,
+                                                   gate_scale=ia.scale if ia is not None else 1.0))
+        return gx, gwl, gbl, gwr, None, None, None
 
 
 class GCNConvFn(torch.autograd.Function):
@@ -448,12 +483,15 @@ class GCNConvFn(torch.autograd.Function):
     forward : MFMA GEMM, then K1 weighted aggregate with fused bias/relu/dropout."""
 
     @staticmethod
-    def forward(ctx, x, w, b, graph: Graph, act: _Act):
+    def forward(ctx, x, w, b, graph: Graph, act: _Act, in_act: Optional[_Act] = None):
         x = _f32c(x)
         xw = gemm([(x, w)], False, True)
         epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
         y = csr_aggregate(graph, xw, "sum", use_values=True, epilogue=epi)
         ctx.graph, ctx.act = graph, act
+        ctx.in_act = in_act if (in_act is not None and in_act.active) else None
+        if ctx.in_act is not None:
+            ctx.in_act.gate_in_consumer = True
         ctx.save_for_backward(x, w, y if act.active else None)
         return y
 
@@ -471,8 +509,10 @@ class GCNConvFn(torch.autograd.Function):
             if need[1]:
                 gw = gemm([(gxw, x)], True, False)
             if need[0]:
-                gx = gemm([(gxw, w)], False, False)
-        return gx, gw, gb, None, None
+                ia = ctx.in_act
+                gx = gemm([(gxw, w)], False, False,
+                          epilogue=L.make_epilogue(gate=x, gate_scale=ia.scale) if ia is not None else None)
+        return gx, gw, gb, None, None, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -500,6 +540,61 @@ class LinearFn(torch.autograd.Function):
         if need[2]:
             gb = colsum(dz)
         return gx, gw, gb, None
+
+
+class MLPStackFn(torch.autograd.Function):
+    """MLPPredictor.lins as ONE autograd node (layer.py:82-86):
+        x_{i+1} = dropout(relu(x_i W_i^T + b_i)), last layer bare.
+    Every hidden layer is an MFMA GEMM with bias/relu/dropout in its epilogue; a single-output
+    last layer is a row reduction (matvec), not a GEMM.  Backward walks the stack once, and the
+    relu/dropout derivative of layer i rides in the epilogue of the kernel that produces the
+    gradient of its output (dgrad GEMM or the outer product of the head) -- no separate passes."""
+
+    @staticmethod
+    def forward(ctx, x, dropout_p: float, training: bool, *params):
+        x = _f32c(x)
+        n_layers = len(params) // 2
+        xs, acts = [x], []
+        for i in range(n_layers):
+            w, b = params[2 * i], params[2 * i + 1]
+            last = i == n_layers - 1
+            act = _Act(not last, 0.0 if last else dropout_p, training)
+            acts.append(act)
+            if last and w.shape[0] == 1:
+                y = matvec(xs[-1], w, b).reshape(-1, 1)
+            else:
+                y = gemm([(xs[-1], w)], False, True,
+                         epilogue=L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed))
+            xs.append(y)
+        ctx.acts, ctx.n_layers = acts, n_layers
+        ctx.save_for_backward(*xs[:-1], *params)
+        return xs[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        nl = ctx.n_layers
+        saved = ctx.saved_tensors
+        xs, params = saved[:nl], saved[nl:]
+        need = ctx.needs_input_grad
+        grads = [None] * (2 * nl)
+        d = _f32c(g)
+        for i in range(nl - 1, -1, -1):
+            w, b = params[2 * i], params[2 * i + 1]
+            xi = xs[i]
+            head = (i == nl - 1) and w.shape[0] == 1
+            if need[3 + 2 * i]:
+                grads[2 * i] = (colsum(xi, row_weight=d).reshape(1, -1) if head
+                                else gemm([(d, xi)], True, False))
+            if b is not None and need[4 + 2 * i]:
+                grads[2 * i + 1] = colsum(d.reshape(-1, 1)) if head else colsum(d)
+            if i == 0 and not need[0]:
+                d = None
+                break
+            # gradient of this layer's input; if that input is a relu/dropout output (i > 0), fold
+            # its derivative in: the result is then d/d(pre-activation of layer i-1)
+            epi = L.make_epilogue(gate=xi, gate_scale=ctx.acts[i - 1].scale) if i > 0 else None
+            d = outer(d, w, epilogue=epi) if head else gemm([(d, w)], False, False, epilogue=epi)
+        return (d, None, None, *grads)
 
 
 # backward of the edge gathers: "segment" (deterministic gather-reduce) or "atomic"
