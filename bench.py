@@ -32,6 +32,10 @@ WORKLOADS = {
     # README.md:35 recipe shape
     "collab": dict(shape="collab", encoder="SAGE", predictor="DOT", loss="WeightedHingeAUC", hidden=256,
                    gnn_layers=1, mlp_layers=2, num_neg=1, dropout=0.3, clip=1.0, batch=65536, weighted=True),
+    # README.md:40 recipe shape (config C4): GCN on [emb 50 | features 128], h=200, local negatives
+    "citation2": dict(shape="citation2", encoder="GCN", predictor="MLP", loss="AUC", hidden=200, emb=50,
+                      feats=128, gnn_layers=2, mlp_layers=2, num_neg=3, dropout=0.0, clip=1.0, batch=65536,
+                      weighted=False),
     # README.md:24 recipe shape (config C2)
     "ddi": dict(shape="ddi", encoder="SAGE", predictor="MLP", loss="AUC", hidden=512, gnn_layers=2,
                 mlp_layers=2, num_neg=3, dropout=0.3, clip=2.0, batch=65536, weighted=False),
@@ -69,20 +73,24 @@ def time_kernel(fn, iters=20, warm=3):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
-def measure_roofline(P, graph, feat, device):
+def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
     x = torch.randn(graph.n_cols, feat, device=device)
     out = torch.empty(graph.n_rows, feat, device=device)
-    t = time_kernel(lambda: P.ops.csr_aggregate(graph, x, "mean", False, out=out))
-    by = agg_bytes(graph.nnz, graph.n_rows, feat)
+    if weighted:
+        t = time_kernel(lambda: P.ops.csr_aggregate(graph, x, "sum", True, out=out))
+    else:
+        t = time_kernel(lambda: P.ops.csr_aggregate(graph, x, "mean", False, out=out))
+    by = agg_bytes(graph.nnz, graph.n_rows, feat, weighted)
     src_mib = graph.n_cols * feat * 4 / 2 ** 20
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"csr_agg_collab_f{feat}")
+            traffic = json.load(open(tpath)).get(f"csr_agg_{shape}_f{feat}")
         except Exception:
             traffic = None
-    return {"bound": "hbm", "kernel": "csr_agg_vec_kernel (mean, F=%d)" % feat, "achieved": by / t / 1e9,
+    return {"bound": "hbm", "kernel": "csr_agg_vec_kernel (%s, F=%d)" % ("weighted sum" if weighted else "mean", feat),
+            "achieved": by / t / 1e9,
             "peak": 8000.0, "unit": "GB/s", "frac": by / t / 8.0e12, "traffic": traffic,
             "algorithmic_bytes": by, "kernel_ms": t * 1e3, "source_MiB": src_mib,
             "note": "gather-model bytes; source %s the 256 MiB Infinity Cache" %
@@ -96,10 +104,13 @@ def cpu_baseline(cfg, g, pos, neg, w, steps):
     torch.set_num_threads(os.cpu_count())
     adj = g["adj_t"]
     csr = O.CSR(adj.rowptr.cpu(), adj.col.cpu().to(torch.int64), None if adj.val is None else adj.val.cpu(), n)
-    enc = O.GNNRef(cfg["encoder"], h, h, h, cfg["gnn_layers"], cfg["dropout"], spmm_impl="sparse_csr")
+    feats = cfg.get("feats", 0)
+    e_dim = cfg.get("emb", h)
+    enc = O.GNNRef(cfg["encoder"], e_dim + feats, h, h, cfg["gnn_layers"], cfg["dropout"], spmm_impl="sparse_csr")
     pred = O.DotPredictorRef() if cfg["predictor"] == "DOT" else O.MLPPredictorRef(h, h, 1, cfg["mlp_layers"], cfg["dropout"])
-    emb = torch.nn.Embedding(n, h)
-    tr = O.TrainerRef(enc, pred, emb, csr, loss_name=cfg["loss"], lr=1e-3, clip_norm=cfg["clip"])
+    emb = torch.nn.Embedding(n, e_dim)
+    x = g["data"].x.cpu() if feats else None
+    tr = O.TrainerRef(enc, pred, emb, csr, x=x, loss_name=cfg["loss"], lr=1e-3, clip_norm=cfg["clip"])
     tr.param_init()
     enc.train()
     B = cfg["batch"]
@@ -144,6 +155,11 @@ def main():
     g = synthetic.make_graph(cfg["shape"], seed=2, device=device, scale=args.scale, weighted=cfg["weighted"])
     n = g["num_nodes"]
     data = g["data"]
+    if cfg["encoder"] == "GCN":          # main.py:177-179
+        g["adj_t"] = data.adj_t = P.gcn_normalization(g["adj_t"])
+    feats = cfg.get("feats", 0)
+    if feats:
+        data.x = torch.randn(n, feats, device=device, generator=torch.Generator(device=device).manual_seed(5))
     gen = torch.Generator(device=device).manual_seed(777)
     need = (K + W) * B * world
     if cfg["shape"] == "collab":      # random-walk augmented pairs, main.py:241-253
@@ -166,10 +182,10 @@ def main():
 
     model = P.BaseModel(lr=1e-3, dropout=cfg["dropout"], grad_clip_norm=cfg["clip"],
                         gnn_num_layers=cfg["gnn_layers"], mlp_num_layers=cfg["mlp_layers"],
-                        emb_hidden_channels=cfg["hidden"], gnn_hidden_channels=cfg["hidden"],
-                        mlp_hidden_channels=cfg["hidden"], num_nodes=n, num_node_feats=0,
+                        emb_hidden_channels=cfg.get("emb", cfg["hidden"]), gnn_hidden_channels=cfg["hidden"],
+                        mlp_hidden_channels=cfg["hidden"], num_nodes=n, num_node_feats=feats,
                         gnn_encoder_name=cfg["encoder"], predictor_name=cfg["predictor"], loss_func=cfg["loss"],
-                        optimizer_name="Adam", device=device, use_node_feats=False, train_node_emb=True,
+                        optimizer_name="Adam", device=device, use_node_feats=feats > 0, train_node_emb=True,
                         process_group=pg)
     model.param_init()
     model.encoder.train()
@@ -208,16 +224,19 @@ def main():
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "ogbl-%s-shaped synthetic graph (N=%d, nnz=%d), %s x%d h=%d, %s predictor, "
-                               "%s loss, B=%d/GPU, num_neg=%d, dropout=%.1f, random-walk pairs"
+                               "%s loss, B=%d/GPU, num_neg=%d, dropout=%.1f, %s"
                                % (cfg["shape"], n, g["adj_t"].nnz, cfg["encoder"], cfg["gnn_layers"], cfg["hidden"],
-                                  cfg["predictor"], cfg["loss"], B, k, cfg["dropout"]),
+                                  cfg["predictor"], cfg["loss"], B, k, cfg["dropout"],
+                                  "random-walk pairs (walk_length 10)" if cfg["shape"] == "collab"
+                                  else "train-edge positives"),
                    "global_batch": B * world, "parallelism": "dp%d (edge-batch, replicated encoder)" % world,
                    "scale": args.scale},
         "final_loss": final_loss, "negative_sampling_s": sampler_s,
     }
     if rank == 0:
         if not args.no_roofline:
-            result["roofline"] = measure_roofline(P, g["adj_t"], cfg["hidden"], device)
+            result["roofline"] = measure_roofline(P, g["adj_t"], cfg["hidden"], device,
+                                                  weighted=cfg["encoder"] == "GCN", shape=cfg["shape"])
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, g, pos_all.cpu(), neg_all.cpu(),
                                                   None if w_all is None else w_all.cpu(), args.cpu_steps)

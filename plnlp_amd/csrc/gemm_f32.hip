@@ -74,22 +74,26 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
         for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const f32x4*>(q + (int64_t)(32 * p) * ld);
         return;
     }
+    // guarded form, branch-free: every address is clamped into the matrix (always loadable) and
+    // out-of-range elements are zeroed by selects, so the 16 loads of a thread are all in flight
+    // together instead of waiting on each other across divergent branches
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int64_t row = row0 + (t >> 3) + 32 * p;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < nrows) {
-            const float* q = base + row * ld + kq;
-            if (vec && kq + 3 < kdim) {
-                v = *reinterpret_cast<const f32x4*>(q);
-            } else {
-                if (kq + 0 < kdim) v.x = q[0];
-                if (kq + 1 < kdim) v.y = q[1];
-                if (kq + 2 < kdim) v.z = q[2];
-                if (kq + 3 < kdim) v.w = q[3];
-            }
+        const bool rok = row < nrows;
+        const float* q = base + (rok ? row : nrows - 1) * ld;
+        f32x4 v;
+        if (vec && kq + 3 < kdim) {            // whole 16-byte group inside: one wide load
+            v = *reinterpret_cast<const f32x4*>(q + kq);
+        } else {
+            const int kl = kdim - 1;
+            v.x = q[kq + 0 < kdim ? kq + 0 : kl]; v.y = q[kq + 1 < kdim ? kq + 1 : kl];
+            v.z = q[kq + 2 < kdim ? kq + 2 : kl]; v.w = q[kq + 3 < kdim ? kq + 3 : kl];
+            v.x = kq + 0 < kdim ? v.x : 0.f; v.y = kq + 1 < kdim ? v.y : 0.f;
+            v.z = kq + 2 < kdim ? v.z : 0.f; v.w = kq + 3 < kdim ? v.w : 0.f;
         }
-        r[p] = v;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        r[p] = rok ? v : zero;
     }
 }
 // row-contiguous operand stored [kdim][nrows]: k [k0,k0+32) x rows [row0,row0+128);
@@ -107,19 +111,20 @@ __device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int k = k0 + (t >> 5) + 8 * p;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < kdim) {
-            const float* q = base + (int64_t)k * ld + rq;
-            if (vec && rq + 3 < nrows) {
-                v = *reinterpret_cast<const f32x4*>(q);
-            } else {
-                if (rq + 0 < nrows) v.x = q[0];
-                if (rq + 1 < nrows) v.y = q[1];
-                if (rq + 2 < nrows) v.z = q[2];
-                if (rq + 3 < nrows) v.w = q[3];
-            }
+        const bool kok = k < kdim;
+        const float* q = base + (int64_t)(kok ? k : kdim - 1) * ld;
+        f32x4 v;
+        if (vec && rq + 3 < nrows) {
+            v = *reinterpret_cast<const f32x4*>(q + rq);
+        } else {
+            const int64_t rl = nrows - 1;
+            v.x = q[rq + 0 < nrows ? rq + 0 : rl]; v.y = q[rq + 1 < nrows ? rq + 1 : rl];
+            v.z = q[rq + 2 < nrows ? rq + 2 : rl]; v.w = q[rq + 3 < nrows ? rq + 3 : rl];
+            v.x = rq + 0 < nrows ? v.x : 0.f; v.y = rq + 1 < nrows ? v.y : 0.f;
+            v.z = rq + 2 < nrows ? v.z : 0.f; v.w = rq + 3 < nrows ? v.w : 0.f;
         }
-        r[p] = v;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        r[p] = kok ? v : zero;
     }
 }
 __device__ __forceinline__ void store_kc(float* __restrict__ tile, const f32x4 (&r)[4], int t) {
