@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even with one rank (exercises the DP path on 1 GPU)")
     return ap.parse_args()
 
 
@@ -139,8 +141,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         torch.distributed.init_process_group("nccl", device_id=device)
         pg = torch.distributed.group.WORLD
 
@@ -197,7 +201,7 @@ def main():
         return pos_all[sl], neg_all[sl], (None if w_all is None else w_all[sl])
 
     def sync():
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -213,7 +217,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if pg is not None:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     final_loss = float(loss.item())
@@ -240,10 +244,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, g, pos_all.cpu(), neg_all.cpu(),
                                                   None if w_all is None else w_all.cpu(), args.cpu_steps)
-        print(json.dumps(result), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:        # last thing on stdout: the one JSON line (RCCL prints its own chatter earlier)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -43,10 +43,10 @@ class SAGEConv(torch.nn.Module):
         self.lin_l.reset_parameters()
         self.lin_r.reset_parameters()
 
-    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None):
+    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, sink=None):
         act = act if act is not None else _Act(False, 0.0, False)
         return ops.SAGEConvFn.apply(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight,
-                                    _require_graph(adj_t), act, in_act)
+                                    _require_graph(adj_t), act, in_act, sink)
 
 
 class GCNConv(torch.nn.Module):
@@ -87,8 +87,9 @@ class BaseGNN(torch.nn.Module):
         for conv in self.convs:
             conv.reset_parameters()
 
-    def forward(self, x, adj_t, fuse_output_gate: bool = False):
-        """fuse_output_gate (only meaningful for a 1-layer encoder, whose output IS a
+    def forward(self, x, adj_t, fuse_output_gate: bool = False, input_grad_sink=None):
+        """input_grad_sink: an ops.GradSink for the gradient of `x` (first conv must be a SAGEConv).
+        fuse_output_gate (only meaningful for a 1-layer encoder, whose output IS a
         relu+dropout result): returns (h, gate_scale) and leaves the derivative of that
         final activation to the consumer's backward (EdgeDotFn), see ops._Act."""
         last = len(self.convs) - 1
@@ -102,7 +103,10 @@ class BaseGNN(torch.nn.Module):
                     act.gate_in_consumer = True
                     out_act = act
                 # the conv's backward folds the derivative of the activation that produced its input
-                x = conv(x, adj_t, act, prev_act if torch.is_grad_enabled() else None)
+                if i == 0 and input_grad_sink is not None and isinstance(conv, SAGEConv):
+                    x = conv(x, adj_t, act, None, input_grad_sink)
+                else:
+                    x = conv(x, adj_t, act, prev_act if torch.is_grad_enabled() else None)
                 prev_act = act
             else:  # foreign conv module: un-fused reference order
                 x = conv(x, adj_t)

@@ -124,15 +124,40 @@ class BaseModel(object):
         return (torch.distributed.get_rank(self.process_group),
                 torch.distributed.get_world_size(self.process_group))
 
+    def _embedding_grad_sink(self, x_in):
+        """Data parallel + SAGE on the raw embedding table: deliver the (large) embedding gradient
+        early so its all-reduce overlaps the encoder's weight-gradient GEMMs (ops.GradSink)."""
+        from .layer import SAGEConv
+        from .ops import GradSink
+        self._early_work = None
+        if (self.process_group is None or self.emb is None or x_in is not self.emb.weight
+                or not self.emb.weight.requires_grad or not x_in.is_cuda
+                or not isinstance(self.encoder.convs[0], SAGEConv)):
+            return None
+        if getattr(self, "_emb_grad_buf", None) is None:
+            self._emb_grad_buf = torch.empty_like(self.emb.weight)
+        self.emb.weight.grad = self._emb_grad_buf
+
+        def start_reduce():
+            self._early_work = torch.distributed.all_reduce(self._emb_grad_buf, group=self.process_group,
+                                                            async_op=True)
+        return GradSink(self._emb_grad_buf, start_reduce)
+
     def _allreduce_grads(self):
         """SUM over ranks, issued before clipping so clipping sees the global gradient."""
         if self.process_group is None:
             return
         works = []
+        early = getattr(self, "_early_work", None)
         for p in self.para_list:
+            if early is not None and p is self.emb.weight:
+                continue            # already in flight since the middle of the backward pass
             if p.grad is None:      # a rank whose slice was empty contributes zeros
                 p.grad = torch.zeros_like(p)
             works.append(torch.distributed.all_reduce(p.grad, group=self.process_group, async_op=True))
+        if early is not None:
+            works.append(early)
+            self._early_work = None
         for w in works:
             w.wait()
 
@@ -168,12 +193,18 @@ class BaseModel(object):
         # a 1-layer encoder ends in relu+dropout (layer.py:24-26); with the fused DOT scorer
         # as the only consumer of h, that activation's backward rides in the scorer's
         # gather-reduce epilogue instead of a separate pass over [N, h]
-        fuse_gate = (local > 0 and isinstance(self.encoder, BaseGNN) and self.encoder.num_layers == 1
+        native = isinstance(self.encoder, BaseGNN)
+        fuse_gate = (local > 0 and native and self.encoder.num_layers == 1
                      and isinstance(self.predictor, DotPredictor))
+        x_in = self.create_input_feat(data)
+        sink = self._embedding_grad_sink(x_in) if native else None
+        kw = {}
+        if sink is not None:
+            kw["input_grad_sink"] = sink
         if fuse_gate:
-            h, gate_scale = self.encoder(self.create_input_feat(data), data.adj_t, fuse_output_gate=True)
+            h, gate_scale = self.encoder(x_in, data.adj_t, fuse_output_gate=True, **kw)
         else:
-            h, gate_scale = self.encoder(self.create_input_feat(data), data.adj_t), 0.0
+            h, gate_scale = self.encoder(x_in, data.adj_t, **kw), 0.0
         if local > 0:
             neg_flat = neg_edge.reshape(-1, 2)
             src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])

@@ -135,7 +135,8 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     return out
 
 
-def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool = False):
+def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool = False,
+                   out1: Optional[torch.Tensor] = None):
     """(a @ op(b)) with the result columns split into two contiguous tensors
     (plnlp_gemm_split_out_f32): returns (out[:, :n_split], out[:, n_split:])."""
     lib = L.load()
@@ -145,7 +146,8 @@ def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool
     n = b.shape[0] if b_trans else b.shape[1]
     ops = (L.GemmOperand * 1)()
     ops[0].a, ops[0].lda, ops[0].b, ops[0].ldb, ops[0].k = a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), k
-    c1 = torch.empty(m, n_split, dtype=torch.float32, device=a.device)
+    c1 = out1 if out1 is not None else torch.empty(m, n_split, dtype=torch.float32, device=a.device)
+    assert c1.shape == (m, n_split) and c1.is_contiguous()
     c2 = torch.empty(m, n - n_split, dtype=torch.float32, device=a.device)
     L.check(lib.plnlp_gemm_split_out_f32(ops, 1, 0, int(b_trans), c1.data_ptr(), _ld(c1), c2.data_ptr(), _ld(c2),
                                          n_split, m, n, None, L.stream_ptr()), "plnlp_gemm_split_out_f32")
@@ -414,6 +416,20 @@ def _act_backward(gy: torch.Tensor, y: torch.Tensor, act: _Act) -> torch.Tensor:
     return gate(gy, y, act.scale)
 
 
+class GradSink:
+    """Where the gradient of an encoder's INPUT goes when the caller wants it early.
+
+    Data-parallel training reduces the (large) embedding gradient over RCCL.  Handing it to
+    autograd means it only becomes visible after the whole backward pass is queued, so the
+    all-reduce cannot overlap anything.  With a sink, the first conv's backward computes the
+    input gradient FIRST, writes it straight into `buffer` (which the caller has installed as
+    `param.grad`), calls `on_ready()` -- the caller starts the asynchronous all-reduce there --
+    and only then queues its weight-gradient GEMMs, which run while the reduction is in flight."""
+
+    def __init__(self, buffer: torch.Tensor, on_ready=None):
+        self.buffer, self.on_ready = buffer, on_ready
+
+
 class AggregateFn(torch.autograd.Function):
     """torch_sparse.matmul(adj_t, x, reduce) with its autograd (Appendix A.3)."""
 
@@ -439,10 +455,13 @@ class SAGEConvFn(torch.autograd.Function):
               transposed CSR accumulating into the root-weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w_l, b_l, w_r, graph: Graph, act: _Act, in_act: Optional[_Act] = None):
+    def forward(ctx, x, w_l, b_l, w_r, graph: Graph, act: _Act, in_act: Optional[_Act] = None,
+                sink: Optional[GradSink] = None):
         """in_act: the relu/dropout that PRODUCED x (previous layer).  When given, backward
         returns the gradient w.r.t. that layer's pre-activation (its derivative rides in the
-        epilogue of the last kernel that touches gx) and in_act.gate_in_consumer is set."""
+        epilogue of the last kernel that touches gx) and in_act.gate_in_consumer is set.
+        sink: see GradSink (the input gradient is delivered there, autograd gets None)."""
+        ctx.sink = sink
         x = _f32c(x)
         agg = csr_aggregate(graph, x, "mean", use_values=False)
         epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
@@ -461,21 +480,27 @@ class SAGEConvFn(torch.autograd.Function):
         dz = _act_backward(gy.contiguous(), y, act)
         need = ctx.needs_input_grad
         gx = gwl = gbl = gwr = None
+        sink = ctx.sink
+        if need[0]:
+            # both data gradients in ONE GEMM: [gx | gagg] = dz @ [Wr | Wl]  (dz read once)
+            cin = w_r.shape[1]
+            gx, gagg = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin,
+                                      out1=sink.buffer if sink is not None else None)
+            ia = ctx.in_act
+            csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(), out=gx,
+                          epilogue=L.make_epilogue(accumulate=True, gate=x if ia is not None else None,
+                                                   gate_scale=ia.scale if ia is not None else 1.0))
+            if sink is not None:
+                if sink.on_ready is not None:
+                    sink.on_ready()          # e.g. start the all-reduce; the GEMMs below overlap it
+                gx = None
         if need[1]:
             gwl = gemm([(dz, agg)], True, False)           # [out, in] = dz^T @ agg
         if need[2]:
             gbl = colsum(dz)
         if need[3]:
             gwr = gemm([(dz, x)], True, False)
-        if need[0]:
-            # both data gradients in ONE GEMM: [gx | gagg] = dz @ [Wr | Wl]  (dz read once)
-            cin = w_r.shape[1]
-            gx, gagg = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin)
-            ia = ctx.in_act
-            csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(), out=gx,
-                          epilogue=L.make_epilogue(accumulate=True, gate=x if ia is not None else None,
-                                                   gate_scale=ia.scale if ia is not None else 1.0))
-        return gx, gwl, gbl, gwr, None, None, None
+        return gx, gwl, gbl, gwr, None, None, None, None
 
 
 class GCNConvFn(torch.autograd.Function):
