@@ -42,9 +42,13 @@ def structured_negative_sampling(edge_index, num_nodes, num_neg_samples, method=
         need = want - picked.size
         if need <= 0:
             break
-        draw = rng.integers(0, population, size=int(over * need * 1.1) + 16, dtype=np.int64)
-        _, first = np.unique(draw, return_index=True)
-        draw = draw[np.sort(first)]                      # distinct, arrival order kept
+        k = min(int(over * need * 1.1) + 16, population)
+        if population <= (1 << 26):                      # distinct by construction, like random.sample
+            draw = rng.choice(population, size=k, replace=False).astype(np.int64)
+        else:
+            draw = rng.integers(0, population, size=k, dtype=np.int64)
+            _, first = np.unique(draw, return_index=True)
+            draw = draw[np.sort(first)]                  # distinct, arrival order kept
         draw = draw[~np.isin(draw, present, assume_unique=False)]
         if picked.size:
             draw = draw[~np.isin(draw, picked)]

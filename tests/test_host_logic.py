@@ -1,0 +1,218 @@
+"""CPU tests of the host-side mirror of the reference interface (plnlp_amd's samplers,
+edge plumbing, batch permutation, evaluator, logger, factories, Graph) against the fixtures
+captured from the reference and against the oracle.  No kernels are launched here."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+import plnlp_amd as P
+from plnlp_amd import negative_sample as NS, utils as U
+
+T = torch.from_numpy
+
+
+def test_local_sampler_bit_exact_vs_reference(golden):
+    g = golden("g4_g5_samplers")
+    torch.manual_seed(0)
+    np.testing.assert_array_equal(NS.local_neg_sample(torch.tensor([[0, 1], [2, 3]]), 10, 3).numpy(), g["local_s0"])
+    for seed in (11, 12, 13):
+        torch.manual_seed(seed)
+        out = NS.local_neg_sample(T(g[f"local_{seed}_pos"]), int(g[f"local_{seed}_N"]), int(g[f"local_{seed}_k"]))
+        np.testing.assert_array_equal(out.numpy(), g[f"local_{seed}_out"])
+
+
+def test_perm_copy_and_global_padding_bit_exact(golden, monkeypatch):
+    g = golden("g4_g5_samplers")
+    ei = T(g["permcopy_in"])
+    torch.manual_seed(21)
+    np.testing.assert_array_equal(NS.sample_perm_copy(ei, 8, 3).numpy(), g["permcopy_out_t8_c3"])
+    torch.manual_seed(22)
+    np.testing.assert_array_equal(NS.sample_perm_copy(ei, 5, 2).numpy(), g["permcopy_out_t5_c2"])
+    # padding branch: same short structured sample as the fixture -> same output
+    short = T(g["globalpad_short"])
+    seen = {}
+
+    def fake(edge_index, num_nodes, num_neg_samples, method="sparse", generator=None):
+        seen.update(ei=edge_index, n=num_nodes, m=num_neg_samples)
+        return short
+    monkeypatch.setattr(NS, "structured_negative_sampling", fake)
+    torch.manual_seed(23)
+    out = NS.global_neg_sample(torch.tensor([[0, 1, 2], [1, 2, 0]]), 10, 3, 2)
+    np.testing.assert_array_equal(out.numpy(), g["globalpad_out"])
+    NS.global_neg_sample(torch.tensor([[0, 1, 2], [1, 2, 0]]), 10, 2, 2)
+    np.testing.assert_array_equal(seen["ei"].numpy(), g["globalcall_edge_index"])     # edges + self loops
+    assert seen["n"] == int(g["globalcall_n"]) and seen["m"] == int(g["globalcall_m"])
+
+
+def test_structured_negative_sampling_contract():
+    rng = np.random.default_rng(1)
+    n = 80
+    lo, hi = np.triu_indices(n, 1)
+    pick = rng.choice(lo.size, 900, replace=False)
+    ei = torch.tensor(np.stack([np.r_[lo[pick], hi[pick]], np.r_[hi[pick], lo[pick]]]))
+    torch.manual_seed(3)
+    out = NS.global_neg_sample(ei, n, 900, 3)
+    assert out.shape == (900, 3, 2) and out.dtype == torch.int64
+    flat = out.reshape(-1, 2)
+    keys = (flat[:, 0] * n + flat[:, 1]).tolist()
+    assert (flat[:, 0] != flat[:, 1]).all()
+    assert len(set(keys)) >= 0.97 * len(keys)        # repeats only through the reference's padding branch
+    assert not set((ei[0] * n + ei[1]).tolist()).intersection(keys)
+    # roughly uniform over the free cells: chi-square on row marginals
+    counts = np.bincount(flat[:, 0].numpy(), minlength=n)
+    assert counts.std() / counts.mean() < 0.35
+
+
+def test_batch_permutation_bit_exact_vs_dataloader(golden):
+    g = golden("g6_dataloader")
+    for seed, n, B in [(123, 10, 4), (5, 1000, 64), (77, 65, 65), (8, 3, 10)]:
+        torch.manual_seed(seed)
+        batches = U.batch_permutation(n, B, True)
+        after = torch.randint(0, 1 << 30, (4,))
+        np.testing.assert_array_equal(torch.cat(batches).numpy(), g[f"s{seed}_n{n}_B{B}_perm"])
+        assert [b.numel() for b in batches] == g[f"s{seed}_n{n}_B{B}_sizes"].tolist()
+        np.testing.assert_array_equal(after.numpy(), g[f"s{seed}_n{n}_B{B}_after"])     # same RNG consumption
+    torch.manual_seed(9)
+    U.batch_permutation(10, 4, False)
+    np.testing.assert_array_equal(torch.randint(0, 1 << 30, (4,)).numpy(), g["noshuffle_after"])
+
+
+def test_get_pos_neg_edges_vs_reference(golden):
+    g = golden("g7_pos_neg_edges")
+    se = {s: {k: T(g[f"cit_in_{s}_{k}"]) for k in ("source_node", "target_node", "target_node_neg")}
+          for s in ("train", "valid", "test")}
+    for s in ("valid", "test"):
+        pos, neg = U.get_pos_neg_edges(s, se)
+        np.testing.assert_array_equal(pos.numpy(), g[f"cit_{s}_pos"])
+        np.testing.assert_array_equal(neg.numpy(), g[f"cit_{s}_neg"])
+    torch.manual_seed(71)
+    pos, neg = U.get_pos_neg_edges("train", se, num_nodes=40, neg_sampler_name="local", num_neg=3)
+    np.testing.assert_array_equal(pos.numpy(), g["cit_train_pos"])
+    np.testing.assert_array_equal(neg.numpy(), g["cit_train_neg"])
+    se2 = {"train": {"edge": torch.zeros(1, 2, dtype=torch.long)},
+           "valid": {"edge": T(g["edge_in_valid_edge"]), "edge_neg": T(g["edge_in_valid_edge_neg"])}}
+    pos, neg = U.get_pos_neg_edges("valid", se2)
+    np.testing.assert_array_equal(neg.numpy(), g["edge_valid_neg"])
+
+
+def test_factories_follow_reference_names(golden):
+    g = golden("g2_predictors")
+    for name, want in zip(g["pred_factory_keys"].tolist(), g["pred_factory_vals"].tolist()):
+        got = P.create_predictor_layer(8, 2, 0.0, name)
+        assert ("None" if got is None else type(got).__name__) == want, name
+    for name, want in zip(g["enc_factory_keys"].tolist(), g["enc_factory_vals"].tolist()):
+        if want in ("WSAGE", "Transformer"):
+            with pytest.raises(NotImplementedError):
+                P.create_gnn_layer(4, 8, 2, 0.0, name)
+        else:
+            assert type(P.create_gnn_layer(4, 8, 2, 0.0, name)).__name__ == want
+    # state_dict keys = PyG's (weight exchange with a reference checkpoint)
+    assert list(P.SAGE(4, 8, 8, 2, 0.0).state_dict()) == [
+        "convs.0.lin_l.weight", "convs.0.lin_l.bias", "convs.0.lin_r.weight",
+        "convs.1.lin_l.weight", "convs.1.lin_l.bias", "convs.1.lin_r.weight"]
+    assert list(P.GCN(4, 8, 8, 1, 0.0).state_dict()) == ["convs.0.bias", "convs.0.lin.weight"]
+    assert list(P.MLPPredictor(8, 8, 1, 2, 0.0).state_dict()) == ["lins.0.weight", "lins.0.bias", "lins.1.weight",
+                                                                    "lins.1.bias"]
+    # init laws: same draws as the oracle modules under the same seed
+    torch.manual_seed(5)
+    a = P.SAGE(6, 6, 6, 2, 0.0)
+    a.reset_parameters()
+    torch.manual_seed(5)
+    b = O.GNNRef("SAGE", 6, 6, 6, 2, 0.0)
+    b.reset_parameters()
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(v, w), k
+    torch.manual_seed(6)
+    a = P.GCN(6, 6, 6, 2, 0.0)
+    a.reset_parameters()
+    torch.manual_seed(6)
+    b = O.GNNRef("GCN", 6, 6, 6, 2, 0.0)
+    b.reset_parameters()
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(v, w), k
+
+
+def test_create_input_layer_branches(tmp_path):
+    d, e = P.create_input_layer(100, 7, 16, use_node_feats=False)
+    assert d == 16 and e.weight.shape == (100, 16)
+    d, e = P.create_input_layer(100, 7, 16, use_node_feats=True, train_node_emb=True)
+    assert d == 23 and e.weight.shape == (100, 16)
+    d, e = P.create_input_layer(100, 7, 16, use_node_feats=True, train_node_emb=False)
+    assert d == 7 and e is None
+    path = str(tmp_path / "emb.pt")
+    torch.save(torch.randn(100, 5), path)
+    d, e = P.create_input_layer(100, 7, 16, use_node_feats=True, train_node_emb=False, pretrain_emb=path)
+    assert d == 12 and not e.weight.requires_grad
+    d, e = P.create_input_layer(100, 7, 16, use_node_feats=False, pretrain_emb=path)
+    assert d == 5
+
+
+def test_logger_and_adjust_lr_vs_reference(golden):
+    g = golden("g9_logger")
+    res = g["results"]
+    lg = P.Logger(3)
+    for r in range(3):
+        for e in range(5):
+            lg.add_result(r, (float(res[r, e, 0]), float(res[r, e, 1])))
+    calls = {"run1": dict(run=1), "run1_last": dict(run=1, last_best=True), "all": dict(), "all_last": dict(last_best=True)}
+    for key, want in zip(g["keys"].tolist(), g["texts"].tolist()):
+        buf = io.StringIO()
+        lg.print_statistics(f=buf, **calls[key])
+        assert buf.getvalue() == want, key
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=0.01)
+    lrs = [P.adjust_lr(opt, r, 0.01) for r in (0.0, 0.25, 0.5, 0.99995, 1.0)]
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12)
+
+
+def test_evaluator_matches_oracle_and_bruteforce():
+    gen = torch.Generator().manual_seed(5)
+    pos, neg = torch.randn(300, generator=gen), torch.randn(700, generator=gen)
+    ev = U.Evaluator("ogbl-collab")
+    res = U.evaluate_hits(ev, pos, neg, pos[:100], neg[:400])
+    ref = O.evaluate_hits_ref(pos, neg, pos[:100], neg[:400])
+    assert res == ref
+    negm = torch.randn(300, 40, generator=gen)
+    res = U.evaluate_mrr(U.Evaluator("ogbl-citation2"), pos, negm.reshape(-1), pos, negm.reshape(-1))
+    ranks = 1 + (negm > pos[:, None]).sum(1)
+    assert abs(res["MRR"][0] - float((1.0 / ranks.float()).mean())) < 1e-6
+    assert U.Evaluator("ogbl-ddi").K == 20 and U.Evaluator("ogbl-collab").K == 50
+
+
+def test_graph_construction_and_normalisation_vs_oracle():
+    gen = torch.Generator().manual_seed(8)
+    n = 60
+    r, c = torch.randint(0, n, (400,), generator=gen), torch.randint(0, n, (400,), generator=gen)
+    v = torch.rand(400, generator=gen) + 0.1
+    g = P.Graph.from_coo(r, c, v, n, n)
+    o = O.CSR.from_coo(r, c, v, n)
+    assert torch.equal(g.rowptr, o.rowptr) and torch.equal(g.col.long(), o.col) and torch.equal(g.val, o.val)
+    gt, ot = g.t(), o.t()
+    assert torch.equal(gt.rowptr, ot.rowptr) and torch.equal(gt.col.long(), ot.col) and torch.equal(gt.val, ot.val)
+    assert g.size(0) == n and g.nnz == 400
+    np.testing.assert_allclose(g.sum(dim=1).numpy(), o.rowsum().numpy(), rtol=1e-6)
+    gn, on = P.gcn_normalization(g), O.gcn_norm_csr(o)
+    assert torch.equal(gn.rowptr, on.rowptr) and torch.equal(gn.col.long(), on.col)
+    np.testing.assert_allclose(gn.val.numpy(), on.val.numpy(), rtol=1e-6)
+    sym = P.Graph.from_coo(r, c, None, n, n).to_symmetric()
+    d = sym.coo()
+    dense = torch.zeros(n, n)
+    dense[d[0], d[1]] = 1
+    assert torch.equal(dense, dense.t()) and int(dense.sum()) == sym.nnz
+    ei = torch.stack([r, c])
+    adj_t = P.Graph.from_edge_index(ei, None, n)          # transposed adjacency: row = target
+    rr, cc, _ = adj_t.coo()
+    assert set(zip(rr.tolist(), cc.tolist())) == set(zip(c.tolist(), r.tolist()))
+
+
+def test_loss_dispatch_names():
+    from plnlp_amd import loss
+    assert loss.BY_NAME["WeightedHingeAUC"][0] is loss.weighted_hinge_auc_loss and loss.BY_NAME["WeightedHingeAUC"][1]
+    assert set(loss.BY_NAME) == {"CE", "InfoNCE", "LogRank", "HingeAUC", "AdaAUC", "WeightedAUC", "AdaHingeAUC",
+                                 "WeightedHingeAUC"}
+    # CE / InfoNCE run on stock ops (CPU fine) and match the reference fixtures
+    pos, neg = torch.randn(6, 1), torch.randn(18, 1)
+    np.testing.assert_allclose(loss.ce_loss(pos, neg).item(), O.LOSSES["ce"](pos, neg).item(), rtol=1e-6)
+    np.testing.assert_allclose(loss.info_nce_loss(pos, neg, 3).item(), O.LOSSES["info_nce"](pos, neg, 3).item(), rtol=1e-6)
