@@ -26,6 +26,7 @@
 // result): grid.z slices write raw partial tiles to a workspace and a second
 // kernel adds them in slice order -- deterministic, no atomics.
 #include "common.hip.h"
+#include <cstdlib>
 
 namespace plnlp {
 
@@ -68,10 +69,16 @@ template <bool FULL>
 __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
     const int kq = (t & 7) * 4 + k0;
-    if constexpr (FULL) {  // interior tile: 4 independent 16-byte loads, no guards, no waits between them
-        const float* q = base + (row0 + (t >> 3)) * ld + kq;
+    if constexpr (FULL) {
+        // 4 independent 16-byte loads, no guards, nothing the compiler must wait on between them.
+        // Rows past the matrix edge are CLAMPED to the last row: they read valid memory and only
+        // feed output rows that the (guarded) store discards.
 #pragma unroll
-        for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const f32x4*>(q + (int64_t)(32 * p) * ld);
+        for (int p = 0; p < 4; ++p) {
+            int64_t row = row0 + (t >> 3) + 32 * p;
+            row = row < nrows ? row : nrows - 1;
+            r[p] = *reinterpret_cast<const f32x4*>(base + row * ld + kq);
+        }
         return;
     }
     // guarded form, branch-free: every address is clamped into the matrix (always loadable) and
@@ -102,8 +109,9 @@ template <bool FULL>
 __device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
     const int64_t rq = row0 + (t & 31) * 4;
-    if constexpr (FULL) {
-        const float* q = base + (int64_t)(k0 + (t >> 5)) * ld + rq;
+    if constexpr (FULL) {   // needs nrows % 4 == 0 (checked on the host): clamp whole float4 groups
+        const int64_t rc = rq < nrows ? rq : nrows - 4;
+        const float* q = base + (int64_t)(k0 + (t >> 5)) * ld + rc;
 #pragma unroll
         for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const f32x4*>(q + (int64_t)(8 * p) * ld);
         return;
@@ -395,6 +403,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     if (a_trans) aligned = aligned && (m % 4 == 0) && m >= 4;    // row-contiguous operands move 4 rows per load
     if (!b_trans) aligned = aligned && (n % 4 == 0) && n >= 4;
     int mode = !aligned ? 0 : (ragged ? 2 : 1);
+    if (const char* fm = getenv("PLNLP_GEMM_FORCE_MODE")) { int v = atoi(fm); if (v == 0 || (v == 2 && aligned)) mode = v; }
     int reduce_slices = split_k;
     GemmArgs tail{};
     bool peel = false;
