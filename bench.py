@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-stress", action="store_true", help="skip the >>256 MiB HBM roofline measurement")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the DP path on 1 GPU)")
@@ -238,12 +239,25 @@ def main():
         "final_loss": final_loss, "negative_sampling_s": sampler_s,
     }
     if rank == 0:
+        nb = 2 * B
+        pos_cpu, neg_cpu = pos_all[:nb].cpu(), neg_all[:nb].cpu()
+        w_cpu = None if w_all is None else w_all[:nb].cpu()
         if not args.no_roofline:
             result["roofline"] = measure_roofline(P, g["adj_t"], cfg["hidden"], device,
                                                   weighted=cfg["encoder"] == "GCN", shape=cfg["shape"])
+        if world == 1 and not args.no_roofline and not args.no_stress:
+            # the workload's source matrix may fit the 256 MiB Infinity Cache; the HBM roofline proper is
+            # taken on a citation2-sized graph without skew or locality at h=512 (6 GB source matrix)
+            del model, pos_all, neg_all
+            torch.cuda.empty_cache()
+            big = synthetic.uniform_graph(2_927_963, 30_387_995, device, seed=3)
+            r = measure_roofline(P, big, 512, device, shape="uniform_big")
+            r["graph"] = "uniform random, N=2927963, nnz=%d (citation2-sized), F=512" % big.nnz
+            result["roofline_hbm_stress"] = r
+            del big
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, g, pos_all.cpu(), neg_all.cpu(),
-                                                  None if w_all is None else w_all.cpu(), args.cpu_steps)
+            result["cpu_baseline"] = cpu_baseline(cfg, g, pos_cpu, neg_cpu, w_cpu, args.cpu_steps)
     if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

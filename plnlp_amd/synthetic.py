@@ -92,3 +92,12 @@ def random_walk_pairs(adj: Graph, start: torch.Tensor, walk_length: int, gen: to
     pairs, weights = torch.cat(pairs), torch.cat(weights)
     keep = pairs[:, 0] != pairs[:, 1]
     return pairs[keep], weights[keep]
+
+
+def uniform_graph(num_nodes: int, num_edges: int, device, seed: int = 0) -> Graph:
+    """symmetric Erdos-Renyi-like graph (no degree skew, no locality): the cache-hostile case
+    used for the HBM roofline of the aggregation kernel"""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    a = torch.randint(0, num_nodes, (num_edges,), generator=gen, device=device)
+    b = torch.randint(0, num_nodes, (num_edges,), generator=gen, device=device)
+    return Graph.from_coo(torch.cat([a, b]), torch.cat([b, a]), None, num_nodes, num_nodes)
