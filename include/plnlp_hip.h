@@ -143,6 +143,15 @@ int plnlp_gemm_split_out_f32(const plnlp_gemm_operand* segs /* HOST ptr */, int 
                              int64_t m, int64_t n, const plnlp_epilogue* epi /* must be NULL / empty */,
                              void* stream);
 
+/* B operand concatenated along N from two buffers: columns [0, nb_split) of op(B) come from seg->b,
+ * columns [nb_split, n) from b2 (nb_split % 128 == 0).  One pass over A yields both weight
+ * gradients of SAGEConv: [dWl | dWr] = dz^T [agg | x] (a_trans = 1, b_trans = 0, split-K). */
+int plnlp_gemm_concat_b_f32(const plnlp_gemm_operand* seg /* HOST ptr, one segment */,
+                            const float* b2, int64_t ldb2, int64_t nb_split,
+                            int a_trans, int b_trans, float* c, int64_t ldc, int64_t m, int64_t n,
+                            const plnlp_epilogue* epi, int split_k, float* workspace,
+                            int64_t workspace_floats, void* stream);
+
 /* column sums: out[f] = sum_r x[r,f] (bias gradients; mean row for eval,
  * plnlp/model.py:193).  workspace: [n_blocks, feat] floats, n_blocks returned by
  * plnlp_colsum_workspace_floats / feat. */

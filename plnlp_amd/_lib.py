@@ -61,6 +61,9 @@ SIGNATURES = {
     "plnlp_gemm_split_out_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64,
                                            C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.POINTER(Epilogue),
                                            C.c_void_p]),
+    "plnlp_gemm_concat_b_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_void_p, c_i64, c_i64, C.c_int, C.c_int,
+                                          C.c_void_p, c_i64, c_i64, c_i64, C.POINTER(Epilogue), C.c_int,
+                                          C.c_void_p, c_i64, C.c_void_p]),
     "plnlp_colsum_workspace_floats": (c_i64, [c_i64, c_i64]),
     "plnlp_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                    c_i64, C.c_void_p]),

@@ -60,6 +60,7 @@ struct GemmArgs {
     int64_t mt0; int nt0; // first row / column tile of the region
     int z0;               // first split-K slice this launch writes
     float* c2; int64_t ldc2; int n_split;   // columns >= n_split go to c2[:, col - n_split] (n_split = n: unused)
+    const float* b2; int64_t ldb2; int nb_split;   // B columns >= nb_split come from b2 (segment 0; nb_split = n: unused)
 };
 
 // ---- global -> registers ------------------------------------------------------
@@ -155,24 +156,32 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
                                           int64_t m0, int n0, int t) {
     const bool s1 = (g.nseg > 1) && (tile >= g.tiles0);
     const float* a = s1 ? g.seg[1].a : g.seg[0].a;
-    const float* b = s1 ? g.seg[1].b : g.seg[0].b;
+    const float* b = s1 ? g.seg[1].b : g.seg[0].b;   // may be redirected to b2 below
     const int64_t lda = s1 ? g.seg[1].lda : g.seg[0].lda;
-    const int64_t ldb = s1 ? g.seg[1].ldb : g.seg[0].ldb;
+    int64_t ldb = s1 ? g.seg[1].ldb : g.seg[0].ldb;
     const int kdim = s1 ? g.seg[1].k : g.seg[0].k;
     const int avec = s1 ? g.seg[1].a_vec : g.seg[0].a_vec;
     const int bvec = s1 ? g.seg[1].b_vec : g.seg[0].b_vec;
     const int k0 = (tile - (s1 ? g.tiles0 : 0)) * BK;
+    int nb = g.n;                         // extent of the B operand along N as seen by this tile
+    if (g.nb_split < g.n) {               // N-concatenated B: [b | b2], tiles never straddle the seam
+        const bool second = n0 >= g.nb_split;
+        b = second ? g.b2 : b;
+        ldb = second ? g.ldb2 : ldb;
+        nb = second ? g.n - g.nb_split : g.nb_split;
+        n0 = second ? n0 - g.nb_split : n0;
+    }
     const bool full = (MODE == 1) || (MODE == 2 && k0 + BK <= kdim);
     if (MODE != 0 && full) {
         if constexpr (A_T) load_rc<true>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
         else               load_kc<true>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-        if constexpr (B_T) load_kc<true>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
-        else               load_rc<true>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
+        if constexpr (B_T) load_kc<true>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
+        else               load_rc<true>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
     } else {
         if constexpr (A_T) load_rc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
         else               load_kc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-        if constexpr (B_T) load_kc<false>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
-        else               load_rc<false>(rb, b, ldb, n0, g.n, k0, kdim, bvec, t);
+        if constexpr (B_T) load_kc<false>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
+        else               load_rc<false>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
     }
 }
 
@@ -310,11 +319,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     }
 }
 
-// sum split-K slices in slice order, apply the epilogue
+// sum split-K slices in slice order, apply the epilogue.  16 bytes per thread, 8 slices in flight.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split_k,
                                                             int64_t stride, float* __restrict__ c, int64_t ldc,
                                                             int64_t m, int n, Epi epi) {
     const int64_t total = m * (int64_t)n;
+    const bool vec = (n % 4 == 0) && (stride % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)ws % 16 == 0) &&
+                     ((uintptr_t)c % 16 == 0);
+    if (vec) {
+        const int64_t total4 = total >> 2;
+        for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
+            const float* p = ws + i4 * 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            int zz = 0;
+            for (; zz + 8 <= split_k; zz += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(zz + u) * stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; zz < split_k; ++zz) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)zz * stride);
+            const int64_t i = i4 * 4;
+            const int64_t row = i / n;
+            const int col = (int)(i - row * n);
+            float* o = c + row * ldc + col;
+            float4 y = make_float4(acc.x, acc.y, acc.z, acc.w);
+            y = epi_apply4(epi, y, row, col, n, c + row * ldc);
+            *reinterpret_cast<float4*>(o) = y;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int zz = 0; zz < split_k; ++zz) v += ws[(int64_t)zz * stride + i];
@@ -333,7 +368,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c, int64_t ldc,
                      int64_t m, int64_t n, float* c2, int64_t ldc2, int64_t n_split, const plnlp_epilogue* epi,
-                     int split_k, float* workspace, int64_t workspace_floats, void* stream);
+                     int split_k, float* workspace, int64_t workspace_floats, void* stream,
+                     const float* b2 = nullptr, int64_t ldb2 = 0, int64_t nb_split = -1);
+
+extern "C" int plnlp_gemm_concat_b_f32(const plnlp_gemm_operand* seg, const float* b2, int64_t ldb2,
+                                       int64_t nb_split, int a_trans, int b_trans, float* c, int64_t ldc,
+                                       int64_t m, int64_t n, const plnlp_epilogue* epi, int split_k,
+                                       float* workspace, int64_t workspace_floats, void* stream) {
+    if (!seg || !b2) return PLNLP_E_NULL;
+    if (nb_split <= 0 || nb_split >= n || nb_split % 128 != 0 || ldc < n) return PLNLP_E_SHAPE;
+    if (ldb2 < (b_trans ? seg->k : n - nb_split)) return PLNLP_E_SHAPE;
+    return gemm_impl(seg, 1, a_trans, b_trans, c, ldc, m, n, nullptr, 0, n, epi, split_k, workspace,
+                     workspace_floats, stream, b2, ldb2, nb_split);
+}
 
 extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c,
                               int64_t ldc, int64_t m, int64_t n, const plnlp_epilogue* epi, int split_k,
@@ -354,7 +401,8 @@ extern "C" int plnlp_gemm_split_out_f32(const plnlp_gemm_operand* segs, int n_se
 
 static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c, int64_t ldc,
                      int64_t m, int64_t n, float* c2, int64_t ldc2, int64_t n_split, const plnlp_epilogue* epi,
-                     int split_k, float* workspace, int64_t workspace_floats, void* stream) {
+                     int split_k, float* workspace, int64_t workspace_floats, void* stream, const float* b2,
+                     int64_t ldb2, int64_t nb_split) {
     using namespace plnlp;
     if (!segs || !c) return PLNLP_E_NULL;
     if (n_seg < 1 || n_seg > 2 || m < 0 || n < 0 || n > 0x7FFFFFF0) return PLNLP_E_SHAPE;
@@ -367,7 +415,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         const plnlp_gemm_operand& o = segs[s];
         if (!o.a || !o.b) return PLNLP_E_NULL;
         if (o.k <= 0 || o.k > 0x7FFFFF00) return PLNLP_E_SHAPE;
-        const int64_t a_inner = a_trans ? m : o.k, b_inner = b_trans ? o.k : n;
+        const int64_t a_inner = a_trans ? m : o.k, b_inner = b_trans ? o.k : (b2 ? nb_split : n);
         if (o.lda < a_inner || o.ldb < b_inner) return PLNLP_E_SHAPE;
         Seg& d = g.seg[s];
         d.a = o.a; d.lda = o.lda; d.b = o.b; d.ldb = o.ldb; d.k = (int)o.k;
@@ -380,6 +428,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     if (split_k > g.tiles_total) split_k = g.tiles_total;
     g.m = m; g.n = (int)n; g.split_k = split_k; g.ws_stride = m * n;
     g.c2 = c2; g.ldc2 = ldc2; g.n_split = (int)n_split;
+    g.b2 = b2; g.ldb2 = ldb2; g.nb_split = b2 ? (int)nb_split : (int)n;
     Epi e;
     if (int rc = make_epi(epi, &e)) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -400,6 +449,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         aligned = aligned && g.seg[si].a_vec && g.seg[si].b_vec;
         ragged = ragged || (g.seg[si].k % BK != 0);
     }
+    if (b2) aligned = aligned && ((uintptr_t)b2 % 16 == 0) && (ldb2 % 4 == 0) && ((n - nb_split) % 4 == 0);
     if (a_trans) aligned = aligned && (m % 4 == 0) && m >= 4;    // row-contiguous operands move 4 rows per load
     if (!b_trans) aligned = aligned && (n % 4 == 0) && n >= 4;
     int mode = !aligned ? 0 : (ragged ? 2 : 1);
@@ -413,6 +463,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         tail = g;
         tail.seg[0].a = a_trans ? g.seg[0].a + (int64_t)kfull * g.seg[0].lda : g.seg[0].a + kfull;
         tail.seg[0].b = b_trans ? g.seg[0].b + kfull : g.seg[0].b + (int64_t)kfull * g.seg[0].ldb;
+        if (b2) tail.b2 = b_trans ? b2 + kfull : b2 + (int64_t)kfull * ldb2;
         tail.seg[0].k = g.seg[0].k - kfull;
         tail.seg[0].a_vec = tail.seg[0].b_vec = 0;
         tail.tiles0 = tail.tiles_total = 1;
@@ -446,8 +497,9 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     if (peel) { if (int rc = launch(tail, 0, 1)) return rc; }
     if (split_k > 1) {
         const int64_t total = m * n;
-        int64_t blocks = (total + 255) / 256;
+        int64_t blocks = (total / 4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, reduce_slices,
                            g.ws_stride, c, ldc, m, (int)n, e);
         return launch_status();

@@ -135,6 +135,29 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     return out
 
 
+def wgrad_pair(dz: torch.Tensor, x1: torch.Tensor, x2: torch.Tensor):
+    """[dW1 | dW2] = dz^T [x1 | x2] in one split-K GEMM (plnlp_gemm_concat_b_f32): dz is read once.
+    Falls back to two products when the seam would cut a 128-column tile."""
+    lib = L.load()
+    L.require_device(dz, x1, x2)
+    dz, x1, x2 = _f32c(dz), _f32c(x1), _f32c(x2)
+    k, m = dz.shape
+    n1, n2 = x1.shape[1], x2.shape[1]
+    if n1 % 128 != 0:
+        return gemm([(dz, x1)], True, False), gemm([(dz, x2)], True, False)
+    n = n1 + n2
+    ops = (L.GemmOperand * 1)()
+    ops[0].a, ops[0].lda, ops[0].b, ops[0].ldb, ops[0].k = dz.data_ptr(), _ld(dz), x1.data_ptr(), _ld(x1), k
+    ktiles = (k + 31) // 32
+    split_k = max(1, min(_pick_split_k(m, n, ktiles), ktiles))
+    out = torch.empty(m, n, dtype=torch.float32, device=dz.device)
+    ws = torch.empty((split_k + 1) * m * n, dtype=torch.float32, device=dz.device) if split_k > 1 else None
+    L.check(lib.plnlp_gemm_concat_b_f32(ops, x2.data_ptr(), _ld(x2), n1, 1, 0, out.data_ptr(), _ld(out), m, n,
+                                        None, split_k, L.ptr(ws), 0 if ws is None else ws.numel(),
+                                        L.stream_ptr()), "plnlp_gemm_concat_b_f32")
+    return out[:, :n1].contiguous(), out[:, n1:].contiguous()
+
+
 def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool = False,
                    out1: Optional[torch.Tensor] = None):
     """(a @ op(b)) with the result columns split into two contiguous tensors
@@ -494,12 +517,15 @@ class SAGEConvFn(torch.autograd.Function):
                 if sink.on_ready is not None:
                     sink.on_ready()          # e.g. start the all-reduce; the GEMMs below overlap it
                 gx = None
-        if need[1]:
-            gwl = gemm([(dz, agg)], True, False)           # [out, in] = dz^T @ agg
+        if need[1] and need[3]:
+            gwl, gwr = wgrad_pair(dz, agg, x)             # [dWl | dWr] = dz^T [agg | x], dz read once
+        else:
+            if need[1]:
+                gwl = gemm([(dz, agg)], True, False)
+            if need[3]:
+                gwr = gemm([(dz, x)], True, False)
         if need[2]:
             gbl = colsum(dz)
-        if need[3]:
-            gwr = gemm([(dz, x)], True, False)
         return gx, gwl, gbl, gwr, None, None, None, None
 
 

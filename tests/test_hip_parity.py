@@ -634,3 +634,16 @@ def test_gemm_edge_tiles_never_read_past_the_operands(P, m, n, k, at, bt):
     torch.cuda.synchronize()
     ref = (a.double().t() if at else a.double()) @ (b.double().t() if bt else b.double())
     close(out, ref, atol=2e-5 * np.sqrt(k) * 4)
+
+
+def test_wgrad_pair_matches_two_products(P):
+    g = torch.Generator().manual_seed(77)
+    dz = torch.randn(5003, 256, generator=g)
+    x1 = torch.randn(5003, 256, generator=g)
+    x2 = torch.randn(5003, 200, generator=g)
+    a, b = P.ops.wgrad_pair(dev(dz), dev(x1), dev(x2))
+    close(a, dz.double().t() @ x1.double(), atol=2e-3)
+    close(b, dz.double().t() @ x2.double(), atol=2e-3)
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == (256, 256) and b.shape == (256, 200)
+    c, d = P.ops.wgrad_pair(dev(dz), dev(x2), dev(x1))          # seam not on a tile boundary -> fallback
+    close(c, dz.double().t() @ x2.double(), atol=2e-3)
