@@ -42,6 +42,7 @@ struct Epi {
     const float* bias;
     const float* gate;
     int64_t      ld_gate;
+    int          vec4;          // bias / gate may be read 16 bytes at a time (f % 4 == 0 callers only)
 };
 
 inline int make_epi(const plnlp_epilogue* e, Epi* out) {
@@ -64,6 +65,8 @@ inline int make_epi(const plnlp_epilogue* e, Epi* out) {
             d.keep_scale = 1.f / (1.f - e->dropout_p);
         }
     }
+    d.vec4 = (!(d.flags & PLNLP_EPI_BIAS) || ((uintptr_t)d.bias % 16 == 0)) &&
+             (!(d.flags & PLNLP_EPI_GATE) || (((uintptr_t)d.gate % 16 == 0) && (d.ld_gate % 4 == 0)));
     *out = d;
     return 0;
 }
@@ -86,6 +89,27 @@ __device__ __forceinline__ float4 epi_apply4(const Epi& e, float4 v, int64_t r, 
     if (e.flags == 0) return v;
     float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e.flags & PLNLP_EPI_ACCUM) prev = *reinterpret_cast<const float4*>(out_row + f);
+    if (e.vec4) {   // bias / gate rows are 16-byte loadable: one wide load each instead of four
+        if (e.flags & PLNLP_EPI_BIAS) {
+            const float4 b = *reinterpret_cast<const float4*>(e.bias + f);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (e.flags & PLNLP_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (e.flags & PLNLP_EPI_DROPOUT) {
+            const uint64_t i0 = (uint64_t)r * (uint64_t)n_cols + (uint64_t)f;
+            v.x = dropout_keep(i0 + 0, e.seed_lo, e.seed_hi, e.thresh) ? v.x * e.keep_scale : 0.f;
+            v.y = dropout_keep(i0 + 1, e.seed_lo, e.seed_hi, e.thresh) ? v.y * e.keep_scale : 0.f;
+            v.z = dropout_keep(i0 + 2, e.seed_lo, e.seed_hi, e.thresh) ? v.z * e.keep_scale : 0.f;
+            v.w = dropout_keep(i0 + 3, e.seed_lo, e.seed_hi, e.thresh) ? v.w * e.keep_scale : 0.f;
+        }
+        if (e.flags & PLNLP_EPI_ACCUM) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
+        if (e.flags & PLNLP_EPI_GATE) {
+            const float4 y = *reinterpret_cast<const float4*>(e.gate + r * e.ld_gate + f);
+            v.x = y.x > 0.f ? v.x * e.gate_scale : 0.f; v.y = y.y > 0.f ? v.y * e.gate_scale : 0.f;
+            v.z = y.z > 0.f ? v.z * e.gate_scale : 0.f; v.w = y.w > 0.f ? v.w * e.gate_scale : 0.f;
+        }
+        return v;
+    }
     v.x = epi_apply(e, v.x, r, f + 0, n_cols, prev.x);
     v.y = epi_apply(e, v.y, r, f + 1, n_cols, prev.y);
     v.z = epi_apply(e, v.z, r, f + 2, n_cols, prev.z);

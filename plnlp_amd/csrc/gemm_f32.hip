@@ -61,6 +61,7 @@ struct GemmArgs {
     int z0;               // first split-K slice this launch writes
     float* c2; int64_t ldc2; int n_split;   // columns >= n_split go to c2[:, col - n_split] (n_split = n: unused)
     const float* b2; int64_t ldb2; int nb_split;   // B columns >= nb_split come from b2 (segment 0; nb_split = n: unused)
+    int vec_store;        // output rows are 16-byte storable (n, ldc, n_split, pointers all 4-float aligned)
 };
 
 // ---- global -> registers ------------------------------------------------------
@@ -285,35 +286,52 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
 
     k_loop<A_T, B_T, MODE>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
 
-    // ---- write back: C/D map of the 32x32 MFMA: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+    // ---- write back.  The MFMA C/D map (col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)) would
+    // give 64 scattered 4-byte stores per lane; instead the block tile is transposed through LDS
+    // (free after the last K-tile) and leaves as 16-byte row stores, with the epilogue applied on
+    // float4 (one wide load each for bias / gate / accumulate operands).
+    constexpr int CS = BN + 4;                       // LDS row stride of the staged C tile (floats)
+    static_assert(BM * CS <= 4 * TILE_FLOATS, "C tile must fit the operand buffers");
     float* cbase = g.c;
     int64_t ldc = g.ldc;
     const bool raw = g.split_k > 1;
     if (raw) { cbase = g.c + (int64_t)(z + g.z0) * g.ws_stride; ldc = g.n; }
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l31;
-            if (col >= g.n) continue;
-            Epi e2 = epi;                       // bias is per column: fetch it once, not per element
-            float bcol = 0.f;
-            if (!raw && (epi.flags & PLNLP_EPI_BIAS)) { bcol = epi.bias[col]; e2.flags &= ~PLNLP_EPI_BIAS; }
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int64_t row = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (row >= g.m) continue;
-                float v = acc[i][j][q] + bcol;
-                float* p = (!raw && col >= g.n_split) ? g.c2 + row * g.ldc2 + (col - g.n_split)
-                                                      : cbase + row * ldc + col;
-                if (!raw && e2.flags) {
-                    const float prev = (e2.flags & PLNLP_EPI_ACCUM) ? *p : 0.f;
-                    v = epi_apply(e2, v, row, col, g.n, prev);
-                }
+            for (int q = 0; q < 16; ++q)
+                lds[(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + wn * 64 + j * 32 + l31] = acc[i][j][q];
+    __syncthreads();
+    const bool vec_out = g.vec_store;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int idx = t + 256 * u;
+        const int rl = idx >> 5, c4 = (idx & 31) * 4;
+        const int64_t row = m0 + rl;
+        const int col = n0 + c4;
+        if (row >= g.m || col >= g.n) continue;
+        float4 v = *reinterpret_cast<const float4*>(lds + rl * CS + c4);
+        const bool second = !raw && col >= g.n_split;
+        float* orow = second ? g.c2 + row * g.ldc2 - g.n_split : cbase + row * ldc;   // index with the global column
 #ifdef ABL_NOSTORE
-                if (v == 123.456f)
+        if (v.x != 123.456f) continue;
 #endif
-                *p = v;
+        if (vec_out && col + 3 < g.n) {
+            if (!raw) v = epi_apply4(epi, v, row, col, g.n, orow);
+            *reinterpret_cast<float4*>(orow + col) = v;
+        } else {
+            const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (col + c >= g.n) break;
+                const bool sec = !raw && (col + c) >= g.n_split;
+                float* p = sec ? g.c2 + row * g.ldc2 + (col + c - g.n_split) : cbase + row * ldc + col + c;
+                float x = e4[c];
+                if (!raw && epi.flags) x = epi_apply(epi, x, row, col + c, g.n, (epi.flags & PLNLP_EPI_ACCUM) ? *p : 0.f);
+                *p = x;
             }
         }
     }
@@ -429,6 +447,9 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     g.m = m; g.n = (int)n; g.split_k = split_k; g.ws_stride = m * n;
     g.c2 = c2; g.ldc2 = ldc2; g.n_split = (int)n_split;
     g.b2 = b2; g.ldb2 = ldb2; g.nb_split = b2 ? (int)nb_split : (int)n;
+    g.vec_store = (n % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)c % 16 == 0) &&
+                  (!c2 || ((n_split % 4 == 0) && (ldc2 % 4 == 0) && ((uintptr_t)c2 % 16 == 0))) &&
+                  (split_k <= 1 || ((uintptr_t)workspace % 16 == 0));
     Epi e;
     if (int rc = make_epi(epi, &e)) return rc;
     hipStream_t s = (hipStream_t)stream;
