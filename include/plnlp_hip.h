@@ -98,13 +98,14 @@ int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int64_t thresho
 
 #define PLNLP_REDUCE_SUM  0
 #define PLNLP_REDUCE_MEAN 1
+#define PLNLP_AGG_SHORT_ROWS 1   /* flags: rows average only a few entries -> several rows per wave */
 int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                             const float* val,        /* nullable: [nnz], or indexed through val_index */
                             const int32_t* val_index,/* nullable: [nnz]; weight of entry e = val[val_index[e]] */
                             const float* src_scale,  /* nullable: [n_src]    */
                             const float* x, int64_t ldx,
                             float* out, int64_t ldo,
-                            int64_t n_rows, int64_t feat, int reduce,
+                            int64_t n_rows, int64_t feat, int reduce, int flags,
                             const plnlp_epilogue* epi /* nullable, HOST ptr */,
                             const plnlp_row_split* split /* nullable, HOST ptr */,
                             void* stream);

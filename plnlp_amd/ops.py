@@ -52,6 +52,9 @@ def _ld(t: torch.Tensor) -> int:
 
 # ------------------------------------------------------------- raw kernels ------
 SPLIT_THRESHOLD = 256   # rows longer than this are cut into chunks (one wave each)
+SHORT_ROW_AVG = 0       # average entries per row below which the multi-row kernel form is used; 0 = never:
+                        # measured on MI355X the one-row-per-wave form wins even at ~1 entry per row (the
+                        # incidence pass is bound by writing / gating the dense [N, F] output, not by latency)
 
 
 def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
@@ -61,7 +64,7 @@ def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
 
 def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
                   src_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                  epilogue: Optional[L.Epilogue] = None, split="auto") -> torch.Tensor:
+                  epilogue: Optional[L.Epilogue] = None, split="auto", short_rows="auto") -> torch.Tensor:
     """out[r] = red_{e in row r} w_e x[col[e]]  (plnlp_csr_aggregate_f32).
     `graph` needs rowptr/col/val/n_rows/n_cols (+ row_split() when split == 'auto')."""
     lib = L.load()
@@ -73,6 +76,8 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
         out = torch.empty(graph.n_rows, feat, dtype=torch.float32, device=x.device)
     val = graph.val if use_values else None
     val_index = getattr(graph, "val_index", None) if use_values else None
+    if short_rows == "auto":     # several rows per wave when the average row has only a few entries
+        short_rows = graph.col.numel() < SHORT_ROW_AVG * graph.n_rows
     sp = None
     if split == "auto":
         split = graph.row_split(SPLIT_THRESHOLD) if _vector_path(x, out, feat) else None
@@ -86,6 +91,7 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
         L.ptr(src_scale),
         x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), graph.n_rows, feat,
         L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM,
+        L.AGG_SHORT_ROWS if short_rows else 0,
         C.byref(epilogue) if epilogue is not None else None,
         C.byref(sp) if sp is not None else None, L.stream_ptr())
     L.check(rc, "plnlp_csr_aggregate_f32")

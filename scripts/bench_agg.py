@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--cases", default="collab,uniform,ddi")
     ap.add_argument("--feat", default="256,512")
     ap.add_argument("--weighted", action="store_true")
+    ap.add_argument("--short-rows", default="auto", choices=["auto", "0", "1"])
     args = ap.parse_args()
     dev = torch.device("cuda")
     for case in args.cases.split(","):
@@ -33,7 +34,8 @@ def main():
         for feat in [int(f) for f in args.feat.split(",")]:
             x = torch.randn(g.n_cols, feat, device=dev)
             out = torch.empty(g.n_rows, feat, device=dev)
-            t = time_kernel(lambda: P.ops.csr_aggregate(g, x, "mean", args.weighted, out=out), iters=10)
+            sr = "auto" if args.short_rows == "auto" else args.short_rows == "1"
+            t = time_kernel(lambda: P.ops.csr_aggregate(g, x, "mean", args.weighted, out=out, short_rows=sr), iters=10)
             by = agg_bytes(g.nnz, g.n_rows, feat, args.weighted)
             print(json.dumps({"case": case, "N": g.n_rows, "nnz": g.nnz, "max_deg": int(deg.max()), "feat": feat,
                               "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),

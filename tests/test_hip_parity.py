@@ -647,3 +647,20 @@ def test_wgrad_pair_matches_two_products(P):
     assert a.is_contiguous() and b.is_contiguous() and a.shape == (256, 256) and b.shape == (256, 200)
     c, d = P.ops.wgrad_pair(dev(dz), dev(x2), dev(x1))          # seam not on a tile boundary -> fallback
     close(c, dz.double().t() @ x2.double(), atol=2e-3)
+
+
+@pytest.mark.parametrize("feat", [64, 128, 200, 256, 512])
+def test_csr_aggregate_short_row_form_matches(P, feat):
+    """several rows per wave (incidence lists, sparse graphs): same numbers as the one-row form"""
+    csr = rand_csr(3000, 4000, feat + 3, weighted=True, hub=600)      # ~1.5 entries per row + one long row
+    x = torch.randn(3000, feat, generator=torch.Generator().manual_seed(2))
+    g = to_graph(P, csr)
+    for reduce in ("sum", "mean"):
+        for use_values in (True, False):
+            ref = O.spmm(csr, x.double(), reduce, use_values)
+            a = P.ops.csr_aggregate(g, dev(x), reduce, use_values, short_rows=True)
+            b = P.ops.csr_aggregate(g, dev(x), reduce, use_values, short_rows=False)
+            close(a, ref, atol=3e-4)
+            close(a, b, atol=1e-5)
+    assert torch.equal(P.ops.csr_aggregate(g, dev(x), "sum", True, short_rows=True),
+                       P.ops.csr_aggregate(g, dev(x), "sum", True, short_rows=True))
