@@ -101,3 +101,36 @@ def uniform_graph(num_nodes: int, num_edges: int, device, seed: int = 0) -> Grap
     a = torch.randint(0, num_nodes, (num_edges,), generator=gen, device=device)
     b = torch.randint(0, num_nodes, (num_edges,), generator=gen, device=device)
     return Graph.from_coo(torch.cat([a, b]), torch.cat([b, a]), None, num_nodes, num_nodes)
+
+
+def rmat_graph(scale: int, num_edges: int, device, seed: int = 0, probs=(0.57, 0.19, 0.19, 0.05),
+               num_nodes: Optional[int] = None, symmetric: bool = False, chunk: int = 1 << 26,
+               permute: bool = True) -> Graph:
+    """R-MAT (a, b, c, d) edge generator on the device (BASELINE.json config 5: the skewed,
+    cache-hostile stress for the aggregation kernel).  2**scale ids, folded mod num_nodes; generated
+    in chunks; duplicates kept (a multigraph row just lists a source twice, like torch_sparse)."""
+    a, b, c, d = probs
+    n = int(num_nodes) if num_nodes is not None else 1 << scale
+    gen = torch.Generator(device=device).manual_seed(seed)
+    rows, cols = [], []
+    done = 0
+    while done < num_edges:
+        m = min(chunk, num_edges - done)
+        r = torch.zeros(m, dtype=torch.int64, device=device)
+        cc = torch.zeros(m, dtype=torch.int64, device=device)
+        for _ in range(scale):
+            u = torch.rand(m, generator=gen, device=device)
+            right = ((u >= a) & (u < a + b)) | (u >= a + b + c)          # quadrants b, d -> column bit
+            down = u >= a + b                                             # quadrants c, d -> row bit
+            r = (r << 1) | down.to(torch.int64)
+            cc = (cc << 1) | right.to(torch.int64)
+        rows.append(r % n)
+        cols.append(cc % n)
+        done += m
+    r, cc = torch.cat(rows), torch.cat(cols)
+    if permute:      # Graph500-style vertex relabelling: raw R-MAT ids put every hub at a power-of-two id
+        relabel = torch.randperm(n, generator=gen, device=device)
+        r, cc = relabel[r], relabel[cc]
+    if symmetric:
+        r, cc = torch.cat([r, cc]), torch.cat([cc, r])
+    return Graph.from_coo(r, cc, None, n, n)

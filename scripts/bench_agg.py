@@ -28,6 +28,10 @@ def main():
             g = uniform_graph(235868, 1179052, dev)
         elif case == "uniform_big":
             g = uniform_graph(2927963, 30387995, dev)
+        elif case.startswith("rmat"):          # rmat<scale>: 2**scale nodes, 16 edges per node (BASELINE config 5, scaled)
+            raw = case.endswith("raw")
+            sc = int(case[4:].replace("raw", "") or 23)
+            g = synthetic.rmat_graph(sc, 16 << sc, dev, seed=1, permute=not raw)
         else:
             g = synthetic.make_graph(case, seed=2, device=dev, weighted=args.weighted)["adj_t"]
         deg = g.degree()
