@@ -186,58 +186,88 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
     }
 }
 
+// one K-tile of MFMAs from the LDS buffers (at, bt)
+template <bool A_T, bool B_T>
+__device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][2], const float* __restrict__ at,
+                                         const float* __restrict__ bt, int wm, int wn, int l31, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a[2][4], b[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + l31;
+            if constexpr (A_T) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[i][s] = at[(8 * q + 4 * h + s) * LDR + row];
+            } else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(at + row * LDK + 8 * q + 4 * h);
+                a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wn * 64 + j * 32 + l31;
+            if constexpr (B_T) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bt + row * LDK + 8 * q + 4 * h);
+                b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[j][s] = bt[(8 * q + 4 * h + s) * LDR + row];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <bool A_T, bool B_T>
+__device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, const f32x4 (&ra)[4],
+                                           const f32x4 (&rb)[4], int t) {
+    float* at = lds + buf * TILE_FLOATS;
+    float* bt = lds + (2 + buf) * TILE_FLOATS;
+    if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
+    if constexpr (B_T) store_kc(bt, rb, t); else store_rc(bt, rb, t);
+}
+
+// K loop.  Global -> register -> LDS staging, two LDS buffers, one barrier per K-tile, and the global
+// loads run TWO tiles ahead of the MFMAs (two register sets, ping-pong): under full load an HBM
+// round trip is longer than one tile of MFMAs (64 x 64 cycles), so one tile of look-ahead left
+// every wave waiting on vmcnt at the top of each iteration.
 template <bool A_T, bool B_T, int MODE>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
                                        int h) {
-    f32x4 ra[4], rb[4];
-    if (tb < te) load_tile<A_T, B_T, MODE>(g, tb, ra, rb, m0, n0, t);
-    for (int tile = tb; tile < te; ++tile) {
-        const int buf = (tile - tb) & 1;
-        float* at = lds + buf * TILE_FLOATS;
-        float* bt = lds + (2 + buf) * TILE_FLOATS;
-        if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
-        if constexpr (B_T) store_kc(bt, rb, t); else store_rc(bt, rb, t);
+    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    if (tb < te) load_tile<A_T, B_T, MODE>(g, tb, ra0, rb0, m0, n0, t);
+    if (tb + 1 < te) load_tile<A_T, B_T, MODE>(g, tb + 1, ra1, rb1, m0, n0, t);
+    int tile = tb;
+    for (; tile + 1 < te; tile += 2) {
+        stage_tile<A_T, B_T>(lds, 0, ra0, rb0, t);
 #ifndef ABL_NOBARRIER
         __syncthreads();
 #endif
 #ifndef ABL_NOGLOAD
-        if (tile + 1 < te) load_tile<A_T, B_T, MODE>(g, tile + 1, ra, rb, m0, n0, t);
+        if (tile + 2 < te) load_tile<A_T, B_T, MODE>(g, tile + 2, ra0, rb0, m0, n0, t);
 #endif
-
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float a[2][4], b[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wm * 64 + i * 32 + l31;
-                if constexpr (A_T) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) a[i][s] = at[(8 * q + 4 * h + s) * LDR + row];
-                } else {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(at + row * LDK + 8 * q + 4 * h);
-                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wn * 64 + j * 32 + l31;
-                if constexpr (B_T) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(bt + row * LDK + 8 * q + 4 * h);
-                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) b[j][s] = bt[(8 * q + 4 * h + s) * LDR + row];
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-        }
+        mma_tile<A_T, B_T>(acc, lds, lds + 2 * TILE_FLOATS, wm, wn, l31, h);
+        stage_tile<A_T, B_T>(lds, 1, ra1, rb1, t);
+#ifndef ABL_NOBARRIER
+        __syncthreads();
+#endif
+#ifndef ABL_NOGLOAD
+        if (tile + 3 < te) load_tile<A_T, B_T, MODE>(g, tile + 3, ra1, rb1, m0, n0, t);
+#endif
+        mma_tile<A_T, B_T>(acc, lds + TILE_FLOATS, lds + 3 * TILE_FLOATS, wm, wn, l31, h);
+    }
+    if (tile < te) {        // odd tile count: last one sits in register set 0
+        stage_tile<A_T, B_T>(lds, 0, ra0, rb0, t);
+        __syncthreads();
+        mma_tile<A_T, B_T>(acc, lds, lds + 2 * TILE_FLOATS, wm, wn, l31, h);
     }
 }
 
