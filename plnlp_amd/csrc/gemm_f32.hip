@@ -235,39 +235,37 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, con
 }
 
 // K loop.  Global -> register -> LDS staging, two LDS buffers, one barrier per K-tile, and the global
-// loads run TWO tiles ahead of the MFMAs (two register sets, ping-pong): under full load an HBM
+// loads run PF tiles ahead of the MFMAs (PF register sets used round-robin): under full load an HBM
 // round trip is longer than one tile of MFMAs (64 x 64 cycles), so one tile of look-ahead left
 // every wave waiting on vmcnt at the top of each iteration.
+#ifndef PLNLP_GEMM_PF
+#define PLNLP_GEMM_PF 2
+#endif
 template <bool A_T, bool B_T, int MODE>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
                                        int h) {
-    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
-    if (tb < te) load_tile<A_T, B_T, MODE>(g, tb, ra0, rb0, m0, n0, t);
-    if (tb + 1 < te) load_tile<A_T, B_T, MODE>(g, tb + 1, ra1, rb1, m0, n0, t);
-    int tile = tb;
-    for (; tile + 1 < te; tile += 2) {
-        stage_tile<A_T, B_T>(lds, 0, ra0, rb0, t);
+    constexpr int PF = PLNLP_GEMM_PF;
+    f32x4 ra[PF][4], rb[PF][4];
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+        if (tb + d < te) load_tile<A_T, B_T, MODE>(g, tb + d, ra[d], rb[d], m0, n0, t);
+    for (int base = tb; base < te; base += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int tile = base + d;
+            if (tile < te) {                                   // block-uniform
+                const int buf = (tile - tb) & 1;
+                stage_tile<A_T, B_T>(lds, buf, ra[d], rb[d], t);
 #ifndef ABL_NOBARRIER
-        __syncthreads();
+                __syncthreads();
 #endif
 #ifndef ABL_NOGLOAD
-        if (tile + 2 < te) load_tile<A_T, B_T, MODE>(g, tile + 2, ra0, rb0, m0, n0, t);
+                if (tile + PF < te) load_tile<A_T, B_T, MODE>(g, tile + PF, ra[d], rb[d], m0, n0, t);
 #endif
-        mma_tile<A_T, B_T>(acc, lds, lds + 2 * TILE_FLOATS, wm, wn, l31, h);
-        stage_tile<A_T, B_T>(lds, 1, ra1, rb1, t);
-#ifndef ABL_NOBARRIER
-        __syncthreads();
-#endif
-#ifndef ABL_NOGLOAD
-        if (tile + 3 < te) load_tile<A_T, B_T, MODE>(g, tile + 3, ra1, rb1, m0, n0, t);
-#endif
-        mma_tile<A_T, B_T>(acc, lds + TILE_FLOATS, lds + 3 * TILE_FLOATS, wm, wn, l31, h);
-    }
-    if (tile < te) {        // odd tile count: last one sits in register set 0
-        stage_tile<A_T, B_T>(lds, 0, ra0, rb0, t);
-        __syncthreads();
-        mma_tile<A_T, B_T>(acc, lds, lds + 2 * TILE_FLOATS, wm, wn, l31, h);
+                mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
+            }
+        }
     }
 }
 
