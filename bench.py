@@ -261,9 +261,14 @@ def main():
     if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
-    if rank == 0:        # last thing on stdout: the one JSON line (RCCL prints its own chatter earlier)
+    if rank == 0:        # last thing on stdout: the one JSON line (RCCL's banner sits in the C stdio buffer)
         sys.stdout.flush()
         sys.stderr.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(result), flush=True)
 
 

@@ -445,6 +445,20 @@ def _act_backward(gy: torch.Tensor, y: torch.Tensor, act: _Act) -> torch.Tensor:
     return gate(gy, y, act.scale)
 
 
+_side_streams = {}
+OVERLAP_BACKWARD = {"enabled": False}   # measured on MI355X: no gain at collab, -4 % at ddi (the two kernels
+                                         # fight for the same CUs); kept as an option
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """second HIP stream per device: bandwidth-bound backward kernels (transposed aggregation) run
+    there next to the MFMA-bound weight-gradient GEMMs instead of after them"""
+    key = torch.device(device).index or 0
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 class GradSink:
     """Where the gradient of an encoder's INPUT goes when the caller wants it early.
 
@@ -516,12 +530,30 @@ class SAGEConvFn(torch.autograd.Function):
             gx, gagg = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin,
                                       out1=sink.buffer if sink is not None else None)
             ia = ctx.in_act
-            csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(), out=gx,
-                          epilogue=L.make_epilogue(accumulate=True, gate=x if ia is not None else None,
-                                                   gate_scale=ia.scale if ia is not None else 1.0))
-            if sink is not None:
-                if sink.on_ready is not None:
+            epi = L.make_epilogue(accumulate=True, gate=x if ia is not None else None,
+                                  gate_scale=ia.scale if ia is not None else 1.0)
+            joined = None
+            if OVERLAP_BACKWARD["enabled"]:
+                # HBM-bound transposed aggregation on the side stream, MFMA-bound weight gradients on
+                # the main stream: different bottlenecks, so they share the CUs instead of queueing
+                main = torch.cuda.current_stream()
+                side = side_stream(dz.device)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(),
+                                  out=gx, epilogue=epi)
+                    if sink is not None and sink.on_ready is not None:
+                        sink.on_ready()      # e.g. start the all-reduce (ordered after the aggregation)
+                    joined = torch.cuda.Event()
+                    joined.record(side)
+            else:
+                csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(), out=gx,
+                              epilogue=epi)
+                if sink is not None and sink.on_ready is not None:
                     sink.on_ready()          # e.g. start the all-reduce; the GEMMs below overlap it
+            if sink is not None:
                 gx = None
         if need[1] and need[3]:
             gwl, gwr = wgrad_pair(dz, agg, x)             # [dWl | dWr] = dz^T [agg | x], dz read once
@@ -532,6 +564,8 @@ class SAGEConvFn(torch.autograd.Function):
                 gwr = gemm([(dz, x)], True, False)
         if need[2]:
             gbl = colsum(dz)
+        if need[0] and OVERLAP_BACKWARD["enabled"] and joined is not None:
+            torch.cuda.current_stream().wait_event(joined)
         return gx, gwl, gbl, gwr, None, None, None, None
 
 
