@@ -302,32 +302,60 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     }
 }
 
-// split pass 2: one wave per long row adds its chunk sums in chunk order, then mean / epilogue / store
+// split pass 2: one BLOCK per long row.  Its 4 waves take the row's chunk sums round-robin (wave w:
+// chunks w, w+4, ...), each adding in increasing chunk order, and wave 0 then adds the 4 wave sums in
+// wave order -- a fixed order, so the result is reproducible; a hub with thousands of chunks no
+// longer serialises on one wave.  Then mean / epilogue / store.
 __global__ __launch_bounds__(256) void csr_agg_finalize_kernel(const int64_t* __restrict__ rowptr, int feat,
                                                                int mean, SplitArgs sp, float* __restrict__ out,
                                                                int64_t ldo, Epi epi) {
+    __shared__ float4 part[3][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t l = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t l = blockIdx.x;
     if (l >= sp.n_long) return;
     const int64_t r = sp.long_rows[l];
-    if (r < 0) return;
+    if (r < 0) return;                                   // idle slot (block-uniform)
     const int64_t c0 = sp.chunk_beg[l], c1 = c0 + sp.chunk_cnt[l];
     const int64_t deg = rowptr[r + 1] - rowptr[r];
     const int nslots = feat >> 2;
-    for (int s = lane; s < nslots; s += 64) {
+    for (int s0 = 0; s0 < nslots; s0 += 64) {
+        const int s = s0 + lane;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t c = c0; c < c1; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(sp.ws + c * (int64_t)feat + s * 4);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        if (s < nslots) {
+            int64_t c = c0 + wave;
+            for (; c + 12 < c1; c += 16) {               // 4 loads in flight
+                const float4 v0 = *reinterpret_cast<const float4*>(sp.ws + (c + 0) * (int64_t)feat + s * 4);
+                const float4 v1 = *reinterpret_cast<const float4*>(sp.ws + (c + 4) * (int64_t)feat + s * 4);
+                const float4 v2 = *reinterpret_cast<const float4*>(sp.ws + (c + 8) * (int64_t)feat + s * 4);
+                const float4 v3 = *reinterpret_cast<const float4*>(sp.ws + (c + 12) * (int64_t)feat + s * 4);
+                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+                acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+                acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+                acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+            }
+            for (; c < c1; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(sp.ws + c * (int64_t)feat + s * 4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
         }
-        if (mean) {
-            const float d = (float)(deg > 0 ? deg : 1);
-            acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d;
+        if (wave > 0) part[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && s < nslots) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float4 v = part[w][lane];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            if (mean) {
+                const float d = (float)(deg > 0 ? deg : 1);
+                acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d;
+            }
+            float* orow = out + r * ldo;
+            const float4 y = epi_apply4(epi, acc, r, (int64_t)s * 4, feat, orow);
+            *reinterpret_cast<float4*>(orow + s * 4) = y;
         }
-        float* orow = out + r * ldo;
-        const float4 y = epi_apply4(epi, acc, r, (int64_t)s * 4, feat, orow);
-        *reinterpret_cast<float4*>(orow + s * 4) = y;
+        __syncthreads();
     }
 }
 
@@ -429,7 +457,7 @@ static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, con
         hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, false>), cgrid, dim3(256), 0, s, rowptr, col, val,
                            val_index, src_scale, x, ldx, feat, *sp);
     if (int rc = launch_status()) return rc;
-    hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)((sp->n_long + 3) / 4)), dim3(256), 0, s, rowptr,
+    hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)sp->n_long), dim3(256), 0, s, rowptr,
                        feat, mean, *sp, out, ldo, e);
     return launch_status();
 }

@@ -152,16 +152,16 @@ __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* __
                                                                  float* __restrict__ partial) {
     __shared__ float4 sm[256];
     const int q = feat >> 2;              // float4 per row
-    const int lanes = 256 / q;            // rows per step (host guarantees q divides 256)
+    const int lanes = 256 / q;            // rows per step; threads past lanes*q idle (e.g. feat = 200: 250 busy)
     const int c4 = threadIdx.x % q, rl = threadIdx.x / q;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < n_rows; r += (int64_t)gridDim.x * lanes) {
+    for (int64_t r = (int64_t)blockIdx.x * lanes + rl; rl < lanes && r < n_rows; r += (int64_t)gridDim.x * lanes) {
         const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
         const float w = rw ? rw[r] : 1.f;
         acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
         acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
     }
-    sm[threadIdx.x] = acc;
+    if (rl < lanes) sm[rl * q + c4] = acc;
     __syncthreads();
     if (rl == 0) {
         for (int k = 1; k < lanes; ++k) {
@@ -343,7 +343,7 @@ extern "C" int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int
     if (workspace_floats < blocks * feat) return PLNLP_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int64_t q = feat / 4;
-    const bool vec = feat % 4 == 0 && q <= 256 && 256 % q == 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0 &&
+    const bool vec = feat % 4 == 0 && q >= 1 && q <= 256 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0 &&
                      (uintptr_t)workspace % 16 == 0;
     if (vec)
         hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, n_rows,
