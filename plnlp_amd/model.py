@@ -100,6 +100,12 @@ class BaseModel(object):
             return self.emb.weight
         feat = data.x.to(self.device)
         if self.train_node_emb:
+            if feat.is_cuda and isinstance(self.encoder, BaseGNN):
+                # same values as torch.cat([emb.weight, x], -1), kept in a persistent padded buffer
+                from .ops import concat_features
+                if not hasattr(self, "_feat_cache"):
+                    self._feat_cache = {}
+                return concat_features(self.emb.weight, feat, self._feat_cache)
             feat = torch.cat([self.emb.weight, feat], dim=-1)
         return feat
 

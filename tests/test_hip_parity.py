@@ -664,3 +664,38 @@ def test_csr_aggregate_short_row_form_matches(P, feat):
             close(a, b, atol=1e-5)
     assert torch.equal(P.ops.csr_aggregate(g, dev(x), "sum", True, short_rows=True),
                        P.ops.csr_aggregate(g, dev(x), "sum", True, short_rows=True))
+
+
+def test_gcn_on_concatenated_unaligned_features_matches_oracle(P):
+    """citation2 layout: input = [embedding 50 | features 128] (178 wide, not 16-byte aligned):
+    the padded-buffer path must give the same outputs and gradients as torch.cat + the oracle GCN"""
+    from plnlp_amd.ops import concat_features
+    torch.manual_seed(4)
+    n, e, f, h = 700, 50, 128, 200
+    csr = O.gcn_norm_csr(rand_csr(n, 8000, 31, weighted=False))
+    ref = O.GNNRef("GCN", e + f, h, h, 2, 0.0).double()
+    enc = P.GCN(e + f, h, h, 2, 0.0)
+    _copy_params(enc, ref.float())
+    ref = ref.double()
+    enc = enc.cuda()
+    emb = torch.randn(n, e)
+    feats = torch.randn(n, f)
+    embd = emb.double().requires_grad_(True)
+    embg = emb.cuda().requires_grad_(True)
+    go = torch.randn(n, h)
+    out_ref = ref(torch.cat([embd, feats.double()], -1), csr)
+    out_ref.backward(go.double())
+    cache = {}
+    x = concat_features(embg, feats.cuda(), cache)
+    assert x.shape == (n, e + f) and x.stride(0) == 180
+    out = enc(x, to_graph(P, csr))
+    out.backward(go.cuda())
+    close(out, out_ref, atol=2e-4)
+    close(embg.grad, embd.grad, atol=2e-4)
+    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad, rtol=1e-4, atol=3e-4 * max(1.0, float(q.grad.abs().max())), msg=k)
+    # second step reuses the buffer and refreshes only the embedding block
+    with torch.no_grad():
+        embg.add_(1.0)
+    x2 = concat_features(embg, feats.cuda(), cache)
+    close(x2, torch.cat([embg.detach().cpu(), feats], -1), rtol=0, atol=0)
