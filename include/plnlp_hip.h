@@ -99,13 +99,15 @@ int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int64_t thresho
 #define PLNLP_REDUCE_SUM  0
 #define PLNLP_REDUCE_MEAN 1
 #define PLNLP_AGG_SHORT_ROWS 1   /* flags: rows average only a few entries -> several rows per wave */
+#define PLNLP_AGG_LDS_STAGE  2   /* flags: small dense graph -> stage feature slabs of x in LDS (needs
+                                    n_src * 16 B <= ~150 KiB, 16-byte aligned rows); gathers then hit LDS */
 int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                             const float* val,        /* nullable: [nnz], or indexed through val_index */
                             const int32_t* val_index,/* nullable: [nnz]; weight of entry e = val[val_index[e]] */
                             const float* src_scale,  /* nullable: [n_src]    */
                             const float* x, int64_t ldx,
                             float* out, int64_t ldo,
-                            int64_t n_rows, int64_t feat, int reduce, int flags,
+                            int64_t n_rows, int64_t n_src /* rows of x */, int64_t feat, int reduce, int flags,
                             const plnlp_epilogue* epi /* nullable, HOST ptr */,
                             const plnlp_row_split* split /* nullable, HOST ptr */,
                             void* stream);

@@ -42,6 +42,7 @@ class GemmOperand(C.Structure):
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE = 1, 2, 4, 8, 16
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 AGG_SHORT_ROWS = 1
+AGG_LDS_STAGE = 2
 LOSS_KINDS = {"auc": 0, "hinge_auc": 1, "weighted_auc": 2, "adaptive_auc": 3,
               "weighted_hinge_auc": 4, "adaptive_hinge_auc": 5, "log_rank": 6}
 
@@ -55,7 +56,7 @@ SIGNATURES = {
     "plnlp_incidence_build": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plnlp_csr_aggregate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64,
-                                          C.c_void_p, c_i64, c_i64, c_i64, C.c_int, C.c_int, C.POINTER(Epilogue),
+                                          C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.c_int, C.c_int, C.POINTER(Epilogue),
                                           C.POINTER(RowSplit), C.c_void_p]),
     "plnlp_gemm_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
                                  c_i64, C.POINTER(Epilogue), C.c_int, C.c_void_p, c_i64, C.c_void_p]),

@@ -17,6 +17,8 @@
 // shuffles at the end.
 #include "common.hip.h"
 
+#define PLNLP_AGG_LDS_BUDGET (152 * 1024)   // bytes of the 160 KiB LDS the staged slab may take
+
 namespace plnlp {
 
 template <int LPR>  // lanes per feature row: 64, 32, 16, 8
@@ -256,6 +258,116 @@ __global__ __launch_bounds__(256) void csr_agg_multirow_kernel(
     finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi);
 }
 
+// LDS-staged form for SMALL, DENSE graphs (ogbl-ddi: 4 267 nodes, ~500 neighbours per row).  The
+// whole source matrix cannot live in LDS, but a feature SLAB of it can: a workgroup stages
+// x[:, s0:s0+S] for every source row (n_src * S * 4 bytes <= ~150 KiB, S = 8 floats for ddi) with
+// coalesced reads, then serves every neighbour gather of its row range from LDS (ds_read_b128)
+// instead of L2: the same 4.4 GB of gathers per layer pass now come from the ~100 TB/s aggregate LDS
+// instead of the ~15 TB/s the cache hierarchy gave.  64/L neighbours are fetched per wave
+// instruction (L = S/4 lanes per neighbour); the partial sums of the lane groups are folded with
+// a wavefront shuffle tree once per row.  Grid = feature slabs x row blocks.
+constexpr int LDS_THREADS = 1024;   // 16 waves share one staged slab: the neighbour loop is a chain of
+                                    // dependent index loads, so it needs many waves to hide them
+template <int S, bool WEIGHTED>
+__global__ __launch_bounds__(LDS_THREADS) void csr_agg_lds_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, const int32_t* __restrict__ val_index,
+    const float* __restrict__ src_scale, const float* __restrict__ x, int64_t ldx,
+    float* __restrict__ out, int64_t ldo, int64_t n_rows, int64_t n_src, int feat, int mean,
+    int64_t rows_per_block, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) float4 slab[];      // [n_src][L]
+    constexpr int L = S / 4;          // float4 parts per source row
+    constexpr int NPW = 64 / L;       // neighbours per wave instruction
+    constexpr int U = 16;             // wave instructions in flight (a ~500-neighbour row in one batch at S = 8)
+    constexpr int NW = LDS_THREADS / 64;
+    const int s0 = blockIdx.x * S;
+    // ---- stage the slab: consecutive threads read consecutive 16-byte parts of a row
+    for (int64_t i = threadIdx.x; i < n_src * L; i += LDS_THREADS) {
+        const int64_t row = i / L;
+        const int f = s0 + (int)(i % L) * 4;
+        slab[i] = f < feat ? *reinterpret_cast<const float4*>(x + row * ldx + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nb = lane / L, part = lane % L;
+    const int64_t r_end = ((int64_t)blockIdx.y + 1) * rows_per_block < n_rows
+                              ? ((int64_t)blockIdx.y + 1) * rows_per_block : n_rows;
+    for (int64_t r = (int64_t)blockIdx.y * rows_per_block + wave; r < r_end; r += NW) {
+        const int64_t beg = rowptr[r], end = rowptr[r + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t e0 = beg; e0 < end; e0 += NPW * U) {
+            int c[U];
+            float w[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t e = e0 + u * NPW + nb;
+                ok[u] = e < end;
+                c[u] = ok[u] ? col[e] : 0;
+                w[u] = 1.f;
+                if constexpr (WEIGHTED) {
+                    if (ok[u]) {
+                        w[u] = val ? val[val_index ? (int64_t)val_index[e] : e] : 1.f;
+                        if (src_scale) w[u] *= src_scale[c[u]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 v = slab[(int64_t)c[u] * L + part];
+                if (ok[u]) {          // never 0 * x
+                    acc.x = fmaf(w[u], v.x, acc.x); acc.y = fmaf(w[u], v.y, acc.y);
+                    acc.z = fmaf(w[u], v.z, acc.z); acc.w = fmaf(w[u], v.w, acc.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = L; o < 64; o <<= 1) {       // fold the NPW lane groups (fixed order)
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        const int f = s0 + part * 4;
+        if (nb == 0 && f < feat) {
+            if (mean) {
+                const float d = (float)((end - beg) > 0 ? (end - beg) : 1);
+                acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d;
+            }
+            float* orow = out + r * ldo;
+            const float4 y = epi_apply4(epi, acc, r, f, feat, orow);
+            *reinterpret_cast<float4*>(orow + f) = y;
+        }
+    }
+}
+
+template <int S>
+static int launch_lds(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
+                      const int32_t* val_index, const float* src_scale, const float* x, int64_t ldx, float* out,
+                      int64_t ldo, int64_t n_rows, int64_t n_src, int feat, int mean, const Epi& e) {
+    const size_t lds_bytes = (size_t)n_src * S * 4;
+    const int slabs = (feat + S - 1) / S;
+    int64_t rb = (256 + slabs - 1) / slabs;      // one 16-wave workgroup per CU, one round
+    if (rb < 1) rb = 1;
+    if (rb > (n_rows + 15) / 16) rb = (n_rows + 15) / 16;
+    const int64_t rows_per_block = (n_rows + rb - 1) / rb;
+    dim3 grid((unsigned)slabs, (unsigned)rb);
+    hipError_t err;
+    if (weighted) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_agg_lds_kernel<S, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (err != hipSuccess) return (int)err;
+        hipLaunchKernelGGL((csr_agg_lds_kernel<S, true>), grid, dim3(LDS_THREADS), lds_bytes, s, rowptr, col, val, val_index,
+                           src_scale, x, ldx, out, ldo, n_rows, n_src, feat, mean, rows_per_block, e);
+    } else {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_agg_lds_kernel<S, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (err != hipSuccess) return (int)err;
+        hipLaunchKernelGGL((csr_agg_lds_kernel<S, false>), grid, dim3(LDS_THREADS), lds_bytes, s, rowptr, col, val,
+                           val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, feat, mean, rows_per_block, e);
+    }
+    return launch_status();
+}
+
 // split pass 1: one wave per chunk (<= threshold edges) of a long row; raw weighted sums to the workspace
 struct SplitArgs {
     int64_t threshold;
@@ -467,8 +579,9 @@ static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, con
 extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                                        const int32_t* val_index, const float* src_scale, const float* x,
                                        int64_t ldx, float* out,
-                                       int64_t ldo, int64_t n_rows, int64_t feat, int reduce, int flags,
-                                       const plnlp_epilogue* epi, const plnlp_row_split* split, void* stream) {
+                                       int64_t ldo, int64_t n_rows, int64_t n_src, int64_t feat, int reduce,
+                                       int flags, const plnlp_epilogue* epi, const plnlp_row_split* split,
+                                       void* stream) {
     using namespace plnlp;
     if (!rowptr || !x || !out) return PLNLP_E_NULL;
     if (n_rows < 0 || feat <= 0 || ldx < feat || ldo < feat || feat > (1 << 20)) return PLNLP_E_SHAPE;
@@ -509,6 +622,16 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
         return launch_status();
     }
     const int nslots = (int)(feat / 4);
+    if ((flags & PLNLP_AGG_LDS_STAGE) && n_src > 0 && n_src * 16 <= PLNLP_AGG_LDS_BUDGET) {
+        // widest slab that fits the LDS budget
+        if (n_src * 128 <= PLNLP_AGG_LDS_BUDGET && feat >= 32)
+            return launch_lds<32>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
+        if (n_src * 64 <= PLNLP_AGG_LDS_BUDGET && feat >= 16)
+            return launch_lds<16>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
+        if (n_src * 32 <= PLNLP_AGG_LDS_BUDGET && feat >= 8)
+            return launch_lds<8>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
+        return launch_lds<4>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
+    }
     if ((flags & PLNLP_AGG_SHORT_ROWS) && nslots >= 16 && nslots <= 128) {   // several rows per wave
         if (nslots <= 32)
             return launch_multirow<2, 16>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo,

@@ -246,6 +246,25 @@ __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ g,
         *p = v;
     }
 }
+// 16-byte form: a wave covers one row per step (feat/4 lanes busy), w stays in registers
+__global__ __launch_bounds__(256) void outer_vec_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                        int64_t n_rows, int feat, float* __restrict__ dx,
+                                                        int64_t lddx, Epi epi) {
+    const int lane = threadIdx.x & 63;
+    const int nslots = feat >> 2;
+    for (int s0 = 0; s0 < nslots; s0 += 64) {
+        const int s = s0 + lane;
+        const float4 wv = s < nslots ? reinterpret_cast<const float4*>(w)[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_rows; r += (int64_t)gridDim.x * 4) {
+            if (s >= nslots) continue;
+            const float gr = g[r];
+            float* orow = dx + r * lddx;
+            float4 v = make_float4(gr * wv.x, gr * wv.y, gr * wv.z, gr * wv.w);
+            v = epi_apply4(epi, v, r, (int64_t)s * 4, feat, orow);
+            reinterpret_cast<float4*>(orow)[s] = v;
+        }
+    }
+}
 
 static inline unsigned ew_grid(int64_t n) {
     int64_t b = (n + 255) / 256;
@@ -383,8 +402,16 @@ extern "C" int plnlp_outer_f32(const float* g, const float* w, int64_t n_rows, i
     if (!g || !w || !dx) return PLNLP_E_NULL;
     Epi e;
     if (int rc = make_epi(epi, &e)) return rc;
-    hipLaunchKernelGGL(outer_kernel, dim3(ew_grid(n_rows * feat)), dim3(256), 0, (hipStream_t)stream, g, w, n_rows,
-                       (int)feat, dx, lddx, e);
+    const bool vec = feat % 4 == 0 && lddx % 4 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)w % 16 == 0;
+    if (vec) {
+        int64_t blocks = (n_rows + 3) / 4;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(outer_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, w, n_rows,
+                           (int)feat, dx, lddx, e);
+    } else {
+        hipLaunchKernelGGL(outer_kernel, dim3(ew_grid(n_rows * feat)), dim3(256), 0, (hipStream_t)stream, g, w,
+                           n_rows, (int)feat, dx, lddx, e);
+    }
     return launch_status();
 }
 

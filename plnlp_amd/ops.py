@@ -52,6 +52,12 @@ def _ld(t: torch.Tensor) -> int:
 
 # ------------------------------------------------------------- raw kernels ------
 SPLIT_THRESHOLD = 256   # rows longer than this are cut into chunks (one wave each)
+LDS_STAGE_BUDGET = 152 * 1024   # bytes of LDS a staged feature slab may take (n_src * 16 B at the narrowest)
+LDS_STAGE_MIN_DEG = 32          # average row length from which staging x in LDS could pay for itself
+LDS_STAGE_AUTO = False          # measured on MI355X (ddi-shaped, F=512): LDS-staged 0.44 ms vs streaming 0.32 ms --
+                                # both issue one wave instruction per KiB gathered, and the staged form adds the
+                                # per-chunk index loads and a shuffle tree; the L2-resident stream wins, so the
+                                # staged form is opt-in (lds_stage=True)
 SHORT_ROW_AVG = 0       # average entries per row below which the multi-row kernel form is used; 0 = never:
                         # measured on MI355X the one-row-per-wave form wins even at ~1 entry per row (the
                         # incidence pass is bound by writing / gating the dense [N, F] output, not by latency)
@@ -64,7 +70,8 @@ def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
 
 def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
                   src_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                  epilogue: Optional[L.Epilogue] = None, split="auto", short_rows="auto") -> torch.Tensor:
+                  epilogue: Optional[L.Epilogue] = None, split="auto", short_rows="auto",
+                  lds_stage="auto") -> torch.Tensor:
     """out[r] = red_{e in row r} w_e x[col[e]]  (plnlp_csr_aggregate_f32).
     `graph` needs rowptr/col/val/n_rows/n_cols (+ row_split() when split == 'auto')."""
     lib = L.load()
@@ -78,6 +85,12 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
     val_index = getattr(graph, "val_index", None) if use_values else None
     if short_rows == "auto":     # several rows per wave when the average row has only a few entries
         short_rows = graph.col.numel() < SHORT_ROW_AVG * graph.n_rows
+    if lds_stage == "auto":      # small AND dense (ddi-like): feature slabs of x fit in LDS and are reused
+        lds_stage = (LDS_STAGE_AUTO and graph.n_cols * 16 <= LDS_STAGE_BUDGET
+                     and graph.col.numel() >= LDS_STAGE_MIN_DEG * graph.n_cols and feat % 4 == 0)
+    flags = (L.AGG_SHORT_ROWS if short_rows else 0) | (L.AGG_LDS_STAGE if lds_stage else 0)
+    if lds_stage:
+        split = None             # the staged form walks whole rows
     sp = None
     if split == "auto":
         split = graph.row_split(SPLIT_THRESHOLD) if _vector_path(x, out, feat) else None
@@ -89,9 +102,8 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
     rc = lib.plnlp_csr_aggregate_f32(
         graph.rowptr.data_ptr(), graph.col.data_ptr() or graph.rowptr.data_ptr(), L.ptr(val), L.ptr(val_index),
         L.ptr(src_scale),
-        x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), graph.n_rows, feat,
-        L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM,
-        L.AGG_SHORT_ROWS if short_rows else 0,
+        x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), graph.n_rows, graph.n_cols, feat,
+        L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM, flags,
         C.byref(epilogue) if epilogue is not None else None,
         C.byref(sp) if sp is not None else None, L.stream_ptr())
     L.check(rc, "plnlp_csr_aggregate_f32")

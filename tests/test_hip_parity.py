@@ -699,3 +699,31 @@ def test_gcn_on_concatenated_unaligned_features_matches_oracle(P):
         embg.add_(1.0)
     x2 = concat_features(embg, feats.cuda(), cache)
     close(x2, torch.cat([embg.detach().cpu(), feats], -1), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("n,feat", [(4267, 512), (1500, 200), (700, 64), (300, 36), (9000, 128)])
+def test_csr_aggregate_lds_staged_form_matches(P, n, feat):
+    """small dense graph: feature slabs staged in LDS; same numbers as the streaming form, every
+    epilogue, weighted and mean"""
+    from plnlp_amd import _lib
+    deg = 40
+    csr = rand_csr(n, n * deg, n + feat, weighted=True)
+    x = torch.randn(n, feat, generator=torch.Generator().manual_seed(3))
+    g = to_graph(P, csr)
+    for reduce in ("sum", "mean"):
+        for use_values in (True, False):
+            ref = O.spmm(csr, x.double(), reduce, use_values)
+            a = P.ops.csr_aggregate(g, dev(x), reduce, use_values, lds_stage=True)
+            b = P.ops.csr_aggregate(g, dev(x), reduce, use_values, lds_stage=False)
+            close(a, ref, atol=3e-4)
+            close(a, b, atol=2e-4)
+    assert torch.equal(P.ops.csr_aggregate(g, dev(x), "sum", True, lds_stage=True),
+                       P.ops.csr_aggregate(g, dev(x), "sum", True, lds_stage=True))
+    s = dev(torch.rand(n) + 0.5)
+    bias = dev(torch.randn(feat))
+    base = torch.randn(n, feat)
+    out = dev(base.clone())
+    P.ops.csr_aggregate(g, dev(x), "sum", False, src_scale=s, out=out, lds_stage=True,
+                        epilogue=_lib.make_epilogue(accumulate=True, bias=bias, relu=False))
+    ref = base.double() + O.spmm(csr, (x * s.cpu()[:, None]).double(), "sum", False) + bias.cpu().double()
+    close(out, ref, atol=3e-4)
