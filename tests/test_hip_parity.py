@@ -727,3 +727,56 @@ def test_csr_aggregate_lds_staged_form_matches(P, n, feat):
                         epilogue=_lib.make_epilogue(accumulate=True, bias=bias, relu=False))
     ref = base.double() + O.spmm(csr, (x * s.cpu()[:, None]).double(), "sum", False) + bias.cpu().double()
     close(out, ref, atol=3e-4)
+
+
+@pytest.mark.parametrize("kind,dims", [("SAGE", (30, 50, 18)), ("GCN", (30, 50, 18)), ("SAGE", (7, 9, 5)),
+                                        ("GCN", (129, 130, 131)), ("SAGE", (200, 200, 200))])
+def test_encoders_with_awkward_widths(P, kind, dims):
+    """feature widths that are not multiples of 4 / 32 / 128: every unaligned and ragged code path of
+    the aggregation and the GEMM (guarded loads, scalar stores, split outputs off a tile seam)"""
+    cin, hid, cout = dims
+    torch.manual_seed(cin + hid)
+    n = 333
+    csr = rand_csr(n, 4000, cin, weighted=True, hub=400)
+    if kind == "GCN":
+        csr = O.gcn_norm_csr(csr)
+    ref = O.GNNRef(kind, cin, hid, cout, 3, 0.0)
+    enc = getattr(P, kind)(cin, hid, cout, 3, 0.0)
+    _copy_params(enc, ref)
+    ref = ref.double()
+    enc = enc.cuda()
+    x = torch.randn(n, cin)
+    xd = x.double().requires_grad_(True)
+    xg = x.cuda().requires_grad_(True)
+    go = torch.randn(n, cout)
+    want = ref(xd, csr)
+    want.backward(go.double())
+    out = enc(xg, to_graph(P, csr))
+    out.backward(go.cuda())
+    close(out, want, atol=3e-4)
+    close(xg.grad, xd.grad, atol=3e-4)
+    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad, rtol=1e-4, atol=3e-4 * max(1.0, float(q.grad.abs().max())), msg=k)
+
+
+def test_mlp_predictor_awkward_widths_and_multi_output(P):
+    torch.manual_seed(9)
+    for cin, hid, cout, L in ((30, 50, 1, 3), (64, 64, 3, 2), (18, 18, 1, 1)):
+        ref = O.MLPPredictorRef(cin, hid, cout, L, 0.0)
+        m = P.MLPPredictor(cin, hid, cout, L, 0.0)
+        _copy_params(m, ref)
+        ref = ref.double()
+        m = m.cuda()
+        h = torch.randn(200, cin)
+        src, dst = torch.randint(0, 200, (1000,)), torch.randint(0, 200, (1000,))
+        hd = h.double().requires_grad_(True)
+        hg = h.cuda().requires_grad_(True)
+        go = torch.randn(1000, cout)
+        want = ref(hd[src], hd[dst])
+        want.backward(go.double())
+        out = m.score_edges(hg, src.cuda(), dst.cuda())
+        out.backward(go.cuda())
+        close(out, want, atol=2e-4)
+        close(hg.grad, hd.grad, atol=5e-4)
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            close(p.grad, q.grad, rtol=1e-4, atol=3e-4 * max(1.0, float(q.grad.abs().max())), msg=k)
