@@ -170,7 +170,7 @@ def main():
     if cfg["shape"] == "collab":      # random-walk augmented pairs, main.py:241-253
         starts = g["edges"].reshape(-1)
         reps = (need // (starts.numel() * 9)) + 1
-        pairs, weights = synthetic.random_walk_pairs(g["adj_t"], starts.repeat(reps), 10, gen)
+        pairs, weights = P.ops.random_walk_pairs(g["adj_t"], starts.repeat(reps), 10, 777)
         sel = torch.randperm(pairs.size(0), generator=gen, device=device)[:need]
         pos_all, w_all = pairs[sel], weights[sel]
     else:

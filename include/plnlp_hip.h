@@ -206,6 +206,13 @@ int64_t plnlp_incidence_temp_bytes(int64_t n_edges);
 int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
                           uint64_t* keys_a, uint64_t* keys_b, void* temp, int64_t temp_bytes,
                           int32_t* item_edge, int32_t* item_other, int64_t* seg_ptr, void* stream);
+/* uniform random walks for the random-walk pair augmentation (main.py:241-253; replaces
+ * torch_cluster.random_walk): walks[w, 0] = start[w], walks[w, l+1] = a uniformly chosen neighbour of
+ * walks[w, l] (the node itself if it has none).  Randomness: counter hash of (seed, w*L + l). */
+int plnlp_random_walk(const int64_t* rowptr, const int32_t* col, const int64_t* start,
+                      int64_t n_walkers, int walk_length, uint64_t seed,
+                      int64_t* walks /* [n_walkers, walk_length + 1] */, void* stream);
+
 /* deterministic variant over a node-sorted incidence list built once per batch:
  * for node slot s (seg_node[s] = node id, or s itself when seg_node is NULL), items
  * [seg_ptr[s], seg_ptr[s+1]) each

@@ -19,7 +19,7 @@ __all__ = [
     "CSR", "spmm", "spmm_dense_check", "gcn_norm_csr",
     "SAGEConvRef", "GCNConvRef", "GNNRef", "MLPPredictorRef", "DotPredictorRef",
     "LOSSES", "pairwise_loss", "select_loss",
-    "dropout_keep_mask", "counter_dropout",
+    "dropout_keep_mask", "counter_dropout", "random_walk_ref",
     "batch_permutation", "local_neg_sample_ref", "pad_negatives_ref",
     "perm_copy_ref", "structured_negative_sampling_ref", "global_neg_sample_ref",
     "pos_neg_edges_ref", "hits_at_k", "mrr_list", "evaluate_hits_ref",
@@ -213,6 +213,31 @@ def dropout_keep_mask(seed: int, n_rows: int, n_cols: int, p: float,
     h = _lowbias32((h + ((hi * np.uint64(0x9E3779B9)) & _M32) + s_hi) & _M32)
     thresh = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
     return h >= thresh
+
+
+def random_walk_ref(adj: "CSR", start: torch.Tensor, walk_length: int, seed: int) -> torch.Tensor:
+    """[3P] torch_cluster.random_walk semantics (Appendix A.6; main.py:242): column 0 = start, then a
+    uniformly chosen neighbour per step, staying put on isolated nodes.  The uniform variate is the
+    counter hash shared with plnlp_amd/csrc/incidence.hip::random_walk_kernel (floor(u * deg) as a
+    32x32 -> high-32 multiply), so walks are bit-exact against the HIP kernel."""
+    rowptr, col = adj.rowptr.numpy(), adj.col.numpy()
+    cur = start.numpy().astype(np.int64).copy()
+    s = cur.size
+    out = np.empty((s, walk_length + 1), dtype=np.int64)
+    out[:, 0] = cur
+    s_lo, s_hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    w = np.arange(s, dtype=np.uint64)
+    for l in range(walk_length):
+        idx = w * np.uint64(walk_length) + np.uint64(l)
+        h = _lowbias32((idx & _M32) ^ s_lo)
+        h = _lowbias32((h + (((idx >> np.uint64(32)) * np.uint64(0x9E3779B9)) & _M32) + s_hi) & _M32)
+        beg = rowptr[cur]
+        deg = (rowptr[cur + 1] - beg).astype(np.uint64)
+        off = ((h * deg) >> np.uint64(32)).astype(np.int64)
+        nxt = col[np.minimum(beg + off, max(col.size - 1, 0))] if col.size else cur
+        cur = np.where(deg > 0, nxt, cur)
+        out[:, l + 1] = cur
+    return torch.from_numpy(out)
 
 
 def counter_dropout(x: torch.Tensor, p: float, seed: int, training: bool = True) -> torch.Tensor:

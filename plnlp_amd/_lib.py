@@ -52,6 +52,8 @@ SIGNATURES = {
     "plnlp_error_string": (C.c_char_p, [C.c_int]),
     "plnlp_row_split_build": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plnlp_random_walk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_uint64, C.c_void_p,
+                                    C.c_void_p]),
     "plnlp_incidence_temp_bytes": (c_i64, [c_i64]),
     "plnlp_incidence_build": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -76,6 +76,32 @@ __global__ __launch_bounds__(256) void row_split_build_kernel(const int64_t* __r
     for (int64_t j = 0; j < nch; ++j) chunk_long[cb + j] = (int32_t)slot;
 }
 
+// uniform random walks (torch_cluster.random_walk semantics, main.py:242): one thread per walker,
+// next = col[rowptr[cur] + floor(u * deg)], stay put on a node without neighbours.  u comes from the
+// counter hash of (seed, walker * L + step), so a walk is reproducible and order-independent.
+__global__ __launch_bounds__(256) void random_walk_kernel(const int64_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col,
+                                                          const int64_t* __restrict__ start, int64_t n_walkers,
+                                                          int walk_length, uint32_t seed_lo, uint32_t seed_hi,
+                                                          int64_t* __restrict__ walks) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_walkers) return;
+    int64_t cur = start[w];
+    int64_t* o = walks + w * (walk_length + 1);
+    o[0] = cur;
+    for (int l = 0; l < walk_length; ++l) {
+        const int64_t beg = rowptr[cur];
+        const uint64_t deg = (uint64_t)(rowptr[cur + 1] - beg);
+        if (deg > 0) {
+            const uint64_t idx = (uint64_t)w * (uint64_t)walk_length + (uint64_t)l;
+            uint32_t h = lowbias32((uint32_t)idx ^ seed_lo);
+            h = lowbias32(h + (uint32_t)(idx >> 32) * 0x9E3779B9u + seed_hi);
+            cur = col[beg + (int64_t)(((uint64_t)h * deg) >> 32)];
+        }
+        o[l + 1] = cur;
+    }
+}
+
 static inline int bits_for(int64_t n) {  // smallest b with (1 << b) >= n
     int b = 0;
     while (((int64_t)1 << b) < n) ++b;
@@ -139,5 +165,17 @@ extern "C" int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int6
     hipLaunchKernelGGL(row_split_build_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, rowptr,
                        n_rows, threshold, n_long_cap, n_chunks_cap, long_rows, chunk_beg, chunk_cnt, chunk_long,
                        reinterpret_cast<unsigned long long*>(counters));
+    return launch_status();
+}
+
+extern "C" int plnlp_random_walk(const int64_t* rowptr, const int32_t* col, const int64_t* start,
+                                 int64_t n_walkers, int walk_length, uint64_t seed, int64_t* walks, void* stream) {
+    using namespace plnlp;
+    if (n_walkers < 0 || walk_length < 0 || walk_length > (1 << 20)) return PLNLP_E_SHAPE;
+    if (n_walkers == 0) return 0;
+    if (!rowptr || !start || !walks || (walk_length > 0 && !col)) return PLNLP_E_NULL;
+    hipLaunchKernelGGL(random_walk_kernel, dim3((unsigned)((n_walkers + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, rowptr, col, start, n_walkers, walk_length, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), walks);
     return launch_status();
 }

@@ -272,13 +272,17 @@ class BaseModel(object):
 
     # ------------------------------------------------------------------- eval ---
     @torch.no_grad()
-    def batch_predict(self, h, edges, batch_size):
-        """model.py:175-182, predictions kept on the device until the end"""
+    def batch_predict(self, h, edges, batch_size, to_cpu=True):
+        """model.py:175-182.  The reference copies every batch of scores to the host
+        (`.squeeze().cpu()` per batch); here they stay on the device, are concatenated once, and
+        move only if the caller asks (test() ranks them on the device)."""
         preds = []
-        for perm in batch_permutation(edges.size(0), batch_size, False):
-            edge = edges[perm.to(edges.device)]
+        batch_permutation(edges.size(0), batch_size, False)      # RNG parity: the loader's base-seed draw
+        for lo in range(0, edges.size(0), batch_size):
+            edge = edges[lo:lo + batch_size]
             preds.append(self._score(h, edge[:, 0], edge[:, 1]).reshape(-1))
-        return torch.cat(preds, dim=0).cpu()
+        out = torch.cat(preds, dim=0) if preds else torch.empty(0, device=h.device)
+        return out.cpu() if to_cpu else out
 
     @torch.no_grad()
     def test(self, data, split_edge, batch_size, evaluator, eval_metric):
@@ -293,10 +297,11 @@ class BaseModel(object):
         h = torch.cat([h, torch.mean(h, dim=0, keepdim=True)], dim=0)
 
         preds = {}
+        on_device = self.device.type == "cuda"      # Hits@K / MRR are torch ops: rank where the scores are
         for split in ('valid', 'test'):
             pos_edge, neg_edge = get_pos_neg_edges(split, split_edge)
-            preds[split] = (self.batch_predict(h, pos_edge.to(self.device), batch_size),
-                            self.batch_predict(h, neg_edge.to(self.device), batch_size))
+            preds[split] = (self.batch_predict(h, pos_edge.to(self.device), batch_size, to_cpu=not on_device),
+                            self.batch_predict(h, neg_edge.to(self.device), batch_size, to_cpu=not on_device))
         # batch_predict consumed base-seed draws as the reference's loaders do (4 loaders)
         fn = evaluate_hits if eval_metric == 'hits' else evaluate_mrr
         return fn(evaluator, preds['valid'][0], preds['valid'][1], preds['test'][0], preds['test'][1])

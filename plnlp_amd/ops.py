@@ -322,6 +322,29 @@ class Incidence:
         return self._split
 
 
+def random_walk(graph, start: torch.Tensor, walk_length: int, seed: int) -> torch.Tensor:
+    """torch_cluster.random_walk(row, col, start, walk_length) on the adjacency `graph`
+    (plnlp_random_walk): int64 [S, walk_length + 1], column 0 = start."""
+    lib = L.load()
+    L.require_device(start, graph.col)
+    start = _edge_idx(start)
+    walks = torch.empty(start.numel(), walk_length + 1, dtype=torch.int64, device=start.device)
+    L.check(lib.plnlp_random_walk(graph.rowptr.data_ptr(), graph.col.data_ptr() or graph.rowptr.data_ptr(),
+                                  start.data_ptr(), start.numel(), walk_length, seed & 0xFFFFFFFFFFFFFFFF,
+                                  walks.data_ptr(), L.stream_ptr()), "plnlp_random_walk")
+    return walks
+
+
+def random_walk_pairs(graph, start: torch.Tensor, walk_length: int, seed: int):
+    """main.py:241-253: pairs (start, j-th hop) for j = 1..L with weight 1/j, self pairs removed."""
+    walk = random_walk(graph, start, walk_length, seed)
+    pairs = torch.cat([walk[:, [0, j + 1]] for j in range(walk_length)], dim=0)
+    weights = torch.cat([torch.full((walk.size(0),), 1.0 / (j + 1), device=walk.device)
+                         for j in range(walk_length)], dim=0)
+    keep = pairs[:, 0] != pairs[:, 1]
+    return pairs[keep], weights[keep]
+
+
 def edge_segment_bwd(h: torch.Tensor, inc: Incidence, g: torch.Tensor,
                      out: Optional[torch.Tensor] = None,
                      epilogue: Optional[L.Epilogue] = None) -> torch.Tensor:

@@ -780,3 +780,32 @@ def test_mlp_predictor_awkward_widths_and_multi_output(P):
         close(hg.grad, hd.grad, atol=5e-4)
         for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
             close(p.grad, q.grad, rtol=1e-4, atol=3e-4 * max(1.0, float(q.grad.abs().max())), msg=k)
+
+
+def test_random_walk_bit_exact_and_valid(P):
+    """HIP random-walk kernel vs the oracle restatement (same counter hash): identical walks; every
+    hop is a real edge; isolated nodes stay put; hop choice is uniform over the neighbours."""
+    csr = rand_csr(500, 3000, 17, weighted=False)
+    g = to_graph(P, csr)
+    gen = torch.Generator().manual_seed(1)
+    start = torch.randint(0, 500, (4000,), generator=gen)
+    for seed, L in ((1, 5), (0xABCDEF0123456789, 10)):
+        walks = P.ops.random_walk(g, dev(start), L, seed).cpu()
+        ref = O.random_walk_ref(csr, start, L, seed)
+        assert torch.equal(walks, ref)
+        assert walks.shape == (4000, L + 1) and torch.equal(walks[:, 0], start)
+        edges = set(zip(csr.row_index().tolist(), csr.col.tolist()))
+        deg = csr.degree()
+        for a, b in zip(walks[:, :-1].reshape(-1).tolist(), walks[:, 1:].reshape(-1).tolist()):
+            assert (a, b) in edges or (deg[a] == 0 and a == b)
+    # uniformity of the first hop from a fixed node with many neighbours
+    hub = int(csr.degree().argmax())
+    w = P.ops.random_walk(g, dev(torch.full((60000,), hub)), 1, 7).cpu()[:, 1]
+    nb = csr.col[csr.rowptr[hub]:csr.rowptr[hub + 1]]
+    counts = torch.stack([(w == v).sum() for v in nb.unique()]).double()
+    mult = torch.stack([(nb == v).sum() for v in nb.unique()]).double()          # multi-edges weigh more
+    expected = 60000 * mult / mult.sum()
+    assert float(((counts - expected) ** 2 / expected).sum()) < 3 * counts.numel()     # chi-square sanity
+    pairs, weights = P.ops.random_walk_pairs(g, dev(start), 3, 5)
+    assert pairs.shape[1] == 2 and (pairs[:, 0] != pairs[:, 1]).all()
+    assert all(min(abs(v - t) for t in (1.0, 0.5, 1.0 / 3)) < 1e-6 for v in weights.unique().tolist())

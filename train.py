@@ -182,8 +182,7 @@ def main(argv=None):
             rw_start = split_edge['train']['edge'].reshape(-1).to(device)
         else:
             rw_start = torch.arange(0, num_nodes, dtype=torch.long, device=device)
-        rw_gen = torch.Generator(device=device)
-        rw_gen.manual_seed(args.seed if args.seed is not None else int(time.time()))
+        rw_seed = args.seed if args.seed is not None else int(time.time())
 
     for run in range(args.runs):
         model.param_init()
@@ -191,7 +190,8 @@ def main(argv=None):
         cur_lr = args.lr
         for epoch in range(1, 1 + args.epochs):
             if args.random_walk_augment:                                   # main.py:241-253
-                pairs, weights = synthetic.random_walk_pairs(rw_graph, rw_start, args.walk_length, rw_gen)
+                rw_seed += 1
+                pairs, weights = P.ops.random_walk_pairs(rw_graph, rw_start, args.walk_length, rw_seed)
                 split_edge['train']['edge'] = pairs.cpu()
                 split_edge['train']['weight'] = weights.cpu()
             loss = model.train(data, split_edge, batch_size=args.batch_size, neg_sampler_name=args.neg_sampler,
