@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the >>256 MiB HBM roofline measurement")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-parity", action="store_true", help="skip the Hits@50 GPU-vs-oracle training parity run")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the DP path on 1 GPU)")
     return ap.parse_args()
@@ -127,6 +128,66 @@ def cpu_baseline(cfg, g, pos, neg, w, steps):
             "sample": "%d full training steps (B=%d, k=%d) of the CPU oracle on the same synthetic %s-shaped "
                       "graph, torch %s CPU, %d threads; %.2f s/step" %
                       (steps, B, cfg["num_neg"], cfg["shape"], torch.__version__, os.cpu_count(), dt)}
+
+
+def hits_parity(P, device, epochs=12):
+    """Hits@50 parity (BASELINE.json metric): train the SAME small collab-shaped problem on the GPU path
+    and on the CPU oracle -- same initial weights, same negatives, same batch permutations, dropout 0
+    so both are deterministic -- and compare Hits@50 on held-out edges after every epoch."""
+    import oracle as O
+    from plnlp_amd import synthetic
+    from plnlp_amd.utils import Evaluator, evaluate_hits
+    g = synthetic.make_graph("collab", seed=11, device="cpu", num_nodes=3000, num_edges=24000, weighted=True)
+    n, h, B, k = g["num_nodes"], 64, 4096, 1
+    edges, w = g["edges"], g["weight"] / 5.0
+    gen = torch.Generator().manual_seed(5)
+    perm = torch.randperm(edges.size(0), generator=gen)
+    held, train = edges[perm[:2000]], edges[perm[2000:]]
+    wtrain = w[perm[2000:]]
+    negs = torch.randint(0, n, (20000, 2), generator=gen)
+    adj = P.Graph.from_coo(torch.cat([train[:, 0], train[:, 1]]), torch.cat([train[:, 1], train[:, 0]]), None, n, n)
+    model = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=1.0, gnn_num_layers=1, mlp_num_layers=2,
+                        emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n,
+                        num_node_feats=0, gnn_encoder_name="SAGE", predictor_name="DOT",
+                        loss_func="WeightedHingeAUC", optimizer_name="Adam", device=device,
+                        use_node_feats=False, train_node_emb=True)
+    torch.manual_seed(21)
+    model.param_init()
+    enc = O.GNNRef("SAGE", h, h, h, 1, 0.0)
+    enc.load_state_dict({k_: v.cpu() for k_, v in model.encoder.state_dict().items()})
+    emb = torch.nn.Embedding(n, h)
+    emb.weight.data.copy_(model.emb.weight.detach().cpu())
+    csr = O.CSR(adj.rowptr, adj.col.to(torch.int64), None, n)
+    ref = O.TrainerRef(enc, O.DotPredictorRef(), emb, csr, loss_name="WeightedHingeAUC", lr=0.01, clip_norm=1.0)
+
+    class D:
+        pass
+    data = D()
+    data.adj_t = adj.to(device)
+    data.edge_index = torch.stack([adj.coo()[1], adj.coo()[0]])
+    split = {"train": {"edge": train, "weight": wtrain},
+             "valid": {"edge": held[:1000], "edge_neg": negs[:10000]},
+             "test": {"edge": held[1000:], "edge_neg": negs[10000:]}}
+    ev = Evaluator("ogbl-collab")
+    rows = []
+    for epoch in range(epochs):
+        torch.manual_seed(1000 + epoch)
+        model.train(data, split, B, "local", k)
+        torch.manual_seed(1000 + epoch)
+        _, neg = O.pos_neg_edges_ref("train", {"train": {"edge": train}}, num_nodes=n, neg_sampler_name="local",
+                                     num_neg=k)
+        ref.train_epoch(train, neg, B, k, wtrain)
+        res = model.test(data, split, B, ev, "hits")["Hits@50"]
+        hh = ref.embed_for_eval()
+        pv = [ref.score(hh, split[s_]["edge"], B) for s_ in ("valid", "test")]
+        nv = [ref.score(hh, split[s_]["edge_neg"], B) for s_ in ("valid", "test")]
+        rres = O.evaluate_hits_ref(pv[0], nv[0], pv[1], nv[1])["Hits@50"]
+        rows.append((100 * res[0], 100 * res[1], 100 * rres[0], 100 * rres[1]))
+    last = rows[-1]
+    return {"epochs": epochs, "gpu_valid": last[0], "gpu_test": last[1], "cpu_valid": last[2], "cpu_test": last[3],
+            "max_abs_diff_points": max(max(abs(r[0] - r[2]), abs(r[1] - r[3])) for r in rows),
+            "note": "Hits@50 (percent) on 1000+1000 held-out edges vs 10000 negatives each, small collab-shaped "
+                    "graph (N=3000), SAGE x1 h=64 + DOT, same seeds on the HIP path and the CPU oracle"}
 
 
 def main():
@@ -256,6 +317,8 @@ def main():
             result["roofline_hbm_stress"] = r
             del big
             torch.cuda.empty_cache()
+        if world == 1 and not args.no_parity:
+            result["hits50_parity"] = hits_parity(P, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, g, pos_cpu, neg_cpu, w_cpu, args.cpu_steps)
     if pg is not None:

@@ -809,3 +809,12 @@ def test_random_walk_bit_exact_and_valid(P):
     pairs, weights = P.ops.random_walk_pairs(g, dev(start), 3, 5)
     assert pairs.shape[1] == 2 and (pairs[:, 0] != pairs[:, 1]).all()
     assert all(min(abs(v - t) for t in (1.0, 0.5, 1.0 / 3)) < 1e-6 for v in weights.unique().tolist())
+
+
+def test_hits50_training_parity_gpu_vs_oracle(P):
+    """BASELINE.json: 'Hits@K within +-0.3 of reference'.  Same seeds on both sides, a dozen epochs of
+    training: Hits@50 of the HIP path tracks the CPU oracle within 0.3 points at every epoch."""
+    import bench
+    r = bench.hits_parity(P, torch.device("cuda"), epochs=8)
+    assert r["max_abs_diff_points"] <= 0.3, r
+    assert r["gpu_test"] > 0.0
