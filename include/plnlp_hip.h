@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PLNLP_ABI_VERSION 1
+#define PLNLP_ABI_VERSION 2
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -46,7 +46,10 @@ const char* plnlp_error_string(int code);
 #define PLNLP_EPI_ACCUM     8u   /* out += result instead of out = result             */
 #define PLNLP_EPI_GATE     16u   /* result = gate[r,f] > 0 ? result*gate_scale : 0
                                     (backward of relu+dropout given the forward output);
-                                    applied LAST, i.e. after PLNLP_EPI_ACCUM */
+                                    applied LAST, i.e. after PLNLP_EPI_ACCUM / ADDEND */
+#define PLNLP_EPI_ADDEND   32u   /* result += addend[a, f], a = addend_index ? addend_index[r] : r,
+                                    skipped when a < 0 (a row-sparse term joining a dense result);
+                                    applied where PLNLP_EPI_ACCUM is */
 
 typedef struct plnlp_epilogue {
     uint32_t     flags;
@@ -56,6 +59,11 @@ typedef struct plnlp_epilogue {
     const float* gate;           /* PLNLP_EPI_GATE: [n_rows, ld_gate]         */
     int64_t      ld_gate;
     float        gate_scale;
+    const int32_t* gate_index;   /* nullable: the gate row of result row r is gate_index[r] (the result
+                                    holds only the rows of a longer matrix listed in gate_index)    */
+    const float* addend;         /* PLNLP_EPI_ADDEND: [*, ld_addend]           */
+    int64_t      ld_addend;
+    const int32_t* addend_index; /* nullable: [n_rows], -1 = no addend row     */
 } plnlp_epilogue;
 
 /* ---- K1/K2: CSR neighbour gather-and-reduce --------------------------------
@@ -105,6 +113,10 @@ int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                             const float* val,        /* nullable: [nnz], or indexed through val_index */
                             const int32_t* val_index,/* nullable: [nnz]; weight of entry e = val[val_index[e]] */
                             const float* src_scale,  /* nullable: [n_src]    */
+                            const int32_t* src_map,  /* nullable: [n_src]; x holds only SOME source rows: entry e
+                                                        reads x[src_map[col[e]]] and is skipped when that is < 0
+                                                        (src_scale still indexes col[e]) -- the transposed
+                                                        aggregation of a row-sparse gradient                */
                             const float* x, int64_t ldx,
                             float* out, int64_t ldo,
                             int64_t n_rows, int64_t n_src /* rows of x */, int64_t feat, int reduce, int flags,
@@ -128,6 +140,9 @@ typedef struct plnlp_gemm_operand {
     const float* a; int64_t lda;
     const float* b; int64_t ldb;
     int64_t k;
+    const int32_t* b_index;   /* nullable, b_trans = 0 and a_trans = 1 only: B's row for reduction index j is
+                                 b_index[j] (weight gradient over the rows of a row-sparse dz: B = the
+                                 layer input, gathered in place; applies to b2 of plnlp_gemm_concat_b_f32 too) */
 } plnlp_gemm_operand;
 
 int plnlp_gemm_f32(const plnlp_gemm_operand* segs /* HOST ptr */, int n_seg,
@@ -206,6 +221,15 @@ int64_t plnlp_incidence_temp_bytes(int64_t n_edges);
 int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
                           uint64_t* keys_a, uint64_t* keys_b, void* temp, int64_t temp_bytes,
                           int32_t* item_edge, int32_t* item_other, int64_t* seg_ptr, void* stream);
+/* rows of a CSR that are not empty, in increasing order (the nodes an edge batch touches: only those
+ * rows of the gathered matrix receive a gradient, so the encoder's last backward step runs on
+ * `count` rows instead of n_rows).  rows[i] = i-th non-empty row, node_map[r] = its position or -1,
+ * rowptr_c[i] = rowptr[rows[i]] and rowptr_c[count] = rowptr[n_rows] (the CSR without its empty
+ * rows), *count = their number.  Capacity of rows / rowptr_c: n_rows (+1).  block_ws: int32
+ * [plnlp_compact_rows_workspace(n_rows)].  Three small launches, deterministic. */
+int64_t plnlp_compact_rows_workspace(int64_t n_rows);
+int plnlp_compact_rows(const int64_t* rowptr, int64_t n_rows, int32_t* rows, int32_t* node_map,
+                       int64_t* rowptr_c, int64_t* count, int32_t* block_ws, void* stream);
 /* uniform random walks for the random-walk pair augmentation (main.py:241-253; replaces
  * torch_cluster.random_walk): walks[w, 0] = start[w], walks[w, l+1] = a uniformly chosen neighbour of
  * walks[w, l] (the node itself if it has none).  Randomness: counter hash of (seed, w*L + l). */

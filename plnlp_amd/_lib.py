@@ -23,7 +23,8 @@ class Epilogue(C.Structure):
     """mirror of plnlp_epilogue"""
     _fields_ = [("flags", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
                 ("bias", C.c_void_p), ("gate", C.c_void_p), ("ld_gate", C.c_int64),
-                ("gate_scale", C.c_float)]
+                ("gate_scale", C.c_float), ("gate_index", C.c_void_p), ("addend", C.c_void_p),
+                ("ld_addend", C.c_int64), ("addend_index", C.c_void_p)]
 
 
 class RowSplit(C.Structure):
@@ -36,10 +37,10 @@ class RowSplit(C.Structure):
 class GemmOperand(C.Structure):
     """mirror of plnlp_gemm_operand"""
     _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64),
-                ("k", C.c_int64)]
+                ("k", C.c_int64), ("b_index", C.c_void_p)]
 
 
-EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND = 1, 2, 4, 8, 16, 32
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 AGG_SHORT_ROWS = 1
 AGG_LDS_STAGE = 2
@@ -57,7 +58,11 @@ SIGNATURES = {
     "plnlp_incidence_temp_bytes": (c_i64, [c_i64]),
     "plnlp_incidence_build": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "plnlp_csr_aggregate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64,
+    "plnlp_compact_rows_workspace": (c_i64, [c_i64]),
+    "plnlp_compact_rows": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "plnlp_csr_aggregate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, c_i64,
                                           C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.c_int, C.c_int, C.POINTER(Epilogue),
                                           C.POINTER(RowSplit), C.c_void_p]),
     "plnlp_gemm_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
@@ -120,7 +125,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.plnlp_abi_version() != 1:
+    if lib.plnlp_abi_version() != 2:
         raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
@@ -149,7 +154,8 @@ def require_device(*tensors: Optional[torch.Tensor]) -> None:
 
 
 def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accumulate=False,
-                  gate=None, gate_scale=1.0) -> Optional[Epilogue]:
+                  gate=None, gate_scale=1.0, gate_index=None, addend=None,
+                  addend_index=None) -> Optional[Epilogue]:
     flags = 0
     e = Epilogue()
     if bias is not None:
@@ -168,8 +174,18 @@ def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accum
         e.gate = gate.data_ptr()
         e.ld_gate = gate.stride(0)
         e.gate_scale = float(gate_scale)
+        if gate_index is not None:
+            assert gate_index.dtype == torch.int32
+            e.gate_index = gate_index.data_ptr()
+    if addend is not None:
+        flags |= EPI_ADDEND
+        e.addend = addend.data_ptr()
+        e.ld_addend = addend.stride(0)
+        if addend_index is not None:
+            assert addend_index.dtype == torch.int32
+            e.addend_index = addend_index.data_ptr()
     if flags == 0:
         return None
     e.flags = flags
-    e._keepalive = (bias, gate)      # the struct holds raw pointers; keep the tensors alive with it
+    e._keepalive = (bias, gate, gate_index, addend, addend_index)      # the struct holds raw pointers; keep the tensors alive with it
     return e

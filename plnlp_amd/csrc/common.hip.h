@@ -42,7 +42,11 @@ struct Epi {
     const float* bias;
     const float* gate;
     int64_t      ld_gate;
-    int          vec4;          // bias / gate may be read 16 bytes at a time (f % 4 == 0 callers only)
+    const int32_t* gate_index;  // gate row of result row r (nullable: r itself)
+    const float* addend;        // PLNLP_EPI_ADDEND
+    int64_t      ld_addend;
+    const int32_t* addend_index;
+    int          vec4;          // bias / gate / addend may be read 16 bytes at a time (f % 4 == 0 callers only)
 };
 
 inline int make_epi(const plnlp_epilogue* e, Epi* out) {
@@ -55,6 +59,11 @@ inline int make_epi(const plnlp_epilogue* e, Epi* out) {
         if (d.flags & PLNLP_EPI_GATE) {
             if (!e->gate) return PLNLP_E_NULL;
             d.gate = e->gate; d.ld_gate = e->ld_gate; d.gate_scale = e->gate_scale;
+            d.gate_index = e->gate_index;
+        }
+        if (d.flags & PLNLP_EPI_ADDEND) {
+            if (!e->addend) return PLNLP_E_NULL;
+            d.addend = e->addend; d.ld_addend = e->ld_addend; d.addend_index = e->addend_index;
         }
         if (d.flags & PLNLP_EPI_DROPOUT) {
             if (!(e->dropout_p >= 0.f) || e->dropout_p >= 1.f) return PLNLP_E_SHAPE;
@@ -66,7 +75,8 @@ inline int make_epi(const plnlp_epilogue* e, Epi* out) {
         }
     }
     d.vec4 = (!(d.flags & PLNLP_EPI_BIAS) || ((uintptr_t)d.bias % 16 == 0)) &&
-             (!(d.flags & PLNLP_EPI_GATE) || (((uintptr_t)d.gate % 16 == 0) && (d.ld_gate % 4 == 0)));
+             (!(d.flags & PLNLP_EPI_GATE) || (((uintptr_t)d.gate % 16 == 0) && (d.ld_gate % 4 == 0))) &&
+             (!(d.flags & PLNLP_EPI_ADDEND) || (((uintptr_t)d.addend % 16 == 0) && (d.ld_addend % 4 == 0)));
     *out = d;
     return 0;
 }
@@ -80,7 +90,14 @@ __device__ __forceinline__ float epi_apply(const Epi& e, float v, int64_t r, int
         v = dropout_keep((uint64_t)r * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh)
                 ? v * e.keep_scale : 0.f;
     if (e.flags & PLNLP_EPI_ACCUM) v += prev;
-    if (e.flags & PLNLP_EPI_GATE) v = e.gate[r * e.ld_gate + f] > 0.f ? v * e.gate_scale : 0.f;
+    if (e.flags & PLNLP_EPI_ADDEND) {
+        const int64_t a = e.addend_index ? (int64_t)e.addend_index[r] : r;
+        if (a >= 0) v += e.addend[a * e.ld_addend + f];
+    }
+    if (e.flags & PLNLP_EPI_GATE) {
+        const int64_t gr = e.gate_index ? (int64_t)e.gate_index[r] : r;
+        v = e.gate[gr * e.ld_gate + f] > 0.f ? v * e.gate_scale : 0.f;
+    }
     return v;
 }
 
@@ -103,8 +120,16 @@ __device__ __forceinline__ float4 epi_apply4(const Epi& e, float4 v, int64_t r, 
             v.w = dropout_keep(i0 + 3, e.seed_lo, e.seed_hi, e.thresh) ? v.w * e.keep_scale : 0.f;
         }
         if (e.flags & PLNLP_EPI_ACCUM) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
+        if (e.flags & PLNLP_EPI_ADDEND) {
+            const int64_t a = e.addend_index ? (int64_t)e.addend_index[r] : r;
+            if (a >= 0) {
+                const float4 y = *reinterpret_cast<const float4*>(e.addend + a * e.ld_addend + f);
+                v.x += y.x; v.y += y.y; v.z += y.z; v.w += y.w;
+            }
+        }
         if (e.flags & PLNLP_EPI_GATE) {
-            const float4 y = *reinterpret_cast<const float4*>(e.gate + r * e.ld_gate + f);
+            const int64_t gr = e.gate_index ? (int64_t)e.gate_index[r] : r;
+            const float4 y = *reinterpret_cast<const float4*>(e.gate + gr * e.ld_gate + f);
             v.x = y.x > 0.f ? v.x * e.gate_scale : 0.f; v.y = y.y > 0.f ? v.y * e.gate_scale : 0.f;
             v.z = y.z > 0.f ? v.z * e.gate_scale : 0.f; v.w = y.w > 0.f ? v.w * e.gate_scale : 0.f;
         }

@@ -78,12 +78,12 @@ template <int VPL, int LPR, bool WEIGHTED>
 __device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64_t end,
                                           const int32_t* __restrict__ col, const float* __restrict__ val,
                                           const int32_t* __restrict__ val_index,
-                                          const float* __restrict__ src_scale, const float* __restrict__ x,
+                                          const float* __restrict__ src_scale, const int32_t* __restrict__ src_map, const float* __restrict__ x,
                                           int64_t ldx, int lane, int sub, int grp, int nslots) {
     constexpr int NG = 64 / LPR;
     constexpr int CH = (VPL >= 4) ? 4 : 8;
     for (int64_t e0 = beg; e0 < end; e0 += 64) {
-        const int n = (int)((end - e0) < 64 ? (end - e0) : 64);
+        int n = (int)((end - e0) < 64 ? (end - e0) : 64);
         int cvec = 0;
         float wvec = 0.f;
         if (lane < n) {
@@ -92,6 +92,24 @@ __device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64
                 wvec = val ? val[val_index ? (int64_t)val_index[e0 + lane] : e0 + lane] : 1.f;
                 if (src_scale) wvec *= src_scale[cvec];
             }
+        }
+        if (src_map) {   // wave-uniform
+            // x holds only the mapped source rows: translate the 64 indices and squeeze the entries
+            // without a row to the back with one lane permutation (order of the rest kept, so the
+            // sum order -- and every bit of the result -- is unchanged); the loops below then
+            // simply see a shorter batch
+            const int cm = (lane < n) ? src_map[cvec] : -1;
+            const bool ok = cm >= 0;
+            const uint64_t mask = __ballot(ok);
+            const int before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            const int nv = __popcll(mask);
+            const int dest = ok ? before : nv + (lane - before);
+            cvec = __builtin_amdgcn_ds_permute(dest << 2, cm);
+            cvec = cvec < 0 ? 0 : cvec;      // lanes past nv: a loadable row (ragged lane groups still issue the load)
+            if constexpr (WEIGHTED) wvec = __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(wvec)));
+            n = nv;
+            if (n == 0) continue;
         }
         const int ngroups = (n + NG - 1) / NG;  // wave instructions needed
         for (int j = 0; j < ngroups; j += CH) {
@@ -166,7 +184,7 @@ template <int VPL, int LPR, bool WEIGHTED>
 __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
-    const float* __restrict__ src_scale,
+    const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
     int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi) {
     const int lane = threadIdx.x & 63;
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     float4 acc[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, x, ldx, lane, sub, grp, nslots);
+    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
     finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi);
@@ -195,7 +213,7 @@ template <int VPL, int LPR, bool WEIGHTED>
 __global__ __launch_bounds__(256) void csr_agg_multirow_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
-    const float* __restrict__ src_scale,
+    const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
     int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi) {
     constexpr int G = 64 / LPR;
@@ -272,7 +290,7 @@ template <int S, bool WEIGHTED>
 __global__ __launch_bounds__(LDS_THREADS) void csr_agg_lds_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
-    const float* __restrict__ src_scale, const float* __restrict__ x, int64_t ldx,
+    const float* __restrict__ src_scale, const int32_t* __restrict__ src_map, const float* __restrict__ x, int64_t ldx,
     float* __restrict__ out, int64_t ldo, int64_t n_rows, int64_t n_src, int feat, int mean,
     int64_t rows_per_block, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float4 slab[];      // [n_src][L]
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(LDS_THREADS) void csr_agg_lds_kernel(
 
 template <int S>
 static int launch_lds(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
-                      const int32_t* val_index, const float* src_scale, const float* x, int64_t ldx, float* out,
+                      const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
                       int64_t ldo, int64_t n_rows, int64_t n_src, int feat, int mean, const Epi& e) {
     const size_t lds_bytes = (size_t)n_src * S * 4;
     const int slabs = (feat + S - 1) / S;
@@ -357,13 +375,13 @@ static int launch_lds(bool weighted, hipStream_t s, const int64_t* rowptr, const
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (err != hipSuccess) return (int)err;
         hipLaunchKernelGGL((csr_agg_lds_kernel<S, true>), grid, dim3(LDS_THREADS), lds_bytes, s, rowptr, col, val, val_index,
-                           src_scale, x, ldx, out, ldo, n_rows, n_src, feat, mean, rows_per_block, e);
+                           src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, feat, mean, rows_per_block, e);
     } else {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_agg_lds_kernel<S, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (err != hipSuccess) return (int)err;
         hipLaunchKernelGGL((csr_agg_lds_kernel<S, false>), grid, dim3(LDS_THREADS), lds_bytes, s, rowptr, col, val,
-                           val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, feat, mean, rows_per_block, e);
+                           val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, feat, mean, rows_per_block, e);
     }
     return launch_status();
 }
@@ -384,7 +402,7 @@ template <int VPL, int LPR, bool WEIGHTED>
 __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
-    const float* __restrict__ src_scale,
+    const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, int feat, SplitArgs sp) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -403,7 +421,7 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     float4 acc[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, x, ldx, lane, sub, grp, nslots);
+    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
     float* w = sp.ws + c * (int64_t)feat;
@@ -476,7 +494,7 @@ template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
-    const float* __restrict__ src_scale,
+    const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
     int64_t n_rows, int feat, int mean, Epi epi) {
     const int lane = threadIdx.x & 63;
@@ -487,12 +505,13 @@ __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
     for (int f0 = 0; f0 < feat; f0 += 64 * 4) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int64_t e = beg; e < end; ++e) {
-            const int c = col[e];
+            int c = col[e];
             float w = 1.f;
             if constexpr (WEIGHTED) {
                 w = val ? val[val_index ? (int64_t)val_index[e] : e] : 1.f;
                 if (src_scale) w *= src_scale[c];
             }
+            if (src_map) { c = src_map[c]; if (c < 0) continue; }
             const float* p = x + (int64_t)c * ldx;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -515,29 +534,29 @@ __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
 
 template <int VPL, int LPR>
 static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
-                        const int32_t* val_index, const float* src_scale, const float* x, int64_t ldx, float* out,
+                        const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
                         int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp);
 
 template <int VPL, int LPR>
 static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* rowptr, const int32_t* col,
-                      const float* val, const int32_t* val_index, const float* src_scale, const float* x,
+                      const float* val, const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x,
                       int64_t ldx, float* out,
                       int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e, const SplitArgs* sp) {
     const int64_t skip = sp ? sp->threshold : 0;
     if (weighted)
         hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true>), grid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
+                           val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
     else
         hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false>), grid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
+                           val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
     if (int rc = launch_status()) return rc;
-    return launch_split<VPL, LPR>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, feat, mean,
+    return launch_split<VPL, LPR>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean,
                                   e, sp);
 }
 
 template <int VPL, int LPR>
 static int launch_multirow(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col,
-                           const float* val, const int32_t* val_index, const float* src_scale, const float* x,
+                           const float* val, const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x,
                            int64_t ldx, float* out, int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e,
                            const SplitArgs* sp) {
     constexpr int G = 64 / LPR;
@@ -545,29 +564,29 @@ static int launch_multirow(bool weighted, hipStream_t s, const int64_t* rowptr, 
     dim3 grid((unsigned)((n_rows + 4 * G - 1) / (4 * G)));
     if (weighted)
         hipLaunchKernelGGL((csr_agg_multirow_kernel<VPL, LPR, true>), grid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
+                           val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
     else
         hipLaunchKernelGGL((csr_agg_multirow_kernel<VPL, LPR, false>), grid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
+                           val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
     if (int rc = launch_status()) return rc;
     // long rows: chunks run on the full-wave kernel geometry of this feature width
-    if (feat <= 256) return launch_split<1, 64>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, feat, mean, e, sp);
-    if (feat <= 512) return launch_split<2, 64>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, feat, mean, e, sp);
-    return launch_split<4, 64>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, feat, mean, e, sp);
+    if (feat <= 256) return launch_split<1, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
+    if (feat <= 512) return launch_split<2, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
+    return launch_split<4, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
 }
 
 template <int VPL, int LPR>
 static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
-                        const int32_t* val_index, const float* src_scale, const float* x, int64_t ldx, float* out,
+                        const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
                         int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp) {
     if (!sp || sp->n_long == 0 || sp->n_chunks == 0) return 0;
     dim3 cgrid((unsigned)((sp->n_chunks + 3) / 4));
     if (weighted)
         hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, true>), cgrid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, x, ldx, feat, *sp);
+                           val_index, src_scale, src_map, x, ldx, feat, *sp);
     else
         hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, false>), cgrid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, x, ldx, feat, *sp);
+                           val_index, src_scale, src_map, x, ldx, feat, *sp);
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)sp->n_long), dim3(256), 0, s, rowptr,
                        feat, mean, *sp, out, ldo, e);
@@ -577,7 +596,7 @@ static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, con
 }  // namespace plnlp
 
 extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col, const float* val,
-                                       const int32_t* val_index, const float* src_scale, const float* x,
+                                       const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x,
                                        int64_t ldx, float* out,
                                        int64_t ldo, int64_t n_rows, int64_t n_src, int64_t feat, int reduce,
                                        int flags, const plnlp_epilogue* epi, const plnlp_row_split* split,
@@ -615,35 +634,36 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
     if (!vec_ok) {
         if (weighted)
             hipLaunchKernelGGL((csr_agg_scalar_kernel<true>), grid, dim3(256), 0, s, rowptr, col, val, val_index,
-                               src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e);
+                               src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e);
         else
             hipLaunchKernelGGL((csr_agg_scalar_kernel<false>), grid, dim3(256), 0, s, rowptr, col, val, val_index,
-                               src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e);
+                               src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e);
         return launch_status();
     }
     const int nslots = (int)(feat / 4);
+    if (src_map) flags = 0;      // the mapped gather exists on the one-row-per-wave forms only
     if ((flags & PLNLP_AGG_LDS_STAGE) && n_src > 0 && n_src * 16 <= PLNLP_AGG_LDS_BUDGET) {
         // widest slab that fits the LDS budget
         if (n_src * 128 <= PLNLP_AGG_LDS_BUDGET && feat >= 32)
-            return launch_lds<32>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
+            return launch_lds<32>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
         if (n_src * 64 <= PLNLP_AGG_LDS_BUDGET && feat >= 16)
-            return launch_lds<16>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
+            return launch_lds<16>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
         if (n_src * 32 <= PLNLP_AGG_LDS_BUDGET && feat >= 8)
-            return launch_lds<8>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
-        return launch_lds<4>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
+            return launch_lds<8>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
+        return launch_lds<4>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
     }
     if ((flags & PLNLP_AGG_SHORT_ROWS) && nslots >= 16 && nslots <= 128) {   // several rows per wave
         if (nslots <= 32)
-            return launch_multirow<2, 16>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo,
+            return launch_multirow<2, 16>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
                                           n_rows, (int)feat, mean, e, sp);
         if (nslots <= 64)
-            return launch_multirow<2, 32>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo,
+            return launch_multirow<2, 32>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
                                           n_rows, (int)feat, mean, e, sp);
-        return launch_multirow<4, 32>(weighted, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo,
+        return launch_multirow<4, 32>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
                                       n_rows, (int)feat, mean, e, sp);
     }
 #define PLNLP_AGG(VPL, LPR) \
-    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp)
+    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp)
     if (nslots <= 8) PLNLP_AGG(1, 8);
     if (nslots <= 16) PLNLP_AGG(1, 16);
     if (nslots <= 32) PLNLP_AGG(1, 32);

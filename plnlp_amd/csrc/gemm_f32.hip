@@ -45,6 +45,7 @@ struct Seg {
     const float* b; int64_t ldb;
     int k;
     int a_vec, b_vec;  // 16-byte path usable
+    const int32_t* b_index;   // B's row for reduction index j (row-contiguous B only), nullable
 };
 
 struct GemmArgs {
@@ -107,12 +108,22 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
 }
 // row-contiguous operand stored [kdim][nrows]: k [k0,k0+32) x rows [row0,row0+128);
 // thread t loads float4 at (k0 + (t>>5) + 8p, row0 + 4*(t&31)).
-template <bool FULL>
+// INDEXED: the operand's row for reduction index k is kidx[k] (rows gathered in place).
+template <bool FULL, bool INDEXED = false>
 __device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
-                                        int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
+                                        int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t,
+                                        const int32_t* __restrict__ kidx = nullptr) {
     const int64_t rq = row0 + (t & 31) * 4;
     if constexpr (FULL) {   // needs nrows % 4 == 0 (checked on the host): clamp whole float4 groups
         const int64_t rc = rq < nrows ? rq : nrows - 4;
+        if constexpr (INDEXED) {
+            int rows[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) rows[p] = kidx[k0 + (t >> 5) + 8 * p];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)rows[p] * ld + rc);
+            return;
+        }
         const float* q = base + (int64_t)(k0 + (t >> 5)) * ld + rc;
 #pragma unroll
         for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const f32x4*>(q + (int64_t)(8 * p) * ld);
@@ -122,7 +133,8 @@ __device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__
     for (int p = 0; p < 4; ++p) {
         const int k = k0 + (t >> 5) + 8 * p;
         const bool kok = k < kdim;
-        const float* q = base + (int64_t)(kok ? k : kdim - 1) * ld;
+        const int kc = kok ? k : kdim - 1;
+        const float* q = base + (int64_t)(INDEXED ? kidx[kc] : kc) * ld;
         f32x4 v;
         if (vec && rq + 3 < nrows) {
             v = *reinterpret_cast<const f32x4*>(q + rq);
@@ -152,9 +164,10 @@ __device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (
 // runtime-indexed struct access: that sent the staging registers to scratch).
 // MODE 0: guarded loads everywhere (unaligned operands); 1: fast loads, every K-tile full;
 // 2: fast loads, except a ragged last K-tile of a segment which takes the guarded (zero-filling) form
-template <bool A_T, bool B_T, int MODE>
+template <bool A_T, bool B_T, int MODE, bool BIDX>
 __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[4], f32x4 (&rb)[4],
                                           int64_t m0, int n0, int t) {
+    static_assert(!BIDX || !B_T, "gathered B rows exist for the row-contiguous layout only");
     const bool s1 = (g.nseg > 1) && (tile >= g.tiles0);
     const float* a = s1 ? g.seg[1].a : g.seg[0].a;
     const float* b = s1 ? g.seg[1].b : g.seg[0].b;   // may be redirected to b2 below
@@ -163,6 +176,7 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
     const int kdim = s1 ? g.seg[1].k : g.seg[0].k;
     const int avec = s1 ? g.seg[1].a_vec : g.seg[0].a_vec;
     const int bvec = s1 ? g.seg[1].b_vec : g.seg[0].b_vec;
+    const int32_t* bidx = s1 ? g.seg[1].b_index : g.seg[0].b_index;
     const int k0 = (tile - (s1 ? g.tiles0 : 0)) * BK;
     int nb = g.n;                         // extent of the B operand along N as seen by this tile
     if (g.nb_split < g.n) {               // N-concatenated B: [b | b2], tiles never straddle the seam
@@ -177,12 +191,12 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
         if constexpr (A_T) load_rc<true>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
         else               load_kc<true>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
         if constexpr (B_T) load_kc<true>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
-        else               load_rc<true>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
+        else               load_rc<true, BIDX>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
     } else {
         if constexpr (A_T) load_rc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
         else               load_kc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
         if constexpr (B_T) load_kc<false>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
-        else               load_rc<false>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
+        else               load_rc<false, BIDX>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
     }
 }
 
@@ -241,7 +255,7 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, con
 #ifndef PLNLP_GEMM_PF
 #define PLNLP_GEMM_PF 2
 #endif
-template <bool A_T, bool B_T, int MODE>
+template <bool A_T, bool B_T, int MODE, bool BIDX>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
                                        int h) {
@@ -249,7 +263,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
     f32x4 ra[PF][4], rb[PF][4];
 #pragma unroll
     for (int d = 0; d < PF; ++d)
-        if (tb + d < te) load_tile<A_T, B_T, MODE>(g, tb + d, ra[d], rb[d], m0, n0, t);
+        if (tb + d < te) load_tile<A_T, B_T, MODE, BIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
     for (int base = tb; base < te; base += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
@@ -261,7 +275,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                 __syncthreads();
 #endif
 #ifndef ABL_NOGLOAD
-                if (tile + PF < te) load_tile<A_T, B_T, MODE>(g, tile + PF, ra[d], rb[d], m0, n0, t);
+                if (tile + PF < te) load_tile<A_T, B_T, MODE, BIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t);
 #endif
                 mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
             }
@@ -271,7 +285,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 
 // MODE (see load_tile): separate kernels so the hot loop of the aligned case carries no guarded
 // code at all (pure dwordx4 loads, nothing between their issue and the MFMAs).
-template <bool A_T, bool B_T, int MODE>
+template <bool A_T, bool B_T, int MODE, bool BIDX = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
 
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    k_loop<A_T, B_T, MODE>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
+    k_loop<A_T, B_T, MODE, BIDX>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
 
     // ---- write back.  The MFMA C/D map (col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)) would
     // give 64 scattered 4-byte stores per lane; instead the block tile is transposed through LDS
@@ -465,6 +479,8 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         if (o.lda < a_inner || o.ldb < b_inner) return PLNLP_E_SHAPE;
         Seg& d = g.seg[s];
         d.a = o.a; d.lda = o.lda; d.b = o.b; d.ldb = o.ldb; d.k = (int)o.k;
+        d.b_index = o.b_index;
+        if (o.b_index && !(a_trans && !b_trans && n_seg == 1)) return PLNLP_E_UNSUPPORTED;
         d.a_vec = ((uintptr_t)o.a % 16 == 0) && (o.lda % 4 == 0);
         d.b_vec = ((uintptr_t)o.b % 16 == 0) && (o.ldb % 4 == 0);
         tiles[s] = (int)((o.k + BK - 1) / BK);
@@ -511,8 +527,12 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         const int kfull = (g.seg[0].k / BK) * BK;
         tail = g;
         tail.seg[0].a = a_trans ? g.seg[0].a + (int64_t)kfull * g.seg[0].lda : g.seg[0].a + kfull;
-        tail.seg[0].b = b_trans ? g.seg[0].b + kfull : g.seg[0].b + (int64_t)kfull * g.seg[0].ldb;
-        if (b2) tail.b2 = b_trans ? b2 + kfull : b2 + (int64_t)kfull * ldb2;
+        if (g.seg[0].b_index) {                     // gathered rows: the tail advances the index, not B
+            tail.seg[0].b_index = g.seg[0].b_index + kfull;
+        } else {
+            tail.seg[0].b = b_trans ? g.seg[0].b + kfull : g.seg[0].b + (int64_t)kfull * g.seg[0].ldb;
+            if (b2) tail.b2 = b_trans ? b2 + kfull : b2 + (int64_t)kfull * ldb2;
+        }
         tail.seg[0].k = g.seg[0].k - kfull;
         tail.seg[0].a_vec = tail.seg[0].b_vec = 0;
         tail.tiles0 = tail.tiles_total = 1;
@@ -536,6 +556,14 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 1>), grid, dim3(256), 0, s, ga, e); break;   \
             case 2: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 2>), grid, dim3(256), 0, s, ga, e); break;   \
             default: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 0>), grid, dim3(256), 0, s, ga, e); break;  \
+        }
+        if (ga.seg[0].b_index) {      // (a_trans, !b_trans) checked above
+            switch (md) {
+                case 1: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1, true>), grid, dim3(256), 0, s, ga, e); break;
+                case 2: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2, true>), grid, dim3(256), 0, s, ga, e); break;
+                default: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 0, true>), grid, dim3(256), 0, s, ga, e); break;
+            }
+            return launch_status();
         }
         if (a_trans) { if (b_trans) { PLNLP_GEMM_M(true, true) } else { PLNLP_GEMM_M(true, false) } }
         else         { if (b_trans) { PLNLP_GEMM_M(false, true) } else { PLNLP_GEMM_M(false, false) } }

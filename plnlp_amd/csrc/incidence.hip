@@ -102,6 +102,82 @@ __global__ __launch_bounds__(256) void random_walk_kernel(const int64_t* __restr
     }
 }
 
+// ---- non-empty rows of a CSR, in order (three launches: block counts, scan of the counts, write) --
+constexpr int CB = 1024;
+
+__device__ __forceinline__ int lanes_below(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+__global__ __launch_bounds__(CB) void compact_count_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows,
+                                                           int32_t* __restrict__ block_cnt) {
+    __shared__ int wcnt[CB / 64];
+    const int64_t r = (int64_t)blockIdx.x * CB + threadIdx.x;
+    const bool f = r < n_rows && rowptr[r + 1] > rowptr[r];
+    const uint64_t m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < CB / 64; ++i) sum += wcnt[i];
+        block_cnt[blockIdx.x] = sum;
+    }
+}
+
+// one block: exclusive scan of block_cnt in place, total to *count
+__global__ __launch_bounds__(CB) void compact_scan_kernel(int32_t* __restrict__ block_cnt, int64_t nb,
+                                                          int64_t* __restrict__ count) {
+    __shared__ int wsum[CB / 64];
+    __shared__ int64_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += CB) {
+        const int64_t i = base + tid;
+        const int v = i < nb ? block_cnt[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int64_t excl = carry + woff + x - v;
+        if (i < nb) block_cnt[i] = (int32_t)excl;
+        __syncthreads();
+        if (tid == CB - 1) carry = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) *count = carry;
+}
+
+__global__ __launch_bounds__(CB) void compact_write_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows,
+                                                           const int32_t* __restrict__ block_off,
+                                                           int32_t* __restrict__ rows, int32_t* __restrict__ node_map,
+                                                           int64_t* __restrict__ rowptr_c) {
+    __shared__ int wcnt[CB / 64];
+    const int64_t r = (int64_t)blockIdx.x * CB + threadIdx.x;
+    const int wave = threadIdx.x >> 6;
+    int64_t beg = 0;
+    bool f = false;
+    if (r < n_rows) { beg = rowptr[r]; f = rowptr[r + 1] > beg; }
+    const uint64_t m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wcnt[w];
+    const int idx = block_off[blockIdx.x] + woff + lanes_below(m);
+    if (r < n_rows) {
+        node_map[r] = f ? idx : -1;
+        if (f) { rows[idx] = (int32_t)r; rowptr_c[idx] = beg; }
+        if (r == n_rows - 1) rowptr_c[idx + (f ? 1 : 0)] = rowptr[n_rows];
+    }
+}
+
 static inline int bits_for(int64_t n) {  // smallest b with (1 << b) >= n
     int b = 0;
     while (((int64_t)1 << b) < n) ++b;
@@ -146,6 +222,32 @@ extern "C" int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int
     if (err != hipSuccess) return (int)err;
     hipLaunchKernelGGL(incidence_items_kernel, dim3(blocks), dim3(256), 0, s, keys_b, src, dst, n_edges, n_nodes,
                        shift, item_edge, item_other, seg_ptr);
+    return launch_status();
+}
+
+extern "C" int64_t plnlp_compact_rows_workspace(int64_t n_rows) {
+    return n_rows <= 0 ? 1 : (n_rows + plnlp::CB - 1) / plnlp::CB;
+}
+
+extern "C" int plnlp_compact_rows(const int64_t* rowptr, int64_t n_rows, int32_t* rows, int32_t* node_map,
+                                  int64_t* rowptr_c, int64_t* count, int32_t* block_ws, void* stream) {
+    using namespace plnlp;
+    if (!rowptr || !rowptr_c || !count) return PLNLP_E_NULL;
+    if (n_rows < 0 || n_rows > 0x7FFFFFFF) return PLNLP_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rows == 0) {
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t), s);
+        if (e == hipSuccess) e = hipMemcpyAsync(rowptr_c, rowptr, sizeof(int64_t), hipMemcpyDeviceToDevice, s);
+        return e == hipSuccess ? 0 : (int)e;
+    }
+    if (!rows || !node_map || !block_ws) return PLNLP_E_NULL;
+    const int64_t nb = (n_rows + CB - 1) / CB;
+    hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nb), dim3(CB), 0, s, rowptr, n_rows, block_ws);
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(CB), 0, s, block_ws, nb, count);
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(compact_write_kernel, dim3((unsigned)nb), dim3(CB), 0, s, rowptr, n_rows, block_ws, rows,
+                       node_map, rowptr_c);
     return launch_status();
 }
 

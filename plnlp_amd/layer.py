@@ -43,10 +43,10 @@ class SAGEConv(torch.nn.Module):
         self.lin_l.reset_parameters()
         self.lin_r.reset_parameters()
 
-    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, sink=None):
+    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, sink=None, channel=None):
         act = act if act is not None else _Act(False, 0.0, False)
         return ops.SAGEConvFn.apply(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight,
-                                    _require_graph(adj_t), act, in_act, sink)
+                                    _require_graph(adj_t), act, in_act, sink, channel)
 
 
 class GCNConv(torch.nn.Module):
@@ -67,9 +67,9 @@ class GCNConv(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.lin.weight)
         torch.nn.init.zeros_(self.bias)
 
-    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None):
+    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, channel=None):
         act = act if act is not None else _Act(False, 0.0, False)
-        return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act, in_act)
+        return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act, in_act, channel)
 
 
 # --------------------------------------------------------------- encoders ------
@@ -87,8 +87,11 @@ class BaseGNN(torch.nn.Module):
         for conv in self.convs:
             conv.reset_parameters()
 
-    def forward(self, x, adj_t, fuse_output_gate: bool = False, input_grad_sink=None):
+    def forward(self, x, adj_t, fuse_output_gate: bool = False, input_grad_sink=None,
+                output_grad_channel=None):
         """input_grad_sink: an ops.GradSink for the gradient of `x` (first conv must be a SAGEConv).
+        output_grad_channel: an ops.SparseGradChannel through which the (single) consumer of the
+        returned h hands back its gradient row-sparse; only honoured by the native convs.
         fuse_output_gate (only meaningful for a 1-layer encoder, whose output IS a
         relu+dropout result): returns (h, gate_scale) and leaves the derivative of that
         final activation to the consumer's backward (EdgeDotFn), see ops._Act."""
@@ -103,10 +106,11 @@ class BaseGNN(torch.nn.Module):
                     act.gate_in_consumer = True
                     out_act = act
                 # the conv's backward folds the derivative of the activation that produced its input
+                ch = output_grad_channel if (i == last and torch.is_grad_enabled()) else None
                 if i == 0 and input_grad_sink is not None and isinstance(conv, SAGEConv):
-                    x = conv(x, adj_t, act, None, input_grad_sink)
+                    x = conv(x, adj_t, act, None, input_grad_sink, ch)
                 else:
-                    x = conv(x, adj_t, act, prev_act if torch.is_grad_enabled() else None)
+                    x = conv(x, adj_t, act, prev_act if torch.is_grad_enabled() else None, channel=ch)
                 prev_act = act
             else:  # foreign conv module: un-fused reference order
                 x = conv(x, adj_t)
@@ -207,8 +211,8 @@ class MLPPredictor(_LinsPredictor):
     def forward(self, x_i, x_j):
         return self._stack(x_i * x_j)
 
-    def score_edges(self, h, src, dst):
-        return self._stack(ops.EdgeHadamardFn.apply(h, src, dst))
+    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None):
+        return self._stack(ops.EdgeHadamardFn.apply(h, src, dst, gate_scale, channel))
 
 
 class MLPCatPredictor(_LinsPredictor):
@@ -271,8 +275,8 @@ class DotPredictor(torch.nn.Module):
     def forward(self, x_i, x_j):
         return torch.sum(x_i * x_j, dim=-1)
 
-    def score_edges(self, h, src, dst, gate_scale: float = 0.0):
-        return ops.EdgeDotFn.apply(h, src, dst, gate_scale)
+    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None):
+        return ops.EdgeDotFn.apply(h, src, dst, gate_scale, channel)
 
 
 class BilinearPredictor(torch.nn.Module):

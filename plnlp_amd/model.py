@@ -23,8 +23,9 @@ from typing import Optional
 import torch
 
 from . import loss as loss_mod
-from .layer import (GCN, SAGE, WSAGE, BaseGNN, BilinearPredictor, DotPredictor, MLPBilPredictor, MLPCatPredictor,
-                    MLPDotPredictor, MLPPredictor, Transformer)
+from . import ops
+from .layer import (GCN, SAGE, WSAGE, BaseGNN, BilinearPredictor, DotPredictor, GCNConv, MLPBilPredictor,
+                    MLPCatPredictor, MLPDotPredictor, MLPPredictor, SAGEConv, Transformer)
 from .optim import FusedAdam, group_sqnorm
 from .utils import batch_permutation, evaluate_hits, evaluate_mrr, get_pos_neg_edges
 
@@ -200,13 +201,19 @@ class BaseModel(object):
         # as the only consumer of h, that activation's backward rides in the scorer's
         # gather-reduce epilogue instead of a separate pass over [N, h]
         native = isinstance(self.encoder, BaseGNN)
-        fuse_gate = (local > 0 and native and self.encoder.num_layers == 1
-                     and isinstance(self.predictor, DotPredictor))
+        fused_scorer = type(self.predictor) in (DotPredictor, MLPPredictor)     # gather fused into the scorer
+        fuse_gate = local > 0 and native and self.encoder.num_layers == 1 and fused_scorer
         x_in = self.create_input_feat(data)
         sink = self._embedding_grad_sink(x_in) if native else None
         kw = {}
         if sink is not None:
             kw["input_grad_sink"] = sink
+        # the batch touches at most 2 * (1 + k) * local nodes: the gradient of h is zero in every other
+        # row, and the scorer hands it to the last conv's backward in row-sparse form
+        channel = None
+        if (local > 0 and native and fused_scorer and all(isinstance(c, (SAGEConv, GCNConv)) for c in self.encoder.convs)
+                and ops.sparse_backward_pays(2 * (local + neg_edge.numel() // 2), x_in.shape[0])):
+            channel = kw["output_grad_channel"] = ops.SparseGradChannel()
         if fuse_gate:
             h, gate_scale = self.encoder(x_in, data.adj_t, fuse_output_gate=True, **kw)
         else:
@@ -215,7 +222,7 @@ class BaseModel(object):
             neg_flat = neg_edge.reshape(-1, 2)
             src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
             dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
-            out = (self.predictor.score_edges(h, src, dst, gate_scale) if fuse_gate
+            out = (self.predictor.score_edges(h, src, dst, gate_scale, channel) if fused_scorer and native
                    else self._score(h, src, dst))
             loss = self.calculate_loss(out[:local], out[local:], num_neg, margin=weight_margin)
         else:                                    # empty slice: still take part in the reduction

@@ -8,6 +8,7 @@ Every function here requires device tensors; there is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -71,13 +72,18 @@ def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
 def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
                   src_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                   epilogue: Optional[L.Epilogue] = None, split="auto", short_rows="auto",
-                  lds_stage="auto") -> torch.Tensor:
+                  lds_stage="auto", src_map: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[r] = red_{e in row r} w_e x[col[e]]  (plnlp_csr_aggregate_f32).
-    `graph` needs rowptr/col/val/n_rows/n_cols (+ row_split() when split == 'auto')."""
+    `graph` needs rowptr/col/val/n_rows/n_cols (+ row_split() when split == 'auto').
+    src_map (int32 [n_cols]): x holds only some source rows; entry e reads x[src_map[col[e]]] and
+    is skipped where that is negative."""
     lib = L.load()
-    L.require_device(x, graph.col)
+    L.require_device(x, graph.col, src_map)
     x = _f32c(x)
-    assert x.shape[0] == graph.n_cols, (x.shape, graph)
+    if src_map is None:
+        assert x.shape[0] == graph.n_cols, (x.shape, graph)
+    else:
+        assert src_map.dtype == torch.int32 and src_map.numel() == graph.n_cols
     feat = x.shape[1]
     if out is None:
         out = torch.empty(graph.n_rows, feat, dtype=torch.float32, device=x.device)
@@ -101,8 +107,8 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
                         ws.numel())
     rc = lib.plnlp_csr_aggregate_f32(
         graph.rowptr.data_ptr(), graph.col.data_ptr() or graph.rowptr.data_ptr(), L.ptr(val), L.ptr(val_index),
-        L.ptr(src_scale),
-        x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), graph.n_rows, graph.n_cols, feat,
+        L.ptr(src_scale), L.ptr(src_map),
+        x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), graph.n_rows, x.shape[0], feat,
         L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM, flags,
         C.byref(epilogue) if epilogue is not None else None,
         C.byref(sp) if sp is not None else None, L.stream_ptr())
@@ -122,9 +128,11 @@ def _pick_split_k(m: int, n: int, ktiles: int) -> int:
 
 def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_trans: bool,
          out: Optional[torch.Tensor] = None, epilogue: Optional[L.Epilogue] = None,
-         split_k: Optional[int] = None) -> torch.Tensor:
+         split_k: Optional[int] = None, b_index: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = EPI(sum_s op(A_s) op(B_s))  (plnlp_gemm_f32).  A_s: [M,K] or [K,M] if
-    a_trans; B_s: [N,K] if b_trans (nn.Linear weight layout) else [K,N]."""
+    a_trans; B_s: [N,K] if b_trans (nn.Linear weight layout) else [K,N].
+    b_index (int32 [K], one segment, a_trans and not b_trans): B's row for reduction index j
+    is b_index[j] -- B is gathered in place."""
     lib = L.load()
     ops = (L.GemmOperand * len(segs))()
     m = n = None
@@ -136,6 +144,10 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
         keep += [a, b]
         ma, ka = (a.shape[1], a.shape[0]) if a_trans else a.shape
         nb, kb = b.shape if b_trans else (b.shape[1], b.shape[0])
+        if b_index is not None:
+            assert b_index.dtype == torch.int32 and len(segs) == 1 and a_trans and not b_trans
+            kb = b_index.numel()
+            ops[i].b_index = b_index.data_ptr()
         assert ka == kb, f"segment {i}: K mismatch {a.shape} {b.shape}"
         assert m in (None, ma) and n in (None, nb)
         m, n = ma, nb
@@ -156,19 +168,24 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     return out
 
 
-def wgrad_pair(dz: torch.Tensor, x1: torch.Tensor, x2: torch.Tensor):
+def wgrad_pair(dz: torch.Tensor, x1: torch.Tensor, x2: torch.Tensor, rows: Optional[torch.Tensor] = None):
     """[dW1 | dW2] = dz^T [x1 | x2] in one split-K GEMM (plnlp_gemm_concat_b_f32): dz is read once.
-    Falls back to two products when the seam would cut a 128-column tile."""
+    Falls back to two products when the seam would cut a 128-column tile.
+    rows (int32 [K]): dz holds only those rows of a row-sparse gradient; x1 / x2 are read at
+    rows[j] (gathered inside the GEMM's loader)."""
     lib = L.load()
-    L.require_device(dz, x1, x2)
+    L.require_device(dz, x1, x2, rows)
     dz, x1, x2 = _f32c(dz), _f32c(x1), _f32c(x2)
     k, m = dz.shape
     n1, n2 = x1.shape[1], x2.shape[1]
     if n1 % 128 != 0:
-        return gemm([(dz, x1)], True, False), gemm([(dz, x2)], True, False)
+        return (gemm([(dz, x1)], True, False, b_index=rows), gemm([(dz, x2)], True, False, b_index=rows))
     n = n1 + n2
     ops = (L.GemmOperand * 1)()
     ops[0].a, ops[0].lda, ops[0].b, ops[0].ldb, ops[0].k = dz.data_ptr(), _ld(dz), x1.data_ptr(), _ld(x1), k
+    if rows is not None:
+        assert rows.dtype == torch.int32 and rows.numel() == k
+        ops[0].b_index = rows.data_ptr()
     ktiles = (k + 31) // 32
     split_k = max(1, min(_pick_split_k(m, n, ktiles), ktiles))
     out = torch.empty(m, n, dtype=torch.float32, device=dz.device)
@@ -324,6 +341,90 @@ class Incidence:
             self._split = RowSplit(self.seg_ptr, self.item_edge.numel(), threshold)
         return self._split
 
+    def compact(self) -> "CompactIncidence":
+        """the same lists over the TOUCHED nodes only (plnlp_compact_rows)"""
+        return CompactIncidence(self)
+
+
+class CompactIncidence:
+    """Incidence restricted to the nodes the batch touches, in increasing node order: row i
+    belongs to node rows[i]; node_map[n] = i or -1.  Only these rows of the gathered matrix
+    receive a gradient.  Reading `count` back is the one host synchronisation of a step."""
+
+    def __init__(self, inc: Incidence):
+        lib = L.load()
+        n = inc.n_nodes
+        dev = inc.seg_ptr.device
+        rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self.node_map = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        rowptr_c = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        count = torch.empty(1, dtype=torch.int64, device=dev)
+        ws = torch.empty(lib.plnlp_compact_rows_workspace(n), dtype=torch.int32, device=dev)
+        L.check(lib.plnlp_compact_rows(inc.seg_ptr.data_ptr(), n, rows.data_ptr(), self.node_map.data_ptr(),
+                                       rowptr_c.data_ptr(), count.data_ptr(), ws.data_ptr(), L.stream_ptr()),
+                "plnlp_compact_rows")
+        self.count = int(count.item())
+        self.rows = rows[:self.count]
+        self.rowptr = self.seg_ptr = rowptr_c[:self.count + 1]
+        self.n_rows, self.n_cols, self.n_nodes = self.count, n, n
+        self.col = self.item_other = inc.item_other
+        self.val_index = self.item_edge = inc.item_edge
+        self.val = None
+        self._split = None
+
+    def row_split(self, threshold: int):
+        if self._split is None:
+            from .graph import RowSplit
+            self._split = RowSplit(self.rowptr, self.item_edge.numel(), threshold)
+        return self._split
+
+
+class RowSparseGrad:
+    """gradient of an [n_rows, F] matrix that is zero outside `rows`: values[i] is row rows[i]"""
+    __slots__ = ("rows", "node_map", "values", "n_rows")
+
+    def __init__(self, rows, node_map, values, n_rows):
+        self.rows, self.node_map, self.values, self.n_rows = rows, node_map, values, n_rows
+
+    def to_dense(self) -> torch.Tensor:
+        out = torch.zeros(self.n_rows, self.values.shape[1], dtype=self.values.dtype, device=self.values.device)
+        out[self.rows.long()] = self.values
+        return out
+
+
+class SparseGradChannel:
+    """Side channel between the backward of an edge scorer (producer) and the backward of the
+    encoder's last conv (consumer) for ONE forward pass.
+
+    A batch touches only some nodes, so the gradient of the encoder output is zero in every other
+    row; autograd would carry it as a dense [N, F] matrix and the conv's backward would run its
+    GEMMs and its transposed aggregation over rows of zeros.  With a channel the scorer's backward
+    leaves a RowSparseGrad here and returns no gradient through autograd; the conv's backward picks
+    it up and works on the touched rows only.  The dense result is identical (rows of exact zeros
+    contribute nothing).  Valid only while the scorer is the sole consumer of the encoder output --
+    a second consumer's (dense) gradient is added on top if autograd delivers one."""
+
+    def __init__(self):
+        self.grad: Optional[RowSparseGrad] = None
+
+    def take(self) -> Optional[RowSparseGrad]:
+        g, self.grad = self.grad, None
+        return g
+
+
+SPARSE_BACKWARD = {"enabled": os.environ.get("PLNLP_SPARSE_BACKWARD", "1") != "0",
+                   # use the channel when the batch can touch at most this fraction of the nodes in
+                   # expectation (1 - exp(-endpoints / nodes)); a batch that touches everything (ddi)
+                   # gains nothing from the indirection
+                   "max_expected_fraction": 0.9}
+
+
+def sparse_backward_pays(n_endpoints: int, n_nodes: int) -> bool:
+    import math
+    if not SPARSE_BACKWARD["enabled"] or n_nodes <= 0:
+        return False
+    return 1.0 - math.exp(-float(n_endpoints) / float(n_nodes)) <= SPARSE_BACKWARD["max_expected_fraction"]
+
 
 def random_walk(graph, start: torch.Tensor, walk_length: int, seed: int) -> torch.Tensor:
     """torch_cluster.random_walk(row, col, start, walk_length) on the adjacency `graph`
@@ -357,7 +458,7 @@ def edge_segment_bwd(h: torch.Tensor, inc: Incidence, g: torch.Tensor,
     h, g = _f32c(h), _f32c(g)
     is_vec = g.dim() == 2
     if out is None:
-        out = torch.empty(inc.n_nodes, h.shape[1], dtype=torch.float32, device=h.device)
+        out = torch.empty(inc.n_rows, h.shape[1], dtype=torch.float32, device=h.device)
     if not is_vec:
         # scalar per-edge gradient (DOT): gh = S h with S[n, other] = g[edge] -- exactly the
         # weighted CSR aggregation, so it runs on K1 (incl. hot-node splitting)
@@ -367,7 +468,7 @@ def edge_segment_bwd(h: torch.Tensor, inc: Incidence, g: torch.Tensor,
         finally:
             inc.val = None
     L.check(lib.plnlp_edge_segment_bwd_f32(
-        h.data_ptr(), _ld(h), inc.seg_ptr.data_ptr(), None, inc.n_nodes, inc.item_edge.data_ptr(),
+        h.data_ptr(), _ld(h), inc.seg_ptr.data_ptr(), None, inc.n_rows, inc.item_edge.data_ptr(),
         inc.item_other.data_ptr(), h.shape[1], g.data_ptr(), _ld(g) if is_vec else 0, int(is_vec),
         out.data_ptr(), _ld(out), C.byref(epilogue) if epilogue is not None else None, L.stream_ptr()),
         "plnlp_edge_segment_bwd_f32")
@@ -537,12 +638,16 @@ class SAGEConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_l, b_l, w_r, graph: Graph, act: _Act, in_act: Optional[_Act] = None,
-                sink: Optional[GradSink] = None):
+                sink: Optional[GradSink] = None, channel: Optional[SparseGradChannel] = None):
         """in_act: the relu/dropout that PRODUCED x (previous layer).  When given, backward
         returns the gradient w.r.t. that layer's pre-activation (its derivative rides in the
         epilogue of the last kernel that touches gx) and in_act.gate_in_consumer is set.
-        sink: see GradSink (the input gradient is delivered there, autograd gets None)."""
+        sink: see GradSink (the input gradient is delivered there, autograd gets None).
+        channel: the gradient of y may arrive row-sparse through it (see SparseGradChannel)."""
         ctx.sink = sink
+        ctx.channel = channel
+        if channel is not None:
+            ctx.set_materialize_grads(False)
         x = _f32c(x)
         agg = csr_aggregate(graph, x, "mean", use_values=False)
         epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
@@ -558,6 +663,16 @@ class SAGEConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, agg, w_l, w_r, y = ctx.saved_tensors
         graph, act = ctx.graph, ctx.act
+        sg = ctx.channel.take() if ctx.channel is not None else None
+        if sg is not None and (gy is not None or (act.active and not act.gate_in_consumer)):
+            # a dense gradient arrived as well (second consumer), or the activation derivative
+            # was not folded in by the producer: fall back to the dense form
+            gy = sg.to_dense() if gy is None else gy + sg.to_dense()
+            sg = None
+        if sg is not None:
+            return SAGEConvFn._backward_sparse(ctx, sg)
+        if gy is None:
+            return (None,) * 9
         dz = _act_backward(gy.contiguous(), y, act)
         need = ctx.needs_input_grad
         gx = gwl = gbl = gwr = None
@@ -604,7 +719,56 @@ class SAGEConvFn(torch.autograd.Function):
             gbl = colsum(dz)
         if need[0] and OVERLAP_BACKWARD["enabled"] and joined is not None:
             torch.cuda.current_stream().wait_event(joined)
-        return gx, gwl, gbl, gwr, None, None, None, None
+        return gx, gwl, gbl, gwr, None, None, None, None, None
+
+    @staticmethod
+    def _backward_sparse(ctx, sg: RowSparseGrad):
+        """dz is zero outside sg.rows (T rows): the data-gradient GEMM runs on T rows, the
+        transposed aggregation gathers only mapped source rows and adds the root term through
+        the map, the weight-gradient GEMM reduces over T rows with [agg | x] gathered in its
+        loader.  Same sums as the dense form minus exact zeros."""
+        x, agg, w_l, w_r, y = ctx.saved_tensors
+        graph = ctx.graph
+        dz = sg.values                                     # [T, out], already d/d(pre-activation)
+        need = ctx.needs_input_grad
+        gx = gwl = gbl = gwr = None
+        sink = ctx.sink
+        if dz.shape[0] == 0:
+            zero = lambda t: torch.zeros_like(t)
+            if need[0]:
+                if sink is not None:
+                    sink.buffer.zero_()
+                    if sink.on_ready is not None:
+                        sink.on_ready()
+                else:
+                    gx = zero(x)
+            return (gx, zero(w_l) if need[1] else None, torch.zeros(w_l.shape[0], device=x.device) if need[2] else None,
+                    zero(w_r) if need[3] else None, None, None, None, None, None)
+        if need[0]:
+            cin = w_r.shape[1]
+            gx_c, gagg_c = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin)
+            ia = ctx.in_act
+            epi = L.make_epilogue(addend=gx_c, addend_index=sg.node_map, gate=x if ia is not None else None,
+                                  gate_scale=ia.scale if ia is not None else 1.0)
+            out = sink.buffer if sink is not None else torch.empty(x.shape[0], cin, dtype=torch.float32,
+                                                                   device=x.device)
+            csr_aggregate(graph.t(), gagg_c, "sum", use_values=False, src_scale=graph.inv_degree(),
+                          src_map=sg.node_map, out=out, epilogue=epi)
+            if sink is not None:
+                if sink.on_ready is not None:
+                    sink.on_ready()
+            else:
+                gx = out
+        if need[1] and need[3]:
+            gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows)
+        else:
+            if need[1]:
+                gwl = gemm([(dz, agg)], True, False, b_index=sg.rows)
+            if need[3]:
+                gwr = gemm([(dz, x)], True, False, b_index=sg.rows)
+        if need[2]:
+            gbl = colsum(dz)
+        return gx, gwl, gbl, gwr, None, None, None, None, None
 
 
 def _pad4(n: int) -> int:
@@ -661,7 +825,11 @@ class GCNConvFn(torch.autograd.Function):
     forward : MFMA GEMM, then K1 weighted aggregate with fused bias/relu/dropout."""
 
     @staticmethod
-    def forward(ctx, x, w, b, graph: Graph, act: _Act, in_act: Optional[_Act] = None):
+    def forward(ctx, x, w, b, graph: Graph, act: _Act, in_act: Optional[_Act] = None,
+                channel: Optional[SparseGradChannel] = None):
+        ctx.channel = channel
+        if channel is not None:
+            ctx.set_materialize_grads(False)
         kin = x.shape[1]
         if kin % 4 != 0:
             # unaligned input width (citation2: 50 + 128 = 178): run the GEMMs on 4-float-padded
@@ -685,13 +853,23 @@ class GCNConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         graph, act = ctx.graph, ctx.act
-        dz = _act_backward(gy.contiguous(), y, act)
+        sg = ctx.channel.take() if ctx.channel is not None else None
+        if sg is not None and (gy is not None or (act.active and not act.gate_in_consumer)
+                               or sg.values.shape[0] == 0):
+            gy = sg.to_dense() if gy is None else gy + sg.to_dense()
+            sg = None
+        if sg is None and gy is None:
+            return (None,) * 7
+        # row-sparse dz (zero outside sg.rows): the bias gradient sums the touched rows and the
+        # transposed aggregation gathers mapped source rows only; its result is dense again
+        dz = sg.values if sg is not None else _act_backward(gy.contiguous(), y, act)
         need = ctx.needs_input_grad
         gx = gw = gb = None
         if need[2]:
             gb = colsum(dz)
         if need[0] or need[1]:
-            gxw = csr_aggregate(graph.t(), dz, "sum", use_values=True)
+            gxw = csr_aggregate(graph.t(), dz, "sum", use_values=True,
+                                src_map=sg.node_map if sg is not None else None)
             kin = ctx.kin
             if need[1]:
                 gw = gemm([(gxw, x)], True, False)
@@ -703,7 +881,7 @@ class GCNConvFn(torch.autograd.Function):
                           epilogue=L.make_epilogue(gate=x, gate_scale=ia.scale) if ia is not None else None)
                 if gx.shape[1] != kin:
                     gx = gx[:, :kin]
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -792,18 +970,29 @@ class MLPStackFn(torch.autograd.Function):
 EDGE_BACKWARD = {"mode": "segment"}
 
 
+def _sparse_edge_backward(h, src, dst, g, gate_scale: float) -> RowSparseGrad:
+    """gradient of the gathered matrix h over the touched nodes only (scalar g: DOT, matrix g:
+    Hadamard), with the producing layer's relu/dropout derivative folded in when gate_scale > 0"""
+    ci = Incidence(src, dst, h.shape[0]).compact()
+    epi = L.make_epilogue(gate=h, gate_scale=gate_scale, gate_index=ci.rows) if gate_scale > 0.0 else None
+    vals = edge_segment_bwd(h, ci, g, epilogue=epi)
+    return RowSparseGrad(ci.rows, ci.node_map, vals, h.shape[0])
+
+
 class EdgeDotFn(torch.autograd.Function):
     """DotPredictor over gathered endpoints: out[e] = <h[src[e]], h[dst[e]]>
     (model.py:155-156 + layer.py:174-176 in one pass)."""
 
     @staticmethod
-    def forward(ctx, h, src, dst, gate_scale=0.0):
+    def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None):
         """gate_scale > 0: h is the output of relu(+dropout, scale = 1/(1-p)) and the returned
         gradient is taken w.r.t. the pre-activation (h > 0 ? g * gate_scale : 0), folding the
-        activation backward into the gather-reduce epilogue (no separate pass over [N, F])."""
+        activation backward into the gather-reduce epilogue (no separate pass over [N, F]).
+        channel: deliver the gradient of h row-sparse through it (see SparseGradChannel)."""
         h = _f32c(h)
         ctx.save_for_backward(h, src, dst)
         ctx.gate_scale = float(gate_scale)
+        ctx.channel = channel
         return edge_dot_fwd(h, src, dst)
 
     @staticmethod
@@ -811,6 +1000,9 @@ class EdgeDotFn(torch.autograd.Function):
         h, src, dst = ctx.saved_tensors
         g = g.contiguous()
         gs = ctx.gate_scale
+        if ctx.channel is not None and EDGE_BACKWARD["mode"] == "segment":
+            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs)
+            return None, None, None, None, None
         if EDGE_BACKWARD["mode"] == "segment":
             epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
             gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g, epilogue=epi)
@@ -818,27 +1010,37 @@ class EdgeDotFn(torch.autograd.Function):
             gh = edge_scatter_bwd(h, src, dst, g)
             if gs > 0.0:
                 gh = gate(gh, h, gs)
-        return gh, None, None, None
+        return gh, None, None, None, None
 
 
 class EdgeHadamardFn(torch.autograd.Function):
     """x[e,:] = h[src[e],:] * h[dst[e],:]  (model.py:155-156 + layer.py:81)."""
 
     @staticmethod
-    def forward(ctx, h, src, dst):
+    def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None):
+        """gate_scale / channel: as in EdgeDotFn"""
         h = _f32c(h)
         ctx.save_for_backward(h, src, dst)
+        ctx.gate_scale = float(gate_scale)
+        ctx.channel = channel
         return edge_hadamard_fwd(h, src, dst)
 
     @staticmethod
     def backward(ctx, g):
         h, src, dst = ctx.saved_tensors
         g = _f32c(g)
+        gs = ctx.gate_scale
+        if ctx.channel is not None and EDGE_BACKWARD["mode"] == "segment":
+            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs)
+            return None, None, None, None, None
         if EDGE_BACKWARD["mode"] == "segment":
-            gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g)
+            epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
+            gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g, epilogue=epi)
         else:
             gh = edge_scatter_bwd(h, src, dst, g)
-        return gh, None, None
+            if gs > 0.0:
+                gh = gate(gh, h, gs)
+        return gh, None, None, None, None
 
 
 class PairwiseLossFn(torch.autograd.Function):

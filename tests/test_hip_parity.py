@@ -818,3 +818,175 @@ def test_hits50_training_parity_gpu_vs_oracle(P):
     r = bench.hits_parity(P, torch.device("cuda"), epochs=8)
     assert r["max_abs_diff_points"] <= 0.3, r
     assert r["gpu_test"] > 0.0
+
+
+# ------------------------------------------------- row-sparse backward pieces ----
+def test_compact_rows_matches_torch(P):
+    from plnlp_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for n, e in [(1, 1), (7, 3), (5000, 2000), (70000, 9000), (3000, 0)]:
+        src = torch.randint(0, n, (e,), generator=g)
+        dst = torch.randint(0, n, (e,), generator=g)
+        if e == 0:
+            continue
+        inc = ops.Incidence(src.cuda(), dst.cuda(), n)
+        ci = inc.compact()
+        deg = (inc.seg_ptr[1:] - inc.seg_ptr[:-1]).cpu()
+        rows = torch.nonzero(deg > 0).reshape(-1)
+        assert ci.count == rows.numel()
+        assert torch.equal(ci.rows.cpu().long(), rows)
+        nm = torch.full((n,), -1, dtype=torch.int32)
+        nm[rows] = torch.arange(rows.numel(), dtype=torch.int32)
+        assert torch.equal(ci.node_map.cpu(), nm)
+        want = torch.cat([inc.seg_ptr.cpu()[rows], inc.seg_ptr.cpu()[-1:]])
+        assert torch.equal(ci.rowptr.cpu(), want)
+
+
+@pytest.mark.parametrize("feat", [16, 32, 64, 128, 200, 256, 512, 1024, 30])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_csr_aggregate_src_map_equals_dense_with_zero_rows(P, feat, weighted):
+    """gathering through src_map == the dense aggregation over a source matrix whose unmapped rows are
+    zero; bit for bit where the summation order is kept (zeros dropped from an in-order sum)"""
+    n = 900
+    csr = rand_csr(n, 7000, feat + 1, weighted=weighted, hub=1500)
+    g = to_graph(P, csr)
+    gen = torch.Generator().manual_seed(feat)
+    x = torch.randn(n, feat, generator=gen)
+    keep = torch.rand(n, generator=gen) < 0.45
+    rows = torch.nonzero(keep).reshape(-1)
+    nmap = torch.full((n,), -1, dtype=torch.int32)
+    nmap[rows] = torch.arange(rows.numel(), dtype=torch.int32)
+    xz = x.clone()
+    xz[~keep] = 0.0
+    scale = torch.rand(n, generator=gen) + 0.5
+    for reduce in ("sum", "mean"):
+        for sc in (None, scale):
+            dense = P.ops.csr_aggregate(g, dev(xz), reduce, weighted, src_scale=dev(sc))
+            comp = P.ops.csr_aggregate(g, dev(x[rows].contiguous()), reduce, weighted, src_scale=dev(sc),
+                                       src_map=dev(nmap))
+            if feat > 128 or feat % 4:      # one neighbour per wave instruction: the order of the sum is kept
+                assert torch.equal(dense, comp), (feat, weighted, reduce, sc is not None)
+            else:                           # lane groups split the row by position, which the squeeze shifts
+                close(comp, dense, rtol=2e-6, msg=f"{feat} {weighted} {reduce}")
+    # nothing mapped at all -> zeros
+    none = torch.full((n,), -1, dtype=torch.int32)
+    out = P.ops.csr_aggregate(g, dev(x[:1].contiguous()), "sum", weighted, src_map=dev(none))
+    assert float(out.abs().max()) == 0.0
+
+
+def test_epilogue_addend_and_indexed_gate(P):
+    from plnlp_amd import _lib as L
+    n, feat = 500, 128
+    csr = rand_csr(n, 4000, 5, weighted=False, hub=600)
+    g = to_graph(P, csr)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(n, feat, generator=gen)
+    rows = torch.nonzero(torch.rand(n, generator=gen) < 0.3).reshape(-1)
+    nmap = torch.full((n,), -1, dtype=torch.int32)
+    nmap[rows] = torch.arange(rows.numel(), dtype=torch.int32)
+    add_c = torch.randn(rows.numel(), feat, generator=gen)
+    y = torch.randn(n, feat, generator=gen)
+    base = O.spmm(csr, x.double(), "sum", False)
+    dense_add = torch.zeros(n, feat, dtype=torch.float64)
+    dense_add[rows] = add_c.double()
+    want = torch.where(y.double() > 0, (base + dense_add) * 1.25, torch.zeros_like(base))
+    addd, nm, yd = dev(add_c), dev(nmap), dev(y)
+    epi = L.make_epilogue(addend=addd, addend_index=nm, gate=yd, gate_scale=1.25)
+    out = P.ops.csr_aggregate(g, dev(x), "sum", False, epilogue=epi)
+    close(out, want)
+    # compact result rows with the gate read through an index
+    inc_rows = dev(rows.to(torch.int32))
+    sub = O.CSR.from_coo(*[t for t in _sub_rows(csr, rows)], None, rows.numel(), n)
+    gs = to_graph(P, sub)
+    epi = L.make_epilogue(gate=yd, gate_scale=2.0, gate_index=inc_rows)
+    out = P.ops.csr_aggregate(gs, dev(x), "sum", False, epilogue=epi)
+    want = torch.where(y[rows].double() > 0, base[rows] * 2.0, torch.zeros_like(base[rows]))
+    close(out, want)
+
+
+def _sub_rows(csr, rows):
+    r, c, _ = csr.coo()
+    pos = torch.full((csr.n_rows,), -1, dtype=torch.long)
+    pos[rows] = torch.arange(rows.numel())
+    keep = pos[r] >= 0
+    return pos[r[keep]], c[keep]
+
+
+@pytest.mark.parametrize("k,m,n1,n2", [(5000, 256, 256, 256), (4097, 128, 128, 64), (333, 64, 200, 200),
+                                       (70001, 256, 256, 256), (31, 8, 12, 12)])
+def test_wgrad_over_gathered_rows_equals_gather_then_gemm(P, k, m, n1, n2):
+    """dz^T [x1 | x2][rows] with the gather inside the GEMM loader == the same GEMM on materialised
+    gathered operands, bit for bit (same tiles, same split-K partition)"""
+    gen = torch.Generator().manual_seed(k)
+    n_all = 2 * k + 7
+    dz = dev(torch.randn(k, m, generator=gen))
+    x1 = dev(torch.randn(n_all, n1, generator=gen))
+    x2 = dev(torch.randn(n_all, n2, generator=gen))
+    rows = torch.sort(torch.randperm(n_all, generator=gen)[:k]).values.to(torch.int32).cuda()
+    a1, a2 = P.ops.wgrad_pair(dz, x1, x2, rows=rows)
+    b1, b2 = P.ops.wgrad_pair(dz, x1[rows.long()].contiguous(), x2[rows.long()].contiguous())
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    ref = dz.double().t() @ x1[rows.long()].double()
+    close(a1, ref, rtol=2e-5)
+    c = P.ops.gemm([(dz, x2)], True, False, b_index=rows)
+    close(c, dz.double().t() @ x2[rows.long()].double(), rtol=2e-5)
+
+
+def _sparse_vs_dense_step(P, enc, layers, pred, n=4000, feat=64, batch=300, k=2, hub=True, in_feats=0):
+    from plnlp_amd import ops
+    csr = rand_csr(n, 6 * n, 17, weighted=False, hub=3000 if hub else None)
+    r, c, _ = csr.coo()
+    adj = P.Graph.from_coo(torch.cat([r, c]), torch.cat([c, r]), None, n, n).to("cuda")
+    if enc == "GCN":
+        adj = P.gcn_normalization(adj)
+
+    class D:
+        pass
+    data = D()
+    data.adj_t = adj
+    if in_feats:
+        data.x = torch.randn(n, in_feats, generator=torch.Generator().manual_seed(8)).cuda()
+    gen = torch.Generator().manual_seed(9)
+    pos = torch.randint(0, n, (batch, 2), generator=gen).cuda()
+    pos[:40, 0] = 3                                   # a hot node in the batch as well
+    neg = torch.randint(0, n, (batch, k, 2), generator=gen).cuda()
+    w = torch.rand(batch, generator=gen).cuda()
+    res = {}
+    old = dict(ops.SPARSE_BACKWARD)
+    try:
+        for mode in ("dense", "sparse"):
+            ops.SPARSE_BACKWARD["enabled"] = mode == "sparse"
+            ops.SPARSE_BACKWARD["max_expected_fraction"] = 1.0
+            torch.manual_seed(77)
+            P.manual_seed(77)
+            m = P.BaseModel(lr=1e-3, dropout=0.3, grad_clip_norm=1.0, gnn_num_layers=layers, mlp_num_layers=2,
+                            emb_hidden_channels=feat, gnn_hidden_channels=feat, mlp_hidden_channels=feat,
+                            num_nodes=n, num_node_feats=in_feats, gnn_encoder_name=enc, predictor_name=pred,
+                            loss_func="WeightedHingeAUC", optimizer_name="Adam", device="cuda",
+                            use_node_feats=in_feats > 0, train_node_emb=True)
+            m.param_init()
+            m.encoder.train()
+            m.predictor.train()
+            loss = m.train_step(data, pos, neg, k, w)
+            grads = {"emb": m.emb.weight.grad.clone()}
+            for nm, p in list(m.encoder.named_parameters()) + list(m.predictor.named_parameters()):
+                grads[nm] = p.grad.clone()
+            res[mode] = (float(loss), grads)
+    finally:
+        ops.SPARSE_BACKWARD.update(old)
+    return res
+
+
+@pytest.mark.parametrize("enc,layers,pred,in_feats", [("SAGE", 1, "DOT", 0), ("SAGE", 1, "MLP", 0), ("SAGE", 2, "MLP", 0),
+                                                     ("GCN", 3, "MLP", 0), ("GCN", 1, "DOT", 0), ("SAGE", 2, "DOT", 0),
+                                                     ("GCN", 2, "MLP", 50)])
+def test_row_sparse_backward_equals_dense_backward(P, enc, layers, pred, in_feats):
+    """the touched-rows-only backward drops exact zeros from the sums: same loss bits, gradients
+    equal to fp32 reassociation (the split-K partition of the weight gradients differs)"""
+    res = _sparse_vs_dense_step(P, enc, layers, pred, in_feats=in_feats)
+    (ld, gd), (ls, gs) = res["dense"], res["sparse"]
+    assert ld == ls
+    for key in gd:
+        scale = max(1e-6, float(gd[key].abs().max()))
+        err = float((gd[key] - gs[key]).abs().max())
+        assert err <= 2e-6 * scale + 1e-7, (enc, layers, pred, key, err, scale)
