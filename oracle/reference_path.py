@@ -207,12 +207,18 @@ def dropout_keep_mask(seed: int, n_rows: int, n_cols: int, p: float,
     plnlp_amd/csrc/common.hip.h::dropout_keep exactly."""
     idx = (np.arange(row0, row0 + n_rows, dtype=np.uint64)[:, None] * np.uint64(n_cols)
            + np.arange(n_cols, dtype=np.uint64)[None, :])
-    lo, hi = idx & _M32, idx >> np.uint64(32)
+    # elements are hashed in groups of four: two rounds over (group, seed) give word a, a third
+    # round word b; element idx takes 16-bit field (idx & 3) of (a, b); P(drop) = thresh / 65536
+    group = idx >> np.uint64(2)
+    lo, hi = group & _M32, group >> np.uint64(32)
     s_lo, s_hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
-    h = _lowbias32(lo ^ s_lo)
-    h = _lowbias32((h + ((hi * np.uint64(0x9E3779B9)) & _M32) + s_hi) & _M32)
-    thresh = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
-    return h >= thresh
+    a = _lowbias32(lo ^ s_lo)
+    a = _lowbias32((a + ((hi * np.uint64(0x9E3779B9)) & _M32) + s_hi) & _M32)
+    b = _lowbias32(a ^ np.uint64(0x85EBCA6B))
+    word = np.where((idx & np.uint64(2)) != 0, b, a)
+    field = (word >> ((idx & np.uint64(1)) * np.uint64(16))) & np.uint64(0xFFFF)
+    thresh = np.uint64(max(0, min(int(p * 65536.0 + 0.5), 65535)))
+    return field >= thresh
 
 
 def random_walk_ref(adj: "CSR", start: torch.Tensor, walk_length: int, seed: int) -> torch.Tensor:

@@ -10,25 +10,57 @@ namespace plnlp {
 
 // ---- counter-based dropout mask ---------------------------------------------
 // keep(element) for logical element index idx = row * n_cols + col under a 64-bit
-// per-call seed.  oracle/reference_path.py::dropout_keep_mask restates this in
-// numpy; the two must stay bit-identical.
+// per-call seed.  Elements are hashed in GROUPS of four (group = idx >> 2): two
+// rounds of a 32-bit mixer over (group, seed) give one word, a third round a second
+// word, and each element takes a 16-bit field of them -- 3 rounds per 4 elements
+// instead of 8 (the hash was ~10 % of the forward GEMM).  P(drop) = thresh / 65536.
+// oracle/reference_path.py::dropout_keep_mask restates this in numpy; the two must
+// stay bit-identical.
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;
     return x;
 }
+// plain two-round counter hash of a 64-bit index (random walks)
+__device__ __forceinline__ uint32_t counter_hash(uint64_t idx, uint32_t seed_lo, uint32_t seed_hi) {
+    uint32_t h = lowbias32((uint32_t)idx ^ seed_lo);
+    return lowbias32(h + (uint32_t)(idx >> 32) * 0x9E3779B9u + seed_hi);
+}
+__device__ __forceinline__ void dropout_words(uint64_t group, uint32_t seed_lo, uint32_t seed_hi,
+                                              uint32_t& a, uint32_t& b) {
+    a = counter_hash(group, seed_lo, seed_hi);
+    b = lowbias32(a ^ 0x85EBCA6Bu);
+}
 __device__ __forceinline__ bool dropout_keep(uint64_t idx, uint32_t seed_lo, uint32_t seed_hi,
                                              uint32_t thresh) {
-    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    uint32_t h = lowbias32(lo ^ seed_lo);
-    h = lowbias32(h + hi * 0x9E3779B9u + seed_hi);
-    return h >= thresh;
+    uint32_t a, b;
+    dropout_words(idx >> 2, seed_lo, seed_hi, a, b);
+    const uint32_t word = (idx & 2) ? b : a;
+    return ((word >> (((uint32_t)idx & 1u) * 16u)) & 0xFFFFu) >= thresh;
 }
-__host__ __device__ inline uint32_t dropout_thresh(float p) {
-    double t = (double)p * 4294967296.0;
+// the four elements i0 .. i0+3 scaled or zeroed; one group hash when i0 is a multiple of 4
+__device__ __forceinline__ float4 dropout_apply4(float4 v, uint64_t i0, uint32_t seed_lo, uint32_t seed_hi,
+                                                 uint32_t thresh, float keep_scale) {
+    if ((i0 & 3) == 0) {
+        uint32_t a, b;
+        dropout_words(i0 >> 2, seed_lo, seed_hi, a, b);
+        v.x = (a & 0xFFFFu) >= thresh ? v.x * keep_scale : 0.f;
+        v.y = (a >> 16) >= thresh ? v.y * keep_scale : 0.f;
+        v.z = (b & 0xFFFFu) >= thresh ? v.z * keep_scale : 0.f;
+        v.w = (b >> 16) >= thresh ? v.w * keep_scale : 0.f;
+        return v;
+    }
+    v.x = dropout_keep(i0 + 0, seed_lo, seed_hi, thresh) ? v.x * keep_scale : 0.f;
+    v.y = dropout_keep(i0 + 1, seed_lo, seed_hi, thresh) ? v.y * keep_scale : 0.f;
+    v.z = dropout_keep(i0 + 2, seed_lo, seed_hi, thresh) ? v.z * keep_scale : 0.f;
+    v.w = dropout_keep(i0 + 3, seed_lo, seed_hi, thresh) ? v.w * keep_scale : 0.f;
+    return v;
+}
+__host__ __device__ inline uint32_t dropout_thresh(float p) {   // 16-bit: P(drop) = thresh / 65536
+    double t = (double)p * 65536.0 + 0.5;
     if (t < 0.0) t = 0.0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    if (t > 65535.0) t = 65535.0;
     return (uint32_t)t;
 }
 
@@ -113,11 +145,8 @@ __device__ __forceinline__ float4 epi_apply4(const Epi& e, float4 v, int64_t r, 
         }
         if (e.flags & PLNLP_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (e.flags & PLNLP_EPI_DROPOUT) {
-            const uint64_t i0 = (uint64_t)r * (uint64_t)n_cols + (uint64_t)f;
-            v.x = dropout_keep(i0 + 0, e.seed_lo, e.seed_hi, e.thresh) ? v.x * e.keep_scale : 0.f;
-            v.y = dropout_keep(i0 + 1, e.seed_lo, e.seed_hi, e.thresh) ? v.y * e.keep_scale : 0.f;
-            v.z = dropout_keep(i0 + 2, e.seed_lo, e.seed_hi, e.thresh) ? v.z * e.keep_scale : 0.f;
-            v.w = dropout_keep(i0 + 3, e.seed_lo, e.seed_hi, e.thresh) ? v.w * e.keep_scale : 0.f;
+            v = dropout_apply4(v, (uint64_t)r * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh,
+                               e.keep_scale);
         }
         if (e.flags & PLNLP_EPI_ACCUM) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
         if (e.flags & PLNLP_EPI_ADDEND) {
@@ -139,6 +168,25 @@ __device__ __forceinline__ float4 epi_apply4(const Epi& e, float4 v, int64_t r, 
     v.y = epi_apply(e, v.y, r, f + 1, n_cols, prev.y);
     v.z = epi_apply(e, v.z, r, f + 2, n_cols, prev.z);
     v.w = epi_apply(e, v.w, r, f + 3, n_cols, prev.w);
+    return v;
+}
+
+// vec4 form with the operands already in registers (the GEMM epilogue loads bias once per thread and
+// gate / accumulate operands ahead of the loop that consumes them, so their latency is not exposed
+// between the LDS read and the store of every output row).  No ADDEND.
+__device__ __forceinline__ float4 epi_apply4_pre(const Epi& e, float4 v, int64_t r, int64_t f, int64_t n_cols,
+                                                 float4 b, float4 y, float4 prev) {
+    if (e.flags & PLNLP_EPI_BIAS) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (e.flags & PLNLP_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (e.flags & PLNLP_EPI_DROPOUT) {
+        v = dropout_apply4(v, (uint64_t)r * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh,
+                           e.keep_scale);
+    }
+    if (e.flags & PLNLP_EPI_ACCUM) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
+    if (e.flags & PLNLP_EPI_GATE) {
+        v.x = y.x > 0.f ? v.x * e.gate_scale : 0.f; v.y = y.y > 0.f ? v.y * e.gate_scale : 0.f;
+        v.z = y.z > 0.f ? v.z * e.gate_scale : 0.f; v.w = y.w > 0.f ? v.w * e.gate_scale : 0.f;
+    }
     return v;
 }
 

@@ -94,8 +94,7 @@ __global__ __launch_bounds__(256) void random_walk_kernel(const int64_t* __restr
         const uint64_t deg = (uint64_t)(rowptr[cur + 1] - beg);
         if (deg > 0) {
             const uint64_t idx = (uint64_t)w * (uint64_t)walk_length + (uint64_t)l;
-            uint32_t h = lowbias32((uint32_t)idx ^ seed_lo);
-            h = lowbias32(h + (uint32_t)(idx >> 32) * 0x9E3779B9u + seed_hi);
+            const uint32_t h = counter_hash(idx, seed_lo, seed_hi);
             cur = col[beg + (int64_t)(((uint64_t)h * deg) >> 32)];
         }
         o[l + 1] = cur;
@@ -210,15 +209,17 @@ extern "C" int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int
     const int shift = bits_for(n_items);
     const int node_bits = bits_for(n_nodes);
     if (shift + node_bits > 64) return PLNLP_E_SHAPE;
+    // the keys are generated in increasing item order and the radix sort is stable, so sorting on the
+    // NODE bits alone already yields the (node, item) order: half the digit passes
+    const unsigned bit0 = (unsigned)shift, bit1 = (unsigned)(shift + (node_bits > 0 ? node_bits : 1));
     size_t need = 0;
-    rocprim::radix_sort_keys(nullptr, need, keys_a, keys_b, (size_t)n_items, 0, (unsigned)(shift + node_bits), s);
+    rocprim::radix_sort_keys(nullptr, need, keys_a, keys_b, (size_t)n_items, bit0, bit1, s);
     if ((int64_t)need > temp_bytes) return PLNLP_E_WORKSPACE;
     const unsigned blocks = (unsigned)((n_items + 255) / 256);
     hipLaunchKernelGGL(incidence_keys_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n_edges, n_nodes, shift, keys_a);
     if (int rc = launch_status()) return rc;
     size_t tb = (size_t)temp_bytes;
-    hipError_t err = rocprim::radix_sort_keys(temp, tb, keys_a, keys_b, (size_t)n_items, 0,
-                                              (unsigned)(shift + node_bits), s);
+    hipError_t err = rocprim::radix_sort_keys(temp, tb, keys_a, keys_b, (size_t)n_items, bit0, bit1, s);
     if (err != hipSuccess) return (int)err;
     hipLaunchKernelGGL(incidence_items_kernel, dim3(blocks), dim3(256), 0, s, keys_b, src, dst, n_edges, n_nodes,
                        shift, item_edge, item_other, seg_ptr);

@@ -9,6 +9,8 @@ from bench import time_kernel
 SHAPES = {
     # name: (M, N, K-segments, a_trans, b_trans, epilogue)
     "collab_fwd": (235868, 256, [256, 256], False, True, True),
+    "collab_fwd_bias_relu": (235868, 256, [256, 256], False, True, "bias_relu"),
+    "collab_fwd_plain": (235868, 256, [256, 256], False, True, False),
     "collab_dgrad": (235868, 256, [256], False, False, False),
     "collab_wgrad": (256, 256, [235868], True, False, False),
     "ddi_pred_fwd": (262144, 512, [512], False, True, True),
@@ -32,7 +34,11 @@ def main():
             b = torch.randn((n, k) if bt else (k, n), device=dev)
             segs.append((a, b))
         bias = torch.randn(n, device=dev)
-        e = _lib.make_epilogue(bias=bias, relu=True, dropout_p=0.3, dropout_seed=1) if epi else None
+        e = None
+        if epi == "bias_relu":
+            e = _lib.make_epilogue(bias=bias, relu=True)
+        elif epi:
+            e = _lib.make_epilogue(bias=bias, relu=True, dropout_p=0.3, dropout_seed=1)
         out = torch.empty(m, n, device=dev)
         t = time_kernel(lambda: P.ops.gemm(segs, at, bt, out=out, epilogue=e), iters=args.iters)
         flop = 2.0 * m * n * sum(ks)
