@@ -56,6 +56,11 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the Hits@50 GPU-vs-oracle training parity run")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the DP path on 1 GPU)")
+    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "grads", "scores"],
+                    help="what the ranks exchange per step (BaseModel docstring): parameter gradients or score gradients")
+    ap.add_argument("--batch-mult", type=int, default=1,
+                    help="multiply the per-GPU batch (debug: the per-rank cost of an N-rank 'scores' job is about the "
+                         "1-GPU step at N times the batch; invalidates the number)")
     return ap.parse_args()
 
 
@@ -214,7 +219,7 @@ def main():
     from plnlp_amd import synthetic
     P._lib.load()
 
-    K, W, B, k = args.steps, args.warmup, cfg["batch"], cfg["num_neg"]
+    K, W, B, k = args.steps, args.warmup, cfg["batch"] * args.batch_mult, cfg["num_neg"]
     torch.manual_seed(1234)
     P.manual_seed(1234)
     # ---- synthetic inputs (identical on every rank: same seeds) -------------------
@@ -252,8 +257,9 @@ def main():
                         mlp_hidden_channels=cfg["hidden"], num_nodes=n, num_node_feats=feats,
                         gnn_encoder_name=cfg["encoder"], predictor_name=cfg["predictor"], loss_func=cfg["loss"],
                         optimizer_name="Adam", device=device, use_node_feats=feats > 0, train_node_emb=True,
-                        process_group=pg)
+                        process_group=pg, dp_exchange=args.dp_exchange)
     model.param_init()
+    dp_mode = model.dp_mode()
     model.encoder.train()
     model.predictor.train()
 
@@ -267,15 +273,20 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(W):
+    def step(i):
+        if dp_mode == "scores":      # every rank passes the global batch and scores its own slice of it
+            sl = slice(i * world * B, (i + 1) * world * B)
+            return model.train_step_global(data, pos_all[sl], neg_all[sl], k, None if w_all is None else w_all[sl])
         p, q, w = batch(i)
-        model.train_step(data, p, q, k, w)
+        return model.train_step(data, p, q, k, w)
+
+    for i in range(W):
+        step(i)
     sync()
     t0 = time.perf_counter()
     loss = None
     for i in range(W, W + K):
-        p, q, w = batch(i)
-        loss = model.train_step(data, p, q, k, w)
+        loss = step(i)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -296,7 +307,7 @@ def main():
                                   "random-walk pairs (walk_length 10)" if cfg["shape"] == "collab"
                                   else "train-edge positives"),
                    "global_batch": B * world, "parallelism": "dp%d (edge-batch, replicated encoder)" % world,
-                   "scale": args.scale},
+                   "dp_exchange": dp_mode, "scale": args.scale, "batch_mult": args.batch_mult},
         "final_loss": final_loss, "negative_sampling_s": sampler_s,
     }
     if rank == 0:
@@ -322,6 +333,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, g, pos_cpu, neg_cpu, w_cpu, args.cpu_steps)
     if pg is not None:
+        result["replicas_in_sync"] = model.check_replicas()
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:        # last thing on stdout: the one JSON line (RCCL's banner sits in the C stdio buffer)

@@ -275,8 +275,8 @@ class DotPredictor(torch.nn.Module):
     def forward(self, x_i, x_j):
         return torch.sum(x_i * x_j, dim=-1)
 
-    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None):
-        return ops.EdgeDotFn.apply(h, src, dst, gate_scale, channel)
+    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None, compute_forward: bool = True):
+        return ops.EdgeDotFn.apply(h, src, dst, gate_scale, channel, compute_forward)
 
 
 class BilinearPredictor(torch.nn.Module):

@@ -33,12 +33,21 @@ from .utils import batch_permutation, evaluate_hits, evaluate_mrr, get_pos_neg_e
 class BaseModel(object):
     """plnlp/model.py:9-226.  Constructor arguments as the reference; keyword-only
     extras: `modules=(encoder, predictor[, loss_fn])` to inject pre-built modules,
-    `process_group` / `dp_scaling` for data parallelism."""
+    `process_group` / `dp_scaling` / `dp_exchange` for data parallelism.
+
+    dp_exchange -- what the ranks exchange per step:
+      'grads'  : SUM all-reduce of every parameter gradient (the embedding table's 4*N*h bytes
+                 dominate; xGMI is point to point, so at 2-4 GPUs this costs more than the step);
+      'scores' : every rank scores its slice of the batch, the ranks all-gather the per-edge score
+                 gradients (4*(1+k)*B bytes) and each then runs the SAME backward pass over the
+                 global batch.  Needs a parameter-free scorer (DOT); the replicas stay identical
+                 because every kernel is deterministic (check_replicas() verifies it);
+      'auto'   : 'scores' when the predictor has no parameters, else 'grads'."""
 
     def __init__(self, lr, dropout, grad_clip_norm, gnn_num_layers, mlp_num_layers, emb_hidden_channels,
                  gnn_hidden_channels, mlp_hidden_channels, num_nodes, num_node_feats, gnn_encoder_name,
                  predictor_name, loss_func, optimizer_name, device, use_node_feats, train_node_emb,
-                 pretrain_emb=None, *, modules=None, process_group=None, dp_scaling="weak"):
+                 pretrain_emb=None, *, modules=None, process_group=None, dp_scaling="weak", dp_exchange="auto"):
         self.loss_func_name = loss_func
         self.num_nodes = num_nodes
         self.num_node_feats = num_node_feats
@@ -48,6 +57,9 @@ class BaseModel(object):
         self.device = torch.device(device)
         self.process_group = process_group
         self.dp_scaling = dp_scaling
+        if dp_exchange not in ("auto", "grads", "scores"):
+            raise ValueError(f"dp_exchange must be auto, grads or scores, not {dp_exchange!r}")
+        self.dp_exchange = dp_exchange
 
         self.input_channels, self.emb = create_input_layer(
             num_nodes=num_nodes, num_node_feats=num_node_feats, hidden_channels=emb_hidden_channels,
@@ -187,6 +199,57 @@ class BaseModel(object):
                     torch.nn.utils.clip_grad_norm_(params, self.clip_norm)
         self.optimizer.step()
 
+    def dp_mode(self) -> str:
+        """the exchange actually used (see the class docstring)"""
+        if self.process_group is None:
+            return "none"
+        scores_ok = not any(True for _ in self.predictor.parameters())
+        if self.dp_exchange == "scores" and not scores_ok:
+            raise ValueError("dp_exchange='scores' needs a predictor without parameters (DOT)")
+        return "scores" if (scores_ok and self.dp_exchange in ("auto", "scores")) else "grads"
+
+    @torch.no_grad()
+    def check_replicas(self) -> bool:
+        """True when every rank holds bit-identical parameters (two checksums, MIN == MAX over
+        ranks).  'scores' mode never exchanges parameters or their gradients: the replicas agree
+        because they compute the same deterministic update; this proves it."""
+        if self.process_group is None:
+            return True
+        acc = torch.zeros(2, dtype=torch.float64, device=self.device)
+        for p in self.para_list:
+            d = p.detach().double()
+            acc[0] += d.sum()
+            acc[1] += (d * d).sum()
+        lo, hi = acc.clone(), acc.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
+        return bool(torch.equal(lo, hi))
+
+    def _encode(self, data, n_edges, n_endpoints, use_sink):
+        """encoder forward of a training step with the fusions the scorer allows; returns
+        (h, gate_scale, channel, fused) -- see train_step"""
+        native = isinstance(self.encoder, BaseGNN)
+        fused = native and type(self.predictor) in (DotPredictor, MLPPredictor)   # gather fused into the scorer
+        # a 1-layer encoder ends in relu+dropout (layer.py:24-26); with a fused scorer as the only
+        # consumer of h, that activation's backward rides in the scorer's gather-reduce epilogue
+        fuse_gate = n_edges > 0 and fused and self.encoder.num_layers == 1
+        x_in = self.create_input_feat(data)
+        kw = {}
+        sink = self._embedding_grad_sink(x_in) if (native and use_sink) else None
+        if sink is not None:
+            kw["input_grad_sink"] = sink
+        # the batch touches at most n_endpoints nodes: the gradient of h is zero in every other row,
+        # and the scorer hands it to the last conv's backward in row-sparse form
+        channel = None
+        if (n_edges > 0 and fused and all(isinstance(c, (SAGEConv, GCNConv)) for c in self.encoder.convs)
+                and ops.sparse_backward_pays(n_endpoints, x_in.shape[0])):
+            channel = kw["output_grad_channel"] = ops.SparseGradChannel()
+        if fuse_gate:
+            h, gate_scale = self.encoder(x_in, data.adj_t, fuse_output_gate=True, **kw)
+        else:
+            h, gate_scale = self.encoder(x_in, data.adj_t, **kw), 0.0
+        return h, gate_scale, channel, fused
+
     def _score(self, h, src, dst):
         if hasattr(self.predictor, "score_edges"):
             return self.predictor.score_edges(h, src, dst)
@@ -197,38 +260,66 @@ class BaseModel(object):
         pos_edge [b,2], neg_edge [b,k,2] (device).  Returns the detached local loss."""
         self.optimizer.zero_grad(set_to_none=True)
         local = pos_edge.size(0)
-        # a 1-layer encoder ends in relu+dropout (layer.py:24-26); with the fused DOT scorer
-        # as the only consumer of h, that activation's backward rides in the scorer's
-        # gather-reduce epilogue instead of a separate pass over [N, h]
-        native = isinstance(self.encoder, BaseGNN)
-        fused_scorer = type(self.predictor) in (DotPredictor, MLPPredictor)     # gather fused into the scorer
-        fuse_gate = local > 0 and native and self.encoder.num_layers == 1 and fused_scorer
-        x_in = self.create_input_feat(data)
-        sink = self._embedding_grad_sink(x_in) if native else None
-        kw = {}
-        if sink is not None:
-            kw["input_grad_sink"] = sink
-        # the batch touches at most 2 * (1 + k) * local nodes: the gradient of h is zero in every other
-        # row, and the scorer hands it to the last conv's backward in row-sparse form
-        channel = None
-        if (local > 0 and native and fused_scorer and all(isinstance(c, (SAGEConv, GCNConv)) for c in self.encoder.convs)
-                and ops.sparse_backward_pays(2 * (local + neg_edge.numel() // 2), x_in.shape[0])):
-            channel = kw["output_grad_channel"] = ops.SparseGradChannel()
-        if fuse_gate:
-            h, gate_scale = self.encoder(x_in, data.adj_t, fuse_output_gate=True, **kw)
-        else:
-            h, gate_scale = self.encoder(x_in, data.adj_t, **kw), 0.0
+        h, gate_scale, channel, fused = self._encode(data, local, 2 * (local + neg_edge.numel() // 2), True)
         if local > 0:
             neg_flat = neg_edge.reshape(-1, 2)
             src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
             dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
-            out = (self.predictor.score_edges(h, src, dst, gate_scale, channel) if fused_scorer and native
+            out = (self.predictor.score_edges(h, src, dst, gate_scale, channel) if fused
                    else self._score(h, src, dst))
             loss = self.calculate_loss(out[:local], out[local:], num_neg, margin=weight_margin)
         else:                                    # empty slice: still take part in the reduction
             loss = h.sum() * 0.0
         loss.backward()
         self._allreduce_grads()
+        self._clip_and_step()
+        return loss.detach().reshape(())
+
+    def train_step_global(self, data, pos_edge, neg_edge, num_neg, weight_margin=None):
+        """One iteration in dp_exchange='scores' mode.  Every rank passes the GLOBAL batch
+        (pos_edge [n,2], neg_edge [n,k,2], weights [n]); rank r scores the slice
+        [r*per, (r+1)*per), per = ceil(n / world), and differentiates the loss of that slice
+        with respect to its scores; the per-edge score gradients are all-gathered and every
+        rank back-propagates the whole batch through the encoder.  The update equals the
+        one-process step on the global batch (the loss is a sum over pairs) and is the same
+        bits on every rank.  Returns the detached loss of the local slice."""
+        rank, world = self._world()
+        self.optimizer.zero_grad(set_to_none=True)
+        n, k = pos_edge.size(0), num_neg
+        per = (n + world - 1) // world
+        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+        local = hi - lo
+        h, gate_scale, channel, fused = self._encode(data, n, 2 * (n + neg_edge.numel() // 2), False)
+        neg_flat = neg_edge.reshape(-1, 2)
+        src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
+        dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
+        # 1. local slice: scores (outside the encoder's graph), loss, d loss / d score
+        g_pad = torch.zeros(per * (1 + k), dtype=h.dtype, device=h.device)
+        loss = torch.zeros((), dtype=h.dtype, device=h.device)
+        if local > 0:
+            with torch.no_grad():
+                out_l = self._score(h, torch.cat([src[lo:hi], src[n + lo * k:n + hi * k]]),
+                                    torch.cat([dst[lo:hi], dst[n + lo * k:n + hi * k]]))
+            out_l = out_l.detach().requires_grad_(True)
+            loss = self.calculate_loss(out_l[:local], out_l[local:], k,
+                                       margin=None if weight_margin is None else weight_margin[lo:hi])
+            loss.backward()
+            gl = out_l.grad.reshape(-1)
+            g_pad[:local] = gl[:local]
+            g_pad[per:per + local * k] = gl[local:]
+        # 2. exchange the score gradients (rank-major order = global edge order)
+        gathered = torch.empty(world * per * (1 + k), dtype=h.dtype, device=h.device)
+        torch.distributed.all_gather_into_tensor(gathered, g_pad, group=self.process_group)
+        gathered = gathered.view(world, per * (1 + k))
+        g_all = torch.cat([gathered[:, :per].reshape(-1)[:n], gathered[:, per:].reshape(-1)[:n * k]])
+        # 3. the whole batch back through the (replicated) encoder; the scores themselves are not needed
+        if fused and isinstance(self.predictor, DotPredictor):
+            out = self.predictor.score_edges(h, src, dst, gate_scale, channel, compute_forward=False)
+        elif fused:
+            out = self.predictor.score_edges(h, src, dst, gate_scale, channel)
+        else:
+            out = self._score(h, src, dst)
+        out.backward(g_all.reshape(out.shape))
         self._clip_and_step()
         return loss.detach().reshape(())
 
@@ -243,6 +334,7 @@ class BaseModel(object):
         self.encoder.train()
         self.predictor.train()
         rank, world = self._world()
+        mode = self.dp_mode()
 
         pos_train_edge, neg_train_edge = get_pos_neg_edges(
             'train', split_edge, edge_index=data.edge_index, num_nodes=self.num_nodes,
@@ -263,6 +355,13 @@ class BaseModel(object):
             n_b = b.numel()
             perm_all = order[start:start + n_b]
             start += n_b
+            if world > 1 and mode == "scores":
+                weight_margin = edge_weight_margin[perm_all] if edge_weight_margin is not None else None
+                loss = self.train_step_global(data, pos_train_edge[perm_all], neg_train_edge[perm_all], num_neg,
+                                              weight_margin)
+                loss_acc += loss.double() * n_b
+                total_examples += n_b
+                continue
             if world > 1:
                 per = (n_b + world - 1) // world
                 perm = perm_all[rank * per:(rank + 1) * per]
@@ -275,6 +374,9 @@ class BaseModel(object):
 
         if world > 1:
             torch.distributed.all_reduce(loss_acc, group=self.process_group)
+            if mode == "scores" and not self.check_replicas():
+                raise RuntimeError("data-parallel replicas diverged (dp_exchange='scores' relies on every rank "
+                                   "computing the same deterministic update)")
         return loss_acc.item() / max(total_examples, 1)
 
     # ------------------------------------------------------------------- eval ---

@@ -984,15 +984,21 @@ class EdgeDotFn(torch.autograd.Function):
     (model.py:155-156 + layer.py:174-176 in one pass)."""
 
     @staticmethod
-    def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None):
+    def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None,
+                compute_forward: bool = True):
         """gate_scale > 0: h is the output of relu(+dropout, scale = 1/(1-p)) and the returned
         gradient is taken w.r.t. the pre-activation (h > 0 ? g * gate_scale : 0), folding the
         activation backward into the gather-reduce epilogue (no separate pass over [N, F]).
-        channel: deliver the gradient of h row-sparse through it (see SparseGradChannel)."""
+        channel: deliver the gradient of h row-sparse through it (see SparseGradChannel).
+        compute_forward=False: the scores are not needed (the caller already has them and only
+        wants this node in the graph for its backward); the returned tensor is uninitialised."""
         h = _f32c(h)
         ctx.save_for_backward(h, src, dst)
         ctx.gate_scale = float(gate_scale)
         ctx.channel = channel
+        if not compute_forward:
+            L.require_device(h, src, dst)
+            return torch.empty(src.numel(), dtype=torch.float32, device=h.device)
         return edge_dot_fwd(h, src, dst)
 
     @staticmethod
@@ -1002,7 +1008,7 @@ class EdgeDotFn(torch.autograd.Function):
         gs = ctx.gate_scale
         if ctx.channel is not None and EDGE_BACKWARD["mode"] == "segment":
             ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs)
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if EDGE_BACKWARD["mode"] == "segment":
             epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
             gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g, epilogue=epi)
@@ -1010,7 +1016,7 @@ class EdgeDotFn(torch.autograd.Function):
             gh = edge_scatter_bwd(h, src, dst, g)
             if gs > 0.0:
                 gh = gate(gh, h, gs)
-        return gh, None, None, None, None
+        return gh, None, None, None, None, None
 
 
 class EdgeHadamardFn(torch.autograd.Function):

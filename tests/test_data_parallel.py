@@ -41,7 +41,7 @@ class _Data:
     pass
 
 
-def _run(rank, world, port, batch, scaling, loss_name, predictor, out_q):
+def _run(rank, world, port, batch, scaling, loss_name, predictor, out_q, exchange="auto"):
     import plnlp_amd as P
     pg = None
     if world > 1:
@@ -60,7 +60,10 @@ def _run(rank, world, port, batch, scaling, loss_name, predictor, out_q):
                     optimizer_name="Adam", device="cpu", use_node_feats=False, train_node_emb=True,
                     modules=(enc, pred, lambda p_, n_, k_, w_: O.LOSSES[O.select_loss(loss_name, w_ is not None)](
                         p_, n_, k_, w_)),
-                    process_group=pg, dp_scaling=scaling)
+                    process_group=pg, dp_scaling=scaling, dp_exchange=exchange)
+    if world > 1:
+        want = "grads" if (predictor == "MLP" or exchange == "grads") else "scores"
+        assert m.dp_mode() == want, (m.dp_mode(), want)
     m.emb.double()
     m.param_init()
     data = _Data()
@@ -80,11 +83,11 @@ def _run(rank, world, port, batch, scaling, loss_name, predictor, out_q):
     return losses, flat
 
 
-def _spawn(world, batch, scaling, loss_name, predictor):
+def _spawn(world, batch, scaling, loss_name, predictor, exchange="auto"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, batch, scaling, loss_name, predictor, q))
+    procs = [ctx.Process(target=_run, args=(r, world, port, batch, scaling, loss_name, predictor, q, exchange))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -95,26 +98,31 @@ def _spawn(world, batch, scaling, loss_name, predictor):
     return sorted(res, key=lambda r: r[0])
 
 
-@pytest.mark.parametrize("scaling,loss_name,predictor", [("strong", "AUC", "MLP"), ("weak", "WeightedHingeAUC", "DOT")])
-def test_two_ranks_equal_one_process(scaling, loss_name, predictor):
+@pytest.mark.parametrize("scaling,loss_name,predictor,exchange",
+                         [("strong", "AUC", "MLP", "auto"), ("weak", "WeightedHingeAUC", "DOT", "grads"),
+                          ("weak", "WeightedHingeAUC", "DOT", "scores"), ("strong", "HingeAUC", "DOT", "auto")])
+def test_two_ranks_equal_one_process(scaling, loss_name, predictor, exchange):
+    """both exchange modes: parameter-gradient all-reduce, and all-gather of the per-edge score
+    gradients followed by the same global backward on every rank"""
     B = 64
     single_batch = B if scaling == "strong" else 2 * B       # weak: global batch = world * B
     ref_losses, ref_flat = _run(0, 1, 0, single_batch, scaling, loss_name, predictor, None)
-    res = _spawn(2, B, scaling, loss_name, predictor)
+    res = _spawn(2, B, scaling, loss_name, predictor, exchange)
     for rank, losses, flat in res:
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-9, err_msg=f"rank {rank}")
         np.testing.assert_allclose(flat, ref_flat, rtol=1e-6, atol=1e-9)
     np.testing.assert_array_equal(res[0][2], res[1][2])        # bit-identical replicas
 
 
-def test_uneven_last_batch_and_empty_slice():
+@pytest.mark.parametrize("exchange", ["grads", "scores"])
+def test_uneven_last_batch_and_empty_slice(exchange):
     """a last global batch smaller than the world size leaves a rank with no edges;
-    it must still join the reduction"""
+    it must still join the exchange"""
     adj, pos, w = _problem()
     n = pos.size(0)
     B = n - 1                      # second global batch has exactly 1 edge -> rank 1 gets none
     ref_losses, ref_flat = _run(0, 1, 0, B, "strong", "AUC", "DOT", None)
-    res = _spawn(2, B, "strong", "AUC", "DOT")
+    res = _spawn(2, B, "strong", "AUC", "DOT", exchange)
     for rank, losses, flat in res:
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-9)
     np.testing.assert_array_equal(res[0][2], res[1][2])
