@@ -261,10 +261,38 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                                        int h) {
     constexpr int PF = PLNLP_GEMM_PF;
     f32x4 ra[PF][4], rb[PF][4];
+    int base = tb;
+    // steady state: entered with all PF sets loaded and every tile of a round reloading its set,
+    // UNCONDITIONALLY.  With any of those loads under a branch (`if (tile + PF < te)`, or a guarded
+    // first fill) the compiler must assume the younger sets may never have been issued and waits for
+    // vmcnt(0) before staging the oldest one -- i.e. for the younger sets too, which halves the
+    // look-ahead.  Branch-free, it knows PF-1 sets are still in flight and waits for vmcnt(8 (PF-1)).
+    if (te - tb >= 2 * PF) {
 #pragma unroll
-    for (int d = 0; d < PF; ++d)
-        if (tb + d < te) load_tile<A_T, B_T, MODE, BIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
-    for (int base = tb; base < te; base += PF) {
+        for (int d = 0; d < PF; ++d) load_tile<A_T, B_T, MODE, BIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
+        do {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                const int tile = base + d;
+                const int buf = (tile - tb) & 1;
+                stage_tile<A_T, B_T>(lds, buf, ra[d], rb[d], t);
+#ifndef ABL_NOBARRIER
+                __syncthreads();
+#endif
+#ifndef ABL_NOGLOAD
+                load_tile<A_T, B_T, MODE, BIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t);
+#endif
+                mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
+            }
+            base += PF;
+        } while (base + 2 * PF <= te);
+    } else {
+#pragma unroll
+        for (int d = 0; d < PF; ++d)
+            if (tb + d < te) load_tile<A_T, B_T, MODE, BIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
+    }
+    // drain: the last < 2 PF tiles
+    for (; base < te; base += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
             const int tile = base + d;
