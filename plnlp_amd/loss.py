@@ -9,7 +9,7 @@ stay on stock device ops.
 """
 import torch
 
-from .ops import PairwiseLossFn
+from .ops import PairwiseLossFn, PairwiseLossJointFn
 
 
 def _fused(kind):
@@ -21,6 +21,7 @@ def _fused(kind):
 
     fn = needs_weight if kind.startswith(("weighted", "adaptive")) else plain
     fn.__name__ = f"{kind}_loss"
+    fn.kind = kind
     return fn
 
 
@@ -45,6 +46,18 @@ def info_nce_loss(pos_out, neg_out, num_neg):
     p = pos_out.reshape(-1, 1).exp()
     n = neg_out.reshape(-1, num_neg).exp().sum(dim=1, keepdim=True)
     return -((p / (p + n)) + 1e-15).log().mean()
+
+
+def joint_loss(name, out, n_pos, num_neg, weight=None):
+    """loss `name` (CLI name, with the reference's fallbacks of model.py:107-126) on one score tensor
+    [pos (n_pos) | neg (n_pos * num_neg)]; None when that loss has no fused kernel"""
+    fn, weighted = BY_NAME.get(name, (auc_loss, False))
+    if weighted and weight is None:
+        fn, weighted = auc_loss, False
+    kind = getattr(fn, "kind", None)
+    if kind is None:
+        return None
+    return PairwiseLossJointFn.apply(out, int(n_pos), weight if weighted else None, kind, int(num_neg))
 
 
 # CLI name -> (function, takes the per-edge weight/margin)   model.py:107-126

@@ -136,6 +136,15 @@ class BaseModel(object):
             return fn(pos_out, neg_out, num_neg, margin)
         return fn(pos_out, neg_out, num_neg)
 
+    def _loss_of_scores(self, out, n_pos, num_neg, margin=None):
+        """calculate_loss on the step's single score tensor [pos | neg] without slicing it (the fused
+        loss kernel then hands back ONE gradient tensor); falls back to the sliced call"""
+        if self._loss_override is None and out.is_cuda:
+            loss = loss_mod.joint_loss(self.loss_func_name, out, n_pos, num_neg, margin)
+            if loss is not None:
+                return loss
+        return self.calculate_loss(out[:n_pos], out[n_pos:], num_neg, margin=margin)
+
     # ------------------------------------------------------------- DP helpers ---
     def _world(self):
         if self.process_group is None:
@@ -267,7 +276,7 @@ class BaseModel(object):
             dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
             out = (self.predictor.score_edges(h, src, dst, gate_scale, channel) if fused
                    else self._score(h, src, dst))
-            loss = self.calculate_loss(out[:local], out[local:], num_neg, margin=weight_margin)
+            loss = self._loss_of_scores(out, local, num_neg, weight_margin)
         else:                                    # empty slice: still take part in the reduction
             loss = h.sum() * 0.0
         loss.backward()
@@ -301,8 +310,7 @@ class BaseModel(object):
                 out_l = self._score(h, torch.cat([src[lo:hi], src[n + lo * k:n + hi * k]]),
                                     torch.cat([dst[lo:hi], dst[n + lo * k:n + hi * k]]))
             out_l = out_l.detach().requires_grad_(True)
-            loss = self.calculate_loss(out_l[:local], out_l[local:], k,
-                                       margin=None if weight_margin is None else weight_margin[lo:hi])
+            loss = self._loss_of_scores(out_l, local, k, None if weight_margin is None else weight_margin[lo:hi])
             loss.backward()
             gl = out_l.grad.reshape(-1)
             g_pad[:local] = gl[:local]

@@ -492,8 +492,10 @@ def edge_scatter_bwd(h: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, g: t
 
 
 def pairwise_loss(kind: str, pos: torch.Tensor, neg: torch.Tensor, num_neg: int,
-                  weight: Optional[torch.Tensor] = None, grad_scale: float = 1.0):
-    """returns (loss[1], gpos[B], gneg[B*k])"""
+                  weight: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
+                  grad_out: Optional[torch.Tensor] = None):
+    """returns (loss[1], gpos[B], gneg[B*k]); grad_out: a [B + B*k] buffer the two gradients are
+    written into back to back (gpos / gneg are then views of it)"""
     lib = L.load()
     L.require_device(pos, neg, weight)
     pos = _f32c(pos.reshape(-1))
@@ -504,8 +506,10 @@ def pairwise_loss(kind: str, pos: torch.Tensor, neg: torch.Tensor, num_neg: int,
         weight = _f32c(weight.reshape(-1))
         assert weight.numel() == b
     loss = torch.empty(1, dtype=torch.float32, device=pos.device)
-    gpos = torch.empty(b, dtype=torch.float32, device=pos.device)
-    gneg = torch.empty(b * num_neg, dtype=torch.float32, device=pos.device)
+    if grad_out is None:
+        grad_out = torch.empty(b + b * num_neg, dtype=torch.float32, device=pos.device)
+    assert grad_out.numel() == b + b * num_neg and grad_out.is_contiguous() and grad_out.dtype == torch.float32
+    gpos, gneg = grad_out[:b], grad_out[b:]
     nws = lib.plnlp_loss_workspace_floats(b)
     ws = torch.empty(nws, dtype=torch.float32, device=pos.device)
     L.check(lib.plnlp_pairwise_loss_f32(L.LOSS_KINDS[kind], pos.data_ptr(), neg.data_ptr(), L.ptr(weight), b,
@@ -1047,6 +1051,26 @@ class EdgeHadamardFn(torch.autograd.Function):
             if gs > 0.0:
                 gh = gate(gh, h, gs)
         return gh, None, None, None, None
+
+
+class PairwiseLossJointFn(torch.autograd.Function):
+    """the same losses on ONE score tensor [pos (n) | neg (n*k)], as the training step produces it:
+    the gradient comes back as one tensor too (slicing the scores first makes autograd rebuild it
+    with two zero fills, two copies and an add)"""
+
+    @staticmethod
+    def forward(ctx, out, n_pos: int, weight, kind: str, num_neg: int):
+        flat = _f32c(out.reshape(-1))
+        gout = torch.empty_like(flat)
+        loss, _, _ = pairwise_loss(kind, flat[:n_pos], flat[n_pos:], num_neg, weight, grad_out=gout)
+        ctx.save_for_backward(gout)
+        ctx.shape = out.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (gout,) = ctx.saved_tensors
+        return (gout * g).reshape(ctx.shape), None, None, None, None
 
 
 class PairwiseLossFn(torch.autograd.Function):
