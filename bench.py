@@ -106,6 +106,27 @@ def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
                     ("fits in" if src_mib <= 256 else "exceeds")}
 
 
+def measure_gemm_roofline(P, n_rows, k_in, hidden, device, sage=True):
+    """the other hot kernel: the encoder's forward linear on the f32-input MFMA (SAGE: lin_l(agg) + lin_r(x)
+    as one concat-K product with bias/relu/dropout in the epilogue), timed live like the aggregation"""
+    from plnlp_amd import _lib
+    a1 = torch.randn(n_rows, k_in, device=device)
+    w1 = torch.randn(hidden, k_in, device=device) * 0.05
+    segs = [(a1, w1)]
+    if sage:
+        segs.append((torch.randn(n_rows, k_in, device=device), torch.randn(hidden, k_in, device=device) * 0.05))
+    bias = torch.zeros(hidden, device=device)
+    out = torch.empty(n_rows, hidden, device=device)
+    epi = _lib.make_epilogue(bias=bias, relu=True, dropout_p=0.3, dropout_seed=1)
+    t = time_kernel(lambda: P.ops.gemm(segs, False, True, out=out, epilogue=epi))
+    flop = 2.0 * n_rows * hidden * k_in * len(segs)
+    return {"bound": "mfma", "kernel": "gemm_f32_kernel (M=%d, N=%d, K=%s, bias+relu+dropout epilogue)"
+                                       % (n_rows, hidden, "+".join([str(k_in)] * len(segs))),
+            "achieved": flop / t / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / t / 157.3e12,
+            "traffic": None, "flops": flop, "kernel_ms": t * 1e3,
+            "note": "v_mfma_f32_32x32x2_f32 (exact fp32; gfx950 has no TF32), peak = 256 CUs x 256 FLOP/clk x 2.4 GHz"}
+
+
 def cpu_baseline(cfg, g, pos, neg, w, steps):
     """the CPU oracle (port of the reference PyG CPU path) on the same workload"""
     import oracle as O
@@ -317,6 +338,9 @@ def main():
         if not args.no_roofline:
             result["roofline"] = measure_roofline(P, g["adj_t"], cfg["hidden"], device,
                                                   weighted=cfg["encoder"] == "GCN", shape=cfg["shape"])
+        if world == 1 and not args.no_roofline:
+            result["roofline_mfma"] = measure_gemm_roofline(
+                P, n, cfg.get("emb", cfg["hidden"]) + feats, cfg["hidden"], device, sage=cfg["encoder"] == "SAGE")
         if world == 1 and not args.no_roofline and not args.no_stress:
             # the workload's source matrix may fit the 256 MiB Infinity Cache; the HBM roofline proper is
             # taken on a citation2-sized graph without skew or locality at h=512 (6 GB source matrix)

@@ -12,6 +12,12 @@
 
 namespace plnlp {
 
+// rocPRIM switches to a merge sort below 1 Mi keys (17 launches, ~100 us for the 262 144 keys of a
+// collab batch, and blind to the bit range); the digit-pass (onesweep) path sorts the 18 node bits in
+// 3 passes.  Limit 0 = always onesweep above one block's worth of keys.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::default_config, 0>;
+
 __device__ __forceinline__ int64_t wrap_node(int64_t i, int64_t n) { return i < 0 ? i + n : i; }
 
 __global__ __launch_bounds__(256) void incidence_keys_kernel(const int64_t* __restrict__ src,
@@ -189,7 +195,7 @@ extern "C" int64_t plnlp_incidence_temp_bytes(int64_t n_edges) {
     size_t bytes = 0;
     uint64_t* k = nullptr;
     if (n_edges <= 0) return 0;
-    rocprim::radix_sort_keys(nullptr, bytes, k, k, (size_t)(2 * n_edges), 0, 64, (hipStream_t)0);
+    rocprim::radix_sort_keys<plnlp::SortConfig>(nullptr, bytes, k, k, (size_t)(2 * n_edges), 0, 64, (hipStream_t)0);
     return (int64_t)bytes + 256;
 }
 
@@ -213,13 +219,13 @@ extern "C" int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int
     // NODE bits alone already yields the (node, item) order: half the digit passes
     const unsigned bit0 = (unsigned)shift, bit1 = (unsigned)(shift + (node_bits > 0 ? node_bits : 1));
     size_t need = 0;
-    rocprim::radix_sort_keys(nullptr, need, keys_a, keys_b, (size_t)n_items, bit0, bit1, s);
+    rocprim::radix_sort_keys<SortConfig>(nullptr, need, keys_a, keys_b, (size_t)n_items, bit0, bit1, s);
     if ((int64_t)need > temp_bytes) return PLNLP_E_WORKSPACE;
     const unsigned blocks = (unsigned)((n_items + 255) / 256);
     hipLaunchKernelGGL(incidence_keys_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n_edges, n_nodes, shift, keys_a);
     if (int rc = launch_status()) return rc;
     size_t tb = (size_t)temp_bytes;
-    hipError_t err = rocprim::radix_sort_keys(temp, tb, keys_a, keys_b, (size_t)n_items, bit0, bit1, s);
+    hipError_t err = rocprim::radix_sort_keys<SortConfig>(temp, tb, keys_a, keys_b, (size_t)n_items, bit0, bit1, s);
     if (err != hipSuccess) return (int)err;
     hipLaunchKernelGGL(incidence_items_kernel, dim3(blocks), dim3(256), 0, s, keys_b, src, dst, n_edges, n_nodes,
                        shift, item_edge, item_other, seg_ptr);
