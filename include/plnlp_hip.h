@@ -225,7 +225,9 @@ int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int64_t n_edge
  * rows of the gathered matrix receive a gradient, so the encoder's last backward step runs on
  * `count` rows instead of n_rows).  rows[i] = i-th non-empty row, node_map[r] = its position or -1,
  * rowptr_c[i] = rowptr[rows[i]] and rowptr_c[count] = rowptr[n_rows] (the CSR without its empty
- * rows), *count = their number.  Capacity of rows / rowptr_c: n_rows (+1).  block_ws: int32
+ * rows), *count = their number; past the count the lists are padded as empty rows (rows[i] = 0,
+ * rowptr_c[i+1] = rowptr[n_rows]) so the compact CSR can be walked over its capacity without the count.
+ * Capacity of rows / rowptr_c: n_rows (+1).  block_ws: int32
  * [plnlp_compact_rows_workspace(n_rows)].  Three small launches, deterministic. */
 int64_t plnlp_compact_rows_workspace(int64_t n_rows);
 int plnlp_compact_rows(const int64_t* rowptr, int64_t n_rows, int32_t* rows, int32_t* node_map,

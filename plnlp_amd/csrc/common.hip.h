@@ -173,9 +173,10 @@ __device__ __forceinline__ float4 epi_apply4(const Epi& e, float4 v, int64_t r, 
 
 // vec4 form with the operands already in registers (the GEMM epilogue loads bias once per thread and
 // gate / accumulate operands ahead of the loop that consumes them, so their latency is not exposed
-// between the LDS read and the store of every output row).  No ADDEND.
+// between the LDS read and the store of every output row).  `add` is the addend row when has_add.
 __device__ __forceinline__ float4 epi_apply4_pre(const Epi& e, float4 v, int64_t r, int64_t f, int64_t n_cols,
-                                                 float4 b, float4 y, float4 prev) {
+                                                 float4 b, float4 y, float4 prev,
+                                                 float4 add = make_float4(0.f, 0.f, 0.f, 0.f), bool has_add = false) {
     if (e.flags & PLNLP_EPI_BIAS) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
     if (e.flags & PLNLP_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (e.flags & PLNLP_EPI_DROPOUT) {
@@ -183,6 +184,7 @@ __device__ __forceinline__ float4 epi_apply4_pre(const Epi& e, float4 v, int64_t
                            e.keep_scale);
     }
     if (e.flags & PLNLP_EPI_ACCUM) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
+    if (has_add) { v.x += add.x; v.y += add.y; v.z += add.z; v.w += add.w; }
     if (e.flags & PLNLP_EPI_GATE) {
         v.x = y.x > 0.f ? v.x * e.gate_scale : 0.f; v.y = y.y > 0.f ? v.y * e.gate_scale : 0.f;
         v.z = y.z > 0.f ? v.z * e.gate_scale : 0.f; v.w = y.w > 0.f ? v.w * e.gate_scale : 0.f;

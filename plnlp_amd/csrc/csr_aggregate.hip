@@ -159,21 +159,65 @@ __device__ __forceinline__ void fold_groups(float4 (&acc)[VPL]) {
     }
 }
 
+// Epilogue operands that do not depend on the row's sum (gate row, accumulate row, addend row):
+// a short row is one chain of dependent round trips (rowptr -> col -> rows -> store), and loading
+// these only after the sum appended two more (index -> operand row).  They are fetched at the START of
+// the row instead and ride along with the index loads.
+template <int VPL>
+struct EpiPre {
+    float4 g[VPL], p[VPL], a[VPL];
+    bool   valid, has_add;
+};
+
+template <int VPL, int LPR>
+__device__ __forceinline__ void epi_prefetch(EpiPre<VPL>& pre, const Epi& epi, int64_t r, int nslots, int sub,
+                                             const float* __restrict__ out, int64_t ldo) {
+    pre.valid = epi.vec4 && (epi.flags & (PLNLP_EPI_GATE | PLNLP_EPI_ACCUM | PLNLP_EPI_ADDEND)) && VPL <= 2;
+    pre.has_add = false;
+    if (!pre.valid) return;
+    const float* grow = nullptr;
+    const float* arow = nullptr;
+    if (epi.flags & PLNLP_EPI_GATE)
+        grow = epi.gate + (epi.gate_index ? (int64_t)epi.gate_index[r] : r) * epi.ld_gate;
+    if (epi.flags & PLNLP_EPI_ADDEND) {
+        const int64_t ai = epi.addend_index ? (int64_t)epi.addend_index[r] : r;
+        if (ai >= 0) { arow = epi.addend + ai * epi.ld_addend; pre.has_add = true; }
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        const int s = sub + k * LPR;
+        if (s < nslots) {
+            if (grow) pre.g[k] = *reinterpret_cast<const float4*>(grow + s * 4);
+            if (arow) pre.a[k] = *reinterpret_cast<const float4*>(arow + s * 4);
+            if (epi.flags & PLNLP_EPI_ACCUM) pre.p[k] = *reinterpret_cast<const float4*>(out + r * ldo + s * 4);
+        }
+    }
+}
+
 template <int VPL, int LPR>
 __device__ __forceinline__ void finish_row(float4 (&acc)[VPL], int64_t r, int64_t deg, int mean, int feat,
                                            int nslots, int sub, float* __restrict__ out, int64_t ldo,
-                                           const Epi& epi) {
+                                           const Epi& epi, const EpiPre<VPL>* pre = nullptr) {
     if (mean) {
         const float d = (float)(deg > 0 ? deg : 1);
 #pragma unroll
         for (int k = 0; k < VPL; ++k) { acc[k].x /= d; acc[k].y /= d; acc[k].z /= d; acc[k].w /= d; }
     }
     float* orow = out + r * ldo;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
         int s = sub + k * LPR;
         if (s < nslots) {
-            float4 y = epi_apply4(epi, acc[k], r, (int64_t)s * 4, feat, orow);
+            float4 y;
+            if (pre && pre->valid) {
+                float4 b4 = zero4;
+                if (epi.flags & PLNLP_EPI_BIAS) b4 = *reinterpret_cast<const float4*>(epi.bias + s * 4);
+                y = epi_apply4_pre(epi, acc[k], r, (int64_t)s * 4, feat, b4, pre->g[k], pre->p[k], pre->a[k],
+                                   pre->has_add);
+            } else {
+                y = epi_apply4(epi, acc[k], r, (int64_t)s * 4, feat, orow);
+            }
             *reinterpret_cast<float4*>(orow + s * 4) = y;
         }
     }
@@ -195,6 +239,9 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     const int nslots = feat >> 2;
     const int64_t beg = rowptr[r], end = rowptr[r + 1];
     if (skip_above > 0 && end - beg > skip_above) return;
+    EpiPre<VPL> pre;
+    pre.valid = false;
+    if (LPR == 64 || grp == 0) epi_prefetch<VPL, LPR>(pre, epi, r, nslots, sub, out, ldo);
 
     float4 acc[VPL];
 #pragma unroll
@@ -202,7 +249,7 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
-    finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi);
+    finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi, &pre);
 }
 
 // short-row form: a wave owns 64/LPR rows at once (one LPR-lane group per row), so 2-4x more rows

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(CB) void compact_scan_kernel(int32_t* __restrict__ 
 __global__ __launch_bounds__(CB) void compact_write_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows,
                                                            const int32_t* __restrict__ block_off,
                                                            int32_t* __restrict__ rows, int32_t* __restrict__ node_map,
-                                                           int64_t* __restrict__ rowptr_c) {
+                                                           int64_t* __restrict__ rowptr_c,
+                                                           const int64_t* __restrict__ count) {
     __shared__ int wcnt[CB / 64];
     const int64_t r = (int64_t)blockIdx.x * CB + threadIdx.x;
     const int wave = threadIdx.x >> 6;
@@ -178,7 +179,16 @@ __global__ __launch_bounds__(CB) void compact_write_kernel(const int64_t* __rest
     const int idx = block_off[blockIdx.x] + woff + lanes_below(m);
     if (r < n_rows) {
         node_map[r] = f ? idx : -1;
-        if (f) { rows[idx] = (int32_t)r; rowptr_c[idx] = beg; }
+        if (f) {
+            rows[idx] = (int32_t)r;
+            rowptr_c[idx] = beg;
+        } else {
+            // the u-th empty row pads the tail: past `count` the compact CSR continues with empty rows
+            // (row id 0, offset = end), so it can be walked over its CAPACITY without knowing the count
+            const int64_t c = *count, u = r - idx;
+            rows[c + u] = 0;
+            rowptr_c[c + 1 + u] = rowptr[n_rows];
+        }
         if (r == n_rows - 1) rowptr_c[idx + (f ? 1 : 0)] = rowptr[n_rows];
     }
 }
@@ -254,7 +264,7 @@ extern "C" int plnlp_compact_rows(const int64_t* rowptr, int64_t n_rows, int32_t
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(CB), 0, s, block_ws, nb, count);
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(compact_write_kernel, dim3((unsigned)nb), dim3(CB), 0, s, rowptr, n_rows, block_ws, rows,
-                       node_map, rowptr_c);
+                       node_map, rowptr_c, count);
     return launch_status();
 }
 

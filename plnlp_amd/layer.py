@@ -211,8 +211,8 @@ class MLPPredictor(_LinsPredictor):
     def forward(self, x_i, x_j):
         return self._stack(x_i * x_j)
 
-    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None):
-        return self._stack(ops.EdgeHadamardFn.apply(h, src, dst, gate_scale, channel))
+    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None, incidence=None):
+        return self._stack(ops.EdgeHadamardFn.apply(h, src, dst, gate_scale, channel, incidence))
 
 
 class MLPCatPredictor(_LinsPredictor):
@@ -275,8 +275,9 @@ class DotPredictor(torch.nn.Module):
     def forward(self, x_i, x_j):
         return torch.sum(x_i * x_j, dim=-1)
 
-    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None, compute_forward: bool = True):
-        return ops.EdgeDotFn.apply(h, src, dst, gate_scale, channel, compute_forward)
+    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None, compute_forward: bool = True,
+                    incidence=None):
+        return ops.EdgeDotFn.apply(h, src, dst, gate_scale, channel, compute_forward, incidence)
 
 
 class BilinearPredictor(torch.nn.Module):

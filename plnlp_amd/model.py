@@ -234,9 +234,12 @@ class BaseModel(object):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
         return bool(torch.equal(lo, hi))
 
-    def _encode(self, data, n_edges, n_endpoints, use_sink):
-        """encoder forward of a training step with the fusions the scorer allows; returns
-        (h, gate_scale, channel, fused) -- see train_step"""
+    def _encode(self, data, src, dst, use_sink):
+        """encoder forward of a training step with the fusions the scorer allows; src / dst are
+        ALL edges whose scores will be back-propagated.  Returns (h, gate_scale, channel, fused,
+        incidence) -- see train_step"""
+        n_edges = src.numel()
+        n_endpoints = 2 * n_edges
         native = isinstance(self.encoder, BaseGNN)
         fused = native and type(self.predictor) in (DotPredictor, MLPPredictor)   # gather fused into the scorer
         # a 1-layer encoder ends in relu+dropout (layer.py:24-26); with a fused scorer as the only
@@ -253,11 +256,16 @@ class BaseModel(object):
         if (n_edges > 0 and fused and all(isinstance(c, (SAGEConv, GCNConv)) for c in self.encoder.convs)
                 and ops.sparse_backward_pays(n_endpoints, x_in.shape[0])):
             channel = kw["output_grad_channel"] = ops.SparseGradChannel()
+        # the index structures of the gather backward depend on the edges alone: build them (sort,
+        # touched-node compaction, its count read-back) NOW, under the forward pass
+        incidence = None
+        if n_edges > 0 and fused and x_in.is_cuda and ops.EDGE_BACKWARD["mode"] == "segment":
+            incidence = ops.prepare_edge_backward(src, dst, x_in.shape[0], compact=channel is not None)
         if fuse_gate:
             h, gate_scale = self.encoder(x_in, data.adj_t, fuse_output_gate=True, **kw)
         else:
             h, gate_scale = self.encoder(x_in, data.adj_t, **kw), 0.0
-        return h, gate_scale, channel, fused
+        return h, gate_scale, channel, fused, incidence
 
     def _score(self, h, src, dst):
         if hasattr(self.predictor, "score_edges"):
@@ -269,12 +277,13 @@ class BaseModel(object):
         pos_edge [b,2], neg_edge [b,k,2] (device).  Returns the detached local loss."""
         self.optimizer.zero_grad(set_to_none=True)
         local = pos_edge.size(0)
-        h, gate_scale, channel, fused = self._encode(data, local, 2 * (local + neg_edge.numel() // 2), True)
+        neg_flat = neg_edge.reshape(-1, 2)
+        src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
+        dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
+        h, gate_scale, channel, fused, incidence = self._encode(data, src, dst, True)
         if local > 0:
-            neg_flat = neg_edge.reshape(-1, 2)
-            src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
-            dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
-            out = (self.predictor.score_edges(h, src, dst, gate_scale, channel) if fused
+            out = (self.predictor.score_edges(h, src, dst, gate_scale=gate_scale, channel=channel,
+                                              incidence=incidence) if fused
                    else self._score(h, src, dst))
             loss = self._loss_of_scores(out, local, num_neg, weight_margin)
         else:                                    # empty slice: still take part in the reduction
@@ -298,10 +307,10 @@ class BaseModel(object):
         per = (n + world - 1) // world
         lo, hi = min(rank * per, n), min((rank + 1) * per, n)
         local = hi - lo
-        h, gate_scale, channel, fused = self._encode(data, n, 2 * (n + neg_edge.numel() // 2), False)
         neg_flat = neg_edge.reshape(-1, 2)
         src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
         dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
+        h, gate_scale, channel, fused, incidence = self._encode(data, src, dst, False)
         # 1. local slice: scores (outside the encoder's graph), loss, d loss / d score
         g_pad = torch.zeros(per * (1 + k), dtype=h.dtype, device=h.device)
         loss = torch.zeros((), dtype=h.dtype, device=h.device)
@@ -322,9 +331,11 @@ class BaseModel(object):
         g_all = torch.cat([gathered[:, :per].reshape(-1)[:n], gathered[:, per:].reshape(-1)[:n * k]])
         # 3. the whole batch back through the (replicated) encoder; the scores themselves are not needed
         if fused and isinstance(self.predictor, DotPredictor):
-            out = self.predictor.score_edges(h, src, dst, gate_scale, channel, compute_forward=False)
+            out = self.predictor.score_edges(h, src, dst, gate_scale=gate_scale, channel=channel,
+                                             compute_forward=False, incidence=incidence)
         elif fused:
-            out = self.predictor.score_edges(h, src, dst, gate_scale, channel)
+            out = self.predictor.score_edges(h, src, dst, gate_scale=gate_scale, channel=channel,
+                                             incidence=incidence)
         else:
             out = self._score(h, src, dst)
         out.backward(g_all.reshape(out.shape))

@@ -346,36 +346,81 @@ class Incidence:
         return CompactIncidence(self)
 
 
+_pinned_counts = {"ring": None, "next": 0}
+
+
+def _pinned_count_buffer() -> torch.Tensor:
+    """a pinned int64 for reading a device-side count back, from a small ring (allocating pinned
+    memory per step would cost more than the copy; a ring so that a few lists can be in flight)"""
+    if _pinned_counts["ring"] is None:
+        _pinned_counts["ring"] = torch.empty(64, dtype=torch.int64, pin_memory=True)
+    i = _pinned_counts["next"]
+    _pinned_counts["next"] = (i + 1) % 64
+    return _pinned_counts["ring"][i:i + 1]
+
+
 class CompactIncidence:
     """Incidence restricted to the nodes the batch touches, in increasing node order: row i
     belongs to node rows[i]; node_map[n] = i or -1.  Only these rows of the gathered matrix
-    receive a gradient.  Reading `count` back is the one host synchronisation of a step."""
+    receive a gradient.
+
+    The number of touched nodes T sizes the launches of the backward pass, so it must reach the
+    host: the one host read-back of a training step.  It is started asynchronously here -- the
+    lists depend only on the batch's edges, so the trainer builds them BEFORE the encoder's forward
+    pass -- and awaited on first use (`count`, `rows`, `rowptr`), by which time the GPU has long
+    passed it: the host waits, the GPU does not idle."""
 
     def __init__(self, inc: Incidence):
         lib = L.load()
         n = inc.n_nodes
         dev = inc.seg_ptr.device
-        rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self._rows_cap = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         self.node_map = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        rowptr_c = torch.empty(n + 1, dtype=torch.int64, device=dev)
-        count = torch.empty(1, dtype=torch.int64, device=dev)
+        self._rowptr_cap = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        self._count_dev = torch.empty(1, dtype=torch.int64, device=dev)
         ws = torch.empty(lib.plnlp_compact_rows_workspace(n), dtype=torch.int32, device=dev)
-        L.check(lib.plnlp_compact_rows(inc.seg_ptr.data_ptr(), n, rows.data_ptr(), self.node_map.data_ptr(),
-                                       rowptr_c.data_ptr(), count.data_ptr(), ws.data_ptr(), L.stream_ptr()),
+        L.check(lib.plnlp_compact_rows(inc.seg_ptr.data_ptr(), n, self._rows_cap.data_ptr(),
+                                       self.node_map.data_ptr(), self._rowptr_cap.data_ptr(),
+                                       self._count_dev.data_ptr(), ws.data_ptr(), L.stream_ptr()),
                 "plnlp_compact_rows")
-        self.count = int(count.item())
-        self.rows = rows[:self.count]
-        self.rowptr = self.seg_ptr = rowptr_c[:self.count + 1]
-        self.n_rows, self.n_cols, self.n_nodes = self.count, n, n
+        self._host = _pinned_count_buffer()
+        self._host.copy_(self._count_dev, non_blocking=True)
+        self._ready = torch.cuda.Event()
+        self._ready.record()
+        self._count = None
+        self.n_cols = self.n_nodes = n
         self.col = self.item_other = inc.item_other
         self.val_index = self.item_edge = inc.item_edge
         self.val = None
         self._split = None
 
+    @property
+    def count(self) -> int:
+        if self._count is None:
+            self._ready.synchronize()
+            self._count = int(self._host.item())
+        return self._count
+
+    @property
+    def n_rows(self) -> int:
+        return self.count
+
+    @property
+    def rows(self) -> torch.Tensor:
+        return self._rows_cap[:self.count]
+
+    @property
+    def rowptr(self) -> torch.Tensor:
+        return self._rowptr_cap[:self.count + 1]
+
+    seg_ptr = rowptr
+
     def row_split(self, threshold: int):
+        """hot nodes of the batch; built over the CAPACITY so it needs no count (rows past the count
+        are empty: rowptr_c there repeats the end offset)"""
         if self._split is None:
             from .graph import RowSplit
-            self._split = RowSplit(self.rowptr, self.item_edge.numel(), threshold)
+            self._split = RowSplit(self._rowptr_cap, self.item_edge.numel(), threshold)
         return self._split
 
 
@@ -628,8 +673,11 @@ class AggregateFn(torch.autograd.Function):
     def backward(ctx, g):
         graph = ctx.graph
         gt = graph.t()
-        gx = csr_aggregate(gt, g.contiguous(), "sum", ctx.use_values,
-                           src_scale=graph.inv_degree() if ctx.reduce == "mean" else None)
+        if ctx.reduce == "mean" and not (ctx.use_values and graph.val is not None):
+            gx = csr_aggregate(graph.t_mean(), g.contiguous(), "sum", True)
+        else:
+            gx = csr_aggregate(gt, g.contiguous(), "sum", ctx.use_values,
+                               src_scale=graph.inv_degree() if ctx.reduce == "mean" else None)
         return gx, None, None, None
 
 
@@ -699,15 +747,13 @@ class SAGEConvFn(torch.autograd.Function):
                 ready.record(main)
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
-                    csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(),
-                                  out=gx, epilogue=epi)
+                    csr_aggregate(graph.t_mean(), gagg, "sum", use_values=True, out=gx, epilogue=epi)
                     if sink is not None and sink.on_ready is not None:
                         sink.on_ready()      # e.g. start the all-reduce (ordered after the aggregation)
                     joined = torch.cuda.Event()
                     joined.record(side)
             else:
-                csr_aggregate(graph.t(), gagg, "sum", use_values=False, src_scale=graph.inv_degree(), out=gx,
-                              epilogue=epi)
+                csr_aggregate(graph.t_mean(), gagg, "sum", use_values=True, out=gx, epilogue=epi)
                 if sink is not None and sink.on_ready is not None:
                     sink.on_ready()          # e.g. start the all-reduce; the GEMMs below overlap it
             if sink is not None:
@@ -756,8 +802,8 @@ class SAGEConvFn(torch.autograd.Function):
                                   gate_scale=ia.scale if ia is not None else 1.0)
             out = sink.buffer if sink is not None else torch.empty(x.shape[0], cin, dtype=torch.float32,
                                                                    device=x.device)
-            csr_aggregate(graph.t(), gagg_c, "sum", use_values=False, src_scale=graph.inv_degree(),
-                          src_map=sg.node_map, out=out, epilogue=epi)
+            csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=out,
+                          epilogue=epi)
             if sink is not None:
                 if sink.on_ready is not None:
                     sink.on_ready()
@@ -974,10 +1020,24 @@ class MLPStackFn(torch.autograd.Function):
 EDGE_BACKWARD = {"mode": "segment"}
 
 
-def _sparse_edge_backward(h, src, dst, g, gate_scale: float) -> RowSparseGrad:
+def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, compact: bool):
+    """Everything the backward of the edge gathers needs that depends on the batch's edges alone:
+    the node-sorted incidence lists, their hot-node tables and -- compact=True -- the touched-node
+    compaction with its count read-back in flight.  A trainer that knows the edges before the encoder
+    runs calls this FIRST and passes the result to the scorer (`incidence=`): the sort and the
+    read-back then overlap the forward pass instead of stalling the backward pass."""
+    inc = Incidence(src, dst, n_nodes)
+    if compact:
+        inc = inc.compact()
+    inc.row_split(SPLIT_THRESHOLD)
+    return inc
+
+
+def _sparse_edge_backward(h, src, dst, g, gate_scale: float, ci=None) -> RowSparseGrad:
     """gradient of the gathered matrix h over the touched nodes only (scalar g: DOT, matrix g:
     Hadamard), with the producing layer's relu/dropout derivative folded in when gate_scale > 0"""
-    ci = Incidence(src, dst, h.shape[0]).compact()
+    if ci is None:
+        ci = Incidence(src, dst, h.shape[0]).compact()
     epi = L.make_epilogue(gate=h, gate_scale=gate_scale, gate_index=ci.rows) if gate_scale > 0.0 else None
     vals = edge_segment_bwd(h, ci, g, epilogue=epi)
     return RowSparseGrad(ci.rows, ci.node_map, vals, h.shape[0])
@@ -989,17 +1049,19 @@ class EdgeDotFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None,
-                compute_forward: bool = True):
+                compute_forward: bool = True, incidence=None):
         """gate_scale > 0: h is the output of relu(+dropout, scale = 1/(1-p)) and the returned
         gradient is taken w.r.t. the pre-activation (h > 0 ? g * gate_scale : 0), folding the
         activation backward into the gather-reduce epilogue (no separate pass over [N, F]).
         channel: deliver the gradient of h row-sparse through it (see SparseGradChannel).
         compute_forward=False: the scores are not needed (the caller already has them and only
-        wants this node in the graph for its backward); the returned tensor is uninitialised."""
+        wants this node in the graph for its backward); the returned tensor is uninitialised.
+        incidence: prepare_edge_backward(src, dst, ...) of the same edges, built ahead of time."""
         h = _f32c(h)
         ctx.save_for_backward(h, src, dst)
         ctx.gate_scale = float(gate_scale)
         ctx.channel = channel
+        ctx.incidence = incidence
         if not compute_forward:
             L.require_device(h, src, dst)
             return torch.empty(src.numel(), dtype=torch.float32, device=h.device)
@@ -1010,29 +1072,34 @@ class EdgeDotFn(torch.autograd.Function):
         h, src, dst = ctx.saved_tensors
         g = g.contiguous()
         gs = ctx.gate_scale
+        inc = ctx.incidence
         if ctx.channel is not None and EDGE_BACKWARD["mode"] == "segment":
-            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs)
-            return None, None, None, None, None, None
+            ci = inc if isinstance(inc, CompactIncidence) else None
+            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs, ci)
+            return None, None, None, None, None, None, None
         if EDGE_BACKWARD["mode"] == "segment":
             epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
-            gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g, epilogue=epi)
+            if not isinstance(inc, Incidence):
+                inc = Incidence(src, dst, h.shape[0])
+            gh = edge_segment_bwd(h, inc, g, epilogue=epi)
         else:
             gh = edge_scatter_bwd(h, src, dst, g)
             if gs > 0.0:
                 gh = gate(gh, h, gs)
-        return gh, None, None, None, None, None
+        return gh, None, None, None, None, None, None
 
 
 class EdgeHadamardFn(torch.autograd.Function):
     """x[e,:] = h[src[e],:] * h[dst[e],:]  (model.py:155-156 + layer.py:81)."""
 
     @staticmethod
-    def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None):
-        """gate_scale / channel: as in EdgeDotFn"""
+    def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None, incidence=None):
+        """gate_scale / channel / incidence: as in EdgeDotFn"""
         h = _f32c(h)
         ctx.save_for_backward(h, src, dst)
         ctx.gate_scale = float(gate_scale)
         ctx.channel = channel
+        ctx.incidence = incidence
         return edge_hadamard_fwd(h, src, dst)
 
     @staticmethod
@@ -1040,17 +1107,21 @@ class EdgeHadamardFn(torch.autograd.Function):
         h, src, dst = ctx.saved_tensors
         g = _f32c(g)
         gs = ctx.gate_scale
+        inc = ctx.incidence
         if ctx.channel is not None and EDGE_BACKWARD["mode"] == "segment":
-            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs)
-            return None, None, None, None, None
+            ci = inc if isinstance(inc, CompactIncidence) else None
+            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs, ci)
+            return None, None, None, None, None, None
         if EDGE_BACKWARD["mode"] == "segment":
             epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
-            gh = edge_segment_bwd(h, Incidence(src, dst, h.shape[0]), g, epilogue=epi)
+            if not isinstance(inc, Incidence):
+                inc = Incidence(src, dst, h.shape[0])
+            gh = edge_segment_bwd(h, inc, g, epilogue=epi)
         else:
             gh = edge_scatter_bwd(h, src, dst, g)
             if gs > 0.0:
                 gh = gate(gh, h, gs)
-        return gh, None, None, None, None
+        return gh, None, None, None, None, None
 
 
 class PairwiseLossJointFn(torch.autograd.Function):

@@ -18,3 +18,10 @@ for r in win:
 print(f"{'us/step':>9s} {'calls/step':>10s}  kernel")
 for n, t in agg.most_common(int(sys.argv[3]) if len(sys.argv) > 3 else 30):
     print(f"{t/1e3/nsteps:9.1f} {cnt[n]/nsteps:10.1f}  {n}")
+
+if len(sys.argv) > 4 and sys.argv[4] == "sequence":      # every launch of the last full step, in order
+    a, b = loss_idx[-2], loss_idx[-1]
+    t0 = int(rows[a]['Start_Timestamp'])
+    print("\nlaunch sequence of one step (start us, duration us, kernel):")
+    for r in rows[a:b]:
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f}  {r['Kernel_Name'][:90]}")
