@@ -98,7 +98,9 @@ typedef struct plnlp_row_split {
 
 /* Build the tables above on the device (no host sync): capacities are upper bounds
  * (a CSR with nnz entries has at most nnz/threshold long rows and nnz/threshold + that
- * many chunks); counters[0..2] receive {long rows, chunks, overflow flag}. */
+ * many chunks); counters[0..2] receive {long rows - 1, chunks - 1, overflow count - 1} (they count up
+ * from -1: tables and counters are cleared by one 0xFF fill when the caller packs
+ * [counters(4 x i64) | long_rows | chunk_beg | chunk_cnt | chunk_long] back to back). */
 int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int64_t threshold,
                           int64_t n_long_cap, int64_t n_chunks_cap,
                           int64_t* long_rows, int64_t* chunk_beg, int32_t* chunk_cnt,

@@ -73,8 +73,9 @@ __global__ __launch_bounds__(256) void row_split_build_kernel(const int64_t* __r
     const int64_t deg = rowptr[r + 1] - rowptr[r];
     if (deg <= threshold) return;
     const int64_t nch = (deg + threshold - 1) / threshold;
-    const int64_t slot = (int64_t)atomicAdd(&counters[0], 1ull);
-    const int64_t cb = (int64_t)atomicAdd(&counters[1], (unsigned long long)nch);
+    // the counters start at ~0 (the tables and the counters are cleared by ONE 0xFF fill): +1 wraps to 0
+    const int64_t slot = (int64_t)(atomicAdd(&counters[0], 1ull) + 1ull);
+    const int64_t cb = (int64_t)(atomicAdd(&counters[1], (unsigned long long)nch) + 1ull);
     if (slot >= n_long_cap || cb + nch > n_chunks_cap) { atomicAdd(&counters[2], 1ull); return; }  // overflow flag
     long_rows[slot] = r;
     chunk_beg[slot] = cb;
@@ -275,10 +276,21 @@ extern "C" int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int6
     if (!rowptr || !long_rows || !chunk_beg || !chunk_cnt || !chunk_long || !counters) return PLNLP_E_NULL;
     if (n_rows < 0 || threshold < 64 || n_long_cap <= 0 || n_chunks_cap <= 0) return PLNLP_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(long_rows, 0xFF, sizeof(int64_t) * n_long_cap, s);   // -1: idle slot
-    if (e == hipSuccess) e = hipMemsetAsync(chunk_long, 0xFF, sizeof(int32_t) * n_chunks_cap, s);
-    if (e == hipSuccess) e = hipMemsetAsync(chunk_cnt, 0, sizeof(int32_t) * n_long_cap, s);
-    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, sizeof(int64_t) * 4, s);
+    // -1 everywhere: idle slots (long_rows, chunk_long), counters at ~0.  When the caller laid the five
+    // arrays out back to back starting at `counters` (plnlp_amd/graph.py does) this is ONE fill.
+    hipError_t e;
+    const char* base = reinterpret_cast<const char*>(counters);
+    const bool packed = reinterpret_cast<const char*>(long_rows) == base + 32 &&
+                        reinterpret_cast<const char*>(chunk_beg) == base + 32 + 8 * n_long_cap &&
+                        reinterpret_cast<const char*>(chunk_cnt) == base + 32 + 16 * n_long_cap &&
+                        reinterpret_cast<const char*>(chunk_long) == base + 32 + 20 * n_long_cap;
+    if (packed) {
+        e = hipMemsetAsync(counters, 0xFF, 32 + 20 * n_long_cap + 4 * n_chunks_cap, s);
+    } else {
+        e = hipMemsetAsync(long_rows, 0xFF, sizeof(int64_t) * n_long_cap, s);
+        if (e == hipSuccess) e = hipMemsetAsync(chunk_long, 0xFF, sizeof(int32_t) * n_chunks_cap, s);
+        if (e == hipSuccess) e = hipMemsetAsync(counters, 0xFF, sizeof(int64_t) * 4, s);
+    }
     if (e != hipSuccess) return (int)e;
     if (n_rows == 0) return 0;
     hipLaunchKernelGGL(row_split_build_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, rowptr,

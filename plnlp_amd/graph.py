@@ -38,17 +38,23 @@ class RowSplit:
         n_rows = rowptr.numel() - 1
         self.n_long = max(1, min(n_rows, nnz // threshold))
         self.n_chunks = max(1, nnz // threshold + self.n_long)
-        self.long_rows = torch.empty(self.n_long, dtype=torch.int64, device=dev)
-        self.chunk_beg = torch.empty(self.n_long, dtype=torch.int64, device=dev)
-        self.chunk_cnt = torch.empty(self.n_long, dtype=torch.int32, device=dev)
-        self.chunk_long = torch.empty(self.n_chunks, dtype=torch.int32, device=dev)
-        self.counters = torch.empty(4, dtype=torch.int64, device=dev)
+        # one buffer [counters(4 i64) | long_rows | chunk_beg | chunk_cnt | chunk_long]: cleared by one fill
+        nl, nc = self.n_long, self.n_chunks
+        nbytes = 32 + 20 * nl + 4 * nc
+        buf = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        raw = buf.view(torch.uint8)
+        self._buf = buf
+        self.counters = buf[:4]
+        self.long_rows = buf[4:4 + nl]
+        self.chunk_beg = buf[4 + nl:4 + 2 * nl]
+        self.chunk_cnt = raw[32 + 16 * nl:32 + 20 * nl].view(torch.int32)
+        self.chunk_long = raw[32 + 20 * nl:32 + 20 * nl + 4 * nc].view(torch.int32)
         L.check(lib.plnlp_row_split_build(rowptr.data_ptr(), n_rows, self.threshold, self.n_long, self.n_chunks,
                                           self.long_rows.data_ptr(), self.chunk_beg.data_ptr(),
                                           self.chunk_cnt.data_ptr(), self.chunk_long.data_ptr(),
                                           self.counters.data_ptr(), L.stream_ptr()), "plnlp_row_split_build")
         if exact:
-            used_long, used_chunks, overflow = (int(v) for v in self.counters[:3].tolist())
+            used_long, used_chunks, overflow = (int(v) + 1 for v in self.counters[:3].tolist())
             assert overflow == 0
             self.n_long, self.n_chunks = used_long, used_chunks     # arrays keep their capacity; grids shrink
 

@@ -288,7 +288,10 @@ class BaseModel(object):
             loss = self._loss_of_scores(out, local, num_neg, weight_margin)
         else:                                    # empty slice: still take part in the reduction
             loss = h.sum() * 0.0
-        loss.backward()
+        if loss.is_cuda and loss.dtype == torch.float32:
+            loss.backward(ops.unit_grad(loss.device))
+        else:
+            loss.backward()
         self._allreduce_grads()
         self._clip_and_step()
         return loss.detach().reshape(())
@@ -320,7 +323,10 @@ class BaseModel(object):
                                     torch.cat([dst[lo:hi], dst[n + lo * k:n + hi * k]]))
             out_l = out_l.detach().requires_grad_(True)
             loss = self._loss_of_scores(out_l, local, k, None if weight_margin is None else weight_margin[lo:hi])
-            loss.backward()
+            if loss.is_cuda and loss.dtype == torch.float32:
+                loss.backward(ops.unit_grad(loss.device))
+            else:
+                loss.backward()
             gl = out_l.grad.reshape(-1)
             g_pad[:local] = gl[:local]
             g_pad[per:per + local * k] = gl[local:]

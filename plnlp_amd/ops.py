@@ -403,15 +403,18 @@ class CompactIncidence:
 
     @property
     def n_rows(self) -> int:
-        return self.count
+        """the count rounded up to a multiple of 32 (within the capacity): the lists continue with
+        empty rows past the count, so consumers may work on this padded extent -- the weight-gradient
+        GEMM then reduces over a whole number of K-tiles (no guarded tail launch)"""
+        return min(self._rows_cap.numel(), (self.count + 31) // 32 * 32)
 
     @property
     def rows(self) -> torch.Tensor:
-        return self._rows_cap[:self.count]
+        return self._rows_cap[:self.n_rows]
 
     @property
     def rowptr(self) -> torch.Tensor:
-        return self._rowptr_cap[:self.count + 1]
+        return self._rowptr_cap[:self.n_rows + 1]
 
     seg_ptr = rowptr
 
@@ -425,15 +428,17 @@ class CompactIncidence:
 
 
 class RowSparseGrad:
-    """gradient of an [n_rows, F] matrix that is zero outside `rows`: values[i] is row rows[i]"""
-    __slots__ = ("rows", "node_map", "values", "n_rows")
+    """gradient of an [n_rows, F] matrix that is zero outside `rows`: values[i] is row rows[i] for
+    i < count; entries past `count` are padding (row id 0, zero values)"""
+    __slots__ = ("rows", "node_map", "values", "n_rows", "count")
 
-    def __init__(self, rows, node_map, values, n_rows):
+    def __init__(self, rows, node_map, values, n_rows, count=None):
         self.rows, self.node_map, self.values, self.n_rows = rows, node_map, values, n_rows
+        self.count = rows.numel() if count is None else int(count)
 
     def to_dense(self) -> torch.Tensor:
         out = torch.zeros(self.n_rows, self.values.shape[1], dtype=self.values.dtype, device=self.values.device)
-        out[self.rows.long()] = self.values
+        out[self.rows[:self.count].long()] = self.values[:self.count]
         return out
 
 
@@ -1040,7 +1045,7 @@ def _sparse_edge_backward(h, src, dst, g, gate_scale: float, ci=None) -> RowSpar
         ci = Incidence(src, dst, h.shape[0]).compact()
     epi = L.make_epilogue(gate=h, gate_scale=gate_scale, gate_index=ci.rows) if gate_scale > 0.0 else None
     vals = edge_segment_bwd(h, ci, g, epilogue=epi)
-    return RowSparseGrad(ci.rows, ci.node_map, vals, h.shape[0])
+    return RowSparseGrad(ci.rows, ci.node_map, vals, h.shape[0], ci.count)
 
 
 class EdgeDotFn(torch.autograd.Function):
@@ -1124,6 +1129,23 @@ class EdgeHadamardFn(torch.autograd.Function):
         return gh, None, None, None, None, None
 
 
+_unit_grads = {}
+
+
+def unit_grad(device) -> torch.Tensor:
+    """a cached scalar 1.0 to seed `loss.backward(unit_grad(dev))`: autograd otherwise fills a fresh
+    one per step, and the fused losses recognise THIS tensor and skip the multiplication by it"""
+    key = torch.device(device)
+    if key not in _unit_grads:
+        _unit_grads[key] = torch.ones((), dtype=torch.float32, device=key)
+    return _unit_grads[key]
+
+
+def _is_unit(g: torch.Tensor) -> bool:
+    u = _unit_grads.get(g.device)
+    return u is not None and g.data_ptr() == u.data_ptr()
+
+
 class PairwiseLossJointFn(torch.autograd.Function):
     """the same losses on ONE score tensor [pos (n) | neg (n*k)], as the training step produces it:
     the gradient comes back as one tensor too (slicing the scores first makes autograd rebuild it
@@ -1141,7 +1163,9 @@ class PairwiseLossJointFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (gout,) = ctx.saved_tensors
-        return (gout * g).reshape(ctx.shape), None, None, None, None
+        if not _is_unit(g):
+            gout = gout * g
+        return gout.reshape(ctx.shape), None, None, None, None
 
 
 class PairwiseLossFn(torch.autograd.Function):

@@ -834,12 +834,15 @@ def test_compact_rows_matches_torch(P):
         deg = (inc.seg_ptr[1:] - inc.seg_ptr[:-1]).cpu()
         rows = torch.nonzero(deg > 0).reshape(-1)
         assert ci.count == rows.numel()
-        assert torch.equal(ci.rows.cpu().long(), rows)
+        assert ci.n_rows == min(n, (ci.count + 31) // 32 * 32)
+        assert torch.equal(ci.rows.cpu().long()[:ci.count], rows)
+        assert not ci.rows.cpu()[ci.count:].any()                     # padding: row id 0 ...
         nm = torch.full((n,), -1, dtype=torch.int32)
         nm[rows] = torch.arange(rows.numel(), dtype=torch.int32)
         assert torch.equal(ci.node_map.cpu(), nm)
         want = torch.cat([inc.seg_ptr.cpu()[rows], inc.seg_ptr.cpu()[-1:]])
-        assert torch.equal(ci.rowptr.cpu(), want)
+        assert torch.equal(ci.rowptr.cpu()[:ci.count + 1], want)
+        assert (ci._rowptr_cap.cpu()[ci.count:] == inc.seg_ptr.cpu()[-1]).all()   # ... and empty rows to the capacity
 
 
 @pytest.mark.parametrize("feat", [16, 32, 64, 128, 200, 256, 512, 1024, 30])
