@@ -297,9 +297,10 @@ def main():
     def step(i):
         if dp_mode == "scores":      # every rank passes the global batch and scores its own slice of it
             sl = slice(i * world * B, (i + 1) * world * B)
-            return model.train_step_global(data, pos_all[sl], neg_all[sl], k, None if w_all is None else w_all[sl])
+            return model.train_step_global(data, pos_all[sl], neg_all[sl], k, None if w_all is None else w_all[sl],
+                                           edges_ready=True)
         p, q, w = batch(i)
-        return model.train_step(data, p, q, k, w)
+        return model.train_step(data, p, q, k, w, edges_ready=True)     # slices of tensors resident since setup
 
     for i in range(W):
         step(i)

@@ -234,11 +234,11 @@ class BaseModel(object):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
         return bool(torch.equal(lo, hi))
 
-    def _encode(self, data, src, dst, use_sink):
-        """encoder forward of a training step with the fusions the scorer allows; src / dst are
-        ALL edges whose scores will be back-propagated.  Returns (h, gate_scale, channel, fused,
-        incidence) -- see train_step"""
-        n_edges = src.numel()
+    def _encode(self, data, pos_edge, neg_flat, use_sink, edges_ready):
+        """encoder forward of a training step with the fusions the scorer allows; pos_edge [n,2] and
+        neg_flat [n*k,2] are ALL edges whose scores will be back-propagated.  Returns (h, gate_scale,
+        channel, fused, batch) with batch an ops.EdgeBatch (src, dst, incidence) -- see train_step"""
+        n_edges = pos_edge.size(0) + neg_flat.size(0)
         n_endpoints = 2 * n_edges
         native = isinstance(self.encoder, BaseGNN)
         fused = native and type(self.predictor) in (DotPredictor, MLPPredictor)   # gather fused into the scorer
@@ -256,31 +256,35 @@ class BaseModel(object):
         if (n_edges > 0 and fused and all(isinstance(c, (SAGEConv, GCNConv)) for c in self.encoder.convs)
                 and ops.sparse_backward_pays(n_endpoints, x_in.shape[0])):
             channel = kw["output_grad_channel"] = ops.SparseGradChannel()
-        # the index structures of the gather backward depend on the edges alone: build them (sort,
-        # touched-node compaction, its count read-back) NOW, under the forward pass
-        incidence = None
-        if n_edges > 0 and fused and x_in.is_cuda and ops.EDGE_BACKWARD["mode"] == "segment":
-            incidence = ops.prepare_edge_backward(src, dst, x_in.shape[0], compact=channel is not None)
+        # src / dst and the index structures of the gather backward depend on the edges alone: build
+        # them (sort, touched-node compaction, its count read-back) NOW -- on the side stream, in the
+        # shadow of the previous step's tail -- and join before the scorer
+        build = n_edges > 0 and fused and x_in.is_cuda and ops.EDGE_BACKWARD["mode"] == "segment"
+        batch = ops.EdgeBatch([pos_edge[:, 0], neg_flat[:, 0]], [pos_edge[:, 1], neg_flat[:, 1]], x_in.shape[0],
+                              build=build, compact=channel is not None, overlap=x_in.is_cuda,
+                              inputs_ready=edges_ready)
         if fuse_gate:
             h, gate_scale = self.encoder(x_in, data.adj_t, fuse_output_gate=True, **kw)
         else:
             h, gate_scale = self.encoder(x_in, data.adj_t, **kw), 0.0
-        return h, gate_scale, channel, fused, incidence
+        return h, gate_scale, channel, fused, batch.join()
 
     def _score(self, h, src, dst):
         if hasattr(self.predictor, "score_edges"):
             return self.predictor.score_edges(h, src, dst)
         return self.predictor(h[src], h[dst])
 
-    def train_step(self, data, pos_edge, neg_edge, num_neg, weight_margin=None):
+    def train_step(self, data, pos_edge, neg_edge, num_neg, weight_margin=None, edges_ready=False):
         """One iteration of the hot loop, model.py:148-167, on this rank's slice:
-        pos_edge [b,2], neg_edge [b,k,2] (device).  Returns the detached local loss."""
+        pos_edge [b,2], neg_edge [b,k,2] (device).  Returns the detached local loss.
+        edges_ready=True: the edge tensors are not the output of work still pending on the current
+        stream (views of resident tensors, or produced on the side stream) -- their pre-processing
+        may then overlap the previous step (ops.EdgeBatch)."""
         self.optimizer.zero_grad(set_to_none=True)
         local = pos_edge.size(0)
-        neg_flat = neg_edge.reshape(-1, 2)
-        src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
-        dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
-        h, gate_scale, channel, fused, incidence = self._encode(data, src, dst, True)
+        h, gate_scale, channel, fused, batch = self._encode(data, pos_edge, neg_edge.reshape(-1, 2), True,
+                                                             edges_ready)
+        src, dst, incidence = batch.src, batch.dst, batch.incidence
         if local > 0:
             out = (self.predictor.score_edges(h, src, dst, gate_scale=gate_scale, channel=channel,
                                               incidence=incidence) if fused
@@ -296,7 +300,7 @@ class BaseModel(object):
         self._clip_and_step()
         return loss.detach().reshape(())
 
-    def train_step_global(self, data, pos_edge, neg_edge, num_neg, weight_margin=None):
+    def train_step_global(self, data, pos_edge, neg_edge, num_neg, weight_margin=None, edges_ready=False):
         """One iteration in dp_exchange='scores' mode.  Every rank passes the GLOBAL batch
         (pos_edge [n,2], neg_edge [n,k,2], weights [n]); rank r scores the slice
         [r*per, (r+1)*per), per = ceil(n / world), and differentiates the loss of that slice
@@ -310,10 +314,9 @@ class BaseModel(object):
         per = (n + world - 1) // world
         lo, hi = min(rank * per, n), min((rank + 1) * per, n)
         local = hi - lo
-        neg_flat = neg_edge.reshape(-1, 2)
-        src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]])
-        dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]])
-        h, gate_scale, channel, fused, incidence = self._encode(data, src, dst, False)
+        h, gate_scale, channel, fused, batch = self._encode(data, pos_edge, neg_edge.reshape(-1, 2), False,
+                                                             edges_ready)
+        src, dst, incidence = batch.src, batch.dst, batch.incidence
         # 1. local slice: scores (outside the encoder's graph), loss, d loss / d score
         g_pad = torch.zeros(per * (1 + k), dtype=h.dtype, device=h.device)
         loss = torch.zeros((), dtype=h.dtype, device=h.device)
@@ -376,14 +379,32 @@ class BaseModel(object):
         loss_acc = torch.zeros((), dtype=torch.float64, device=self.device)   # Python-float accumulation in the reference
         total_examples = 0
         start = 0
+        # the per-batch gathers of the epoch tensors run on the side stream, like the rest of a batch's
+        # pre-processing (ops.EdgeBatch): they depend on nothing the training steps produce
+        side = main = None
+        if self.device.type == "cuda" and ops.PROLOGUE_OVERLAP["enabled"]:
+            main, side = torch.cuda.current_stream(self.device), ops.side_stream(self.device)
+            side.wait_stream(main)              # the epoch tensors above
+
+        def take(perm):
+            if side is None:
+                return (pos_train_edge[perm], neg_train_edge[perm],
+                        edge_weight_margin[perm] if edge_weight_margin is not None else None)
+            with torch.cuda.stream(side):
+                out = (pos_train_edge[perm], neg_train_edge[perm],
+                       edge_weight_margin[perm] if edge_weight_margin is not None else None)
+            for t in out:
+                if t is not None:
+                    t.record_stream(main)
+            return out
+
         for b in batches:
             n_b = b.numel()
             perm_all = order[start:start + n_b]
             start += n_b
             if world > 1 and mode == "scores":
-                weight_margin = edge_weight_margin[perm_all] if edge_weight_margin is not None else None
-                loss = self.train_step_global(data, pos_train_edge[perm_all], neg_train_edge[perm_all], num_neg,
-                                              weight_margin)
+                pos_b, neg_b, weight_margin = take(perm_all)
+                loss = self.train_step_global(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None)
                 loss_acc += loss.double() * n_b
                 total_examples += n_b
                 continue
@@ -392,8 +413,8 @@ class BaseModel(object):
                 perm = perm_all[rank * per:(rank + 1) * per]
             else:
                 perm = perm_all
-            weight_margin = edge_weight_margin[perm] if edge_weight_margin is not None else None
-            loss = self.train_step(data, pos_train_edge[perm], neg_train_edge[perm], num_neg, weight_margin)
+            pos_b, neg_b, weight_margin = take(perm)
+            loss = self.train_step(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None)
             loss_acc += loss.double() * n_b
             total_examples += n_b
 

@@ -60,8 +60,8 @@ LDS_STAGE_AUTO = False          # measured on MI355X (ddi-shaped, F=512): LDS-st
                                 # per-chunk index loads and a shuffle tree; the L2-resident stream wins, so the
                                 # staged form is opt-in (lds_stage=True)
 SHORT_ROW_AVG = 0       # average entries per row below which the multi-row kernel form is used; 0 = never:
-                        # measured on MI355X the one-row-per-wave form wins even at ~1 entry per row (the
-                        # incidence pass is bound by writing / gating the dense [N, F] output, not by latency)
+                        # measured on MI355X the one-row-per-wave form wins even at ~1 entry per row, on the
+                        # dense [N, F] incidence output and on the compact one (2.59 vs 2.52 ms per step)
 
 
 def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
@@ -388,6 +388,7 @@ class CompactIncidence:
         self._ready = torch.cuda.Event()
         self._ready.record()
         self._count = None
+        self._base = inc                     # keeps the sorted lists (shared below) alive
         self.n_cols = self.n_nodes = n
         self.col = self.item_other = inc.item_other
         self.val_index = self.item_edge = inc.item_edge
@@ -1036,6 +1037,73 @@ def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, co
         inc = inc.compact()
     inc.row_split(SPLIT_THRESHOLD)
     return inc
+
+
+PROLOGUE_OVERLAP = {"enabled": os.environ.get("PLNLP_PROLOGUE_OVERLAP", "1") != "0"}
+
+
+class EdgeBatch:
+    """The scored edges of one training step -- src / dst (positives then negatives) -- and the index
+    structures of their backward pass (prepare_edge_backward).
+
+    All of it depends on the batch's edge lists alone, and it is ~25 short dependent launches (a radix
+    sort, a scan, a few fills: ~130 us of mostly idle GPU).  With overlap=True it is produced on the
+    device's side stream: the host runs a step ahead of the GPU, so these launches execute in the shadow
+    of the PREVIOUS step's bandwidth-bound kernels (Adam, aggregation) instead of at the head of this
+    step.  `join()` makes the current stream wait for them; it must precede the first use of
+    src / dst / incidence.  inputs_ready=False (the safe default) first makes the side stream wait for
+    everything already queued on the current stream -- correct for any caller, but then nothing
+    overlaps; a caller whose edge tensors are not produced by still-pending work on the current
+    stream passes True."""
+
+    def __init__(self, src_parts, dst_parts, n_nodes: int, build: bool, compact: bool, overlap: bool,
+                 inputs_ready: bool = False):
+        dev = src_parts[0].device
+        overlap = overlap and PROLOGUE_OVERLAP["enabled"] and dev.type == "cuda"
+        self._done = None
+        if overlap:
+            main = torch.cuda.current_stream(dev)
+            side = side_stream(dev)
+            if not inputs_ready:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._produce(src_parts, dst_parts, n_nodes, build, compact)
+                self._done = torch.cuda.Event()
+                self._done.record(side)
+            for t in self._tensors():          # allocated under the side stream, consumed on the main one
+                t.record_stream(main)
+        else:
+            self._produce(src_parts, dst_parts, n_nodes, build, compact)
+
+    def _produce(self, src_parts, dst_parts, n_nodes, build, compact):
+        self.src = torch.cat(src_parts) if len(src_parts) > 1 else src_parts[0].contiguous()
+        self.dst = torch.cat(dst_parts) if len(dst_parts) > 1 else dst_parts[0].contiguous()
+        self.incidence = None
+        if build and self.src.numel() > 0:
+            self.incidence = prepare_edge_backward(self.src, self.dst, n_nodes, compact)
+
+    def _tensors(self):
+        out = [self.src, self.dst]
+        inc = self.incidence
+        if inc is not None:
+            for name in ("item_edge", "item_other", "seg_ptr", "_rows_cap", "node_map", "_rowptr_cap", "_count_dev"):
+                t = getattr(inc, name, None)
+                if isinstance(t, torch.Tensor):
+                    out.append(t)
+            base = getattr(inc, "_base", None)
+            if base is not None:
+                out += [base.item_edge, base.item_other, base.seg_ptr]
+            for holder in (inc, base):
+                sp = getattr(holder, "_split", None) if holder is not None else None
+                if sp is not None:
+                    out.append(sp._buf)
+        return out
+
+    def join(self) -> "EdgeBatch":
+        if self._done is not None:
+            torch.cuda.current_stream().wait_event(self._done)
+            self._done = None
+        return self
 
 
 def _sparse_edge_backward(h, src, dst, g, gate_scale: float, ci=None) -> RowSparseGrad:
