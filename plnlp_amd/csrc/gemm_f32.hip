@@ -244,6 +244,11 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, con
                                            const f32x4 (&rb)[4], int t) {
     float* at = lds + buf * TILE_FLOATS;
     float* bt = lds + (2 + buf) * TILE_FLOATS;
+#ifdef ABL_NOSTAGE
+    // ablation: consume the loaded registers without the LDS writes (an impossible condition keeps them live)
+    if (ra[0].x == 123.456f && rb[3].w == 654.321f) { at[t] = ra[1].y + ra[2].z + ra[3].w; bt[t] = rb[0].x + rb[1].y + rb[2].z; }
+    return;
+#endif
     if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
     if constexpr (B_T) store_kc(bt, rb, t); else store_rc(bt, rb, t);
 }
