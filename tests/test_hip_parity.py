@@ -993,3 +993,47 @@ def test_row_sparse_backward_equals_dense_backward(P, enc, layers, pred, in_feat
         scale = max(1e-6, float(gd[key].abs().max()))
         err = float((gd[key] - gs[key]).abs().max())
         assert err <= 2e-6 * scale + 1e-7, (enc, layers, pred, key, err, scale)
+
+
+def test_side_stream_prologue_gives_identical_training(P):
+    """the edge pre-processing of a step runs on the side stream under the previous step's kernels
+    (ops.EdgeBatch); 25 steps must end on the very bits of the single-stream run"""
+    from plnlp_amd import ops
+    n, feat, batch, k = 20000, 64, 2048, 1
+    csr = rand_csr(n, 5 * n, 23, weighted=False, hub=5000)
+    r, c, _ = csr.coo()
+    adj = P.Graph.from_coo(torch.cat([r, c]), torch.cat([c, r]), None, n, n).to("cuda")
+
+    class D:
+        pass
+    data = D()
+    data.adj_t = adj
+    gen = torch.Generator().manual_seed(4)
+    steps = 25
+    pos = torch.randint(0, n, (steps * batch, 2), generator=gen).cuda()
+    neg = torch.randint(0, n, (steps * batch, k, 2), generator=gen).cuda()
+    w = torch.rand(steps * batch, generator=gen).cuda()
+    out = {}
+    old = dict(ops.PROLOGUE_OVERLAP)
+    try:
+        for mode in (False, True):
+            ops.PROLOGUE_OVERLAP["enabled"] = mode
+            torch.manual_seed(5)
+            P.manual_seed(5)
+            m = P.BaseModel(lr=1e-2, dropout=0.2, grad_clip_norm=1.0, gnn_num_layers=1, mlp_num_layers=2,
+                            emb_hidden_channels=feat, gnn_hidden_channels=feat, mlp_hidden_channels=feat,
+                            num_nodes=n, num_node_feats=0, gnn_encoder_name="SAGE", predictor_name="DOT",
+                            loss_func="WeightedHingeAUC", optimizer_name="Adam", device="cuda",
+                            use_node_feats=False, train_node_emb=True)
+            m.param_init()
+            m.encoder.train()
+            losses = []
+            for i in range(steps):
+                sl = slice(i * batch, (i + 1) * batch)
+                losses.append(m.train_step(data, pos[sl], neg[sl], k, w[sl], edges_ready=True))
+            torch.cuda.synchronize()
+            out[mode] = (torch.stack(losses).cpu(), torch.cat([p.detach().reshape(-1) for p in m.para_list]).cpu())
+    finally:
+        ops.PROLOGUE_OVERLAP.update(old)
+    assert torch.equal(out[False][0], out[True][0])
+    assert torch.equal(out[False][1], out[True][1])
