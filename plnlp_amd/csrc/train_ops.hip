@@ -107,15 +107,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         coef *= c < 1.f ? c : 1.f;
     }
     const float step = lr / bc1;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float gi = g[i] * coef;
-        float pi = p[i];
+    auto update = [&](float& pi, float gi, float& mi, float& vi) {
+        gi *= coef;
         if (wd != 0.f) { if (decoupled) pi *= (1.f - lr * wd); else gi = fmaf(wd, pi, gi); }
-        float mi = m[i], vi = v[i];
         mi = mi + (1.f - b1) * (gi - mi);            // lerp, as torch.optim.Adam
         vi = fmaf(1.f - b2, gi * gi, b2 * vi);
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         pi = pi - step * (mi / denom);
+    };
+    int64_t done = 0;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0) {   // 16 bytes per lane
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            float4 p4 = reinterpret_cast<float4*>(p)[i];
+            const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+            float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+            update(p4.x, g4.x, m4.x, v4.x); update(p4.y, g4.y, m4.y, v4.y);
+            update(p4.z, g4.z, m4.z, v4.z); update(p4.w, g4.w, m4.w, v4.w);
+            reinterpret_cast<float4*>(p)[i] = p4; reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4;
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        update(pi, g[i], mi, vi);
         p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
