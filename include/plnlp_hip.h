@@ -291,6 +291,29 @@ int plnlp_adam_step_f32(float* param, const float* grad, float* exp_avg, float* 
                         float weight_decay, int decoupled_wd, int64_t step,
                         const float* sqnorm /* nullable DEVICE ptr */, float max_norm,
                         float grad_scale, void* stream);
+
+/* The same two steps over a LIST of tensors in one launch each (a model has a handful of small
+ * parameters next to one large one; every dependent launch costs >= 4.5 us whatever it does):
+ *   plnlp_sqnorm_multi_f32: partials of all tensors back to back (tensor i gets
+ *     plnlp_sqnorm_partials(n_i) entries), to be summed by plnlp_sum_partials_f32;
+ *   plnlp_adam_multi_f32: one fused clip + Adam update per listed tensor (each with its own step
+ *     count and clip group).  At most PLNLP_MULTI_MAX tensors per call. */
+#define PLNLP_MULTI_MAX 16
+typedef struct plnlp_adam_tensor {
+    float*       param;
+    const float* grad;
+    float*       exp_avg;
+    float*       exp_avg_sq;
+    int64_t      n;
+    int64_t      step;        /* >= 1 */
+    const float* sqnorm;      /* nullable: squared norm of the tensor's clip group (device scalar) */
+    float        max_norm;
+} plnlp_adam_tensor;
+int plnlp_sqnorm_multi_f32(const float* const* grads /* HOST array */, const int64_t* sizes /* HOST */,
+                           int n_tensors, float* partial, int64_t n_partial, void* stream);
+int plnlp_adam_multi_f32(const plnlp_adam_tensor* tensors /* HOST array */, int n_tensors,
+                         float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int decoupled_wd, float grad_scale, void* stream);
 /* grad *= min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) -- clip_grad_norm_ for callers that
  * keep torch.optim as the optimiser */
 int plnlp_clip_scale_f32(float* grad, int64_t n, const float* sqnorm, float max_norm, void* stream);

@@ -40,6 +40,13 @@ class GemmOperand(C.Structure):
                 ("k", C.c_int64), ("b_index", C.c_void_p)]
 
 
+class AdamTensor(C.Structure):
+    """mirror of plnlp_adam_tensor"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("step", C.c_int64), ("sqnorm", C.c_void_p), ("max_norm", C.c_float)]
+
+
+MULTI_MAX = 16
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND = 1, 2, 4, 8, 16, 32
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 AGG_SHORT_ROWS = 1
@@ -98,6 +105,10 @@ SIGNATURES = {
     "plnlp_adam_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_float,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, c_i64, C.c_void_p,
                                       C.c_float, C.c_float, C.c_void_p]),
+    "plnlp_sqnorm_multi_f32": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(c_i64), C.c_int, C.c_void_p, c_i64,
+                                         C.c_void_p]),
+    "plnlp_adam_multi_f32": (C.c_int, [C.POINTER(AdamTensor), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "plnlp_clip_scale_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_void_p]),
     "plnlp_gate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, c_i64, C.c_void_p]),
     "plnlp_dropout_f32": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_float, C.c_uint64, C.c_void_p]),

@@ -135,6 +135,105 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ---------------- the same over a list of tensors, one launch ---------------------------
+struct MultiSq {
+    const float* g[PLNLP_MULTI_MAX];
+    int64_t      n[PLNLP_MULTI_MAX];
+    int          first_block[PLNLP_MULTI_MAX + 1];   // block range of tensor i = its range of partials
+    int          count;
+};
+__global__ __launch_bounds__(256) void sqnorm_multi_kernel(MultiSq a, float* __restrict__ partial) {
+    __shared__ float sm[4];
+    int ti = 0;
+#pragma unroll
+    for (int i = 1; i < PLNLP_MULTI_MAX; ++i) ti += (i < a.count && (int)blockIdx.x >= a.first_block[i]) ? 1 : 0;
+    const float* g = a.g[0];
+    int64_t n = a.n[0];
+    int fb = 0;
+#pragma unroll
+    for (int i = 1; i < PLNLP_MULTI_MAX; ++i) if (i == ti) { g = a.g[i]; n = a.n[i]; fb = a.first_block[i]; }
+    const int64_t beg = (int64_t)((int)blockIdx.x - fb) * SQ_CHUNK;
+    const int64_t end = beg + SQ_CHUNK < n ? beg + SQ_CHUNK : n;
+    float v = 0.f;
+    if (((uintptr_t)g % 16) == 0) {
+        int64_t i = beg + (int64_t)threadIdx.x * 4;
+        for (; i + 3 < end; i += 1024) {
+            const float4 x = *reinterpret_cast<const float4*>(g + i);
+            v = fmaf(x.x, x.x, v); v = fmaf(x.y, x.y, v); v = fmaf(x.z, x.z, v); v = fmaf(x.w, x.w, v);
+        }
+        for (; i < end; ++i) { if (i < end) v = fmaf(g[i], g[i], v); }
+    } else {
+        for (int64_t i = beg + threadIdx.x; i < end; i += 256) v = fmaf(g[i], g[i], v);
+    }
+    const float tot = block_sum_256(v, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+struct MultiAdam {
+    float*       p[PLNLP_MULTI_MAX];
+    const float* g[PLNLP_MULTI_MAX];
+    float*       m[PLNLP_MULTI_MAX];
+    float*       v[PLNLP_MULTI_MAX];
+    int64_t      n[PLNLP_MULTI_MAX];
+    const float* sqnorm[PLNLP_MULTI_MAX];
+    float        max_norm[PLNLP_MULTI_MAX];
+    float        bc1[PLNLP_MULTI_MAX], bc2_sqrt[PLNLP_MULTI_MAX];
+    int          first_block[PLNLP_MULTI_MAX + 1];
+    int          count;
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(MultiAdam a, float lr, float b1, float b2, float eps,
+                                                         float wd, int decoupled, float grad_scale) {
+    int ti = 0;
+#pragma unroll
+    for (int i = 1; i < PLNLP_MULTI_MAX; ++i) ti += (i < a.count && (int)blockIdx.x >= a.first_block[i]) ? 1 : 0;
+    float* p = a.p[0]; const float* g = a.g[0]; float* m = a.m[0]; float* v = a.v[0];
+    int64_t n = a.n[0];
+    const float* sqnorm = a.sqnorm[0];
+    float max_norm = a.max_norm[0], bc1 = a.bc1[0], bc2_sqrt = a.bc2_sqrt[0];
+    int fb = 0, nb = a.first_block[1];
+#pragma unroll
+    for (int i = 1; i < PLNLP_MULTI_MAX; ++i)
+        if (i == ti) {      // selects, not a runtime-indexed struct read (that would go through scratch)
+            p = a.p[i]; g = a.g[i]; m = a.m[i]; v = a.v[i]; n = a.n[i]; sqnorm = a.sqnorm[i];
+            max_norm = a.max_norm[i]; bc1 = a.bc1[i]; bc2_sqrt = a.bc2_sqrt[i];
+            fb = a.first_block[i]; nb = a.first_block[i + 1];
+        }
+    float coef = grad_scale;
+    if (sqnorm) {
+        const float c = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
+        coef *= c < 1.f ? c : 1.f;
+    }
+    const float step = lr / bc1;
+    auto update = [&](float& pi, float gi, float& mi, float& vi) {
+        gi *= coef;
+        if (wd != 0.f) { if (decoupled) pi *= (1.f - lr * wd); else gi = fmaf(wd, pi, gi); }
+        mi = mi + (1.f - b1) * (gi - mi);
+        vi = fmaf(1.f - b2, gi * gi, b2 * vi);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step * (mi / denom);
+    };
+    const int64_t tid = (int64_t)((int)blockIdx.x - fb) * 256 + threadIdx.x;
+    const int64_t nthreads = (int64_t)(nb - fb) * 256;
+    int64_t done = 0;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            float4 p4 = reinterpret_cast<float4*>(p)[i];
+            const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+            float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+            update(p4.x, g4.x, m4.x, v4.x); update(p4.y, g4.y, m4.y, v4.y);
+            update(p4.z, g4.z, m4.z, v4.z); update(p4.w, g4.w, m4.w, v4.w);
+            reinterpret_cast<float4*>(p)[i] = p4; reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4;
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        update(pi, g[i], mi, vi);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
 // scale a gradient in place by the clip coefficient (used when the optimiser is not ours)
 __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, int64_t n,
                                                          const float* __restrict__ sqnorm, float max_norm) {
@@ -347,6 +446,58 @@ extern "C" int plnlp_adam_step_f32(float* param, const float* grad, float* exp_a
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, (float)bc1,
                        (float)sqrt(bc2), sqnorm, max_norm, grad_scale);
+    return launch_status();
+}
+
+extern "C" int plnlp_sqnorm_multi_f32(const float* const* grads, const int64_t* sizes, int n_tensors, float* partial,
+                                      int64_t n_partial, void* stream) {
+    using namespace plnlp;
+    if (n_tensors < 0 || n_tensors > PLNLP_MULTI_MAX) return PLNLP_E_SHAPE;
+    if (n_tensors == 0) return 0;
+    if (!grads || !sizes || !partial) return PLNLP_E_NULL;
+    MultiSq a{};
+    int blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (sizes[i] < 0) return PLNLP_E_SHAPE;
+        if (sizes[i] > 0 && !grads[i]) return PLNLP_E_NULL;
+        a.g[i] = grads[i]; a.n[i] = sizes[i]; a.first_block[i] = blocks;
+        const int64_t b = plnlp_sqnorm_partials(sizes[i]);
+        if (blocks + b > 0x7FFFFFF0) return PLNLP_E_SHAPE;
+        blocks += (int)b;
+    }
+    for (int i = n_tensors; i <= PLNLP_MULTI_MAX; ++i) a.first_block[i] = blocks;
+    a.count = n_tensors;
+    if (n_partial < blocks) return PLNLP_E_WORKSPACE;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(sqnorm_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, partial);
+    return launch_status();
+}
+
+extern "C" int plnlp_adam_multi_f32(const plnlp_adam_tensor* tensors, int n_tensors, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int decoupled_wd, float grad_scale,
+                                    void* stream) {
+    using namespace plnlp;
+    if (n_tensors < 0 || n_tensors > PLNLP_MULTI_MAX) return PLNLP_E_SHAPE;
+    if (n_tensors == 0) return 0;
+    if (!tensors) return PLNLP_E_NULL;
+    MultiAdam a{};
+    int blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        const plnlp_adam_tensor& t = tensors[i];
+        if (t.n < 0 || t.step < 1) return PLNLP_E_SHAPE;
+        if (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) return PLNLP_E_NULL;
+        a.p[i] = t.param; a.g[i] = t.grad; a.m[i] = t.exp_avg; a.v[i] = t.exp_avg_sq; a.n[i] = t.n;
+        a.sqnorm[i] = t.sqnorm; a.max_norm[i] = t.max_norm;
+        a.bc1[i] = (float)(1.0 - pow((double)beta1, (double)t.step));
+        a.bc2_sqrt[i] = (float)sqrt(1.0 - pow((double)beta2, (double)t.step));
+        a.first_block[i] = blocks;
+        blocks += (int)ew_grid((t.n + 3) / 4);          // 16 bytes per lane
+    }
+    for (int i = n_tensors; i <= PLNLP_MULTI_MAX; ++i) a.first_block[i] = blocks;
+    a.count = n_tensors;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, lr, beta1,
+                       beta2, eps, weight_decay, decoupled_wd, grad_scale);
     return launch_status();
 }
 

@@ -577,15 +577,40 @@ def sqnorm_into(tensors: Sequence[torch.Tensor], out: torch.Tensor) -> torch.Ten
     part = torch.empty(max(total, 1), dtype=torch.float32, device=out.device)
     off = 0
     s = L.stream_ptr()
-    for t, c in zip(tensors, counts):
+    for t in tensors:
         L.require_device(t)
         assert t.is_contiguous() and t.dtype == torch.float32
-        if c:
-            L.check(lib.plnlp_sqnorm_f32(t.data_ptr(), t.numel(), part.data_ptr() + 4 * off, c, s),
-                    "plnlp_sqnorm_f32")
+    for lo in range(0, len(tensors), L.MULTI_MAX):          # one launch per <= 16 tensors
+        chunk = tensors[lo:lo + L.MULTI_MAX]
+        ptrs = (C.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+        sizes = (C.c_int64 * len(chunk))(*[t.numel() for t in chunk])
+        c = sum(counts[lo:lo + L.MULTI_MAX])
+        L.check(lib.plnlp_sqnorm_multi_f32(ptrs, sizes, len(chunk), part.data_ptr() + 4 * off, c, s),
+                "plnlp_sqnorm_multi_f32")
         off += c
     L.check(lib.plnlp_sum_partials_f32(part.data_ptr(), total, out.data_ptr(), 0, s), "plnlp_sum_partials_f32")
     return out
+
+
+def adam_multi(entries, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False,
+               grad_scale=1.0) -> None:
+    """one fused clip + Adam launch per <= 16 tensors (plnlp_adam_multi_f32).
+    entries: (param, grad, exp_avg, exp_avg_sq, step, sqnorm | None, max_norm)"""
+    lib = L.load()
+    s = L.stream_ptr()
+    for lo in range(0, len(entries), L.MULTI_MAX):
+        chunk = entries[lo:lo + L.MULTI_MAX]
+        arr = (L.AdamTensor * len(chunk))()
+        for i, (p, g, m, v, step, sq, max_norm) in enumerate(chunk):
+            L.require_device(p, g, m, v, sq)
+            assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32
+            arr[i].param, arr[i].grad, arr[i].exp_avg, arr[i].exp_avg_sq = (p.data_ptr(), g.data_ptr(), m.data_ptr(),
+                                                                           v.data_ptr())
+            arr[i].n, arr[i].step = p.numel(), int(step)
+            arr[i].sqnorm = L.ptr(sq)
+            arr[i].max_norm = float(max_norm)
+        L.check(lib.plnlp_adam_multi_f32(arr, len(chunk), lr, beta1, beta2, eps, weight_decay, int(decoupled),
+                                         grad_scale, s), "plnlp_adam_multi_f32")
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,

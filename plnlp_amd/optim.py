@@ -22,6 +22,7 @@ class FusedAdam(torch.optim.Optimizer):
         """clip: id(param) -> (squared-norm device scalar of the param's clip group, max_norm)"""
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            entries = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -33,10 +34,12 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 sq, max_norm = (clip or {}).get(id(p), (None, 0.0))
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], lr=group["lr"], beta1=b1, beta2=b2,
-                              eps=group["eps"], weight_decay=group["weight_decay"],
-                              decoupled=group["decoupled"], step=st["step"], sqnorm=sq, max_norm=max_norm,
-                              grad_scale=grad_scale)
+                entries.append((p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], sq, max_norm))
+            # all tensors of the group in one launch (per 16): the handful of small encoder / predictor
+            # weights next to the embedding table would otherwise cost a launch each
+            ops.adam_multi(entries, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
+                           weight_decay=group["weight_decay"], decoupled=group["decoupled"],
+                           grad_scale=grad_scale)
 
 
 def group_sqnorm(params: Sequence[torch.nn.Parameter]) -> Optional[torch.Tensor]:
