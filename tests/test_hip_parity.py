@@ -1037,3 +1037,46 @@ def test_side_stream_prologue_gives_identical_training(P):
         ops.PROLOGUE_OVERLAP.update(old)
     assert torch.equal(out[False][0], out[True][0])
     assert torch.equal(out[False][1], out[True][1])
+
+
+def test_full_size_collab_shape_properties(P):
+    """BASELINE.json's headline size (collab-shaped: N = 235 868, nnz = 2.36 M, h = 256) through
+    size-independent properties: constants are fixed points of the mean, the column checksum of the sum
+    aggregation equals the degree-weighted checksum of the input, the transposed pass is the adjoint,
+    and two runs agree bit for bit."""
+    from plnlp_amd import synthetic
+    g = synthetic.make_graph("collab", seed=2, device="cuda", weighted=False)
+    adj, n = g["adj_t"], g["num_nodes"]
+    assert n == 235868 and adj.nnz > 2_300_000
+    feat = 256
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(n, feat, device="cuda", generator=gen)
+    deg = adj.degree()
+    # 1. mean of a constant row vector is that vector on every non-empty row, 0 on empty rows
+    c = torch.randn(feat, device="cuda", generator=gen)
+    out = P.ops.csr_aggregate(adj, c.expand(n, feat).contiguous(), "mean", False)
+    want = torch.where((deg > 0)[:, None], c[None, :].expand(n, feat), torch.zeros((), device="cuda"))
+    close(out, want, rtol=2e-6)
+    # 2. checksum of checksums: column sums of A x == sum over source nodes of outdeg(source) * x[source]
+    y = P.ops.csr_aggregate(adj, x, "sum", False)
+    outdeg = adj.t().degree().double()
+    scale = (outdeg[:, None] * x.double().abs()).sum(0)           # the magnitude the fp32 row sums round against
+    err = (y.double().sum(0) - (outdeg[:, None] * x.double()).sum(0)).abs()
+    assert bool((err <= 3e-7 * scale).all()), float((err / scale).max())
+    # 3. adjoint: <A x, z> == <x, A^T z>
+    z = torch.randn(n, feat, device="cuda", generator=gen)
+    zt = P.ops.csr_aggregate(adj.t(), z, "sum", False)
+    lhs, rhs = float((y.double() * z.double()).sum()), float((x.double() * zt.double()).sum())
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs)) + 1e-3, (lhs, rhs)
+    # 4. determinism at full size, hub rows included (max degree 44 243)
+    assert int(deg.max()) > 40000
+    assert torch.equal(y, P.ops.csr_aggregate(adj, x, "sum", False))
+    # 5. the mapped (row-sparse) transposed gather at full size == the dense one over zeroed rows
+    keep = torch.rand(n, device="cuda", generator=gen) < 0.55
+    rows = torch.nonzero(keep).reshape(-1)
+    nmap = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    nmap[rows] = torch.arange(rows.numel(), dtype=torch.int32, device="cuda")
+    zz = torch.where(keep[:, None], z, torch.zeros((), device="cuda"))
+    dense = P.ops.csr_aggregate(adj.t_mean(), zz, "sum", True)
+    comp = P.ops.csr_aggregate(adj.t_mean(), z[rows].contiguous(), "sum", True, src_map=nmap)
+    assert torch.equal(dense, comp)
