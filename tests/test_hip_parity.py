@@ -1080,3 +1080,31 @@ def test_full_size_collab_shape_properties(P):
     dense = P.ops.csr_aggregate(adj.t_mean(), zz, "sum", True)
     comp = P.ops.csr_aggregate(adj.t_mean(), z[rows].contiguous(), "sum", True, src_map=nmap)
     assert torch.equal(dense, comp)
+
+
+def test_sparse_channel_tolerates_a_second_consumer(P):
+    """the row-sparse hand-over assumes the scorer is the only consumer of h; when something else also
+    back-propagates into h (here a regulariser), the conv must add both gradients (dense fallback)"""
+    from plnlp_amd import ops
+    n, feat = 3000, 64
+    csr = rand_csr(n, 6 * n, 31, weighted=False, hub=900)
+    r, c, _ = csr.coo()
+    adj = P.Graph.from_coo(torch.cat([r, c]), torch.cat([c, r]), None, n, n).to("cuda")
+    gen = torch.Generator().manual_seed(12)
+    src = torch.randint(0, n, (500,), generator=gen).cuda()
+    dst = torch.randint(0, n, (500,), generator=gen).cuda()
+    x0 = torch.randn(n, feat, generator=gen).cuda()
+    grads = {}
+    for use_channel in (False, True):
+        torch.manual_seed(3)
+        enc = P.SAGE(feat, feat, feat, 2, 0.0).cuda()
+        enc.train()
+        x = x0.clone().requires_grad_(True)
+        ch = ops.SparseGradChannel() if use_channel else None
+        h = enc(x, adj, output_grad_channel=ch)
+        out = P.DotPredictor().score_edges(h, src, dst, channel=ch)
+        loss = (out ** 2).sum() + 0.01 * (h ** 2).sum()          # second consumer of h
+        loss.backward()
+        grads[use_channel] = [x.grad.clone()] + [p.grad.clone() for p in enc.parameters()]
+    for a, b in zip(grads[False], grads[True]):
+        close(b, a, rtol=2e-6)
