@@ -24,4 +24,5 @@ if len(sys.argv) > 4 and sys.argv[4] == "sequence":      # every launch of the l
     t0 = int(rows[a]['Start_Timestamp'])
     print("\nlaunch sequence of one step (start us, duration us, kernel):")
     for r in rows[a:b]:
-        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f}  {r['Kernel_Name'][:90]}")
+        q = r.get('Stream_Id', r.get('Queue_Id', '?'))
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f}  s{q:>3s}  {r['Kernel_Name'][:86]}")
