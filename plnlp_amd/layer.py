@@ -69,6 +69,12 @@ class GCNConv(torch.nn.Module):
 
     def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, channel=None):
         act = act if act is not None else _Act(False, 0.0, False)
+        parts = getattr(x, "_plnlp_parts", None)
+        if parts is not None and channel is None and in_act is None and ops.GCN_INPUT_FUSION["enabled"]:
+            # x = [emb.weight | constant features]: aggregate first, the feature block once (ops.GCNInputConvFn)
+            emb_weight, feats, cache = parts
+            return ops.GCNInputConvFn.apply(emb_weight, self.lin.weight, self.bias, _require_graph(adj_t), act, feats,
+                                            cache)
         return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act, in_act, channel)
 
 

@@ -686,7 +686,8 @@ def test_gcn_on_concatenated_unaligned_features_matches_oracle(P):
     out_ref = ref(torch.cat([embd, feats.double()], -1), csr)
     out_ref.backward(go.double())
     cache = {}
-    x = concat_features(embg, feats.cuda(), cache)
+    fcu = feats.cuda()                  # one resident feature tensor, as data.x is
+    x = concat_features(embg, fcu, cache)
     assert x.shape == (n, e + f) and x.stride(0) == 180
     out = enc(x, to_graph(P, csr))
     out.backward(go.cuda())
@@ -697,8 +698,34 @@ def test_gcn_on_concatenated_unaligned_features_matches_oracle(P):
     # second step reuses the buffer and refreshes only the embedding block
     with torch.no_grad():
         embg.add_(1.0)
-    x2 = concat_features(embg, feats.cuda(), cache)
+    x2 = concat_features(embg, fcu, cache)
     close(x2, torch.cat([embg.detach().cpu(), feats], -1), rtol=0, atol=0)
+    # ... and the first GCNConv took the parts (ops.GCNInputConvFn: aggregate first, A x cached): the
+    # second step must see the NEW embedding with the cached feature block, and must equal the
+    # transform-first form (fusion off)
+    from plnlp_amd import ops
+    assert "gcn_input" in cache
+    g = to_graph(P, csr)
+    out2 = enc(x2, g)
+    ref2 = ref(torch.cat([embg.detach().cpu().double(), feats.double()], -1), csr)
+    close(out2, ref2, atol=2e-4)
+    old = ops.GCN_INPUT_FUSION["enabled"]
+    try:
+        ops.GCN_INPUT_FUSION["enabled"] = False
+        out3 = enc(concat_features(embg, fcu, cache), g)
+    finally:
+        ops.GCN_INPUT_FUSION["enabled"] = old
+    close(out2, out3, rtol=2e-5, atol=2e-5 * float(out3.abs().max()))
+    # features edited in place -> the cached block is rebuilt
+    fc = feats.cuda()
+    cache2 = {}
+    enc(concat_features(embg, fc, cache2), g)
+    key_before = cache2["gcn_input"]["key"]
+    fc.mul_(2.0)
+    out4 = enc(concat_features(embg, fc, cache2), g)
+    assert cache2["gcn_input"]["key"] != key_before
+    ref4 = ref(torch.cat([embg.detach().cpu().double(), 2.0 * feats.double()], -1), csr)
+    close(out4, ref4, atol=4e-4)
 
 
 @pytest.mark.parametrize("n,feat", [(4267, 512), (1500, 200), (700, 64), (300, 36), (9000, 128)])
