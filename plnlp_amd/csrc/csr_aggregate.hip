@@ -236,10 +236,10 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
-    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi) {
+    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, int64_t row_base) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t r = row_base + (int64_t)blockIdx.x * 4 + wave;
     if (r >= n_rows) return;
     const int sub = lane % LPR, grp = lane / LPR;
     const int nslots = feat >> 2;
@@ -549,10 +549,10 @@ __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
-    int64_t n_rows, int feat, int mean, Epi epi) {
+    int64_t n_rows, int feat, int mean, Epi epi, int64_t row_base) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t r = row_base + (int64_t)blockIdx.x * 4 + wave;
     if (r >= n_rows) return;
     const int64_t beg = rowptr[r], end = rowptr[r + 1];
     for (int f0 = 0; f0 < feat; f0 += 64 * 4) {
@@ -596,13 +596,19 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
                       int64_t ldx, float* out,
                       int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e, const SplitArgs* sp) {
     const int64_t skip = sp ? sp->threshold : 0;
-    if (weighted)
-        hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true>), grid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
-    else
-        hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false>), grid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
-    if (int rc = launch_status()) return rc;
+    // a launch may not exceed 2^32 threads: beyond 2^22 blocks (16 Mi rows) the rows go in slices
+    constexpr int64_t MAX_BLOCKS = (int64_t)1 << 22;
+    const int64_t blocks = grid.x;
+    for (int64_t b0 = 0; b0 < blocks; b0 += MAX_BLOCKS) {
+        const dim3 g((unsigned)((blocks - b0) < MAX_BLOCKS ? (blocks - b0) : MAX_BLOCKS));
+        if (weighted)
+            hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true>), g, dim3(256), 0, s, rowptr, col, val,
+                               val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4);
+        else
+            hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false>), g, dim3(256), 0, s, rowptr, col, val,
+                               val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4);
+        if (int rc = launch_status()) return rc;
+    }
     return launch_split<VPL, LPR>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean,
                                   e, sp);
 }
@@ -685,13 +691,18 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
         sp = &sa;
     }
     if (!vec_ok) {
-        if (weighted)
-            hipLaunchKernelGGL((csr_agg_scalar_kernel<true>), grid, dim3(256), 0, s, rowptr, col, val, val_index,
-                               src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e);
-        else
-            hipLaunchKernelGGL((csr_agg_scalar_kernel<false>), grid, dim3(256), 0, s, rowptr, col, val, val_index,
-                               src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e);
-        return launch_status();
+        constexpr int64_t MAX_BLOCKS = (int64_t)1 << 22;          // < 2^32 threads per launch
+        for (int64_t b0 = 0; b0 < (int64_t)grid.x; b0 += MAX_BLOCKS) {
+            const dim3 g((unsigned)(((int64_t)grid.x - b0) < MAX_BLOCKS ? ((int64_t)grid.x - b0) : MAX_BLOCKS));
+            if (weighted)
+                hipLaunchKernelGGL((csr_agg_scalar_kernel<true>), g, dim3(256), 0, s, rowptr, col, val, val_index,
+                                   src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, b0 * 4);
+            else
+                hipLaunchKernelGGL((csr_agg_scalar_kernel<false>), g, dim3(256), 0, s, rowptr, col, val, val_index,
+                                   src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, b0 * 4);
+            if (int rc = launch_status()) return rc;
+        }
+        return 0;
     }
     const int nslots = (int)(feat / 4);
     if (src_map) flags = 0;      // the mapped gather exists on the one-row-per-wave forms only
