@@ -1135,3 +1135,18 @@ def test_sparse_channel_tolerates_a_second_consumer(P):
         grads[use_channel] = [x.grad.clone()] + [p.grad.clone() for p in enc.parameters()]
     for a, b in zip(grads[False], grads[True]):
         close(b, a, rtol=2e-6)
+
+
+def test_csr_aggregate_more_than_16Mi_rows(P):
+    """a launch may not exceed 2^32 threads; beyond 2^22 workgroups the rows go in slices"""
+    n, e, feat = (1 << 24) + 12345, 3_000_000, 8
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    r = torch.randint(0, n, (e,), device="cuda", generator=gen)
+    c = torch.randint(0, n, (e,), device="cuda", generator=gen)
+    r[:5] = n - 1                                   # the very last row, in the second slice
+    g = P.Graph.from_coo(r, c, None, n, n)
+    x = torch.randn(n, feat, device="cuda", generator=gen)
+    out = P.ops.csr_aggregate(g, x, "sum", False)
+    want = torch.zeros(n, feat, device="cuda", dtype=torch.float64).index_add_(0, r, x[c].double())
+    assert float((out.double() - want).abs().max()) <= 1e-5
+    assert float(out[n - 1].abs().sum()) > 0
