@@ -847,6 +847,23 @@ def test_hits50_training_parity_gpu_vs_oracle(P):
     assert r["gpu_test"] > 0.0
 
 
+def test_hits20_training_parity_ddi_recipe(P):
+    """the ddi recipe (BASELINE config 2): SAGE x2 + MLP predictor, AUC loss, 3 negatives per positive,
+    Hits@20, 6 epochs from the same seeds on the GPU path, the CPU oracle (fp32) and the CPU oracle in
+    float64.  With Adam this recipe is chaotic in fp32: the reference arithmetic ITSELF moves by ~1 Hits
+    point (and weights by lr per step where a gradient is zero up to round-off) between fp32 and fp64,
+    and the first step's loss is identical on all three -- so the GPU path is held to the reference's
+    own fp32-vs-fp64 drift, not to +-0.3 of one fp32 realisation (the DOT recipe above does meet +-0.3)."""
+    import bench
+    r = bench.hits_parity(P, torch.device("cuda"), epochs=6, recipe="ddi", with_f64=True)
+    assert r["metric"] == "Hits@20"
+    lo = r["epoch_losses"]
+    g, c, d = (np.array(lo[k_]) for k_ in ("gpu", "cpu", "cpu64"))
+    assert abs(g[0] - d[0]) <= 4 * abs(c[0] - d[0]) + 2e-3 * d[0], (g, c, d)
+    assert (np.abs(g - d) <= 6 * np.abs(c - d).max() + 2e-3 * d).all(), (g, c, d)
+    assert r["gpu_vs_f64_points"] <= 4 * r["cpu32_vs_f64_points"] + 2.0, r
+
+
 # ------------------------------------------------- row-sparse backward pieces ----
 def test_compact_rows_matches_torch(P):
     from plnlp_amd import ops
