@@ -112,6 +112,7 @@ def measure_gemm_roofline(P, n_rows, k_in, hidden, device, sage=True):
     """the other hot kernel: the encoder's forward linear on the f32-input MFMA (SAGE: lin_l(agg) + lin_r(x)
     as one concat-K product with bias/relu/dropout in the epilogue), timed live like the aggregation"""
     from plnlp_amd import _lib
+    k_in = (k_in + 3) // 4 * 4          # the encoder's operands are 16-byte-aligned (padded) buffers
     a1 = torch.randn(n_rows, k_in, device=device)
     w1 = torch.randn(hidden, k_in, device=device) * 0.05
     segs = [(a1, w1)]
