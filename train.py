@@ -124,6 +124,7 @@ def main(argv=None):
     data, split_edge, num_nodes = load_dataset(args, device)
     num_node_feats = getattr(data, 'num_features', 0) if data.x is not None else 0
     print(args)
+    os.makedirs(args.res_dir or '.', exist_ok=True)
     log_file = os.path.join(args.res_dir, 'log_' + args.data_name + '_' + str(int(time.time())) + '.txt')
     with open(log_file, 'a') as f:
         f.write(str(args) + '\n')
