@@ -364,8 +364,13 @@ class BaseModel(object):
         rank, world = self._world()
         mode = self.dp_mode()
 
+        # the structured ("global") samplers run on the device the edge list lives on: on the host they
+        # cost ten times the epoch's GPU time at collab scale (seeded from the CPU generator either way)
+        edge_index = data.edge_index
+        if neg_sampler_name != 'local' and edge_index is not None and self.device.type == "cuda":
+            edge_index = edge_index.to(self.device)
         pos_train_edge, neg_train_edge = get_pos_neg_edges(
-            'train', split_edge, edge_index=data.edge_index, num_nodes=self.num_nodes,
+            'train', split_edge, edge_index=edge_index, num_nodes=self.num_nodes,
             neg_sampler_name=neg_sampler_name, num_neg=num_neg)
         pos_train_edge, neg_train_edge = pos_train_edge.to(self.device), neg_train_edge.to(self.device)
         edge_weight_margin = None

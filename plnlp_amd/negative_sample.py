@@ -10,10 +10,11 @@ reference does, so that every data-parallel rank regenerates the identical
 A.4): `structured_negative_sampling` keeps its contract -- no returned pair is
 an existing edge or a self loop, no duplicates, at most the requested count --
 and the reference's own padding / reshaping around it is bit-exact (fixture G5).
+It runs on the device the edge list lives on (torch ops), seeded from the CPU
+generator, so ranks still agree.
 """
 from typing import Optional
 
-import numpy as np
 import torch
 
 
@@ -25,36 +26,52 @@ def add_self_loops(edge_index: torch.Tensor, num_nodes: Optional[int] = None):
 
 
 def structured_negative_sampling(edge_index, num_nodes, num_neg_samples, method="sparse",
-                                 generator: Optional[np.random.Generator] = None):
+                                 generator: Optional[torch.Generator] = None):
     """Stand-in for torch_geometric.utils.negative_sampling(method='sparse'):
     candidate ids drawn uniformly from the N*N grid, existing ids removed, up to
-    three rounds, truncated to the requested count.  Returns int64 [2, <=n]."""
-    rng = generator if generator is not None else np.random.default_rng(
-        int(torch.empty((), dtype=torch.int64).random_().item()))
+    three rounds, truncated to the requested count.  Returns int64 [2, <=n] on
+    edge_index's device.
+
+    Pure torch ops on whatever device the edge list lives on: for an epoch of the
+    random-walk-augmented collab recipe (11.8 M negatives) the host numpy version
+    took 5-10 s -- ten times the epoch's GPU time; on the device it is a sort and a
+    binary search (milliseconds).  The private generator is seeded from ONE draw of
+    the default CPU generator, so every data-parallel rank that seeded
+    torch.manual_seed alike produces the identical tensor."""
+    dev = edge_index.device
+    gen = generator
+    if gen is None:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
     n = int(num_nodes)
     population = n * n
-    present = np.unique((edge_index[0].to(torch.int64) * n + edge_index[1].to(torch.int64)).cpu().numpy())
-    want = int(min(num_neg_samples, population - present.size))
-    density = present.size / float(population)
+    present = torch.unique(edge_index[0].to(torch.int64) * n + edge_index[1].to(torch.int64))     # sorted
+    want = int(min(num_neg_samples, population - present.numel()))
+    density = present.numel() / float(population)
     over = 1.0 / max(1.0 - 1.1 * density, 0.05)
-    picked = np.empty(0, dtype=np.int64)
+
+    def absent(sorted_set, ids):
+        if sorted_set.numel() == 0:
+            return torch.ones_like(ids, dtype=torch.bool)
+        pos = torch.searchsorted(sorted_set, ids).clamp_(max=sorted_set.numel() - 1)
+        return sorted_set[pos] != ids
+
+    picked = torch.empty(0, dtype=torch.int64, device=dev)
     for _ in range(3):
-        need = want - picked.size
+        need = want - picked.numel()
         if need <= 0:
             break
         k = min(int(over * need * 1.1) + 16, population)
         if population <= (1 << 26):                      # distinct by construction, like random.sample
-            draw = rng.choice(population, size=k, replace=False).astype(np.int64)
+            draw = torch.randperm(population, generator=gen, device=dev)[:k]
         else:
-            draw = rng.integers(0, population, size=k, dtype=np.int64)
-            _, first = np.unique(draw, return_index=True)
-            draw = draw[np.sort(first)]                  # distinct, arrival order kept
-        draw = draw[~np.isin(draw, present, assume_unique=False)]
-        if picked.size:
-            draw = draw[~np.isin(draw, picked)]
-        picked = np.concatenate([picked, draw])[:want]
-    out = torch.from_numpy(picked)
-    return torch.stack([out // n, out % n], dim=0)
+            draw = torch.unique(torch.randint(0, population, (k,), generator=gen, device=dev, dtype=torch.int64))
+            draw = draw[torch.randperm(draw.numel(), generator=gen, device=dev)]       # back to a random order
+        draw = draw[absent(present, draw)]
+        if picked.numel():
+            draw = draw[absent(torch.sort(picked).values, draw)]
+        picked = torch.cat([picked, draw])[:want]
+    return torch.stack([picked // n, picked % n], dim=0)
 
 
 def _pad_short(neg_edge: torch.Tensor, want: int):
@@ -62,7 +79,7 @@ def _pad_short(neg_edge: torch.Tensor, want: int):
     src, dst = neg_edge[0], neg_edge[1]
     have = neg_edge.size(1)
     if have < want:
-        extra = torch.randperm(have)[: want - have]
+        extra = torch.randperm(have)[: want - have].to(src.device)
         src, dst = torch.cat((src, src[extra])), torch.cat((dst, dst[extra]))
     return src, dst
 
@@ -80,7 +97,7 @@ def sample_perm_copy(edge_index, target_num_sample, num_perm_copy):
     src, dst = _pad_short(edge_index, target_num_sample)
     base_src, base_dst = src, dst
     for _ in range(num_perm_copy - 1):
-        shuffle = torch.randperm(target_num_sample)
+        shuffle = torch.randperm(target_num_sample).to(base_src.device)
         src, dst = torch.cat((src, base_src[shuffle])), torch.cat((dst, base_dst[shuffle]))
     return torch.stack((src, dst), dim=-1).reshape(-1, num_perm_copy, 2)
 
