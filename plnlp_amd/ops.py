@@ -466,8 +466,10 @@ class SparseGradChannel:
 SPARSE_BACKWARD = {"enabled": os.environ.get("PLNLP_SPARSE_BACKWARD", "1") != "0",
                    # use the channel when the batch can touch at most this fraction of the nodes in
                    # expectation (1 - exp(-endpoints / nodes)); a batch that touches everything (ddi)
-                   # gains nothing from the indirection
-                   "max_expected_fraction": 0.9}
+                   # gains nothing from the indirection.  Measured on collab at 1/2/3/4/6/8x the batch
+                   # (expectation 0.67 / 0.89 / 0.96 / 0.99 / ~1 / ~1; degree-biased positives touch fewer):
+                   # row-sparse vs dense 2.52/3.15, 2.90/3.14, 3.10/3.18, 3.24/3.24, 3.41/3.38, 3.59/3.54 ms
+                   "max_expected_fraction": float(os.environ.get("PLNLP_SPARSE_MAX_FRACTION", "0.97"))}
 
 
 def sparse_backward_pays(n_endpoints: int, n_nodes: int) -> bool:
