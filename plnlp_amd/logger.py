@@ -1,14 +1,29 @@
-"""Run statistics, same report as the reference's plnlp/logger.py: per run the
-test score at the best-validation evaluation point, over runs mean and std."""
+"""Run statistics with the report format of the reference's plnlp/logger.py (its text is the
+contract, fixture G9): per run the test score at the best-validation evaluation point; over runs
+the mean and (unbiased) standard deviation of those picks."""
 import sys
+from typing import List, Sequence, Tuple
 
 import torch
+
+_RUN_LINES = ("Run {run:02d}:", "Highest Valid: {valid:.2f}", "Highest Eval Point: {point}", "   Final Test: {test:.2f}")
+_ALL_LINES = ("All runs:", "Highest Valid: {vm:.2f}  {vs:.2f}", "   Final Test: {tm:.2f}  {ts:.2f}")
+
+
+def _pick(history: Sequence[Tuple[float, float]], last_best: bool):
+    """(best validation score, its 0-based evaluation point, the test score there), in percent"""
+    scores = torch.tensor(history, dtype=torch.get_default_dtype()) * 100
+    valid = scores[:, 0]
+    at = int(valid.argmax())
+    if last_best:                       # the LAST evaluation point that reaches the maximum
+        at = valid.numel() - 1 - int(valid.flip(0).argmax())
+    return valid.max(), at, scores[at, 1]
 
 
 class Logger(object):
     def __init__(self, runs, info=None):
         self.info = info
-        self.results = [[] for _ in range(runs)]
+        self.results: List[list] = [[] for _ in range(runs)]
 
     def add_result(self, run, result):
         if len(result) != 2:
@@ -17,26 +32,13 @@ class Logger(object):
             raise IndexError(run)
         self.results[run].append(result)
 
-    @staticmethod
-    def _best_index(valid: torch.Tensor, last_best: bool) -> int:
-        if last_best:  # last occurrence of the maximum
-            return valid.numel() - 1 - int(valid.flip(dims=[0]).argmax())
-        return int(valid.argmax())
-
     def print_statistics(self, run=None, f=sys.stdout, last_best=False):
-        if run is not None:
-            table = 100 * torch.tensor(self.results[run])
-            best = self._best_index(table[:, 0], last_best)
-            print(f'Run {run + 1:02d}:', file=f)
-            print(f'Highest Valid: {table[:, 0].max():.2f}', file=f)
-            print(f'Highest Eval Point: {best + 1}', file=f)
-            print(f'   Final Test: {table[best, 1]:.2f}', file=f)
-            return
-        picks = []
-        for table in 100 * torch.tensor(self.results):
-            best = self._best_index(table[:, 0], last_best)
-            picks.append((table[:, 0].max().item(), table[best, 1].item()))
-        picks = torch.tensor(picks)
-        print('All runs:', file=f)
-        print(f'Highest Valid: {picks[:, 0].mean():.2f}  {picks[:, 0].std():.2f}', file=f)
-        print(f'   Final Test: {picks[:, 1].mean():.2f}  {picks[:, 1].std():.2f}', file=f)
+        if run is None:
+            picks = torch.stack([torch.stack([p[0], p[2]]) for p in (_pick(h, last_best) for h in self.results)])
+            fields = dict(vm=picks[:, 0].mean(), vs=picks[:, 0].std(), tm=picks[:, 1].mean(), ts=picks[:, 1].std())
+            text = [line.format(**fields) for line in _ALL_LINES]
+        else:
+            valid, at, test = _pick(self.results[run], last_best)
+            text = [line.format(run=run + 1, valid=valid, point=at + 1, test=test) for line in _RUN_LINES]
+        for line in text:
+            print(line, file=f)
