@@ -157,11 +157,23 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def require_device(*tensors: Optional[torch.Tensor]) -> None:
+    """every operand must live on the CURRENT device: the kernels are launched on the current
+    device's current stream (stream_ptr), so a tensor of another GPU would be touched from the wrong
+    device's queue -- callers select the device first (torch.cuda.set_device / torch.cuda.device)"""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise PlnlpHipError(
                 "plnlp_amd ops run only on an MI355X device tensor (got a CPU tensor); "
                 "there is no CPU path in the product -- the CPU oracle lives in oracle/ for tests")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise PlnlpHipError(
+                f"operand on cuda:{t.device.index} but the current device is cuda:{cur}: kernels launch on the "
+                "current device's stream -- call torch.cuda.set_device(device) (BaseModel does) first")
 
 
 def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accumulate=False,

@@ -26,7 +26,6 @@
 // result): grid.z slices write raw partial tiles to a workspace and a second
 // kernel adds them in slice order -- deterministic, no atomics.
 #include "common.hip.h"
-#include <cstdlib>
 
 namespace plnlp {
 
@@ -580,7 +579,6 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     if (a_trans) aligned = aligned && (m % 4 == 0) && m >= 4;    // row-contiguous operands move 4 rows per load
     if (!b_trans) aligned = aligned && (n % 4 == 0) && n >= 4;
     int mode = !aligned ? 0 : (ragged ? 2 : 1);
-    if (const char* fm = getenv("PLNLP_GEMM_FORCE_MODE")) { int v = atoi(fm); if (v == 0 || (v == 2 && aligned)) mode = v; }
     int reduce_slices = split_k;
     GemmArgs tail{};
     bool peel = false;

@@ -55,6 +55,9 @@ class BaseModel(object):
         self.train_node_emb = train_node_emb
         self.clip_norm = grad_clip_norm
         self.device = torch.device(device)
+        if self.device.type == "cuda":
+            # the kernels launch on the CURRENT device's current stream (plnlp_amd/_lib.py::stream_ptr)
+            torch.cuda.set_device(self.device)
         self.process_group = process_group
         self.dp_scaling = dp_scaling
         if dp_exchange not in ("auto", "grads", "scores"):
@@ -146,6 +149,19 @@ class BaseModel(object):
         return self.calculate_loss(out[:n_pos], out[n_pos:], num_neg, margin=margin)
 
     # ------------------------------------------------------------- DP helpers ---
+    # losses that average over the batch (loss.py:45-62); every other one is a SUM over pairs
+    MEAN_LOSSES = ("CE", "InfoNCE", "LogRank")
+
+    def _slice_loss_scale(self, local: int, global_count: Optional[int]) -> float:
+        """factor that turns the loss of this rank's slice into its share of the global batch's loss.
+        A sum over pairs splits over slices as it is (1.0); a MEAN over the global batch is
+        sum_r (n_r / n) * mean_r, so the slice's mean is weighted by n_r / n -- then the SUM over ranks
+        of the slice losses (and of their gradients) equals the one-process loss (gradient) again."""
+        if (self.process_group is None or global_count is None or local <= 0
+                or self.loss_func_name not in self.MEAN_LOSSES):
+            return 1.0
+        return float(local) / float(global_count)
+
     def _world(self):
         if self.process_group is None:
             return 0, 1
@@ -274,9 +290,12 @@ class BaseModel(object):
             return self.predictor.score_edges(h, src, dst)
         return self.predictor(h[src], h[dst])
 
-    def train_step(self, data, pos_edge, neg_edge, num_neg, weight_margin=None, edges_ready=False):
+    def train_step(self, data, pos_edge, neg_edge, num_neg, weight_margin=None, edges_ready=False,
+                   global_count=None):
         """One iteration of the hot loop, model.py:148-167, on this rank's slice:
-        pos_edge [b,2], neg_edge [b,k,2] (device).  Returns the detached local loss.
+        pos_edge [b,2], neg_edge [b,k,2] (device).  Returns the detached local loss -- this rank's
+        SHARE of the global batch's loss (global_count = positives in the global batch; only the
+        batch-averaged losses need it, see _slice_loss_scale).
         edges_ready=True: the edge tensors are not the output of work still pending on the current
         stream (views of resident tensors, or produced on the side stream) -- their pre-processing
         may then overlap the previous step (ops.EdgeBatch)."""
@@ -290,6 +309,9 @@ class BaseModel(object):
                                               incidence=incidence) if fused
                    else self._score(h, src, dst))
             loss = self._loss_of_scores(out, local, num_neg, weight_margin)
+            scale = self._slice_loss_scale(local, global_count)
+            if scale != 1.0:
+                loss = loss * scale
         else:                                    # empty slice: still take part in the reduction
             loss = h.sum() * 0.0
         if loss.is_cuda and loss.dtype == torch.float32:
@@ -326,6 +348,9 @@ class BaseModel(object):
                                     torch.cat([dst[lo:hi], dst[n + lo * k:n + hi * k]]))
             out_l = out_l.detach().requires_grad_(True)
             loss = self._loss_of_scores(out_l, local, k, None if weight_margin is None else weight_margin[lo:hi])
+            scale = self._slice_loss_scale(local, n)
+            if scale != 1.0:
+                loss = loss * scale
             if loss.is_cuda and loss.dtype == torch.float32:
                 loss.backward(ops.unit_grad(loss.device))
             else:
@@ -363,6 +388,13 @@ class BaseModel(object):
         self.predictor.train()
         rank, world = self._world()
         mode = self.dp_mode()
+        if world > 1 and self.device.type == "cuda":
+            # replicated encoder passes must draw the same dropout masks: rank 0's stream state wins
+            st = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in ops.seed_state()], dtype=torch.int64,
+                              device=self.device)
+            torch.distributed.broadcast(st, 0, group=self.process_group)
+            base, counter = (int(v) for v in st.tolist())
+            ops.set_seed_state(base, counter)
 
         # the structured ("global") samplers run on the device the edge list lives on: on the host they
         # cost ten times the epoch's GPU time at collab scale (seeded from the CPU generator either way)
@@ -419,7 +451,8 @@ class BaseModel(object):
             else:
                 perm = perm_all
             pos_b, neg_b, weight_margin = take(perm)
-            loss = self.train_step(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None)
+            loss = self.train_step(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None,
+                                   global_count=n_b)
             loss_acc += loss.double() * n_b
             total_examples += n_b
 

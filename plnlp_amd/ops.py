@@ -17,20 +17,34 @@ from . import _lib as L
 from .graph import Graph
 
 # ------------------------------------------------------------------ seeds ------
-_seed_state = {"base": 0x5DEECE66D, "counter": 0}
+_seed_state = {"base": None, "counter": 0}
 
 
 def manual_seed(seed: int) -> None:
-    """Seed the counter-based dropout stream (independent of torch's generators;
-    identical on every data-parallel rank so replicated encoder passes agree)."""
+    """Seed the counter-based dropout stream (identical on every data-parallel rank so replicated
+    encoder passes agree).  Without this call the base is taken from torch's default generator on
+    first use (`torch.initial_seed()`), so `torch.manual_seed(s)` alone also fixes the masks and an
+    unseeded run -- the reference never seeds -- draws fresh masks per launch."""
     _seed_state["base"] = int(seed) & 0xFFFFFFFFFFFFFFFF
     _seed_state["counter"] = 0
 
 
+def seed_state():
+    """(base, counter) of the dropout stream -- what a data-parallel trainer broadcasts from rank 0"""
+    if _seed_state["base"] is None:
+        _seed_state["base"] = (int(torch.initial_seed()) ^ 0x5DEECE66D) & 0xFFFFFFFFFFFFFFFF
+    return _seed_state["base"], _seed_state["counter"]
+
+
+def set_seed_state(base: int, counter: int) -> None:
+    _seed_state["base"], _seed_state["counter"] = int(base) & 0xFFFFFFFFFFFFFFFF, int(counter)
+
+
 def next_seed() -> int:
     """splitmix64(base + counter * golden): one fresh 64-bit seed per dropout call."""
+    base, _ = seed_state()
     _seed_state["counter"] += 1
-    z = (_seed_state["base"] + _seed_state["counter"] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = (base + _seed_state["counter"] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
     z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
     z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
     return z ^ (z >> 31)
@@ -883,12 +897,12 @@ class ConcatFeatFn(torch.autograd.Function):
 
 def concat_features(emb_weight: torch.Tensor, feats: torch.Tensor, cache: dict) -> torch.Tensor:
     n, e, f = emb_weight.shape[0], emb_weight.shape[1], feats.shape[1]
-    key = (feats.data_ptr(), n, e, f)
-    if cache.get("key") != key:
+    key = (feats.data_ptr(), feats._version, n, e, f)
+    if cache.get("key") != key or cache.get("feats") is not feats:
         buf = torch.zeros(n, _pad4(e + f), dtype=torch.float32, device=emb_weight.device)
         buf[:, e:e + f].copy_(feats)
         cache.clear()
-        cache.update(key=key, buf=buf)
+        cache.update(key=key, buf=buf, feats=feats)     # holding `feats` keeps its id / pointer from being reused
     out = ConcatFeatFn.apply(emb_weight, feats, cache["buf"])
     out._plnlp_padded = cache["buf"]        # the GEMM wrappers may use the padded width
     out._plnlp_parts = (emb_weight, feats, cache)      # a first GCNConv may take the parts instead (GCNInputConvFn)
@@ -929,14 +943,17 @@ class GCNInputConvFn(torch.autograd.Function):
     def forward(ctx, emb_weight, w, b, graph: Graph, act: _Act, feats, cache: dict):
         n, e, f = emb_weight.shape[0], emb_weight.shape[1], feats.shape[1]
         ep, fp = _pad4(e), _pad4(f)
-        key = ("gcn_input", id(graph), feats.data_ptr(), feats._version, n, e, f)
+        key = ("gcn_input", feats.data_ptr(), feats._version, n, e, f)
         st = cache.get("gcn_input")
-        if st is None or st["key"] != key:
+        # the entry holds the graph and the feature tensor themselves (compared by identity): an id() or a
+        # data pointer alone can be reused by a different object once the old one is freed
+        if st is None or st["key"] != key or st["graph"] is not graph or st["feats"] is not feats:
             ax = torch.zeros(n, ep + fp, dtype=torch.float32, device=emb_weight.device)
             fpad = torch.zeros(n, fp, dtype=torch.float32, device=emb_weight.device)
             fpad[:, :f].copy_(feats)
             csr_aggregate(graph, fpad, "sum", use_values=True, out=ax[:, ep:])        # A_hat x, once
-            st = {"key": key, "ax": ax, "emb_pad": torch.zeros(n, ep, dtype=torch.float32, device=ax.device)}
+            st = {"key": key, "graph": graph, "feats": feats, "ax": ax,
+                  "emb_pad": torch.zeros(n, ep, dtype=torch.float32, device=ax.device)}
             cache["gcn_input"] = st
         ax, emb_pad = st["ax"], st["emb_pad"]
         emb_pad[:, :e].copy_(emb_weight.detach())

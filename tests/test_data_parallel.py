@@ -100,7 +100,10 @@ def _spawn(world, batch, scaling, loss_name, predictor, exchange="auto"):
 
 @pytest.mark.parametrize("scaling,loss_name,predictor,exchange",
                          [("strong", "AUC", "MLP", "auto"), ("weak", "WeightedHingeAUC", "DOT", "grads"),
-                          ("weak", "WeightedHingeAUC", "DOT", "scores"), ("strong", "HingeAUC", "DOT", "auto")])
+                          ("weak", "WeightedHingeAUC", "DOT", "scores"), ("strong", "HingeAUC", "DOT", "auto"),
+                          # batch-AVERAGED losses (loss.py:45-62): the slice mean is weighted by n_r / n
+                          ("strong", "LogRank", "DOT", "grads"), ("weak", "LogRank", "DOT", "scores"),
+                          ("strong", "CE", "MLP", "auto")])
 def test_two_ranks_equal_one_process(scaling, loss_name, predictor, exchange):
     """both exchange modes: parameter-gradient all-reduce, and all-gather of the per-edge score
     gradients followed by the same global backward on every rank"""

@@ -115,9 +115,19 @@ def to_undirected(edge_index, edge_weight, num_nodes):
     return torch.stack([uniq // num_nodes, uniq % num_nodes]), out_w
 
 
+def coalesce(edge_index, edge_weight, num_nodes):
+    """torch_sparse.coalesce(index, value, m, n) (main.py:140, default op 'add'): entries sorted by
+    (row, col), duplicates merged with their values summed"""
+    key = edge_index[0] * num_nodes + edge_index[1]
+    uniq, inv = torch.unique(key, return_inverse=True)
+    w = torch.zeros(uniq.numel(), dtype=edge_weight.dtype).index_add_(0, inv, edge_weight)
+    return torch.stack([uniq // num_nodes, uniq % num_nodes]), w
+
+
 def main(argv=None):
     args = argument(argv)
     device = torch.device(f'cuda:{args.device}')
+    torch.cuda.set_device(device)      # kernels launch on the current device's stream
     if args.seed is not None:
         torch.manual_seed(args.seed)
         P.manual_seed(args.seed)
@@ -146,6 +156,8 @@ def main(argv=None):
             ei, ew = to_undirected(full_ei, full_w, num_nodes)
             data.adj_t = Graph.from_coo(ei[0], ei[1], ew.to(torch.float32), num_nodes, num_nodes)
             data.edge_index = ei
+            if args.use_coalesce:                                          # main.py:139-140
+                full_ei, full_w = coalesce(full_ei, full_w, num_nodes)
             split_edge['train']['edge'] = full_ei.t()
             deg = data.adj_t.sum(dim=1).to(torch.float)
             dis = deg.pow(-0.5)
