@@ -126,6 +126,28 @@ int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                             const plnlp_row_split* split /* nullable, HOST ptr */,
                             void* stream);
 
+/* reduce = max (torch_sparse.matmul(adj_t, x, reduce='max'); SAGEConv(aggr='max') in PyG, the third
+ * reduction SURVEY.md 8(b) lists next to sum / mean):
+ *   out[r, f] = max_e w_e * x[col[e], f], 0 for a row without entries;
+ *   arg[r, f] = row-relative position of the FIRST entry attaining the maximum, -1 for an empty row
+ *               (int32 [n_rows, ld_arg]; what the backward needs).
+ * Lane groups fold their candidates with a wavefront-shuffle (max, arg) tree; long rows go through
+ * `split` like the sum kernel, with arg_workspace (int32 [n_chunks, feat]) next to split->workspace. */
+int plnlp_csr_aggregate_max_f32(const int64_t* rowptr, const int32_t* col,
+                                const float* val /* nullable: [nnz] */,
+                                const float* x, int64_t ldx, float* out, int64_t ldo,
+                                int32_t* arg, int64_t ld_arg, int64_t n_rows, int64_t feat,
+                                const plnlp_row_split* split /* nullable, HOST ptr */,
+                                int32_t* arg_workspace /* nullable unless split */, void* stream);
+/* its backward as a gather over the TRANSPOSED CSR (no atomics, fixed order):
+ *   gx[j, f] = sum_{t in [rowptr_t[j], rowptr_t[j+1])} [arg[col_t[t], f] == pos_t[t]] * w_t * gy[col_t[t], f]
+ * col_t[t] = the row i fed by source j, pos_t[t] = position of that (i <- j) entry in row i of the
+ * forward CSR, val_t[t] = its weight (nullable). */
+int plnlp_csr_aggregate_max_bwd_f32(const int64_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
+                                    const float* val_t, const float* gy, int64_t ldg,
+                                    const int32_t* arg, int64_t ld_arg, float* gx, int64_t ldgx,
+                                    int64_t n_src, int64_t feat, void* stream);
+
 /* ---- K4: dense fp32 linear on the f32-input MFMA ---------------------------
  * C[M,N] = EPI( sum_s  op(A_s)[M,K_s] * op(B_s)[K_s,N] )     s = 0 .. n_seg-1 (<= 2)
  *   a_trans = 0: A_s stored [M,K_s] (lda = row stride)   1: stored [K_s,M]

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 __all__ = [
-    "CSR", "spmm", "spmm_dense_check", "gcn_norm_csr",
+    "CSR", "spmm", "spmm_max", "spmm_dense_check", "gcn_norm_csr",
     "SAGEConvRef", "GCNConvRef", "GNNRef", "MLPPredictorRef", "DotPredictorRef",
     "LOSSES", "pairwise_loss", "select_loss",
     "dropout_keep_mask", "counter_dropout", "random_walk_ref",
@@ -139,6 +139,8 @@ def spmm(adj: CSR, x: torch.Tensor, reduce: str = "sum", use_values: bool = True
             adj._torch_csr = cache
         A, At = cache[key]
         return _SpMM.apply(x, A, At)
+    if reduce == "max":
+        return spmm_max(adj, x, use_values)[0]
     row = adj.row_index()
     msg = x[adj.col]
     if val is not None:
@@ -149,6 +151,31 @@ def spmm(adj: CSR, x: torch.Tensor, reduce: str = "sum", use_values: bool = True
     elif reduce != "sum":
         raise ValueError(reduce)
     return out
+
+
+def spmm_max(adj: CSR, x: torch.Tensor, use_values: bool = True):
+    """[3P] torch_sparse spmm_max (matmul(adj_t, x, reduce='max')): out[i,f] = max over the stored
+    entries of row i of (val *) x[col, f]; the FIRST maximal entry in CSR order wins (strict `>` in
+    the row loop), its position is the arg; rows without entries give 0 and arg = -1; autograd sends
+    the gradient to the arg-max entry only.  Returns (out, arg) with arg the row-relative position."""
+    val = adj.val if use_values else None
+    row = adj.row_index()
+    msg = x[adj.col]
+    if val is not None:
+        msg = msg * val.to(x.dtype).unsqueeze(-1)
+    nnz, feat = msg.shape
+    idx = row.unsqueeze(-1).expand(-1, feat)
+    top = torch.full((adj.n_rows, feat), float("-inf"), dtype=x.dtype).scatter_reduce(
+        0, idx, msg.detach(), "amax", include_self=True)
+    eidx = torch.arange(nnz).unsqueeze(-1).expand(-1, feat)
+    cand = torch.where(msg.detach() == top[row], eidx, torch.full_like(eidx, nnz))
+    arg = torch.full((adj.n_rows, feat), nnz, dtype=torch.int64).scatter_reduce(0, idx, cand, "amin",
+                                                                                include_self=True)
+    has = arg < nnz
+    picked = msg.gather(0, arg.clamp(max=max(nnz - 1, 0))) if nnz else torch.zeros_like(top)
+    out = torch.where(has, picked, torch.zeros_like(picked))
+    rel = torch.where(has, arg - adj.rowptr[:-1].unsqueeze(-1), torch.full_like(arg, -1))
+    return out, rel
 
 
 def spmm_dense_check(adj: CSR, x: torch.Tensor, reduce="sum", use_values=True) -> torch.Tensor:

@@ -72,6 +72,11 @@ SIGNATURES = {
                                           C.c_void_p, c_i64,
                                           C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.c_int, C.c_int, C.POINTER(Epilogue),
                                           C.POINTER(RowSplit), C.c_void_p]),
+    "plnlp_csr_aggregate_max_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, c_i64,
+                                              C.c_void_p, c_i64, c_i64, c_i64, C.POINTER(RowSplit), C.c_void_p,
+                                              C.c_void_p]),
+    "plnlp_csr_aggregate_max_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64,
+                                                  C.c_void_p, c_i64, C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p]),
     "plnlp_gemm_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
                                  c_i64, C.POINTER(Epilogue), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
     "plnlp_gemm_split_out_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64,

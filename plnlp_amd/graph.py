@@ -201,6 +201,17 @@ class Graph:
             self._t._t = self
         return self._t
 
+    def t_pos(self) -> torch.Tensor:
+        """int32 [nnz], aligned with t(): the row-relative position, in THIS graph's row, of the entry each
+        transposed entry mirrors (what the backward of the max aggregation compares the saved arg
+        with).  t() orders the entries by (col, row) with a stable sort; the same sort is repeated here."""
+        if getattr(self, "_t_pos", None) is None:
+            r, c, _ = self.coo()
+            rel = torch.arange(self.nnz, device=self.device) - self.rowptr[r]
+            order = torch.argsort(c * self.n_rows + r, stable=True)
+            self._t_pos = rel[order].to(torch.int32).contiguous()
+        return self._t_pos
+
     def t_mean(self) -> "Graph":
         """The operator of the mean aggregation's backward as ONE valued CSR: A^T D^-1, i.e. the
         transposed structure with entry value 1 / max(deg(source row of A), 1).  Built once per static

@@ -31,10 +31,15 @@ def _require_graph(adj_t) -> Graph:
 class SAGEConv(torch.nn.Module):
     """PyG 2.0.1 SAGEConv(in, out) defaults as used at layer.py:36: mean
     aggregation (edge values ignored), root weight, bias on lin_l only.
-    Parameters: lin_l.weight, lin_l.bias, lin_r.weight."""
+    Parameters: lin_l.weight, lin_l.bias, lin_r.weight.
+    aggr: 'mean' (the reference's, fused path) | 'max' | 'add' (PyG's other SAGEConv reductions, on the
+    max / sum aggregation kernels followed by the two linears)."""
 
-    def __init__(self, in_channels: int, out_channels: int):
+    def __init__(self, in_channels: int, out_channels: int, aggr: str = "mean"):
         super().__init__()
+        if aggr not in ("mean", "max", "add", "sum"):
+            raise ValueError(f"aggr must be mean, max or add, not {aggr!r}")
+        self.aggr = aggr
         self.in_channels, self.out_channels = in_channels, out_channels
         self.lin_l = torch.nn.Linear(in_channels, out_channels, bias=True)
         self.lin_r = torch.nn.Linear(in_channels, out_channels, bias=False)
@@ -45,6 +50,10 @@ class SAGEConv(torch.nn.Module):
 
     def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, sink=None, channel=None):
         act = act if act is not None else _Act(False, 0.0, False)
+        if self.aggr != "mean":
+            agg = ops.AggregateFn.apply(x, _require_graph(adj_t), "sum" if self.aggr == "add" else self.aggr, False)
+            return ops.LinearFn.apply(torch.cat([agg, x], dim=1),
+                                      torch.cat([self.lin_l.weight, self.lin_r.weight], dim=1), self.lin_l.bias, act)
         return ops.SAGEConvFn.apply(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight,
                                     _require_graph(adj_t), act, in_act, sink, channel)
 
@@ -113,7 +122,12 @@ class BaseGNN(torch.nn.Module):
                     out_act = act
                 # the conv's backward folds the derivative of the activation that produced its input
                 ch = output_grad_channel if (i == last and torch.is_grad_enabled()) else None
-                if i == 0 and input_grad_sink is not None and isinstance(conv, SAGEConv):
+                if isinstance(conv, SAGEConv) and conv.aggr != "mean":
+                    # un-fused reductions (max / add): no sink, no row-sparse channel, no folded input gate
+                    if ch is not None or (i == 0 and input_grad_sink is not None):
+                        raise ValueError("gradient sinks / channels need the fused (mean) SAGEConv")
+                    x = conv(x, adj_t, act)
+                elif i == 0 and input_grad_sink is not None and isinstance(conv, SAGEConv):
                     x = conv(x, adj_t, act, None, input_grad_sink, ch)
                 else:
                     x = conv(x, adj_t, act, prev_act if torch.is_grad_enabled() else None, channel=ch)

@@ -176,7 +176,7 @@ class BaseModel(object):
         self._early_work = None
         if (self.process_group is None or self.emb is None or x_in is not self.emb.weight
                 or not self.emb.weight.requires_grad or not x_in.is_cuda
-                or not isinstance(self.encoder.convs[0], SAGEConv)):
+                or not isinstance(self.encoder.convs[0], SAGEConv) or self.encoder.convs[0].aggr != "mean"):
             return None
         if getattr(self, "_emb_grad_buf", None) is None:
             self._emb_grad_buf = torch.empty_like(self.emb.weight)
@@ -270,6 +270,7 @@ class BaseModel(object):
         # and the scorer hands it to the last conv's backward in row-sparse form
         channel = None
         if (n_edges > 0 and fused and all(isinstance(c, (SAGEConv, GCNConv)) for c in self.encoder.convs)
+                and getattr(self.encoder.convs[-1], "aggr", "mean") == "mean"
                 and ops.sparse_backward_pays(n_endpoints, x_in.shape[0])):
             channel = kw["output_grad_channel"] = ops.SparseGradChannel()
         # src / dst and the index structures of the gather backward depend on the edges alone: build

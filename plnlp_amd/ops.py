@@ -130,6 +130,51 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
     return out
 
 
+def csr_aggregate_max(graph, x: torch.Tensor, use_values: bool = True, split="auto"):
+    """(out, arg) = max-aggregation of x over the rows of `graph` (plnlp_csr_aggregate_max_f32):
+    out[r] = max_e w_e x[col[e]] (0 for an empty row), arg[r, f] = row-relative position of the first
+    maximal entry (-1 for an empty row)."""
+    lib = L.load()
+    L.require_device(x, graph.col)
+    x = _f32c(x)
+    assert x.shape[0] == graph.n_cols, (x.shape, graph)
+    feat = x.shape[1]
+    out = torch.empty(graph.n_rows, feat, dtype=torch.float32, device=x.device)
+    arg = torch.empty(graph.n_rows, feat, dtype=torch.int32, device=x.device)
+    val = graph.val if use_values else None
+    sp = ws_arg = None
+    if split == "auto":
+        split = graph.row_split(SPLIT_THRESHOLD) if _vector_path(x, out, feat) else None
+    if split is not None and split.active and _vector_path(x, out, feat):
+        ws = torch.empty(split.n_chunks * feat, dtype=torch.float32, device=x.device)
+        ws_arg = torch.empty(split.n_chunks * feat, dtype=torch.int32, device=x.device)
+        sp = L.RowSplit(split.threshold, split.n_long, split.long_rows.data_ptr(), split.chunk_beg.data_ptr(),
+                        split.chunk_cnt.data_ptr(), split.n_chunks, split.chunk_long.data_ptr(), ws.data_ptr(),
+                        ws.numel())
+    L.check(lib.plnlp_csr_aggregate_max_f32(
+        graph.rowptr.data_ptr(), graph.col.data_ptr() or graph.rowptr.data_ptr(), L.ptr(val), x.data_ptr(), _ld(x),
+        out.data_ptr(), _ld(out), arg.data_ptr(), _ld(arg), graph.n_rows, feat,
+        C.byref(sp) if sp is not None else None, L.ptr(ws_arg), L.stream_ptr()), "plnlp_csr_aggregate_max_f32")
+    return out, arg
+
+
+def csr_aggregate_max_bwd(graph, gy: torch.Tensor, arg: torch.Tensor, use_values: bool = True) -> torch.Tensor:
+    """gradient of csr_aggregate_max w.r.t. x: a gather over the transposed CSR
+    (plnlp_csr_aggregate_max_bwd_f32); deterministic, no atomics."""
+    lib = L.load()
+    L.require_device(gy, arg)
+    gy = _f32c(gy)
+    gt, pos = graph.t(), graph.t_pos()
+    feat = gy.shape[1]
+    gx = torch.empty(graph.n_cols, feat, dtype=torch.float32, device=gy.device)
+    val_t = gt.val if use_values else None
+    L.check(lib.plnlp_csr_aggregate_max_bwd_f32(
+        gt.rowptr.data_ptr(), gt.col.data_ptr() or gt.rowptr.data_ptr(), pos.data_ptr() or gt.rowptr.data_ptr(),
+        L.ptr(val_t), gy.data_ptr(), _ld(gy), arg.data_ptr(), _ld(arg), gx.data_ptr(), _ld(gx), graph.n_cols, feat,
+        L.stream_ptr()), "plnlp_csr_aggregate_max_bwd_f32")
+    return gx
+
+
 def _pick_split_k(m: int, n: int, ktiles: int) -> int:
     """split-K so that tiles x slices fills the 512 workgroup slots (256 CUs x 2) exactly once: a
     second, partly filled round leaves SIMDs with one wave (measured: 768 blocks -> 1.27 waves/SIMD,
@@ -719,11 +764,18 @@ class AggregateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, graph: Graph, reduce: str, use_values: bool):
         ctx.graph, ctx.reduce, ctx.use_values = graph, reduce, use_values
+        if reduce == "max":
+            out, arg = csr_aggregate_max(graph, x, use_values)
+            ctx.save_for_backward(arg)
+            return out
         return csr_aggregate(graph, x, reduce, use_values)
 
     @staticmethod
     def backward(ctx, g):
         graph = ctx.graph
+        if ctx.reduce == "max":
+            (arg,) = ctx.saved_tensors
+            return csr_aggregate_max_bwd(graph, g, arg, ctx.use_values), None, None, None
         gt = graph.t()
         if ctx.reduce == "mean" and not (ctx.use_values and graph.val is not None):
             gx = csr_aggregate(graph.t_mean(), g.contiguous(), "sum", True)

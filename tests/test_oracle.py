@@ -355,3 +355,31 @@ def test_dropout_mask_statistics_and_determinism():
     assert (m4 == m1[50:150]).all()
     # column correlation sanity
     assert abs(np.corrcoef(m1[:, 0], m1[:, 1])[0, 1]) < 0.15
+
+
+def test_spmm_max_first_maximum_wins_and_gradient_goes_to_it():
+    """[3P] torch_sparse spmm_max restated (unpinned): checked against a brute-force row loop with
+    strict `>` (first maximal entry in CSR order), empty rows -> 0 / arg -1, gradient to the arg only"""
+    g = torch.Generator().manual_seed(5)
+    r = torch.cat([torch.randint(0, 40, (300,), generator=g), torch.full((90,), 3)])
+    c = torch.randint(0, 40, (390,), generator=g)
+    keep = r != 7
+    csr = O.CSR.from_coo(r[keep], c[keep], torch.rand(int(keep.sum()), generator=g).double() + 0.1, 40)
+    x = torch.randint(-3, 4, (40, 5), generator=g).double().requires_grad_(True)      # ties everywhere
+    out, arg = O.spmm_max(csr, x, True)
+    want_grad = torch.zeros_like(x)
+    for i in range(40):
+        b, e = int(csr.rowptr[i]), int(csr.rowptr[i + 1])
+        for f in range(5):
+            best, a = None, -1
+            for k in range(b, e):
+                v = float(csr.val[k]) * float(x[csr.col[k], f])
+                if best is None or v > best:
+                    best, a = v, k - b
+            assert int(arg[i, f]) == a
+            assert float(out[i, f]) == (0.0 if a < 0 else best)
+            if a >= 0:
+                want_grad[csr.col[b + a], f] += float(csr.val[b + a])
+    out.sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), want_grad.detach().numpy(), rtol=1e-12)
+    assert int(csr.rowptr[8] - csr.rowptr[7]) == 0 and float(out[7].abs().max()) == 0.0
