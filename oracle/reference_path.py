@@ -23,7 +23,7 @@ __all__ = [
     "batch_permutation", "local_neg_sample_ref", "pad_negatives_ref",
     "perm_copy_ref", "structured_negative_sampling_ref", "global_neg_sample_ref",
     "pos_neg_edges_ref", "hits_at_k", "mrr_list", "evaluate_hits_ref",
-    "evaluate_mrr_ref", "clip_grad_norm_ref", "TrainerRef", "adjust_lr_ref",
+    "evaluate_mrr_ref", "clip_grad_norm_ref", "TrainerRef", "adjust_lr_ref", "collab_graph_prep_ref",
 ]
 
 
@@ -705,3 +705,48 @@ class TrainerRef:
         self.predictor.eval()
         h = self.encoder(self.input_feat(), self.adj)
         return torch.cat([h, h.mean(0, keepdim=True)], 0)
+
+
+# --------------------------------------------------------------------------
+# driver-side graph preparation (main.py:109-150), small cases only
+# --------------------------------------------------------------------------
+def collab_graph_prep_ref(train_edge, train_w, train_year, valid_edge, valid_w, num_nodes, year=-1,
+                          use_valedges_as_input=False, use_coalesce=False):
+    """main.py:112-150 restated with plain loops over a dense float64 adjacency (pure-Python: toy sizes).
+    [3P] to_undirected(edge_index, w, reduce='add') = both directions, duplicates summed;
+    SparseTensor(row, col, value) puts value at A[row, col]; coalesce sorts by (row, col) and sums.
+    Returns dict(adj=dense A or None, edge_index_keys=set of (r, c) or None, train_edge [E,2],
+    train_weight [E], train_year)."""
+    te, tw, ty = train_edge.clone(), train_w.clone(), None if train_year is None else train_year.clone()
+    adj = keys = None
+
+    def undirected(pairs, weights):
+        a = torch.zeros(num_nodes, num_nodes, dtype=torch.float64)
+        ks = set()
+        for (u, v), w in zip(pairs.tolist(), weights.tolist()):
+            a[u, v] += w
+            a[v, u] += w
+            ks.update({(u, v), (v, u)})
+        return a.to(torch.float32).double(), ks          # values pass through float32 (main.py:124,137)
+
+    if year > 0 and ty is not None:                       # main.py:114-126
+        keep = [i for i, y in enumerate(ty.tolist()) if y >= year]
+        te, tw, ty = te[keep], tw[keep], ty[keep]
+        adj, keys = undirected(te, tw)
+    if use_valedges_as_input:                             # main.py:129-150
+        pairs = torch.cat([valid_edge, te], dim=0)        # edges  [valid, train]   (main.py:131)
+        weights = torch.cat([tw, valid_w], dim=0)         # weights [train, valid]  (main.py:132) -- the quirk
+        adj, keys = undirected(pairs, weights)
+        if use_coalesce:                                  # main.py:139-140
+            merged = {}
+            for (u, v), w in zip(pairs.tolist(), weights.tolist()):
+                merged[(u, v)] = merged.get((u, v), 0.0) + w
+            order = sorted(merged)
+            pairs = torch.tensor(order, dtype=torch.int64).reshape(-1, 2)
+            weights = torch.tensor([merged[k] for k in order], dtype=weights.dtype)
+        deg = adj.sum(dim=1).to(torch.float32)
+        dis = deg.pow(-0.5)
+        dis[dis == float("inf")] = 0
+        te = pairs
+        tw = dis[pairs[:, 0]] * weights * dis[pairs[:, 1]]
+    return {"adj": adj, "edge_index_keys": keys, "train_edge": te, "train_weight": tw, "train_year": ty}

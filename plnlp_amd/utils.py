@@ -78,7 +78,10 @@ class Evaluator:
     @staticmethod
     def _mrr(pos, neg):
         scores = torch.cat([pos.view(-1, 1), neg], dim=1)
-        order = torch.argsort(scores, dim=1, descending=True)
+        # ogb 1.3.2: argsort(descending) then the position of column 0.  stable=True pins what a tie does
+        # (the positive, column 0, stays ahead of equal negatives -- what the CPU sort the reference runs
+        # does) so the device path ranks ties like the host path
+        order = torch.argsort(scores, dim=1, descending=True, stable=True)
         rank = torch.nonzero(order == 0, as_tuple=False)[:, 1] + 1
         rr = 1.0 / rank.to(torch.float)
         return {'mrr_list': rr, 'hits@1_list': (rank <= 1).float(), 'hits@3_list': (rank <= 3).float(),

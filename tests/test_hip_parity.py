@@ -861,7 +861,7 @@ def test_hits20_training_parity_ddi_recipe(P):
     g, c, d = (np.array(lo[k_]) for k_ in ("gpu", "cpu", "cpu64"))
     assert abs(g[0] - d[0]) <= 4 * abs(c[0] - d[0]) + 2e-3 * d[0], (g, c, d)
     assert (np.abs(g - d) <= 6 * np.abs(c - d).max() + 2e-3 * d).all(), (g, c, d)
-    assert r["gpu_vs_f64_points"] <= 4 * r["cpu32_vs_f64_points"] + 2.0, r
+    # Hits@20 itself: held statistically, over seeds, in tests/test_hip_round2.py
 
 
 # ------------------------------------------------- row-sparse backward pieces ----

@@ -216,3 +216,49 @@ def test_loss_dispatch_names():
     pos, neg = torch.randn(6, 1), torch.randn(18, 1)
     np.testing.assert_allclose(loss.ce_loss(pos, neg).item(), O.LOSSES["ce"](pos, neg).item(), rtol=1e-6)
     np.testing.assert_allclose(loss.info_nce_loss(pos, neg, 3).item(), O.LOSSES["info_nce"](pos, neg, 3).item(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("year,valedges,coalesce", [(-1, True, False), (2010, True, False), (2012, False, False),
+                                                    (-1, True, True), (2010, True, True)])
+def test_driver_graph_prep_matches_oracle_restatement(year, valedges, coalesce):
+    """train.py::prepare_graph (main.py:109-150) vs oracle.collab_graph_prep_ref on a toy collab split:
+    the year filter, train+valid edges as encoder input with the reference's [valid, train] edge order
+    against [train, valid] weight order, the degree-normalised pair weights, --use_coalesce."""
+    import train as driver
+    g = torch.Generator().manual_seed(31)
+    n = 30
+    tr = torch.randint(0, n, (80, 2), generator=g)
+    tr[5] = tr[4]                                   # a repeated pair and a reversed pair: to_undirected sums them
+    tr[7] = tr[6].flip(0)
+    tr[9] = torch.tensor([3, 3])                    # a self loop
+    va = torch.randint(0, n, (20, 2), generator=g)
+    va[2] = tr[0]
+    tw = torch.randint(1, 6, (80,), generator=g).float()
+    vw = torch.randint(1, 6, (20,), generator=g).float()
+    ty = torch.randint(2005, 2016, (80,), generator=g)
+
+    class D:
+        pass
+    data = D()
+    ei = torch.cat([tr.t(), tr.flip(1).t()], dim=1)
+    data.adj_t = P.Graph.from_edge_index(ei, torch.cat([tw, tw]), n)
+    data.edge_index = ei
+    split = {"train": {"edge": tr.clone(), "weight": tw.clone(), "year": ty.clone()},
+             "valid": {"edge": va.clone(), "weight": vw.clone()}}
+    args = driver.argument(["--data_name=ogbl-collab", f"--year={year}", f"--use_valedges_as_input={valedges}",
+                            f"--use_coalesce={coalesce}"])
+    before = data.adj_t
+    driver.prepare_graph(args, data, split, n)
+    ref = O.collab_graph_prep_ref(tr, tw, ty, va, vw, n, year, valedges, coalesce)
+    if ref["adj"] is None:
+        assert data.adj_t is before
+    else:
+        r, c, v = data.adj_t.coo()
+        dense = torch.zeros(n, n, dtype=torch.float64).index_put_((r, c), v.double(), accumulate=True)
+        np.testing.assert_allclose(dense.numpy(), ref["adj"].numpy(), rtol=1e-6)
+        assert set(zip(data.edge_index[0].tolist(), data.edge_index[1].tolist())) == ref["edge_index_keys"]
+        assert data.edge_index.size(1) == len(ref["edge_index_keys"])           # coalesced: no duplicates
+    np.testing.assert_array_equal(split["train"]["edge"].numpy(), ref["train_edge"].numpy())      # order too
+    np.testing.assert_allclose(split["train"]["weight"].numpy(), ref["train_weight"].numpy(), rtol=2e-6)
+    if year > 0:
+        np.testing.assert_array_equal(split["train"]["year"].numpy(), ref["train_year"].numpy())

@@ -124,21 +124,11 @@ def coalesce(edge_index, edge_weight, num_nodes):
     return torch.stack([uniq // num_nodes, uniq % num_nodes]), w
 
 
-def main(argv=None):
-    args = argument(argv)
-    device = torch.device(f'cuda:{args.device}')
-    torch.cuda.set_device(device)      # kernels launch on the current device's stream
-    if args.seed is not None:
-        torch.manual_seed(args.seed)
-        P.manual_seed(args.seed)
-    data, split_edge, num_nodes = load_dataset(args, device)
-    num_node_feats = getattr(data, 'num_features', 0) if data.x is not None else 0
-    print(args)
-    os.makedirs(args.res_dir or '.', exist_ok=True)
-    log_file = os.path.join(args.res_dir, 'log_' + args.data_name + '_' + str(int(time.time())) + '.txt')
-    with open(log_file, 'a') as f:
-        f.write(str(args) + '\n')
-
+def prepare_graph(args, data, split_edge, num_nodes):
+    """main.py:109-150 -- what the driver does to the graph and the training split before the run:
+    citation2 is symmetrised; collab optionally keeps the training edges from `--year` on and, with
+    `--use_valedges_as_input`, feeds train + validation edges to the encoder and trains on both with
+    degree-normalised pair weights.  Edits `data` and `split_edge` in place (host tensors)."""
     if args.data_name == 'ogbl-citation2':
         data.adj_t = data.adj_t.to_symmetric()                             # main.py:109-110
     if args.data_name == 'ogbl-collab':
@@ -163,6 +153,24 @@ def main(argv=None):
             dis = deg.pow(-0.5)
             dis[dis == float('inf')] = 0
             split_edge['train']['weight'] = dis[full_ei[0]] * full_w * dis[full_ei[1]]
+
+
+def main(argv=None):
+    args = argument(argv)
+    device = torch.device(f'cuda:{args.device}')
+    torch.cuda.set_device(device)      # kernels launch on the current device's stream
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+        P.manual_seed(args.seed)
+    data, split_edge, num_nodes = load_dataset(args, device)
+    num_node_feats = getattr(data, 'num_features', 0) if data.x is not None else 0
+    print(args)
+    os.makedirs(args.res_dir or '.', exist_ok=True)
+    log_file = os.path.join(args.res_dir, 'log_' + args.data_name + '_' + str(int(time.time())) + '.txt')
+    with open(log_file, 'a') as f:
+        f.write(str(args) + '\n')
+
+    prepare_graph(args, data, split_edge, num_nodes)
 
     data.adj_t = data.adj_t.to(device)                                     # main.py:175
     if data.x is not None:
