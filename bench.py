@@ -56,8 +56,11 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the Hits@50 GPU-vs-oracle training parity run")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the DP path on 1 GPU)")
-    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "grads", "scores"],
-                    help="what the ranks exchange per step (BaseModel docstring): parameter gradients or score gradients")
+    ap.add_argument("--dp-exchange", default="default", choices=["default", "auto", "grads", "scores", "shard"],
+                    help="what the ranks exchange per step (BaseModel docstring): parameter gradients, score "
+                         "gradients, or -- shard -- activations of a row-sharded encoder.  default: shard for the "
+                         "SAGE-on-embedding workloads (collab, ddi), grads otherwise")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling and control measurements (N > 1)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher check without GPUs: the ranks rendezvous over gloo, do one all-reduce and rank 0 "
                          "prints a JSON line (no kernels run; not a measurement)")
@@ -392,51 +395,82 @@ def main():
     sampler_s = time.perf_counter() - t_s
     assert neg_all.shape == (need, k, 2) and neg_all.is_cuda
 
-    model = P.BaseModel(lr=1e-3, dropout=cfg["dropout"], grad_clip_norm=cfg["clip"],
+    exchange = args.dp_exchange
+    if exchange == "default":
+        exchange = "shard" if (pg is not None and cfg["encoder"] == "SAGE" and feats == 0) else "auto"
+
+    def make_model(group, how):
+        m = P.BaseModel(lr=1e-3, dropout=cfg["dropout"], grad_clip_norm=cfg["clip"],
                         gnn_num_layers=cfg["gnn_layers"], mlp_num_layers=cfg["mlp_layers"],
                         emb_hidden_channels=cfg.get("emb", cfg["hidden"]), gnn_hidden_channels=cfg["hidden"],
                         mlp_hidden_channels=cfg["hidden"], num_nodes=n, num_node_feats=feats,
                         gnn_encoder_name=cfg["encoder"], predictor_name=cfg["predictor"], loss_func=cfg["loss"],
                         optimizer_name="Adam", device=device, use_node_feats=feats > 0, train_node_emb=True,
-                        process_group=pg, dp_exchange=args.dp_exchange)
-    model.param_init()
-    dp_mode = model.dp_mode()
-    model.encoder.train()
-    model.predictor.train()
+                        process_group=group, dp_exchange=how)
+        m.param_init()
+        m.encoder.train()
+        m.predictor.train()
+        return m
 
-    def batch(i):
-        lo = (i * world + rank) * B
-        sl = slice(lo, lo + B)
-        return pos_all[sl], neg_all[sl], (None if w_all is None else w_all[sl])
+    model = make_model(pg, exchange)
+    dp_mode = model.dp_mode()
 
     def sync():
         if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def step(i):
-        if dp_mode == "scores":      # every rank passes the global batch and scores its own slice of it
-            sl = slice(i * world * B, (i + 1) * world * B)
-            return model.train_step_global(data, pos_all[sl], neg_all[sl], k, None if w_all is None else w_all[sl],
-                                           edges_ready=True)
-        p, q, w = batch(i)
-        return model.train_step(data, p, q, k, w, edges_ready=True)     # slices of tensors resident since setup
+    def timed_steps(m, mode, ranks, global_batch, my_rank, collective=True):
+        """W warm-up + K timed steps of `m` at the given GLOBAL batch over `ranks` ranks (every rank holds the
+        same resident edge tensors); returns (seconds of the K steps, max over ranks; last loss)"""
+        def step(i):
+            sl = slice(i * global_batch, (i + 1) * global_batch)
+            wts = None if w_all is None else w_all[sl]
+            if mode == "shard":       # every rank passes the global batch; it scores its own slice of it
+                return m.train_step_sharded(data, pos_all[sl], neg_all[sl], k, wts)
+            if mode == "scores":
+                return m.train_step_global(data, pos_all[sl], neg_all[sl], k, wts, edges_ready=True)
+            per = global_batch // ranks
+            mine = slice(sl.start + my_rank * per, sl.start + (my_rank + 1) * per)
+            return m.train_step(data, pos_all[mine], neg_all[mine], k, None if w_all is None else w_all[mine],
+                                edges_ready=True, global_count=global_batch)
+        fence = sync if collective else torch.cuda.synchronize      # a solo run beside idle ranks: no barrier
+        for i in range(W):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        last = None
+        for i in range(W, W + K):
+            last = step(i)
+        fence()
+        dt = time.perf_counter() - t0
+        if ranks > 1 and collective:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, float(last.item())
 
-    for i in range(W):
-        step(i)
-    sync()
-    t0 = time.perf_counter()
-    loss = None
-    for i in range(W, W + K):
-        loss = step(i)
-    sync()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if pg is not None:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
-    final_loss = float(loss.item())
+    n_ranks = world if pg is not None else 1
+    dt, final_loss = timed_steps(model, dp_mode, n_ranks, B * world, rank)
     edges_per_step = B * (1 + k) * world
+
+    extra = {}
+    if world > 1 and not args.no_strong:
+        # the same job at the reference's FIXED global batch (B positives in total, B / N per rank): what N GPUs
+        # buy for the reference's own step; and, on rank 0 alone, ONE GPU fed the N-fold batch (what the
+        # weak-scaling number would be without any second GPU)
+        dts, _ = timed_steps(model, dp_mode, n_ranks, B, rank)
+        extra["strong_scaling"] = {"global_batch": B, "ms_per_step": dts / K * 1e3,
+                                   "value": B * (1 + k) * K / dts, "unit": "edges/s",
+                                   "note": "same ranks, global batch fixed at the reference's B (B/N per rank)"}
+        if rank == 0:
+            solo = make_model(None, "auto")
+            dtc, _ = timed_steps(solo, "none", 1, B * world, 0, collective=False)
+            extra["control_1gpu_at_Nx_batch"] = {"global_batch": B * world, "ms_per_step": dtc / K * 1e3,
+                                                 "value": B * world * (1 + k) * K / dtc, "unit": "edges/s",
+                                                 "note": "ONE GPU (rank 0, no process group) stepping the N-fold batch"}
+            del solo
+        torch.distributed.barrier()
 
     result = {
         "metric": "pos+neg edges scored/sec", "value": edges_per_step * K / dt, "unit": "edges/s",
@@ -448,12 +482,16 @@ def main():
                                   cfg["predictor"], cfg["loss"], B, k, cfg["dropout"],
                                   "random-walk pairs (walk_length 10)" if cfg["shape"] == "collab"
                                   else "train-edge positives"),
-                   "global_batch": B * world, "parallelism": "dp%d (edge-batch, replicated encoder)" % world,
+                   "global_batch": B * world,
+                   "parallelism": ("dp%d (edge batch sliced over ranks; encoder rows, embedding table and its Adam state "
+                                   "sharded over ranks)" if dp_mode == "shard" else
+                                   "dp%d (edge-batch, replicated encoder)") % world,
                    "dp_exchange": dp_mode, "scale": args.scale, "batch_mult": args.batch_mult},
         "final_loss": final_loss, "negative_sampling_s": sampler_s,
         "negative_sampler": "%s (plnlp_amd.negative_sample, %d negatives in one call)" % (sampler, need * k),
         "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 1,
     }
+    result.update(extra)
     if rank == 0:
         nb = 2 * B
         pos_cpu, neg_cpu = pos_all[:nb].cpu(), neg_all[:nb].cpu()

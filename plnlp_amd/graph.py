@@ -193,6 +193,20 @@ class Graph:
     def cuda(self):
         return self.to("cuda")
 
+    def row_block(self, lo: int, n_rows: int, n_cols: Optional[int] = None) -> "Graph":
+        """destination rows [lo, lo + n_rows) as their own (rectangular) graph: the CSR slice a rank of a
+        row-sharded encoder owns.  Rows past this graph's end are empty rows (every rank's
+        block has the same height, ceil(N / world)); n_cols may be padded the same way."""
+        hi = min(self.n_rows, lo + n_rows)
+        lo_c = min(lo, self.n_rows)
+        e0, e1 = int(self.rowptr[lo_c]), int(self.rowptr[hi])
+        rp = self.rowptr[lo_c:hi + 1] - e0
+        if rp.numel() < n_rows + 1:
+            rp = torch.cat([rp, rp[-1:].expand(n_rows + 1 - rp.numel())])
+        val = None if self.val is None else self.val[e0:e1].contiguous()
+        return Graph(rp.contiguous(), self.col[e0:e1].contiguous(), val, n_rows,
+                     self.n_cols if n_cols is None else int(n_cols))
+
     # ---- transposed view (backward pass) --------------------------------------------
     def t(self) -> "Graph":
         if self._t is None:

@@ -58,6 +58,16 @@ class SAGEConv(torch.nn.Module):
                                     _require_graph(adj_t), act, in_act, sink, channel)
 
 
+    def forward_block(self, x_full, adj_block, row_lo: int, act: _Act = None):
+        """this conv on one destination-row block of a row-sharded encoder: x_full holds every source
+        row, adj_block the rank's CSR slice; returns the block's output rows (ops.SAGEConvBlockFn)"""
+        if self.aggr != "mean":
+            raise NotImplementedError("row-sharded SAGEConv: mean aggregation only")
+        act = act if act is not None else _Act(False, 0.0, False)
+        return ops.SAGEConvBlockFn.apply(x_full, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight,
+                                         _require_graph(adj_block), act, int(row_lo))
+
+
 class GCNConv(torch.nn.Module):
     """PyG 2.0.1 GCNConv(in, out, normalize=False) as used at layer.py:45:
     glorot `lin` without bias, then aggregation with the stored (pre-normalised,
@@ -102,14 +112,35 @@ class BaseGNN(torch.nn.Module):
         for conv in self.convs:
             conv.reset_parameters()
 
+    def _forward_sharded(self, x, adj_block, shard):
+        """row-sharded pass (plnlp_amd/shard.py): x holds ALL source rows, adj_block is this rank's CSR
+        slice; every conv produces the rank's S output rows, and between layers the blocks are
+        all-gathered into the next layer's source matrix (its backward reduce-scatters the gradient)."""
+        last = len(self.convs) - 1
+        for i, conv in enumerate(self.convs):
+            if not isinstance(conv, SAGEConv):
+                raise NotImplementedError("row-sharded encoder: SAGE layers (GCN recipes use dp_exchange='grads')")
+            activated = i < last or self.num_layers == 1
+            act = _Act(True, self.dropout, self.training) if activated else None
+            if act is not None and act.p > 0.0:
+                # a row is computed by exactly one rank and the mask is indexed by the row's position in
+                # the block: give every block its own stream so equal positions do not share a mask
+                act.seed = (act.seed ^ (0x9E3779B97F4A7C15 * (shard.rank + 1))) & 0xFFFFFFFFFFFFFFFF
+            y = conv.forward_block(x, adj_block, shard.lo, act)
+            x = shard.all_gather(y) if i < last else y
+        return x
+
     def forward(self, x, adj_t, fuse_output_gate: bool = False, input_grad_sink=None,
-                output_grad_channel=None):
-        """input_grad_sink: an ops.GradSink for the gradient of `x` (first conv must be a SAGEConv).
+                output_grad_channel=None, shard=None):
+        """shard: a plnlp_amd.shard.ShardContext -> row-sharded pass (see _forward_sharded).
+        input_grad_sink: an ops.GradSink for the gradient of `x` (first conv must be a SAGEConv).
         output_grad_channel: an ops.SparseGradChannel through which the (single) consumer of the
         returned h hands back its gradient row-sparse; only honoured by the native convs.
         fuse_output_gate (only meaningful for a 1-layer encoder, whose output IS a
         relu+dropout result): returns (h, gate_scale) and leaves the derivative of that
         final activation to the consumer's backward (EdgeDotFn), see ops._Act."""
+        if shard is not None:
+            return self._forward_sharded(x, adj_t, shard)
         last = len(self.convs) - 1
         out_act = None
         prev_act = None        # activation that produced the current x (native convs only)

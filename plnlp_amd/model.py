@@ -42,7 +42,13 @@ class BaseModel(object):
                  gradients (4*(1+k)*B bytes) and each then runs the SAME backward pass over the
                  global batch.  Needs a parameter-free scorer (DOT); the replicas stay identical
                  because every kernel is deterministic (check_replicas() verifies it);
-      'auto'   : 'scores' when the predictor has no parameters, else 'grads'."""
+      'auto'   : 'scores' when the predictor has no parameters, else 'grads';
+      'shard'  : the full-graph encoder itself is divided: rank r owns a block of destination rows of the
+                 CSR, of the embedding table and of its Adam state, computes only those rows of every
+                 layer, and the ranks exchange activations (all-gather between layers, an all-to-all of
+                 just the rows a rank's edge slice touches for the scorer) instead of replicating the
+                 encoder -- see plnlp_amd/shard.py and train_step_sharded.  SAGE encoders on the
+                 embedding table (the ddi / collab recipes)."""
 
     def __init__(self, lr, dropout, grad_clip_norm, gnn_num_layers, mlp_num_layers, emb_hidden_channels,
                  gnn_hidden_channels, mlp_hidden_channels, num_nodes, num_node_feats, gnn_encoder_name,
@@ -56,12 +62,15 @@ class BaseModel(object):
         self.clip_norm = grad_clip_norm
         self.device = torch.device(device)
         if self.device.type == "cuda":
-            # the kernels launch on the CURRENT device's current stream (plnlp_amd/_lib.py::stream_ptr)
+            # the kernels launch on the CURRENT device's current stream (plnlp_amd/_lib.py::stream_ptr):
+            # a bare "cuda" means the current device, an indexed one becomes current
+            if self.device.index is None:
+                self.device = torch.device("cuda", torch.cuda.current_device())
             torch.cuda.set_device(self.device)
         self.process_group = process_group
         self.dp_scaling = dp_scaling
-        if dp_exchange not in ("auto", "grads", "scores"):
-            raise ValueError(f"dp_exchange must be auto, grads or scores, not {dp_exchange!r}")
+        if dp_exchange not in ("auto", "grads", "scores", "shard"):
+            raise ValueError(f"dp_exchange must be auto, grads, scores or shard, not {dp_exchange!r}")
         self.dp_exchange = dp_exchange
 
         self.input_channels, self.emb = create_input_layer(
@@ -87,17 +96,64 @@ class BaseModel(object):
         if self.emb is not None:
             self.para_list += list(self.emb.parameters())
 
+        # what the optimiser updates: the parameter list itself, or -- row-sharded -- the small weights
+        # plus only the OWNED rows of the embedding table
+        opt_params = self.para_list
+        self._shard = None
+        if dp_exchange == "shard" and process_group is not None:
+            opt_params = self._setup_shard()
+
         self._fused_step = self.device.type == "cuda" and optimizer_name != 'SGD'
         if self._fused_step:
-            self.optimizer = FusedAdam(self.para_list, lr=lr, decoupled=(optimizer_name == 'AdamW'),
+            self.optimizer = FusedAdam(opt_params, lr=lr, decoupled=(optimizer_name == 'AdamW'),
                                        weight_decay=0.01 if optimizer_name == 'AdamW' else 0.0)
         elif optimizer_name == 'AdamW':
-            self.optimizer = torch.optim.AdamW(self.para_list, lr=lr)
+            self.optimizer = torch.optim.AdamW(opt_params, lr=lr)
         elif optimizer_name == 'SGD':
-            self.optimizer = torch.optim.SGD(self.para_list, lr=lr, momentum=0.9, weight_decay=1e-5,
+            self.optimizer = torch.optim.SGD(opt_params, lr=lr, momentum=0.9, weight_decay=1e-5,
                                              nesterov=True)
         else:
-            self.optimizer = torch.optim.Adam(self.para_list, lr=lr)
+            self.optimizer = torch.optim.Adam(opt_params, lr=lr)
+
+    def _setup_shard(self):
+        """dp_exchange='shard': partition the node rows over the ranks and re-seat the embedding table in a
+        buffer padded to world * S rows.  `emb.weight` stays the full [N, F] table (a view of the buffer:
+        state_dict, eval and the reference-style surface see what they always saw) but is no longer
+        trained directly: the optimiser owns `_emb_shard`, the view of this rank's S rows."""
+        from . import shard
+        if self.emb is None or self.use_node_feats or not self.train_node_emb:
+            raise NotImplementedError("dp_exchange='shard' needs a trainable embedding table as the encoder's only "
+                                      "input (the ddi / collab recipes); use 'grads' otherwise")
+        rank, world = self._world()
+        part = shard.RowPartition(self.num_nodes, world, rank)
+        self._shard = shard.ShardContext(self.process_group, part)
+        w = self.emb.weight
+        full = torch.zeros(part.padded, w.shape[1], dtype=w.dtype, device=self.device)
+        full[:self.num_nodes].copy_(w.detach())
+        w.data = full[:self.num_nodes]
+        w.requires_grad_(False)
+        self._emb_full = full
+        self._emb_shard = torch.nn.Parameter(full[part.lo:part.lo + part.rows])      # same storage
+        self._blocks = {}
+        self._table_work = None
+        return list(self.encoder.parameters()) + list(self.predictor.parameters()) + [self._emb_shard]
+
+    def _table_wait(self):
+        """the embedding table's all-gather of the previous step must have landed before it is read"""
+        if getattr(self, "_table_work", None) is not None:
+            self._table_work.wait()
+            self._table_work = None
+
+    def _adj_block(self, data):
+        """this rank's destination-row slice of data.adj_t (built once per graph object)"""
+        key = id(data.adj_t)
+        hit = self._blocks.get(key)
+        if hit is None or hit[0] is not data.adj_t:
+            part = self._shard.part
+            blk = data.adj_t.row_block(part.lo, part.rows, part.padded)
+            self._blocks = {key: (data.adj_t, blk.to(self.device) if blk.device != self.device else blk)}
+            hit = self._blocks[key]
+        return hit[1]
 
     # ------------------------------------------------------------------ setup ---
     def param_init(self):
@@ -228,6 +284,8 @@ class BaseModel(object):
         """the exchange actually used (see the class docstring)"""
         if self.process_group is None:
             return "none"
+        if self._shard is not None:
+            return "shard"
         scores_ok = not any(True for _ in self.predictor.parameters())
         if self.dp_exchange == "scores" and not scores_ok:
             raise ValueError("dp_exchange='scores' needs a predictor without parameters (DOT)")
@@ -240,6 +298,7 @@ class BaseModel(object):
         because they compute the same deterministic update; this proves it."""
         if self.process_group is None:
             return True
+        self._table_wait()
         acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         for p in self.para_list:
             d = p.detach().double()
@@ -377,6 +436,55 @@ class BaseModel(object):
         self._clip_and_step()
         return loss.detach().reshape(())
 
+    def train_step_sharded(self, data, pos_edge, neg_edge, num_neg, weight_margin=None):
+        """One iteration in dp_exchange='shard' mode (plnlp_amd/shard.py).  Every rank passes the GLOBAL
+        batch (pos_edge [n,2], neg_edge [n,k,2], weights [n]); rank r computes its block of rows of the
+        encoder, scores the slice [r*per, (r+1)*per) of the batch on the rows that slice touches, and
+        owns the update of its block of the embedding table.  The update equals the one-process step
+        on the global batch (model.py:148-167) up to the order of floating-point sums.  Returns the
+        detached loss of the local slice (its share of the global loss)."""
+        from . import shard
+        sc = self._shard
+        rank, world = sc.rank, sc.world
+        self.optimizer.zero_grad(set_to_none=True)
+        n, k = pos_edge.size(0), num_neg
+        per = (n + world - 1) // world
+        neg_flat = neg_edge.reshape(-1, 2)
+        plan = shard.ShardPlan(sc.part, pos_edge, neg_flat, k, per)
+        lo, hi, local = plan.lo, plan.hi, plan.local
+        self._table_wait()
+        x_full = sc.leaf(self._emb_shard, self._emb_full)
+        h_block = self.encoder(x_full, self._adj_block(data), shard=sc)
+        hq = shard.ExchangeRows.apply(h_block, plan, sc.group)             # [rows my slice touches, h]
+        if local > 0:
+            fused = isinstance(self.encoder, BaseGNN) and type(self.predictor) in (DotPredictor, MLPPredictor)
+            if fused and hq.is_cuda and ops.EDGE_BACKWARD["mode"] == "segment":
+                inc = ops.prepare_edge_backward(plan.src_c, plan.dst_c, max(plan.count, 1), compact=False)
+                out = self.predictor.score_edges(hq, plan.src_c, plan.dst_c, incidence=inc)
+            else:
+                out = self._score(hq, plan.src_c, plan.dst_c)
+            loss = self._loss_of_scores(out, local, k, None if weight_margin is None else weight_margin[lo:hi])
+            scale = self._slice_loss_scale(local, n)
+            if scale != 1.0:
+                loss = loss * scale
+        else:                                    # empty slice: still take part in every exchange
+            loss = hq.sum() * 0.0 + h_block.sum() * 0.0
+        if loss.is_cuda and loss.dtype == torch.float32 and local > 0:
+            loss.backward(ops.unit_grad(loss.device))
+        else:
+            loss.backward()
+        small = []
+        for p in list(self.encoder.parameters()) + list(self.predictor.parameters()):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            small.append(p.grad)
+        shard.allreduce_sum(small, sc.group)
+        if self._emb_shard.grad is None:
+            self._emb_shard.grad = torch.zeros_like(self._emb_shard)
+        self._clip_and_step()
+        self._table_work = sc.sync_table(self._emb_full, self._emb_shard)
+        return loss.detach().reshape(())
+
     # ------------------------------------------------------------------ train ---
     def train(self, data, split_edge, batch_size, neg_sampler_name, num_neg):
         """model.py:128-173: one epoch; returns sum(loss_b * B_b) / sum(B_b).
@@ -420,7 +528,7 @@ class BaseModel(object):
         # the per-batch gathers of the epoch tensors run on the side stream, like the rest of a batch's
         # pre-processing (ops.EdgeBatch): they depend on nothing the training steps produce
         side = main = None
-        if self.device.type == "cuda" and ops.PROLOGUE_OVERLAP["enabled"]:
+        if self.device.type == "cuda" and ops.PROLOGUE_OVERLAP["enabled"] and mode != "shard":
             main, side = torch.cuda.current_stream(self.device), ops.side_stream(self.device)
             side.wait_stream(main)              # the epoch tensors above
 
@@ -440,6 +548,12 @@ class BaseModel(object):
             n_b = b.numel()
             perm_all = order[start:start + n_b]
             start += n_b
+            if mode == "shard":
+                pos_b, neg_b, weight_margin = take(perm_all)
+                loss = self.train_step_sharded(data, pos_b, neg_b, num_neg, weight_margin)
+                loss_acc += loss.double() * n_b
+                total_examples += n_b
+                continue
             if world > 1 and mode == "scores":
                 pos_b, neg_b, weight_margin = take(perm_all)
                 loss = self.train_step_global(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None)
@@ -457,9 +571,11 @@ class BaseModel(object):
             loss_acc += loss.double() * n_b
             total_examples += n_b
 
-        if world > 1:
+        if mode == "shard":
+            self._table_wait()
+        if world > 1 or mode == "shard":
             torch.distributed.all_reduce(loss_acc, group=self.process_group)
-            if mode == "scores" and not self.check_replicas():
+            if mode in ("scores", "shard") and not self.check_replicas():
                 raise RuntimeError("data-parallel replicas diverged (dp_exchange='scores' relies on every rank "
                                    "computing the same deterministic update)")
         return loss_acc.item() / max(total_examples, 1)
@@ -485,6 +601,7 @@ class BaseModel(object):
         (model.py:204-206); that pass is redundant and is not repeated."""
         self.encoder.eval()
         self.predictor.eval()
+        self._table_wait()
 
         h = self.encoder(self.create_input_feat(data), data.adj_t)
         # index -1 = unseen node = mean of all seen representations (model.py:191-194)

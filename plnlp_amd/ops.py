@@ -925,6 +925,68 @@ class SAGEConvFn(torch.autograd.Function):
         return gx, gwl, gbl, gwr, None, None, None, None, None
 
 
+def _root_map(graph: Graph, row_lo: int) -> torch.Tensor:
+    """int32 [n_cols]: position of source row r inside the block of destination rows this rank owns
+    (r - row_lo), or -1 outside it -- where the root-path gradient of a row block joins the gradient
+    of all source rows (addend_index of the transposed aggregation's epilogue).  Cached on the graph."""
+    cache = getattr(graph, "_root_maps", None)
+    if cache is None:
+        cache = graph._root_maps = {}
+    if row_lo not in cache:
+        m = torch.full((graph.n_cols,), -1, dtype=torch.int32, device=graph.device)
+        hi = min(graph.n_cols, row_lo + graph.n_rows)
+        m[row_lo:hi] = torch.arange(hi - row_lo, dtype=torch.int32, device=graph.device)
+        cache[row_lo] = m
+    return cache[row_lo]
+
+
+class SAGEConvBlockFn(torch.autograd.Function):
+    """SAGEConv on ONE destination-row block of a row-sharded encoder (plnlp_amd/shard.py):
+        y[S, out] = act( mean_agg_block(x_full) @ Wl^T + bl + x_full[row_lo : row_lo + S] @ Wr^T )
+    `graph` is the rank's CSR slice (S rows, sources anywhere in x_full).  Same kernels as SAGEConvFn;
+    the gradient of x_full is the PARTIAL sum over this block's rows -- all n_cols rows of it: the
+    transposed aggregation writes every source row and adds the root-path term where the source row is
+    one of the block's own (indexed addend epilogue).  The caller reduce-scatters it to the row owners."""
+
+    @staticmethod
+    def forward(ctx, x, w_l, b_l, w_r, graph: Graph, act: _Act, row_lo: int):
+        x = _f32c(x)
+        assert x.shape[0] == graph.n_cols, (x.shape, graph)
+        s = graph.n_rows
+        agg = csr_aggregate(graph, x, "mean", use_values=False)
+        x_root = x[row_lo:row_lo + s]
+        epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+        y = gemm([(agg, w_l), (x_root, w_r)], False, True, epilogue=epi)
+        ctx.graph, ctx.act, ctx.row_lo = graph, act, int(row_lo)
+        ctx.save_for_backward(x, agg, w_l, w_r, y if act.active else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, agg, w_l, w_r, y = ctx.saved_tensors
+        graph, act, row_lo = ctx.graph, ctx.act, ctx.row_lo
+        s = graph.n_rows
+        x_root = x[row_lo:row_lo + s]
+        dz = _act_backward(gy.contiguous(), y, act)
+        need = ctx.needs_input_grad
+        gx = gwl = gbl = gwr = None
+        if need[0]:
+            cin = w_r.shape[1]
+            gx_root, gagg = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin)
+            epi = L.make_epilogue(addend=gx_root, addend_index=_root_map(graph, row_lo))
+            gx = csr_aggregate(graph.t_mean(), gagg, "sum", use_values=True, epilogue=epi)
+        if need[1] and need[3]:
+            gwl, gwr = wgrad_pair(dz, agg, x_root)
+        else:
+            if need[1]:
+                gwl = gemm([(dz, agg)], True, False)
+            if need[3]:
+                gwr = gemm([(dz, x_root)], True, False)
+        if need[2]:
+            gbl = colsum(dz)
+        return gx, gwl, gbl, gwr, None, None, None
+
+
 def _pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 

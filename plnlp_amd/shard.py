@@ -1,0 +1,235 @@
+"""Row-sharded full-graph encoder across the GPUs of one node (SURVEY.md 8e "destination-row
+partition"; the reference itself is single-device, main.py:71-72, and recomputes the whole-graph
+encoder every step, model.py:150-151).
+
+Rank r owns the destination rows [r*S, (r+1)*S), S = ceil(N / world) (rounded up to 4), of
+  * the CSR (its rows list sources anywhere in the graph),
+  * the embedding table and its Adam state,
+  * every layer's output.
+One training step on rank r (plnlp_amd.BaseModel.train_step_sharded):
+
+  forward   layer l:  y_r = conv(x_full, A_r)          aggregation + GEMM over S rows only
+            between layers: x_full = all-gather(y_r)   (AllGatherRows; backward = reduce-scatter)
+            scorer: rank r scores ITS slice of the global edge batch and needs h only at the nodes
+            that slice touches: one all-to-all moves exactly those rows (ExchangeRows) -- at
+            B = 65 536 over 8 ranks that is ~30 K rows per rank instead of the whole [N, h] matrix
+  backward  the row gradients travel back through the same all-to-all and are added per owner in
+            rank order (fixed order -> reproducible); each layer's input gradient is a partial sum
+            over all N rows and is reduce-scattered to the row owners; the few small weights are
+            SUM all-reduced (they stay bit-identical on every rank)
+  update    fused Adam on the small weights (replicated) and on the OWNED embedding rows only,
+            then one in-place all-gather refreshes every rank's copy of the table.
+
+What every rank needs to know about the OTHER ranks' slices (which of my rows they will ask for) it
+computes locally: all ranks hold the same global batch (same seeds), so the request lists need no
+exchange of their own (ShardPlan) -- the only host read-back of a step is the [world, world] table of
+row counts that sizes the all-to-all.
+
+Everything here is torch + torch.distributed (RCCL on the GPU box, gloo in the CPU tests); the
+arithmetic stays in the HIP kernels (ops.SAGEConvBlockFn, the fused scorer)."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class RowPartition:
+    """contiguous, equal-height row blocks; the last ones may be partly (or wholly) padding"""
+
+    def __init__(self, n: int, world: int, rank: int):
+        self.n, self.world, self.rank = int(n), int(world), int(rank)
+        s = (self.n + self.world - 1) // self.world
+        self.rows = max(4, (s + 3) // 4 * 4)          # S: multiple of 4 keeps every block 16-byte aligned
+        self.padded = self.rows * self.world
+        self.lo = self.rank * self.rows
+        self.owned = max(0, min(self.n, self.lo + self.rows) - self.lo)     # real rows in this block
+
+    def __repr__(self):
+        return f"RowPartition(n={self.n}, world={self.world}, rank={self.rank}, rows={self.rows})"
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """[S, F] block of every rank -> [world * S, F]; backward: reduce-scatter of the (partial-sum)
+    gradient to the row owners"""
+
+    @staticmethod
+    def forward(ctx, block, group):
+        ctx.group = group
+        block = block.contiguous()
+        world = dist.get_world_size(group)
+        out = torch.empty(world * block.shape[0], block.shape[1], dtype=block.dtype, device=block.device)
+        dist.all_gather_into_tensor(out, block, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        world = dist.get_world_size(ctx.group)
+        g = g.contiguous()
+        out = torch.empty(g.shape[0] // world, g.shape[1], dtype=g.dtype, device=g.device)
+        dist.reduce_scatter_tensor(out, g, group=ctx.group)
+        return out, None
+
+
+class _ShardedLeaf(torch.autograd.Function):
+    """the full (already synchronised) table as a function of the OWNED rows: forward hands out the
+    replica, backward reduce-scatters the partial gradient of all rows to the owners"""
+
+    @staticmethod
+    def forward(ctx, shard_param, full, group):
+        ctx.group = group
+        ctx.rows = shard_param.shape[0]
+        return full.view_as(full)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = torch.empty(ctx.rows, g.shape[1], dtype=g.dtype, device=g.device)
+        dist.reduce_scatter_tensor(out, g, group=ctx.group)
+        return out, None, None
+
+
+class ShardContext:
+    """what the sharded encoder / trainer need of the process group and the partition"""
+
+    def __init__(self, group, partition: RowPartition):
+        self.group, self.part = group, partition
+        self.rank, self.world = partition.rank, partition.world
+        self.lo, self.rows = partition.lo, partition.rows
+
+    def all_gather(self, block: torch.Tensor) -> torch.Tensor:
+        return _AllGatherRows.apply(block, self.group)
+
+    def leaf(self, shard_param: torch.Tensor, full: torch.Tensor) -> torch.Tensor:
+        return _ShardedLeaf.apply(shard_param, full, self.group)
+
+    @torch.no_grad()
+    def sync_table(self, full: torch.Tensor, shard: torch.Tensor):
+        """full[r*S:(r+1)*S] = rank r's shard, for every r.  `shard` is this rank's block of `full`
+        (same storage): on RCCL the all-gather runs in place (the input is the output's own slice at the
+        rank offset, the in-place form the collective defines); gloo gets a copy of the block.
+        Returns the pending work: the table's readers wait for it (the next step's first aggregation --
+        its edge pre-processing, which does not read the table, overlaps the transfer)."""
+        src = shard.detach()
+        if not full.is_cuda:
+            src = src.clone()
+        return dist.all_gather_into_tensor(full, src, group=self.group, async_op=True)
+
+
+_pinned = {"ring": None, "next": 0}
+
+
+def _pinned_i64(n: int) -> torch.Tensor:
+    """pinned staging for the per-step count table (a small ring: a few plans may be in flight)"""
+    if _pinned["ring"] is None or _pinned["ring"].shape[1] < n:
+        _pinned["ring"] = torch.empty(16, max(n, 128), dtype=torch.int64, pin_memory=True)
+        _pinned["next"] = 0
+    i = _pinned["next"]
+    _pinned["next"] = (i + 1) % 16
+    return _pinned["ring"][i, :n]
+
+
+class ShardPlan:
+    """Who needs which rows for ONE global edge batch.
+
+    Rank q scores the positives [q*per, (q+1)*per) and their negatives; U_q = the distinct endpoints of
+    that slice, in increasing node order, is the row list rank q gathers into its compact matrix
+    H_q [|U_q|, h].  Every rank holds the whole batch, so every rank can tell which of ITS rows each
+    other rank asks for -- flags over the (slice, node) pairs, a prefix sum and one [world, world]
+    count table (the step's one host read-back), no request messages.
+
+      src_c / dst_c : the slice's edges in compact coordinates (row of H_q), positives then negatives
+      send_rows     : block-local ids of my rows the ranks 0 .. W-1 ask for, grouped by asker
+      in_splits     : rows I send to each rank          out_splits : rows each rank sends me
+      count         : |U_me|"""
+
+    def __init__(self, part: RowPartition, pos_edge: torch.Tensor, neg_flat: torch.Tensor, num_neg: int, per: int):
+        W, S, me = part.world, part.rows, part.rank
+        dev = pos_edge.device
+        n = pos_edge.size(0)
+        k = int(num_neg)
+        span = W * S                                      # one slice's id space (node ids < N <= W * S)
+        lo, hi = min(me * per, n), min((me + 1) * per, n)
+        self.lo, self.hi, self.local = lo, hi, hi - lo
+        # slice of every edge of the batch: positives, then the k negatives of each positive
+        sid_pos = torch.arange(n, device=dev, dtype=torch.int64).div_(max(per, 1), rounding_mode="floor")
+        sid = torch.cat([sid_pos, sid_pos.repeat_interleave(k)]) if k > 0 else sid_pos
+        src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]]).to(torch.int64)
+        dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]]).to(torch.int64)
+        base = sid * span
+        vid = torch.cat([base + src, base + dst])          # (slice, node) pairs touched by the batch
+        flags = torch.zeros(W * span, dtype=torch.int32, device=dev)
+        flags.index_fill_(0, vid, 1)
+        csum = torch.cumsum(flags, 0, dtype=torch.int64)
+        cnt = flags.view(W, W, S).sum(dim=-1, dtype=torch.int64)          # [asker, owner]
+        off = torch.zeros(W * W + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(cnt.reshape(-1), 0, out=off[1:])
+        cap = min(vid.numel(), W * span)
+        rows_v = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        pos_v = csum - 1                                    # compact position of a flagged pair
+        rows_v.index_copy_(0, pos_v.index_select(0, vid), vid)            # duplicates write the same value
+        # ---- the one host read-back: the count table
+        if dev.type == "cuda":
+            host = _pinned_i64(off.numel())
+            host.copy_(off, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
+            offs = host.tolist()
+        else:
+            offs = off.tolist()
+        self.count = offs[(me + 1) * W] - offs[me * W]
+        self.out_splits = [offs[me * W + r + 1] - offs[me * W + r] for r in range(W)]
+        self.in_splits = [offs[q * W + me + 1] - offs[q * W + me] for q in range(W)]
+        segs = [rows_v[offs[q * W + me]:offs[q * W + me + 1]] for q in range(W)]
+        self.send_rows = (torch.cat(segs) if W > 1 else segs[0]).remainder(S)
+        # ---- my slice in compact coordinates
+        e_pos = slice(lo, hi)
+        e_neg = slice(n + lo * k, n + hi * k)
+        mine = me * span
+        first = offs[me * W]
+        src_m = torch.cat([src[e_pos], src[e_neg]])
+        dst_m = torch.cat([dst[e_pos], dst[e_neg]])
+        self.src_c = pos_v.index_select(0, src_m + mine) - first
+        self.dst_c = pos_v.index_select(0, dst_m + mine) - first
+        self.rows = rows_v[first:first + self.count] - mine      # global node id of every row of H_me (sorted)
+        self.incidence = None
+
+
+class ExchangeRows(torch.autograd.Function):
+    """H_me = rows U_me of the (row-sharded) encoder output, gathered from their owners by ONE
+    all-to-all; backward: the row gradients return the same way and are added to the owner's block in
+    asker order (each asker's list has distinct rows, the askers are taken one after the other: a
+    fixed summation order)."""
+
+    @staticmethod
+    def forward(ctx, h_block, plan: ShardPlan, group):
+        ctx.plan, ctx.group, ctx.block_shape = plan, group, h_block.shape
+        send = h_block.index_select(0, plan.send_rows)
+        recv = torch.empty(plan.count, h_block.shape[1], dtype=h_block.dtype, device=h_block.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=plan.out_splits, input_split_sizes=plan.in_splits,
+                               group=group)
+        return recv
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        g = g.contiguous()
+        back = torch.empty(plan.send_rows.numel(), g.shape[1], dtype=g.dtype, device=g.device)
+        dist.all_to_all_single(back, g, output_split_sizes=plan.in_splits, input_split_sizes=plan.out_splits,
+                               group=ctx.group)
+        out = torch.zeros(ctx.block_shape, dtype=g.dtype, device=g.device)
+        at = 0
+        for c in plan.in_splits:                       # asker 0, 1, ..: distinct rows within one asker
+            if c:
+                out.index_add_(0, plan.send_rows[at:at + c], back[at:at + c])
+            at += c
+        return out, None, None
+
+
+def allreduce_sum(tensors: List[torch.Tensor], group) -> None:
+    """SUM all-reduce of the (small, replicated) weight gradients, in list order on every rank"""
+    works = [dist.all_reduce(t, group=group, async_op=True) for t in tensors]
+    for w in works:
+        w.wait()

@@ -322,3 +322,86 @@ def test_hits20_ddi_recipe_parity_over_seeds(P):
           f"pooled sigma / sqrt(n) {pooled / np.sqrt(n_seeds):.3f}, per-seed |gpu - cpu| max {np.abs(gpu - cpu).max():.3f}")
     assert gpu.mean() > 1.0 and cpu.mean() > 1.0                  # both actually learn something
     assert diff <= 0.3 or diff <= pooled / np.sqrt(n_seeds), (gpu, cpu)
+
+
+# ------------------------------------------------------- row-sharded encoder ----
+@pytest.mark.parametrize("feat,out", [(64, 32), (256, 256)])
+def test_sage_block_conv_equals_full_conv(P, feat, out):
+    """ops.SAGEConvBlockFn over the 3 destination-row blocks of a graph == SAGEConvFn on the whole
+    graph: outputs equal (same per-row arithmetic), the partial input gradients of the blocks
+    add up to the full one, the weight gradients too (what the reduce-scatter / all-reduce of
+    plnlp_amd/shard.py sum over ranks)."""
+    from plnlp_amd import shard
+    from plnlp_amd.ops import SAGEConvBlockFn, SAGEConvFn, _Act
+    n, W = 301, 3
+    csr = rand_csr(n, 4000, 23, weighted=False, hub=400)
+    g = to_graph(P, csr)
+    part = [shard.RowPartition(n, W, r) for r in range(W)]
+    S, npad = part[0].rows, part[0].padded
+    gen = torch.Generator().manual_seed(1)
+    x = torch.zeros(npad, feat)
+    x[:n] = torch.randn(n, feat, generator=gen)
+    wl, wr = torch.randn(out, feat, generator=gen) * 0.1, torch.randn(out, feat, generator=gen) * 0.1
+    bl = torch.randn(out, generator=gen)
+    gy = torch.randn(npad, out, generator=gen)
+
+    def leaves():
+        return [dev(t).requires_grad_(True) for t in (x, wl, bl, wr)]
+
+    xf, wlf, blf, wrf = leaves()
+    gpad = P.Graph(torch.cat([g.rowptr, g.rowptr[-1:].expand(npad - n)]), g.col, None, npad, npad)
+    y_full = SAGEConvFn.apply(xf, wlf, blf, wrf, gpad, _Act(True, 0.0, True), None, None, None)
+    y_full.backward(dev(gy))
+    acc = None
+    ys = []
+    for r in range(W):
+        xb, wlb, blb, wrb = leaves()
+        blk = g.row_block(part[r].lo, S, npad)
+        yb = SAGEConvBlockFn.apply(xb, wlb, blb, wrb, blk, _Act(True, 0.0, True), part[r].lo)
+        yb.backward(dev(gy)[part[r].lo:part[r].lo + S])
+        ys.append(yb.detach())
+        grads = [xb.grad, wlb.grad, blb.grad, wrb.grad]
+        acc = grads if acc is None else [a + b for a, b in zip(acc, grads)]
+    close(torch.cat(ys), y_full.detach(), rtol=1e-6)          # same kernels, same per-row sums (split-K may regroup)
+    for got, want, name in zip(acc, (xf.grad, wlf.grad, blf.grad, wrf.grad), ("x", "wl", "bl", "wr")):
+        close(got, want, rtol=3e-5, msg=name)
+
+
+def test_sharded_step_on_one_rank_rccl_group_matches_plain_step(P):
+    """BaseModel(dp_exchange='shard') driven through a 1-rank RCCL group on the GPU: every collective of
+    the sharded step runs (all-gather, all-to-all, reduce-scatter, all-reduce), on the HIP kernels, and
+    the losses track the plain single-process trainer from the same weights and batches."""
+    import torch.distributed as dist
+    from test_sharded_encoder import _free_port
+    n, h, B, k = 2000, 64, 1024, 1
+    from plnlp_amd import synthetic
+    g = synthetic.make_graph("collab", seed=4, device="cpu", num_nodes=n, num_edges=12000, weighted=True)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        def make(pg, exchange):
+            m = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=1.0, gnn_num_layers=2, mlp_num_layers=2,
+                            emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n,
+                            num_node_feats=0, gnn_encoder_name="SAGE", predictor_name="DOT",
+                            loss_func="WeightedHingeAUC", optimizer_name="Adam", device="cuda",
+                            use_node_feats=False, train_node_emb=True, process_group=pg, dp_exchange=exchange)
+            torch.manual_seed(31)
+            m.param_init()
+            return m
+        plain, sharded = make(None, "auto"), make(dist.group.WORLD, "shard")
+        assert sharded.dp_mode() == "shard"
+        data = g["data"]
+        data.adj_t = g["adj_t"].to("cuda")
+        split = {"train": {"edge": g["edges"], "weight": g["weight"] / 5.0}}
+        la, lb = [], []
+        for epoch in range(2):
+            torch.manual_seed(50 + epoch)
+            la.append(plain.train(data, split, B, "local", k))
+            torch.manual_seed(50 + epoch)
+            lb.append(sharded.train(data, split, B, "local", k))
+        close(np.array(lb), np.array(la), rtol=2e-4)
+        close(sharded.emb.weight, plain.emb.weight, rtol=1e-3, atol=2e-2)       # Adam: O(lr) on round-off-zero grads
+        assert sharded.check_replicas()
+    finally:
+        dist.destroy_process_group()
