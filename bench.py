@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="collab", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="collab", choices=sorted(WORKLOADS) + ["rmat"],
+                    help="rmat = BASELINE config 5, forward-only row-sharded stress (use --scale <= 0.5 on one GPU)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -115,6 +116,93 @@ def dry_run_cpu(world, rank):
                           "all_reduce_ok": ok, "note": "launcher check only; no kernel ran, not a measurement"}),
               flush=True)
     return 0 if ok else 1
+
+
+def run_rmat_stress(args, P, world, rank, device, pg):
+    """BASELINE.json config 5 -- R-MAT 50 M nodes / 1 B edges, SAGE x2 h = 512, FORWARD ONLY (a training
+    replica of it does not exist: X alone is 102 GB).  Row-sharded: rank r builds and keeps
+    only its destination-row block of the graph, X is replicated, layer 1 produces the rank's rows, ONE
+    all-gather (into X's own storage) makes them the next layer's sources, layer 2 produces the rank's
+    output rows.  --scale shrinks nodes and edges alike (one GPU holds scale <= 0.5)."""
+    from plnlp_amd import synthetic, shard, _lib
+    F = 512
+    n = max(1024, int(round(50_000_000 * args.scale)))
+    nnz = max(4096, int(round(1_000_000_000 * args.scale)))
+    rscale = max(10, (n - 1).bit_length())
+    part = shard.RowPartition(n, world, rank)
+    S, npad = part.rows, part.padded
+    t0 = time.perf_counter()
+    blk = synthetic.rmat_row_block(rscale, nnz, n, part.lo, S, npad, device, seed=11)
+    torch.cuda.synchronize()
+    t_graph = time.perf_counter() - t0
+    gen = torch.Generator(device=device).manual_seed(12)
+    x = torch.empty(npad, F, device=device)
+    step_rows = 1 << 20
+    for lo in range(0, npad, step_rows):                     # same stream on every rank: replicated X
+        x[lo:lo + step_rows].normal_(generator=gen)
+    ws = [torch.randn(F, F, device=device, generator=gen) * 0.03 for _ in range(4)]
+    bs = [torch.zeros(F, device=device) for _ in range(2)]
+    agg = torch.empty(S, F, device=device)
+    y = torch.empty(S, F, device=device)
+    y2 = torch.empty(S, F, device=device)
+
+    def layer(src, out, wl, wr, b, relu):
+        P.ops.csr_aggregate(blk, src, "mean", False, out=agg)
+        P.ops.gemm([(agg, wl), (src[part.lo:part.lo + S], wr)], False, True, out=out,
+                   epilogue=_lib.make_epilogue(bias=b, relu=relu))
+
+    def forward():
+        layer(x, y, ws[0], ws[1], bs[0], True)
+        if pg is not None:
+            torch.distributed.all_gather_into_tensor(x, y, group=pg)       # the layer's output replaces its input
+        else:
+            x[:S].copy_(y)
+        layer(x, y2, ws[2], ws[3], bs[1], False)
+
+    def sync():
+        if pg is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    K, W = args.steps, args.warmup
+    for _ in range(W):
+        forward()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        forward()
+    sync()
+    dt = time.perf_counter() - t0
+    if pg is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    t_agg = time_kernel(lambda: P.ops.csr_aggregate(blk, x, "mean", False, out=agg), iters=5, warm=1)
+    by = agg_bytes(blk.nnz, S, F)
+    checksum = float(y2.double().sum().item())
+    total_nnz = torch.tensor([blk.nnz], dtype=torch.float64, device=device)
+    if pg is not None:
+        torch.distributed.all_reduce(total_nnz)
+    result = {
+        "metric": "edges aggregated/sec, R-MAT forward stress (2 SAGE layers)", "value": 2 * float(total_nnz.item()) * K / dt,
+        "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "R-MAT (.57,.19,.19,.05) N=%d, nnz=%d, SAGE x2 h=512 forward only, X replicated, "
+                               "destination rows sharded over %d rank(s)" % (n, int(total_nnz.item()), world),
+                   "scale": args.scale, "rows_per_rank": S, "parallelism": "row-sharded x%d, one all-gather between layers" % world},
+        "roofline": {"bound": "hbm", "kernel": "csr_agg_vec_kernel (mean, F=512) on this rank's row block",
+                     "achieved": by / t_agg / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by / t_agg / 8.0e12,
+                     "traffic": None, "algorithmic_bytes": by, "kernel_ms": t_agg * 1e3,
+                     "source_MiB": npad * F * 4 / 2 ** 20},
+        "graph_build_s": t_graph, "output_checksum": checksum,
+        "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 1,
+    }
+    if pg is not None:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 def agg_bytes(nnz, n_out, feat, weighted=False):
@@ -332,7 +420,7 @@ def hits_parity(P, device, epochs=12, recipe="collab", with_f64=False, seed=0):
 
 def main():
     args = parse()
-    cfg = WORKLOADS[args.workload]
+    cfg = WORKLOADS.get(args.workload)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))         # nothing has touched the GPU yet in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -355,6 +443,8 @@ def main():
     import plnlp_amd as P
     from plnlp_amd import synthetic
     P._lib.load()
+    if args.workload == "rmat":
+        return run_rmat_stress(args, P, world, rank, device, pg)
 
     K, W, B, k = args.steps, args.warmup, cfg["batch"] * args.batch_mult, cfg["num_neg"]
     torch.manual_seed(1234)
@@ -423,11 +513,20 @@ def main():
     def timed_steps(m, mode, ranks, global_batch, my_rank, collective=True):
         """W warm-up + K timed steps of `m` at the given GLOBAL batch over `ranks` ranks (every rank holds the
         same resident edge tensors); returns (seconds of the K steps, max over ranks; last loss)"""
+        plans = {}
+
         def step(i):
             sl = slice(i * global_batch, (i + 1) * global_batch)
             wts = None if w_all is None else w_all[sl]
             if mode == "shard":       # every rank passes the global batch; it scores its own slice of it
-                return m.train_step_sharded(data, pos_all[sl], neg_all[sl], k, wts)
+                # the request plan of the next batch is started one step ahead, as BaseModel.train does
+                plan = plans.pop(i, None)
+                if plan is None:
+                    plan = m.shard_plan(pos_all[sl], neg_all[sl], k)
+                if i + 1 < W + K:
+                    nx = slice((i + 1) * global_batch, (i + 2) * global_batch)
+                    plans[i + 1] = m.shard_plan(pos_all[nx], neg_all[nx], k)
+                return m.train_step_sharded(data, pos_all[sl], neg_all[sl], k, wts, plan=plan)
             if mode == "scores":
                 return m.train_step_global(data, pos_all[sl], neg_all[sl], k, wts, edges_ready=True)
             per = global_batch // ranks

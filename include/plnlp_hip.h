@@ -111,6 +111,13 @@ int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int64_t thresho
 #define PLNLP_AGG_SHORT_ROWS 1   /* flags: rows average only a few entries -> several rows per wave */
 #define PLNLP_AGG_LDS_STAGE  2   /* flags: small dense graph -> stage feature slabs of x in LDS (needs
                                     n_src * 16 B <= ~150 KiB, 16-byte aligned rows); gathers then hit LDS */
+#define PLNLP_AGG_NT_LOADS   4   /* flags: gathered rows are loaded with the streaming (non-temporal) hint -- for a
+                                    source matrix far beyond the 256 MiB Infinity Cache (F = 256 / 512 forms)   */
+#define PLNLP_AGG_FEW_IN_FLIGHT 8 /* flags: 4 instead of 8 neighbour rows in flight per wave at F = 512 (fewer
+                                    registers -> more waves per SIMD)                                            */
+#define PLNLP_AGG_SLABS_128 16    /* flags: one wave per (row, 128-column slab) instead of one per row: more    */
+#define PLNLP_AGG_SLABS_256 32    /* (256-column slab) independent gather chains in flight -- for a source matrix
+                                     far beyond the caches (HBM-bound); not combined with a dropout epilogue  */
 int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                             const float* val,        /* nullable: [nnz], or indexed through val_index */
                             const int32_t* val_index,/* nullable: [nnz]; weight of entry e = val[val_index[e]] */
@@ -193,6 +200,16 @@ int plnlp_gemm_concat_b_f32(const plnlp_gemm_operand* seg /* HOST ptr, one segme
                             int a_trans, int b_trans, float* c, int64_t ldc, int64_t m, int64_t n,
                             const plnlp_epilogue* epi, int split_k, float* workspace,
                             int64_t workspace_floats, void* stream);
+
+/* both at once -- B read from two buffers along N, the result written to two buffers along N, optional
+ * split-K (the reduce kernel writes the two halves): the two data gradients of SAGEConv without first
+ * concatenating the weights ([gx | gagg] = dz [Wr | Wl]: b = Wr, b2 = Wl), and its two weight gradients
+ * as two contiguous tensors ([dWl | dWr] = dz^T [agg | x]).  b2 nullable (B is then one buffer); no epilogue. */
+int plnlp_gemm_pair_f32(const plnlp_gemm_operand* seg /* HOST ptr, one segment */,
+                        const float* b2, int64_t ldb2, int64_t nb_split,
+                        int a_trans, int b_trans, float* c, int64_t ldc, float* c2, int64_t ldc2,
+                        int64_t n_split, int64_t m, int64_t n, int split_k, float* workspace,
+                        int64_t workspace_floats, void* stream);
 
 /* column sums: out[f] = sum_r x[r,f] (bias gradients; mean row for eval,
  * plnlp/model.py:193).  workspace: [n_blocks, feat] floats, n_blocks returned by

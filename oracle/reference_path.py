@@ -585,10 +585,13 @@ def hits_at_k(pos_pred, neg_pred, k: int) -> float:
 
 
 def mrr_list(pos_pred, neg_pred) -> torch.Tensor:
-    """rank of the positive inside [pos | negs] by descending score, ties by
-    argsort order (positive first)."""
+    """rank of the positive inside [pos | negs] by descending score.  ogb 1.3.2 takes
+    `torch.argsort(y, dim=1, descending=True)` and leaves the order of EQUAL scores to the sort
+    implementation (it differs between torch's CPU and device sorts, and between torch versions); this
+    restatement pins it with a stable sort: the positive (column 0) stays ahead of negatives it ties
+    with.  Without ties the two are the same function."""
     y = torch.cat([pos_pred.reshape(-1, 1), neg_pred], dim=1)
-    order = torch.argsort(y, dim=1, descending=True)
+    order = torch.argsort(y, dim=1, descending=True, stable=True)
     rank = (order == 0).nonzero(as_tuple=False)[:, 1] + 1
     return 1.0 / rank.to(torch.float)
 

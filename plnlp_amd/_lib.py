@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplnlp_hip.so")
+# PLNLP_HIP_LIB: another build of the same ABI (A/B runs of a kernel variant); read once at import
+LIB_PATH = os.environ.get("PLNLP_HIP_LIB") or os.path.join(_HERE, "libplnlp_hip.so")
 
 c_f32p = C.c_void_p   # device pointers travel as integers
 c_i64 = C.c_int64
@@ -51,6 +52,10 @@ EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND = 1, 2, 4, 8, 1
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 AGG_SHORT_ROWS = 1
 AGG_LDS_STAGE = 2
+AGG_NT_LOADS = 4
+AGG_FEW_IN_FLIGHT = 8
+AGG_SLABS_128 = 16
+AGG_SLABS_256 = 32
 LOSS_KINDS = {"auc": 0, "hinge_auc": 1, "weighted_auc": 2, "adaptive_auc": 3,
               "weighted_hinge_auc": 4, "adaptive_hinge_auc": 5, "log_rank": 6}
 
@@ -85,6 +90,9 @@ SIGNATURES = {
     "plnlp_gemm_concat_b_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_void_p, c_i64, c_i64, C.c_int, C.c_int,
                                           C.c_void_p, c_i64, c_i64, c_i64, C.POINTER(Epilogue), C.c_int,
                                           C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_gemm_pair_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_void_p, c_i64, c_i64, C.c_int, C.c_int, C.c_void_p,
+                                      c_i64, C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.c_int, C.c_void_p, c_i64,
+                                      C.c_void_p]),
     "plnlp_colsum_workspace_floats": (c_i64, [c_i64, c_i64]),
     "plnlp_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                    c_i64, C.c_void_p]),

@@ -27,7 +27,20 @@ struct AggGeom {
 };
 
 // gather up to CH neighbour rows (m of them valid, wave-uniform) then accumulate.
-template <int VPL, int LPR, int CH, bool WEIGHTED>
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+// a gathered feature row is used once by this wave: with NT the load carries the streaming hint (the line
+// need not stay in L2 / the Infinity Cache: right when the source matrix is far larger than both)
+template <bool NT>
+__device__ __forceinline__ float4 load_row16(const float4* p) {
+    if constexpr (NT) {
+        const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+
+template <int VPL, int LPR, int CH, bool WEIGHTED, bool NT = false>
 __device__ __forceinline__ void agg_chunk(float4 (&acc)[VPL], const float* __restrict__ x, int64_t ldx,
                                           int cvec, float wvec, int j0, int m, int sub, int grp,
                                           int nslots) {
@@ -47,7 +60,7 @@ __device__ __forceinline__ void agg_chunk(float4 (&acc)[VPL], const float* __res
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
                 int s = sub + k * LPR;
-                v[u][k] = (s < nslots) ? p[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u][k] = (s < nslots) ? load_row16<NT>(p + s) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -80,14 +93,14 @@ __device__ __forceinline__ void agg_chunk(float4 (&acc)[VPL], const float* __res
 }
 
 // accumulate edges [beg, end) of one row into acc (wave-cooperative)
-template <int VPL, int LPR, bool WEIGHTED>
+template <int VPL, int LPR, bool WEIGHTED, int CHX = 0, bool NT = false>
 __device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64_t end,
                                           const int32_t* __restrict__ col, const float* __restrict__ val,
                                           const int32_t* __restrict__ val_index,
                                           const float* __restrict__ src_scale, const int32_t* __restrict__ src_map, const float* __restrict__ x,
                                           int64_t ldx, int lane, int sub, int grp, int nslots) {
     constexpr int NG = 64 / LPR;
-    constexpr int CH = (VPL >= 4) ? 4 : 8;
+    constexpr int CH = CHX > 0 ? CHX : ((VPL >= 4) ? 4 : 8);     // neighbour rows in flight per wave
     for (int64_t e0 = beg; e0 < end; e0 += 64) {
         int n = (int)((end - e0) < 64 ? (end - e0) : 64);
         int cvec = 0;
@@ -121,7 +134,7 @@ __device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64
         for (int j = 0; j < ngroups; j += CH) {
             const int m = (ngroups - j) < CH ? (ngroups - j) : CH;
             if constexpr (NG == 1) {
-                agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j, m, sub, grp, nslots);
+                agg_chunk<VPL, LPR, CH, WEIGHTED, NT>(acc, x, ldx, cvec, wvec, j, m, sub, grp, nslots);
             } else {
                 // a lane group whose neighbour index runs past n must contribute nothing
                 // (not even 0*x: x may hold inf): complete groups first, the ragged one under a select.
@@ -230,18 +243,33 @@ __device__ __forceinline__ void finish_row(float4 (&acc)[VPL], int64_t r, int64_
 }
 
 // main pass: one wave per row; rows longer than skip_above (> 0) are left to the split passes
-template <int VPL, int LPR, bool WEIGHTED>
+template <int VPL, int LPR, bool WEIGHTED, int CHX = 0, bool NT = false>
 __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
-    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, int64_t row_base) {
+    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, int64_t row_base, int slab_feat) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t r = row_base + (int64_t)blockIdx.x * 4 + wave;
     if (r >= n_rows) return;
     const int sub = lane % LPR, grp = lane / LPR;
+    if (slab_feat > 0) {
+        // feature slabs (blockIdx.y): this wave owns columns [c0, c0 + slab_feat) of its row.  A row of a
+        // source matrix far beyond the caches is one chain of dependent round trips (rowptr -> col ->
+        // batches of neighbour rows); a narrow slab puts 64/LPR neighbours into every wave instruction, so
+        // a ~20-neighbour row is fetched in one or two batches instead of three, and there are
+        // feat/slab_feat times as many independent chains in flight (the index lists are re-read per
+        // slab: 4 bytes per 512).  No dropout epilogue here (its counter is the full-width column).
+        const int c0 = blockIdx.y * slab_feat;
+        x += c0;
+        out += c0;
+        if (epi.bias) epi.bias += c0;
+        if (epi.gate) epi.gate += c0;
+        if (epi.addend) epi.addend += c0;
+        feat = (feat - c0) < slab_feat ? (feat - c0) : slab_feat;
+    }
     const int nslots = feat >> 2;
     const int64_t beg = rowptr[r], end = rowptr[r + 1];
     if (skip_above > 0 && end - beg > skip_above) return;
@@ -252,7 +280,7 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     float4 acc[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
+    agg_range<VPL, LPR, WEIGHTED, CHX, NT>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
     finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi, &pre);
@@ -590,24 +618,33 @@ static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, con
                         const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
                         int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp);
 
-template <int VPL, int LPR>
+template <int VPL, int LPR, int CHX = 0, bool NT = false>
 static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* rowptr, const int32_t* col,
                       const float* val, const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x,
                       int64_t ldx, float* out,
-                      int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e, const SplitArgs* sp) {
+                      int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e, const SplitArgs* sp,
+                      int slab_feat = 0) {
     const int64_t skip = sp ? sp->threshold : 0;
     // a launch may not exceed 2^32 threads: beyond 2^22 blocks (16 Mi rows) the rows go in slices
-    constexpr int64_t MAX_BLOCKS = (int64_t)1 << 22;
+    const int n_slabs = slab_feat > 0 ? (feat + slab_feat - 1) / slab_feat : 1;
+    const int64_t MAX_BLOCKS = ((int64_t)1 << 22) / n_slabs;
     const int64_t blocks = grid.x;
     for (int64_t b0 = 0; b0 < blocks; b0 += MAX_BLOCKS) {
-        const dim3 g((unsigned)((blocks - b0) < MAX_BLOCKS ? (blocks - b0) : MAX_BLOCKS));
+        const dim3 g((unsigned)((blocks - b0) < MAX_BLOCKS ? (blocks - b0) : MAX_BLOCKS), (unsigned)n_slabs);
         if (weighted)
-            hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true>), g, dim3(256), 0, s, rowptr, col, val,
-                               val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4);
+            hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true, CHX, NT>), g, dim3(256), 0, s, rowptr, col, val,
+                               val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4,
+                               slab_feat);
         else
-            hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false>), g, dim3(256), 0, s, rowptr, col, val,
-                               val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4);
+            hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false, CHX, NT>), g, dim3(256), 0, s, rowptr, col, val,
+                               val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4,
+                               slab_feat);
         if (int rc = launch_status()) return rc;
+    }
+    if (slab_feat > 0) {      // the long rows' chunk / finalize passes run on the full width
+        if (feat <= 256) return launch_split<1, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
+        if (feat <= 512) return launch_split<2, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
+        return launch_split<4, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
     }
     return launch_split<VPL, LPR>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean,
                                   e, sp);
@@ -728,6 +765,25 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
     }
 #define PLNLP_AGG(VPL, LPR) \
     return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp)
+#define PLNLP_AGGX(VPL, LPR, CHX, NT) \
+    return launch_vec<VPL, LPR, CHX, NT>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp)
+    // feature slabs: 128 or 256 columns per wave (see csr_agg_vec_kernel); rows and slabs fill the grid
+    if ((flags & (PLNLP_AGG_SLABS_128 | PLNLP_AGG_SLABS_256)) && nslots > 32 && !(e.flags & PLNLP_EPI_DROPOUT)) {
+        if ((flags & PLNLP_AGG_SLABS_128))
+            return launch_vec<1, 32>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
+                                     n_rows, (int)feat, mean, e, sp, 128);
+        if (nslots > 64)
+            return launch_vec<1, 64>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
+                                     n_rows, (int)feat, mean, e, sp, 256);
+    }
+    // tuning variants of the full-wave forms (flags): streaming-hint row loads, fewer rows in flight
+    if (nslots > 32 && nslots <= 64 && (flags & PLNLP_AGG_NT_LOADS)) PLNLP_AGGX(1, 64, 0, true);
+    if (nslots > 64 && nslots <= 128) {
+        const bool nt = flags & PLNLP_AGG_NT_LOADS, few = flags & PLNLP_AGG_FEW_IN_FLIGHT;
+        if (nt && few) PLNLP_AGGX(2, 64, 4, true);
+        if (nt) PLNLP_AGGX(2, 64, 0, true);
+        if (few) PLNLP_AGGX(2, 64, 4, false);
+    }
     if (nslots <= 8) PLNLP_AGG(1, 8);
     if (nslots <= 16) PLNLP_AGG(1, 16);
     if (nslots <= 32) PLNLP_AGG(1, 32);
@@ -735,4 +791,5 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
     if (nslots <= 128) PLNLP_AGG(2, 64);
     PLNLP_AGG(4, 64);
 #undef PLNLP_AGG
+#undef PLNLP_AGGX
 }

@@ -67,19 +67,25 @@ struct GemmArgs {
 // ---- global -> registers ------------------------------------------------------
 // K-contiguous operand: rows [row0, row0+128) x k [k0, k0+32); thread t loads
 // float4 at (row0 + (t>>3) + 32p, k0 + 4*(t&7)), p = 0..3.
-template <bool FULL>
+// FAST: 16-byte loads, no branches.  RAGGED (the segment's last K-tile may be partial; needs kdim % 4 == 0):
+// a float4 whose k lies past kdim is loaded from the last valid group instead and zeroed by a select.
+template <bool FAST, bool RAGGED = false>
 __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
     const int kq = (t & 7) * 4 + k0;
-    if constexpr (FULL) {
+    if constexpr (FAST) {
         // 4 independent 16-byte loads, no guards, nothing the compiler must wait on between them.
         // Rows past the matrix edge are CLAMPED to the last row: they read valid memory and only
         // feed output rows that the (guarded) store discards.
+        const bool kin = !RAGGED || kq < kdim;
+        const int kc = (!RAGGED || kq < kdim) ? kq : kdim - 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int64_t row = row0 + (t >> 3) + 32 * p;
             row = row < nrows ? row : nrows - 1;
-            r[p] = *reinterpret_cast<const f32x4*>(base + row * ld + kq);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + row * ld + kc);
+            r[p] = kin ? v : zero;
         }
         return;
     }
@@ -108,24 +114,29 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
 // row-contiguous operand stored [kdim][nrows]: k [k0,k0+32) x rows [row0,row0+128);
 // thread t loads float4 at (k0 + (t>>5) + 8p, row0 + 4*(t&31)).
 // INDEXED: the operand's row for reduction index k is kidx[k] (rows gathered in place).
-template <bool FULL, bool INDEXED = false>
+template <bool FAST, bool INDEXED = false, bool RAGGED = false>
 __device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t,
                                         const int32_t* __restrict__ kidx = nullptr) {
     const int64_t rq = row0 + (t & 31) * 4;
-    if constexpr (FULL) {   // needs nrows % 4 == 0 (checked on the host): clamp whole float4 groups
+    if constexpr (FAST) {   // needs nrows % 4 == 0 (checked on the host): clamp whole float4 groups
         const int64_t rc = rq < nrows ? rq : nrows - 4;
-        if constexpr (INDEXED) {
-            int rows[4];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        int ks[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) rows[p] = kidx[k0 + (t >> 5) + 8 * p];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)rows[p] * ld + rc);
-            return;
+        for (int p = 0; p < 4; ++p) {
+            const int k = k0 + (t >> 5) + 8 * p;
+            ks[p] = (!RAGGED || k < kdim) ? k : kdim - 1;            // a k row past the end: reload the last one
         }
-        const float* q = base + (int64_t)(k0 + (t >> 5)) * ld + rc;
+        if constexpr (INDEXED) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const f32x4*>(q + (int64_t)(8 * p) * ld);
+            for (int p = 0; p < 4; ++p) ks[p] = kidx[ks[p]];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)ks[p] * ld + rc);
+            r[p] = (!RAGGED || k0 + (t >> 5) + 8 * p < kdim) ? v : zero;
+        }
         return;
     }
 #pragma unroll
@@ -162,7 +173,7 @@ __device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (
 // one K-tile of both operands, global -> registers.  The segment is picked with selects (no
 // runtime-indexed struct access: that sent the staging registers to scratch).
 // MODE 0: guarded loads everywhere (unaligned operands); 1: fast loads, every K-tile full;
-// 2: fast loads, except a ragged last K-tile of a segment which takes the guarded (zero-filling) form
+// 2: fast loads, a segment's last K-tile may be partial (k % 4 == 0): out-of-range groups zeroed by selects
 template <bool A_T, bool B_T, int MODE, bool BIDX>
 __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[4], f32x4 (&rb)[4],
                                           int64_t m0, int n0, int t) {
@@ -185,12 +196,15 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
         nb = second ? g.n - g.nb_split : g.nb_split;
         n0 = second ? n0 - g.nb_split : n0;
     }
-    const bool full = (MODE == 1) || (MODE == 2 && k0 + BK <= kdim);
-    if (MODE != 0 && full) {
-        if constexpr (A_T) load_rc<true>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-        else               load_kc<true>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-        if constexpr (B_T) load_kc<true>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
-        else               load_rc<true, BIDX>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
+    // MODE 1 / 2: the fast loaders on every tile (MODE 2 zeroes the k positions past a ragged segment end
+    // with selects) -- no branch decides which loads are issued, so the compiler's counted vmcnt waits
+    // stay exact across the look-ahead
+    if constexpr (MODE != 0) {
+        constexpr bool RG = MODE == 2;
+        if constexpr (A_T) load_rc<true, false, RG>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+        else               load_kc<true, RG>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+        if constexpr (B_T) load_kc<true, RG>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
+        else               load_rc<true, BIDX, RG>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
     } else {
         if constexpr (A_T) load_rc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
         else               load_kc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
@@ -259,6 +273,7 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, con
 #ifndef PLNLP_GEMM_PF
 #define PLNLP_GEMM_PF 2
 #endif
+#ifndef ABL_CLAMPED_LOOP
 template <bool A_T, bool B_T, int MODE, bool BIDX>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
@@ -315,6 +330,54 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
     }
 }
 
+#else
+// ablation (measured on MI355X, profiles/r02_gemm_ab_loop.txt): one loop without a drain phase, every
+// look-ahead load unconditional with its tile index clamped to the slice's last tile.  1-3 % SLOWER than the
+// steady + drain form above on the 8..16-tile shapes of this path (the two `if (live)` regions cost more
+// than the two conditional loads of the drain), so it is not the default.
+template <bool A_T, bool B_T, int MODE, bool BIDX>
+__device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
+                                       int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
+                                       int h) {
+    constexpr int PF = PLNLP_GEMM_PF;
+    f32x4 ra[PF][4], rb[PF][4];
+    // Every global load of the loop is UNCONDITIONAL: a load under a branch (`if (tile + PF < te)`) makes
+    // the compiler assume the younger register sets may never have been issued and wait for vmcnt(0)
+    // before staging the oldest one -- i.e. for the younger sets too, which halves the look-ahead.  The
+    // tile index of a look-ahead load is CLAMPED to the slice's last tile instead: past the end the same
+    // tile is simply fetched again (an L2 hit) and never staged.  Short reductions (K = 180 .. 512: 6 to
+    // 16 tiles, the forward and data-gradient shapes of this path) used to spend a third to a half of their
+    // tiles in a drain loop full of vmcnt(0) waits.
+    const int last = te - 1;          // te >= 1 (a launch has at least one K-tile); an empty slice reloads it, stages nothing
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        const int tl = tb + d < last ? tb + d : last;
+        load_tile<A_T, B_T, MODE, BIDX>(g, tl, ra[d], rb[d], m0, n0, t);
+    }
+    for (int base = tb; base < te; base += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int tile = base + d;
+            const bool live = tile < te;                       // block-uniform; guards no global load
+            const int buf = (tile - tb) & 1;
+            if (live) {
+                stage_tile<A_T, B_T>(lds, buf, ra[d], rb[d], t);
+#ifndef ABL_NOBARRIER
+                __syncthreads();
+#endif
+            }
+#ifndef ABL_NOGLOAD
+            {
+                const int tn = tile + PF < last ? tile + PF : last;
+                load_tile<A_T, B_T, MODE, BIDX>(g, tn, ra[d], rb[d], m0, n0, t);
+            }
+#endif
+            if (live) mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
+        }
+    }
+}
+
+#endif
 // MODE (see load_tile): separate kernels so the hot loop of the aligned case carries no guarded
 // code at all (pure dwordx4 loads, nothing between their issue and the MFMAs).
 template <bool A_T, bool B_T, int MODE, bool BIDX = false>
@@ -441,12 +504,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
 }
 
 // sum split-K slices in slice order, apply the epilogue.  16 bytes per thread, 8 slices in flight.
+// c2 != nullptr: result columns >= n_split go to c2[:, col - n_split] (the pair form; no epilogue there)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split_k,
                                                             int64_t stride, float* __restrict__ c, int64_t ldc,
-                                                            int64_t m, int n, Epi epi) {
+                                                            int64_t m, int n, Epi epi, float* __restrict__ c2,
+                                                            int64_t ldc2, int n_split) {
     const int64_t total = m * (int64_t)n;
     const bool vec = (n % 4 == 0) && (stride % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)ws % 16 == 0) &&
-                     ((uintptr_t)c % 16 == 0);
+                     ((uintptr_t)c % 16 == 0) &&
+                     (!c2 || ((n_split % 4 == 0) && (ldc2 % 4 == 0) && ((uintptr_t)c2 % 16 == 0)));
     if (vec) {
         const int64_t total4 = total >> 2;
         for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
@@ -464,8 +530,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             const int64_t i = i4 * 4;
             const int64_t row = i / n;
             const int col = (int)(i - row * n);
-            float* o = c + row * ldc + col;
             float4 y = make_float4(acc.x, acc.y, acc.z, acc.w);
+            if (c2 && col >= n_split) {
+                *reinterpret_cast<float4*>(c2 + row * ldc2 + (col - n_split)) = y;
+                continue;
+            }
+            float* o = c + row * ldc + col;
             y = epi_apply4(epi, y, row, col, n, c + row * ldc);
             *reinterpret_cast<float4*>(o) = y;
         }
@@ -476,6 +546,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (int zz = 0; zz < split_k; ++zz) v += ws[(int64_t)zz * stride + i];
         const int64_t row = i / n;
         const int col = (int)(i - row * n);
+        if (c2 && col >= n_split) { c2[row * ldc2 + (col - n_split)] = v; continue; }
         float* p = c + row * ldc + col;
         if (epi.flags) {
             const float prev = (epi.flags & PLNLP_EPI_ACCUM) ? *p : 0.f;
@@ -501,6 +572,20 @@ extern "C" int plnlp_gemm_concat_b_f32(const plnlp_gemm_operand* seg, const floa
     if (ldb2 < (b_trans ? seg->k : n - nb_split)) return PLNLP_E_SHAPE;
     return gemm_impl(seg, 1, a_trans, b_trans, c, ldc, m, n, nullptr, 0, n, epi, split_k, workspace,
                      workspace_floats, stream, b2, ldb2, nb_split);
+}
+
+extern "C" int plnlp_gemm_pair_f32(const plnlp_gemm_operand* seg, const float* b2, int64_t ldb2, int64_t nb_split,
+                                   int a_trans, int b_trans, float* c, int64_t ldc, float* c2, int64_t ldc2,
+                                   int64_t n_split, int64_t m, int64_t n, int split_k, float* workspace,
+                                   int64_t workspace_floats, void* stream) {
+    if (!seg || !c2) return PLNLP_E_NULL;
+    if (n_split <= 0 || n_split >= n || ldc < n_split || ldc2 < n - n_split) return PLNLP_E_SHAPE;
+    if (b2) {
+        if (nb_split <= 0 || nb_split >= n || nb_split % 128 != 0) return PLNLP_E_SHAPE;
+        if (ldb2 < (b_trans ? seg->k : n - nb_split)) return PLNLP_E_SHAPE;
+    }
+    return gemm_impl(seg, 1, a_trans, b_trans, c, ldc, m, n, c2, ldc2, n_split, nullptr, split_k, workspace,
+                     workspace_floats, stream, b2, ldb2, b2 ? nb_split : -1);
 }
 
 extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c,
@@ -568,47 +653,22 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         g.c = c; g.ldc = ldc;
     }
     if (gm * gn > 0x7FFFFFFF) return PLNLP_E_SHAPE;
-    // aligned operands take the fast loaders (edge rows clamped).  A ragged K tail is one guarded tile
-    // (MODE 2); under split-K it is peeled into its own extra slice so the hot slices stay MODE 1.
+    // aligned operands take the fast loaders (edge rows clamped).
     bool aligned = true, ragged = false;
     for (int si = 0; si < n_seg; ++si) {
         aligned = aligned && g.seg[si].a_vec && g.seg[si].b_vec;
-        ragged = ragged || (g.seg[si].k % BK != 0);
+        if (g.seg[si].k % BK != 0) {
+            ragged = true;
+            // a K-contiguous operand is cut in whole 16-byte groups: the ragged form needs k % 4 == 0
+            if ((!a_trans || b_trans) && g.seg[si].k % 4 != 0) aligned = false;
+        }
     }
     if (b2) aligned = aligned && ((uintptr_t)b2 % 16 == 0) && (ldb2 % 4 == 0) && ((n - nb_split) % 4 == 0);
     if (a_trans) aligned = aligned && (m % 4 == 0) && m >= 4;    // row-contiguous operands move 4 rows per load
     if (!b_trans) aligned = aligned && (n % 4 == 0) && n >= 4;
     int mode = !aligned ? 0 : (ragged ? 2 : 1);
-    int reduce_slices = split_k;
-    GemmArgs tail{};
-    bool peel = false;
-    if (mode == 2 && split_k > 1 && n_seg == 1 && g.seg[0].k >= 2 * BK &&
-        workspace_floats >= (int64_t)(split_k + 1) * m * n) {
-        const int kfull = (g.seg[0].k / BK) * BK;
-        tail = g;
-        tail.seg[0].a = a_trans ? g.seg[0].a + (int64_t)kfull * g.seg[0].lda : g.seg[0].a + kfull;
-        if (g.seg[0].b_index) {                     // gathered rows: the tail advances the index, not B
-            tail.seg[0].b_index = g.seg[0].b_index + kfull;
-        } else {
-            tail.seg[0].b = b_trans ? g.seg[0].b + kfull : g.seg[0].b + (int64_t)kfull * g.seg[0].ldb;
-            if (b2) tail.b2 = b_trans ? b2 + kfull : b2 + (int64_t)kfull * ldb2;
-        }
-        tail.seg[0].k = g.seg[0].k - kfull;
-        tail.seg[0].a_vec = tail.seg[0].b_vec = 0;
-        tail.tiles0 = tail.tiles_total = 1;
-        tail.split_k = split_k + 1;     // > 1: raw write into the workspace
-        tail.z0 = split_k;
-        g.seg[0].k = kfull;
-        g.tiles0 = g.tiles_total = kfull / BK;
-        if (split_k > g.tiles_total) split_k = g.tiles_total;
-        g.split_k = split_k;
-        reduce_slices = split_k + 1;
-        tail.z0 = split_k;
-        mode = 1;
-        peel = true;
-    }
+    const int reduce_slices = split_k;
     g.mt0 = 0; g.nt0 = 0; g.gm = gm; g.gn = (int)gn; g.z0 = 0;
-    tail.mt0 = 0; tail.nt0 = 0; tail.gm = gm; tail.gn = (int)gn;
     auto launch = [&](const GemmArgs& ga, int md, int slices) -> int {
         dim3 grid((unsigned)(gm * gn), 1, (unsigned)slices);
 #define PLNLP_GEMM_M(AT, BT)                                                                              \
@@ -631,14 +691,13 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         return launch_status();
     };
     if (int rc = launch(g, mode, split_k)) return rc;
-    if (peel) { if (int rc = launch(tail, 0, 1)) return rc; }
     if (split_k > 1) {
         const int64_t total = m * n;
         int64_t blocks = (total / 4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, reduce_slices,
-                           g.ws_stride, c, ldc, m, (int)n, e);
+                           g.ws_stride, c, ldc, m, (int)n, e, c2, ldc2, (int)n_split);
         return launch_status();
     }
     return 0;

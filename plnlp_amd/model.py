@@ -436,13 +436,27 @@ class BaseModel(object):
         self._clip_and_step()
         return loss.detach().reshape(())
 
-    def train_step_sharded(self, data, pos_edge, neg_edge, num_neg, weight_margin=None):
+    def shard_plan(self, pos_edge, neg_edge, num_neg):
+        """start the request plan of a FUTURE global batch on the side stream (plnlp_amd/shard.py::ShardPlan):
+        it depends on the edges alone, so the trainer starts it one batch ahead -- its device work runs in
+        the shadow of the current step and its count table is on the host by the time the step needs it.
+        The edge tensors must not be the output of work still pending on the current stream."""
+        from . import shard
+        n = pos_edge.size(0)
+        per = (n + self._shard.world - 1) // self._shard.world
+        stream = None
+        if pos_edge.is_cuda and ops.PROLOGUE_OVERLAP["enabled"]:
+            stream = ops.side_stream(self.device)
+        return shard.ShardPlan(self._shard.part, pos_edge, neg_edge.reshape(-1, 2), num_neg, per, stream=stream)
+
+    def train_step_sharded(self, data, pos_edge, neg_edge, num_neg, weight_margin=None, plan=None):
         """One iteration in dp_exchange='shard' mode (plnlp_amd/shard.py).  Every rank passes the GLOBAL
         batch (pos_edge [n,2], neg_edge [n,k,2], weights [n]); rank r computes its block of rows of the
         encoder, scores the slice [r*per, (r+1)*per) of the batch on the rows that slice touches, and
         owns the update of its block of the embedding table.  The update equals the one-process step
         on the global batch (model.py:148-167) up to the order of floating-point sums.  Returns the
-        detached loss of the local slice (its share of the global loss)."""
+        detached loss of the local slice (its share of the global loss).
+        plan: shard_plan(...) of this same batch, started earlier (else it is built here, in line)."""
         from . import shard
         sc = self._shard
         rank, world = sc.rank, sc.world
@@ -450,17 +464,20 @@ class BaseModel(object):
         n, k = pos_edge.size(0), num_neg
         per = (n + world - 1) // world
         neg_flat = neg_edge.reshape(-1, 2)
-        plan = shard.ShardPlan(sc.part, pos_edge, neg_flat, k, per)
+        fused = isinstance(self.encoder, BaseGNN) and type(self.predictor) in (DotPredictor, MLPPredictor)
+        want_inc = fused and pos_edge.is_cuda and ops.EDGE_BACKWARD["mode"] == "segment"
+        if plan is None:
+            plan = shard.ShardPlan(sc.part, pos_edge, neg_flat, k, per)
+        plan.finish(build_incidence=want_inc)
         lo, hi, local = plan.lo, plan.hi, plan.local
         self._table_wait()
         x_full = sc.leaf(self._emb_shard, self._emb_full)
         h_block = self.encoder(x_full, self._adj_block(data), shard=sc)
+        plan.join()
         hq = shard.ExchangeRows.apply(h_block, plan, sc.group)             # [rows my slice touches, h]
         if local > 0:
-            fused = isinstance(self.encoder, BaseGNN) and type(self.predictor) in (DotPredictor, MLPPredictor)
-            if fused and hq.is_cuda and ops.EDGE_BACKWARD["mode"] == "segment":
-                inc = ops.prepare_edge_backward(plan.src_c, plan.dst_c, max(plan.count, 1), compact=False)
-                out = self.predictor.score_edges(hq, plan.src_c, plan.dst_c, incidence=inc)
+            if want_inc:
+                out = self.predictor.score_edges(hq, plan.src_c, plan.dst_c, incidence=plan.incidence)
             else:
                 out = self._score(hq, plan.src_c, plan.dst_c)
             loss = self._loss_of_scores(out, local, k, None if weight_margin is None else weight_margin[lo:hi])
@@ -544,13 +561,39 @@ class BaseModel(object):
                     t.record_stream(main)
             return out
 
-        for b in batches:
+        pending = None
+
+        def shard_batch(perm, first):
+            """gather one global batch on the side stream and start its request plan there"""
+            if self.device.type == "cuda" and ops.PROLOGUE_OVERLAP["enabled"]:
+                cur, sd = torch.cuda.current_stream(self.device), ops.side_stream(self.device)
+                if first:
+                    sd.wait_stream(cur)                 # the epoch tensors were produced on the current stream
+                with torch.cuda.stream(sd):
+                    got = take(perm)
+                for t in got:
+                    if t is not None:
+                        t.record_stream(cur)
+            else:
+                got = take(perm)
+            return got + (self.shard_plan(got[0], got[1], num_neg),)
+
+        for bi, b in enumerate(batches):
             n_b = b.numel()
             perm_all = order[start:start + n_b]
             start += n_b
             if mode == "shard":
-                pos_b, neg_b, weight_margin = take(perm_all)
-                loss = self.train_step_sharded(data, pos_b, neg_b, num_neg, weight_margin)
+                # one batch of look-ahead: the request plan of the NEXT batch is started before this step
+                # is enqueued, so its device work and its count read-back hide behind this step
+                if pending is None:
+                    pending = shard_batch(perm_all, True)
+                pos_b, neg_b, weight_margin, plan_b = pending
+                pending = None
+                if bi + 1 < len(batches):
+                    pending = shard_batch(order[start:start + batches[bi + 1].numel()], False)
+                # (the step touches the batch tensors only after plan.join(), which orders the main stream
+                # behind everything the side stream did for this batch, the gather included)
+                loss = self.train_step_sharded(data, pos_b, neg_b, num_neg, weight_margin, plan=plan_b)
                 loss_acc += loss.double() * n_b
                 total_examples += n_b
                 continue

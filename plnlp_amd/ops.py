@@ -86,7 +86,7 @@ def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
 def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
                   src_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                   epilogue: Optional[L.Epilogue] = None, split="auto", short_rows="auto",
-                  lds_stage="auto", src_map: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  lds_stage="auto", src_map: Optional[torch.Tensor] = None, tune: int = 0) -> torch.Tensor:
     """out[r] = red_{e in row r} w_e x[col[e]]  (plnlp_csr_aggregate_f32).
     `graph` needs rowptr/col/val/n_rows/n_cols (+ row_split() when split == 'auto').
     src_map (int32 [n_cols]): x holds only some source rows; entry e reads x[src_map[col[e]]] and
@@ -108,7 +108,7 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
     if lds_stage == "auto":      # small AND dense (ddi-like): feature slabs of x fit in LDS and are reused
         lds_stage = (LDS_STAGE_AUTO and graph.n_cols * 16 <= LDS_STAGE_BUDGET
                      and graph.col.numel() >= LDS_STAGE_MIN_DEG * graph.n_cols and feat % 4 == 0)
-    flags = (L.AGG_SHORT_ROWS if short_rows else 0) | (L.AGG_LDS_STAGE if lds_stage else 0)
+    flags = (L.AGG_SHORT_ROWS if short_rows else 0) | (L.AGG_LDS_STAGE if lds_stage else 0) | int(tune)
     if lds_stage:
         split = None             # the staged form walks whole rows
     sp = None
@@ -228,31 +228,59 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
 
 
 def wgrad_pair(dz: torch.Tensor, x1: torch.Tensor, x2: torch.Tensor, rows: Optional[torch.Tensor] = None):
-    """[dW1 | dW2] = dz^T [x1 | x2] in one split-K GEMM (plnlp_gemm_concat_b_f32): dz is read once.
-    Falls back to two products when the seam would cut a 128-column tile.
+    """(dW1, dW2) = dz^T x1, dz^T x2 in one split-K GEMM that reads dz once (gemm_pair); two products when
+    the seam would cut a 128-column tile.
     rows (int32 [K]): dz holds only those rows of a row-sparse gradient; x1 / x2 are read at
     rows[j] (gathered inside the GEMM's loader)."""
-    lib = L.load()
-    L.require_device(dz, x1, x2, rows)
-    dz, x1, x2 = _f32c(dz), _f32c(x1), _f32c(x2)
-    k, m = dz.shape
-    n1, n2 = x1.shape[1], x2.shape[1]
-    if n1 % 128 != 0:
+    out = gemm_pair(dz, x1, x2, True, rows=rows)
+    if out is None:
         return (gemm([(dz, x1)], True, False, b_index=rows), gemm([(dz, x2)], True, False, b_index=rows))
+    return out
+
+
+def dgrad_pair(dz: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, out1: Optional[torch.Tensor] = None):
+    """(dz @ w1, dz @ w2) for two weights stored [out, in] (nn.Linear layout): one launch, dz read once,
+    no concatenated copy of the weights (gemm_pair); the concatenated form when the seam does not fit"""
+    out = gemm_pair(dz, w1, w2, False, out1=out1)
+    if out is None:
+        return gemm_split_out(dz, torch.cat([w1, w2], dim=1), w1.shape[1], out1=out1)
+    return out
+
+
+def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool, out1: Optional[torch.Tensor] = None,
+              rows: Optional[torch.Tensor] = None):
+    """(c1, c2) = op(a) @ b1, op(a) @ b2 in ONE launch (plnlp_gemm_pair_f32): `a` is read once, B comes
+    from the two buffers as they are (no concatenated copy) and the two results are two contiguous
+    tensors (no strided halves to copy out).  b1 / b2: [K, n1] / [K, n2] (row-contiguous).
+      a_trans=False: a [M, K]   -- the two data gradients of SAGEConv  [gx | gagg] = dz [Wr | Wl]
+      a_trans=True : a [K, M]   -- its two weight gradients  [dWl | dWr] = dz^T [agg | x]  (split-K;
+                                  rows (int32 [K]): b1 / b2 are read at rows[j], gathered in the loader)
+    None when the seam would cut a 128-column tile (the caller falls back to two products)."""
+    n1, n2 = b1.shape[1], b2.shape[1]
+    if n1 % 128 != 0:
+        return None
+    lib = L.load()
+    L.require_device(a, b1, b2, rows)
+    a, b1, b2 = _f32c(a), _f32c(b1), _f32c(b2)
+    k, m = (a.shape[0], a.shape[1]) if a_trans else (a.shape[1], a.shape[0])
     n = n1 + n2
     ops = (L.GemmOperand * 1)()
-    ops[0].a, ops[0].lda, ops[0].b, ops[0].ldb, ops[0].k = dz.data_ptr(), _ld(dz), x1.data_ptr(), _ld(x1), k
+    ops[0].a, ops[0].lda, ops[0].b, ops[0].ldb, ops[0].k = a.data_ptr(), _ld(a), b1.data_ptr(), _ld(b1), k
     if rows is not None:
-        assert rows.dtype == torch.int32 and rows.numel() == k
+        assert rows.dtype == torch.int32 and rows.numel() == k and a_trans
         ops[0].b_index = rows.data_ptr()
+    else:
+        assert b1.shape[0] == k and b2.shape[0] == k, (a.shape, b1.shape, b2.shape)
     ktiles = (k + 31) // 32
-    split_k = max(1, min(_pick_split_k(m, n, ktiles), ktiles))
-    out = torch.empty(m, n, dtype=torch.float32, device=dz.device)
-    ws = torch.empty((split_k + 1) * m * n, dtype=torch.float32, device=dz.device) if split_k > 1 else None
-    L.check(lib.plnlp_gemm_concat_b_f32(ops, x2.data_ptr(), _ld(x2), n1, 1, 0, out.data_ptr(), _ld(out), m, n,
-                                        None, split_k, L.ptr(ws), 0 if ws is None else ws.numel(),
-                                        L.stream_ptr()), "plnlp_gemm_concat_b_f32")
-    return out[:, :n1].contiguous(), out[:, n1:].contiguous()
+    split_k = max(1, min(_pick_split_k(m, n, ktiles), ktiles)) if a_trans else 1
+    c1 = out1 if out1 is not None else torch.empty(m, n1, dtype=torch.float32, device=a.device)
+    assert c1.shape == (m, n1) and c1.is_contiguous()
+    c2 = torch.empty(m, n2, dtype=torch.float32, device=a.device)
+    ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device) if split_k > 1 else None
+    L.check(lib.plnlp_gemm_pair_f32(ops, b2.data_ptr(), _ld(b2), n1, int(a_trans), 0, c1.data_ptr(), _ld(c1),
+                                    c2.data_ptr(), _ld(c2), n1, m, n, split_k, L.ptr(ws),
+                                    0 if ws is None else ws.numel(), L.stream_ptr()), "plnlp_gemm_pair_f32")
+    return c1, c2
 
 
 def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool = False,
@@ -836,8 +864,7 @@ class SAGEConvFn(torch.autograd.Function):
         if need[0]:
             # both data gradients in ONE GEMM: [gx | gagg] = dz @ [Wr | Wl]  (dz read once)
             cin = w_r.shape[1]
-            gx, gagg = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin,
-                                      out1=sink.buffer if sink is not None else None)
+            gx, gagg = dgrad_pair(dz, w_r, w_l, out1=sink.buffer if sink is not None else None)
             ia = ctx.in_act
             epi = L.make_epilogue(accumulate=True, gate=x if ia is not None else None,
                                   gate_scale=ia.scale if ia is not None else 1.0)
@@ -900,7 +927,7 @@ class SAGEConvFn(torch.autograd.Function):
                     zero(w_r) if need[3] else None, None, None, None, None, None)
         if need[0]:
             cin = w_r.shape[1]
-            gx_c, gagg_c = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin)
+            gx_c, gagg_c = dgrad_pair(dz, w_r, w_l)
             ia = ctx.in_act
             epi = L.make_epilogue(addend=gx_c, addend_index=sg.node_map, gate=x if ia is not None else None,
                                   gate_scale=ia.scale if ia is not None else 1.0)
@@ -972,7 +999,7 @@ class SAGEConvBlockFn(torch.autograd.Function):
         gx = gwl = gbl = gwr = None
         if need[0]:
             cin = w_r.shape[1]
-            gx_root, gagg = gemm_split_out(dz, torch.cat([w_r, w_l], dim=1), cin)
+            gx_root, gagg = dgrad_pair(dz, w_r, w_l)
             epi = L.make_epilogue(addend=gx_root, addend_index=_root_map(graph, row_lo))
             gx = csr_aggregate(graph.t_mean(), gagg, "sum", use_values=True, epilogue=epi)
         if need[1] and need[3]:
@@ -1067,12 +1094,15 @@ class GCNInputConvFn(torch.autograd.Function):
             fpad[:, :f].copy_(feats)
             csr_aggregate(graph, fpad, "sum", use_values=True, out=ax[:, ep:])        # A_hat x, once
             st = {"key": key, "graph": graph, "feats": feats, "ax": ax,
-                  "emb_pad": torch.zeros(n, ep, dtype=torch.float32, device=ax.device)}
+                  "emb_pad": torch.zeros(n, ep, dtype=torch.float32, device=ax.device),
+                  # W in the aggregated operand's layout; the pad columns stay zero, the two blocks are
+                  # refreshed per step (two copies instead of a fresh zero-filled matrix)
+                  "wa": torch.zeros(w.shape[0], ep + fp, dtype=torch.float32, device=w.device)}
             cache["gcn_input"] = st
         ax, emb_pad = st["ax"], st["emb_pad"]
         emb_pad[:, :e].copy_(emb_weight.detach())
         csr_aggregate(graph, emb_pad, "sum", use_values=True, out=ax[:, :ep])          # A_hat emb, every step
-        wa = torch.zeros(w.shape[0], ep + fp, dtype=torch.float32, device=w.device)    # W in the operand's layout
+        wa = st["wa"]
         wa[:, :e].copy_(w[:, :e])
         wa[:, ep:ep + f].copy_(w[:, e:])
         epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)

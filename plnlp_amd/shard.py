@@ -144,57 +144,116 @@ class ShardPlan:
       in_splits     : rows I send to each rank          out_splits : rows each rank sends me
       count         : |U_me|"""
 
-    def __init__(self, part: RowPartition, pos_edge: torch.Tensor, neg_flat: torch.Tensor, num_neg: int, per: int):
+    def __init__(self, part: RowPartition, pos_edge: torch.Tensor, neg_flat: torch.Tensor, num_neg: int, per: int,
+                 stream=None):
+        """phase 1: everything that depends on the batch alone, enqueued on `stream` (the trainer's side
+        stream, one batch AHEAD of the step that uses it) or on the current stream, ending with the
+        asynchronous copy of the count table to pinned memory.  finish() picks the table up."""
         W, S, me = part.world, part.rows, part.rank
         dev = pos_edge.device
-        n = pos_edge.size(0)
-        k = int(num_neg)
+        self._part, self._k, self._n, self._dev = part, int(num_neg), pos_edge.size(0), dev
+        n, k = self._n, self._k
         span = W * S                                      # one slice's id space (node ids < N <= W * S)
         lo, hi = min(me * per, n), min((me + 1) * per, n)
         self.lo, self.hi, self.local = lo, hi, hi - lo
-        # slice of every edge of the batch: positives, then the k negatives of each positive
-        sid_pos = torch.arange(n, device=dev, dtype=torch.int64).div_(max(per, 1), rounding_mode="floor")
-        sid = torch.cat([sid_pos, sid_pos.repeat_interleave(k)]) if k > 0 else sid_pos
-        src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]]).to(torch.int64)
-        dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]]).to(torch.int64)
-        base = sid * span
-        vid = torch.cat([base + src, base + dst])          # (slice, node) pairs touched by the batch
-        flags = torch.zeros(W * span, dtype=torch.int32, device=dev)
-        flags.index_fill_(0, vid, 1)
-        csum = torch.cumsum(flags, 0, dtype=torch.int64)
-        cnt = flags.view(W, W, S).sum(dim=-1, dtype=torch.int64)          # [asker, owner]
-        off = torch.zeros(W * W + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(cnt.reshape(-1), 0, out=off[1:])
-        cap = min(vid.numel(), W * span)
-        rows_v = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
-        pos_v = csum - 1                                    # compact position of a flagged pair
-        rows_v.index_copy_(0, pos_v.index_select(0, vid), vid)            # duplicates write the same value
-        # ---- the one host read-back: the count table
-        if dev.type == "cuda":
-            host = _pinned_i64(off.numel())
-            host.copy_(off, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            ev.synchronize()
-            offs = host.tolist()
+        self._stream = stream if dev.type == "cuda" else None
+        self._finished = False
+        self._joined = None
+        ctx = torch.cuda.stream(self._stream) if self._stream is not None else _NullCtx()
+        with ctx:
+            # slice of every edge of the batch: positives, then the k negatives of each positive
+            sid_pos = torch.arange(n, device=dev, dtype=torch.int64).div_(max(per, 1), rounding_mode="floor")
+            sid = torch.cat([sid_pos, sid_pos.repeat_interleave(k)]) if k > 0 else sid_pos
+            src = torch.cat([pos_edge[:, 0], neg_flat[:, 0]]).to(torch.int64)
+            dst = torch.cat([pos_edge[:, 1], neg_flat[:, 1]]).to(torch.int64)
+            base = sid * span
+            vid = torch.cat([base + src, base + dst])          # (slice, node) pairs touched by the batch
+            flags = torch.zeros(W * span, dtype=torch.int32, device=dev)
+            flags.index_fill_(0, vid, 1)
+            csum = torch.cumsum(flags, 0, dtype=torch.int64)
+            cnt = flags.view(W, W, S).sum(dim=-1, dtype=torch.int64)          # [asker, owner]
+            off = torch.zeros(W * W + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(cnt.reshape(-1), 0, out=off[1:])
+            cap = min(vid.numel(), W * span)
+            rows_v = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+            pos_v = csum - 1                                    # compact position of a flagged pair
+            rows_v.index_copy_(0, pos_v.index_select(0, vid), vid)            # duplicates write the same value
+            self._src, self._dst, self._rows_v, self._pos_v, self._off = src, dst, rows_v, pos_v, off
+            # ---- the one host read-back: the count table, copied asynchronously
+            self._host = self._ev = None
+            if dev.type == "cuda":
+                self._host = _pinned_i64(off.numel())
+                self._host.copy_(off, non_blocking=True)
+                self._ev = torch.cuda.Event()
+                self._ev.record()
+
+    def finish(self, build_incidence: bool = False) -> "ShardPlan":
+        """phase 2: wait for the count table (host), then cut the lists this rank needs -- on the plan's
+        stream; join() makes the consuming stream wait for them.
+        build_incidence: also build the node-sorted incidence list of the slice in compact coordinates
+        (the deterministic backward of the fused scorers, ops.prepare_edge_backward)."""
+        if self._finished:
+            return self
+        part = self._part
+        W, S, me = part.world, part.rows, part.rank
+        n, k = self._n, self._k
+        if self._ev is not None:
+            self._ev.synchronize()
+            offs = self._host.tolist()
         else:
-            offs = off.tolist()
+            offs = self._off.tolist()
+        span = W * S
         self.count = offs[(me + 1) * W] - offs[me * W]
         self.out_splits = [offs[me * W + r + 1] - offs[me * W + r] for r in range(W)]
         self.in_splits = [offs[q * W + me + 1] - offs[q * W + me] for q in range(W)]
-        segs = [rows_v[offs[q * W + me]:offs[q * W + me + 1]] for q in range(W)]
-        self.send_rows = (torch.cat(segs) if W > 1 else segs[0]).remainder(S)
-        # ---- my slice in compact coordinates
-        e_pos = slice(lo, hi)
-        e_neg = slice(n + lo * k, n + hi * k)
-        mine = me * span
-        first = offs[me * W]
-        src_m = torch.cat([src[e_pos], src[e_neg]])
-        dst_m = torch.cat([dst[e_pos], dst[e_neg]])
-        self.src_c = pos_v.index_select(0, src_m + mine) - first
-        self.dst_c = pos_v.index_select(0, dst_m + mine) - first
-        self.rows = rows_v[first:first + self.count] - mine      # global node id of every row of H_me (sorted)
-        self.incidence = None
+        ctx = torch.cuda.stream(self._stream) if self._stream is not None else _NullCtx()
+        with ctx:
+            rows_v, pos_v, src, dst = self._rows_v, self._pos_v, self._src, self._dst
+            segs = [rows_v[offs[q * W + me]:offs[q * W + me + 1]] for q in range(W)]
+            self.send_rows = (torch.cat(segs) if W > 1 else segs[0]).remainder(S)
+            # ---- my slice in compact coordinates
+            lo, hi = self.lo, self.hi
+            mine = me * span
+            first = offs[me * W]
+            src_m = torch.cat([src[lo:hi], src[n + lo * k:n + hi * k]])
+            dst_m = torch.cat([dst[lo:hi], dst[n + lo * k:n + hi * k]])
+            self.src_c = pos_v.index_select(0, src_m + mine) - first
+            self.dst_c = pos_v.index_select(0, dst_m + mine) - first
+            self.rows = rows_v[first:first + self.count] - mine      # global node id of every row of H_me (sorted)
+            self.incidence = None
+            if build_incidence and self.local > 0 and self._dev.type == "cuda":
+                from . import ops
+                self.incidence = ops.prepare_edge_backward(self.src_c, self.dst_c, max(self.count, 1), compact=False)
+            if self._stream is not None:
+                self._joined = torch.cuda.Event()
+                self._joined.record()
+        self._src = self._dst = self._rows_v = self._pos_v = self._off = None
+        self._finished = True
+        return self
+
+    def join(self) -> "ShardPlan":
+        """the current stream waits for the lists (no-op when they were built on it)"""
+        if self._joined is not None:
+            cur = torch.cuda.current_stream(self._dev)
+            cur.wait_event(self._joined)
+            for t in (self.send_rows, self.src_c, self.dst_c, self.rows):
+                t.record_stream(cur)
+            inc = self.incidence
+            if inc is not None:
+                for name in ("item_edge", "item_other", "seg_ptr"):
+                    getattr(inc, name).record_stream(cur)
+                if getattr(inc, "_split", None) is not None:
+                    inc._split._buf.record_stream(cur)
+            self._joined = None
+        return self
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class ExchangeRows(torch.autograd.Function):

@@ -134,3 +134,37 @@ def rmat_graph(scale: int, num_edges: int, device, seed: int = 0, probs=(0.57, 0
     if symmetric:
         r, cc = torch.cat([r, cc]), torch.cat([cc, r])
     return Graph.from_coo(r, cc, None, n, n)
+
+
+def rmat_row_block(scale: int, num_edges: int, num_nodes: int, row_lo: int, n_rows: int, n_cols: int, device,
+                   seed: int = 0, probs=(0.57, 0.19, 0.19, 0.05), chunk: int = 1 << 26) -> Graph:
+    """destination rows [row_lo, row_lo + n_rows) of the SAME R-MAT multigraph rmat_graph(scale, num_edges,
+    num_nodes=..., seed=...) would build -- every rank of a row-sharded run replays the identical edge
+    stream (same generator seed) and keeps only the entries of its own rows, so no rank ever holds the
+    whole edge list (BASELINE.json config 5: 1 B edges over 8 ranks)."""
+    a, b, c, d = probs
+    n = int(num_nodes)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    rows, cols = [], []
+    done = 0
+    pending = []
+    while done < num_edges:
+        m = min(chunk, num_edges - done)
+        r = torch.zeros(m, dtype=torch.int64, device=device)
+        cc = torch.zeros(m, dtype=torch.int64, device=device)
+        for _ in range(scale):
+            u = torch.rand(m, generator=gen, device=device)
+            right = ((u >= a) & (u < a + b)) | (u >= a + b + c)
+            down = u >= a + b
+            r = (r << 1) | down.to(torch.int64)
+            cc = (cc << 1) | right.to(torch.int64)
+        pending.append(((r % n).to(torch.int32), (cc % n).to(torch.int32)))      # 8 bytes per edge while waiting
+        done += m
+    relabel = torch.randperm(n, generator=gen, device=device)       # drawn after the edges, as in rmat_graph
+    for r, cc in pending:
+        r, cc = relabel[r.long()], relabel[cc.long()]
+        keep = (r >= row_lo) & (r < row_lo + n_rows)
+        rows.append(r[keep] - row_lo)
+        cols.append(cc[keep])
+    del pending
+    return Graph.from_coo(torch.cat(rows), torch.cat(cols), None, n_rows, n_cols)

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--feat", default="256,512")
     ap.add_argument("--weighted", action="store_true")
     ap.add_argument("--short-rows", default="auto", choices=["auto", "0", "1"])
+    ap.add_argument("--tune", default="0", help="comma list of tuning flag sets (plnlp_hip.h: 4 = NT loads, 8 = fewer rows "
+                                                "in flight, 12 = both; 'halves' = two launches over column halves)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     for case in args.cases.split(","):
@@ -39,12 +41,21 @@ def main():
             x = torch.randn(g.n_cols, feat, device=dev)
             out = torch.empty(g.n_rows, feat, device=dev)
             sr = "auto" if args.short_rows == "auto" else args.short_rows == "1"
-            t = time_kernel(lambda: P.ops.csr_aggregate(g, x, "mean", args.weighted, out=out, short_rows=sr), iters=10)
-            by = agg_bytes(g.nnz, g.n_rows, feat, args.weighted)
-            print(json.dumps({"case": case, "N": g.n_rows, "nnz": g.nnz, "max_deg": int(deg.max()), "feat": feat,
-                              "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
-                              "frac_of_8TBps": round(by / t / 8e12, 4),
-                              "source_MiB": round(g.n_cols * feat * 4 / 2 ** 20, 1)}), flush=True)
+            for tune in args.tune.split(","):
+                if tune == "halves":
+                    hf = feat // 2
+                    def run():
+                        P.ops.csr_aggregate(g, x[:, :hf], "mean", args.weighted, out=out[:, :hf], short_rows=sr)
+                        P.ops.csr_aggregate(g, x[:, hf:], "mean", args.weighted, out=out[:, hf:], short_rows=sr)
+                else:
+                    def run(tv=int(tune)):
+                        P.ops.csr_aggregate(g, x, "mean", args.weighted, out=out, short_rows=sr, tune=tv)
+                t = time_kernel(run, iters=10)
+                by = agg_bytes(g.nnz, g.n_rows, feat, args.weighted)
+                print(json.dumps({"case": case, "N": g.n_rows, "nnz": g.nnz, "max_deg": int(deg.max()), "feat": feat,
+                                  "tune": tune, "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
+                                  "frac_of_8TBps": round(by / t / 8e12, 4),
+                                  "source_MiB": round(g.n_cols * feat * 4 / 2 ** 20, 1)}), flush=True)
             del x, out
         del g
         torch.cuda.empty_cache()

@@ -17,6 +17,15 @@ SHAPES = {
     "ddi_pred_wgrad": (512, 512, [262144], True, False, False),
     "ddi_enc_fwd": (4267, 512, [512, 512], False, True, True),
     "square4k": (4096, 4096, [4096], False, True, False),
+    # citation2 (GCN h=200): first layer over [A emb | A x] (52 + 128 = 180 columns), padded to 192, second layer
+    "cit_in_fwd_k180": (2927963, 200, [180], False, True, "bias_relu"),
+    "cit_in_fwd_k192": (2927963, 200, [192], False, True, "bias_relu"),
+    "cit_l2_fwd_k200": (2927963, 200, [200], False, True, False),
+    # tail quantisation probes: 3584 tiles = exactly 7 rounds of the 512 workgroup slots, vs 7.2 rounds above
+    "collab_fwd_7rounds": (229376, 256, [256, 256], False, True, True),
+    "collab_fwd_plain_7rounds": (229376, 256, [256, 256], False, True, False),
+    "collab_dgrad_T": (131072, 512, [256], False, False, False),
+    "collab_wgrad_T": (256, 512, [131072], True, False, False),
 }
 
 

@@ -163,7 +163,7 @@ def test_shard_plan_lists_exactly_the_touched_rows():
     pos = torch.randint(0, n_nodes, (n, 2), generator=g)
     neg = torch.randint(0, n_nodes, (n * k, 2), generator=g)
     per = (n + W - 1) // W
-    plans = [ShardPlan(RowPartition(n_nodes, W, r), pos, neg, k, per) for r in range(W)]
+    plans = [ShardPlan(RowPartition(n_nodes, W, r), pos, neg, k, per).finish() for r in range(W)]
     S = plans[0].send_rows.new_tensor(RowPartition(n_nodes, W, 0).rows).item()
     for q, p in enumerate(plans):
         lo, hi = min(q * per, n), min((q + 1) * per, n)
