@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PLNLP_ABI_VERSION 2
+#define PLNLP_ABI_VERSION 3
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -64,6 +64,9 @@ typedef struct plnlp_epilogue {
     const float* addend;         /* PLNLP_EPI_ADDEND: [*, ld_addend]           */
     int64_t      ld_addend;
     const int32_t* addend_index; /* nullable: [n_rows], -1 = no addend row     */
+    const int32_t* dropout_row_index; /* nullable: the dropout counter of result row r is taken at row
+                                    dropout_row_index[r] (the result holds only SOME rows of the full matrix
+                                    and must draw the mask the full matrix would)                     */
 } plnlp_epilogue;
 
 /* ---- K1/K2: CSR neighbour gather-and-reduce --------------------------------
@@ -126,6 +129,10 @@ int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                                                         reads x[src_map[col[e]]] and is skipped when that is < 0
                                                         (src_scale still indexes col[e]) -- the transposed
                                                         aggregation of a row-sparse gradient                */
+                            const int32_t* row_index,/* nullable: [n_rows]; result row r aggregates CSR row row_index[r]
+                                                        (only the rows an edge batch reads are produced)          */
+                            const int32_t* split_out_map, /* with row_index and split: [CSR rows] result row of a
+                                                        long CSR row, < 0 = not produced                           */
                             const float* x, int64_t ldx,
                             float* out, int64_t ldo,
                             int64_t n_rows, int64_t n_src /* rows of x */, int64_t feat, int reduce, int flags,
@@ -174,6 +181,9 @@ typedef struct plnlp_gemm_operand {
     const int32_t* b_index;   /* nullable, b_trans = 0 and a_trans = 1 only: B's row for reduction index j is
                                  b_index[j] (weight gradient over the rows of a row-sparse dz: B = the
                                  layer input, gathered in place; applies to b2 of plnlp_gemm_concat_b_f32 too) */
+    const int32_t* a_index;   /* nullable, a_trans = 0 and b_trans = 1 only: A's row for result row i is
+                                 a_index[i] (a layer evaluated only at the rows an edge batch reads: the
+                                 root operand x is gathered in the loader)                              */
 } plnlp_gemm_operand;
 
 int plnlp_gemm_f32(const plnlp_gemm_operand* segs /* HOST ptr */, int n_seg,
@@ -207,6 +217,7 @@ int plnlp_gemm_concat_b_f32(const plnlp_gemm_operand* seg /* HOST ptr, one segme
  * as two contiguous tensors ([dWl | dWr] = dz^T [agg | x]).  b2 nullable (B is then one buffer); no epilogue. */
 int plnlp_gemm_pair_f32(const plnlp_gemm_operand* seg /* HOST ptr, one segment */,
                         const float* b2, int64_t ldb2, int64_t nb_split,
+                        int b_index_on /* seg->b_index applies to: 3 = b and b2, 1 = b only, 2 = b2 only */,
                         int a_trans, int b_trans, float* c, int64_t ldc, float* c2, int64_t ldc2,
                         int64_t n_split, int64_t m, int64_t n, int split_k, float* workspace,
                         int64_t workspace_floats, void* stream);

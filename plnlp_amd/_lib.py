@@ -25,7 +25,7 @@ class Epilogue(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
                 ("bias", C.c_void_p), ("gate", C.c_void_p), ("ld_gate", C.c_int64),
                 ("gate_scale", C.c_float), ("gate_index", C.c_void_p), ("addend", C.c_void_p),
-                ("ld_addend", C.c_int64), ("addend_index", C.c_void_p)]
+                ("ld_addend", C.c_int64), ("addend_index", C.c_void_p), ("dropout_row_index", C.c_void_p)]
 
 
 class RowSplit(C.Structure):
@@ -38,7 +38,7 @@ class RowSplit(C.Structure):
 class GemmOperand(C.Structure):
     """mirror of plnlp_gemm_operand"""
     _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64),
-                ("k", C.c_int64), ("b_index", C.c_void_p)]
+                ("k", C.c_int64), ("b_index", C.c_void_p), ("a_index", C.c_void_p)]
 
 
 class AdamTensor(C.Structure):
@@ -74,7 +74,7 @@ SIGNATURES = {
     "plnlp_compact_rows": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "plnlp_csr_aggregate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_void_p, c_i64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, c_i64,
                                           C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.c_int, C.c_int, C.POINTER(Epilogue),
                                           C.POINTER(RowSplit), C.c_void_p]),
     "plnlp_csr_aggregate_max_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, c_i64,
@@ -90,7 +90,7 @@ SIGNATURES = {
     "plnlp_gemm_concat_b_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_void_p, c_i64, c_i64, C.c_int, C.c_int,
                                           C.c_void_p, c_i64, c_i64, c_i64, C.POINTER(Epilogue), C.c_int,
                                           C.c_void_p, c_i64, C.c_void_p]),
-    "plnlp_gemm_pair_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_void_p, c_i64, c_i64, C.c_int, C.c_int, C.c_void_p,
+    "plnlp_gemm_pair_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_void_p, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       c_i64, C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.c_int, C.c_void_p, c_i64,
                                       C.c_void_p]),
     "plnlp_colsum_workspace_floats": (c_i64, [c_i64, c_i64]),
@@ -149,7 +149,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.plnlp_abi_version() != 2:
+    if lib.plnlp_abi_version() != 3:
         raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
@@ -191,7 +191,7 @@ def require_device(*tensors: Optional[torch.Tensor]) -> None:
 
 def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accumulate=False,
                   gate=None, gate_scale=1.0, gate_index=None, addend=None,
-                  addend_index=None) -> Optional[Epilogue]:
+                  addend_index=None, dropout_rows=None) -> Optional[Epilogue]:
     flags = 0
     e = Epilogue()
     if bias is not None:
@@ -203,6 +203,9 @@ def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accum
         flags |= EPI_DROPOUT
         e.dropout_p = float(dropout_p)
         e.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
+        if dropout_rows is not None:
+            assert dropout_rows.dtype == torch.int32
+            e.dropout_row_index = dropout_rows.data_ptr()
     if accumulate:
         flags |= EPI_ACCUM
     if gate is not None:
@@ -223,5 +226,5 @@ def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accum
     if flags == 0:
         return None
     e.flags = flags
-    e._keepalive = (bias, gate, gate_index, addend, addend_index)      # the struct holds raw pointers; keep the tensors alive with it
+    e._keepalive = (bias, gate, gate_index, addend, addend_index, dropout_rows)      # the struct holds raw pointers; keep the tensors alive with it
     return e

@@ -78,6 +78,7 @@ struct Epi {
     const float* addend;        // PLNLP_EPI_ADDEND
     int64_t      ld_addend;
     const int32_t* addend_index;
+    const int32_t* drop_row;    // dropout counter row of result row r (nullable: r itself)
     int          vec4;          // bias / gate / addend may be read 16 bytes at a time (f % 4 == 0 callers only)
 };
 
@@ -104,6 +105,7 @@ inline int make_epi(const plnlp_epilogue* e, Epi* out) {
             d.seed_lo = (uint32_t)e->dropout_seed;
             d.seed_hi = (uint32_t)(e->dropout_seed >> 32);
             d.keep_scale = 1.f / (1.f - e->dropout_p);
+            d.drop_row = e->dropout_row_index;
         }
     }
     d.vec4 = (!(d.flags & PLNLP_EPI_BIAS) || ((uintptr_t)d.bias % 16 == 0)) &&
@@ -118,9 +120,10 @@ __device__ __forceinline__ float epi_apply(const Epi& e, float v, int64_t r, int
                                            int64_t n_cols, float prev) {
     if (e.flags & PLNLP_EPI_BIAS) v += e.bias[f];
     if (e.flags & PLNLP_EPI_RELU) v = fmaxf(v, 0.f);
-    if (e.flags & PLNLP_EPI_DROPOUT)
-        v = dropout_keep((uint64_t)r * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh)
-                ? v * e.keep_scale : 0.f;
+    if (e.flags & PLNLP_EPI_DROPOUT) {
+        const uint64_t dr = e.drop_row ? (uint64_t)e.drop_row[r] : (uint64_t)r;
+        v = dropout_keep(dr * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh) ? v * e.keep_scale : 0.f;
+    }
     if (e.flags & PLNLP_EPI_ACCUM) v += prev;
     if (e.flags & PLNLP_EPI_ADDEND) {
         const int64_t a = e.addend_index ? (int64_t)e.addend_index[r] : r;
@@ -145,8 +148,8 @@ __device__ __forceinline__ float4 epi_apply4(const Epi& e, float4 v, int64_t r, 
         }
         if (e.flags & PLNLP_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (e.flags & PLNLP_EPI_DROPOUT) {
-            v = dropout_apply4(v, (uint64_t)r * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh,
-                               e.keep_scale);
+            const uint64_t dr = e.drop_row ? (uint64_t)e.drop_row[r] : (uint64_t)r;
+            v = dropout_apply4(v, dr * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh, e.keep_scale);
         }
         if (e.flags & PLNLP_EPI_ACCUM) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
         if (e.flags & PLNLP_EPI_ADDEND) {
@@ -180,8 +183,8 @@ __device__ __forceinline__ float4 epi_apply4_pre(const Epi& e, float4 v, int64_t
     if (e.flags & PLNLP_EPI_BIAS) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
     if (e.flags & PLNLP_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (e.flags & PLNLP_EPI_DROPOUT) {
-        v = dropout_apply4(v, (uint64_t)r * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh,
-                           e.keep_scale);
+        const uint64_t dr = e.drop_row ? (uint64_t)e.drop_row[r] : (uint64_t)r;
+        v = dropout_apply4(v, dr * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh, e.keep_scale);
     }
     if (e.flags & PLNLP_EPI_ACCUM) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
     if (has_add) { v.x += add.x; v.y += add.y; v.z += add.z; v.w += add.w; }

@@ -249,11 +249,13 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
-    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, int64_t row_base, int slab_feat) {
+    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, int64_t row_base, int slab_feat,
+    const int32_t* __restrict__ row_index) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t r = row_base + (int64_t)blockIdx.x * 4 + wave;
     if (r >= n_rows) return;
+    const int64_t rg = row_index ? (int64_t)row_index[r] : r;      // CSR row behind result row r
     const int sub = lane % LPR, grp = lane / LPR;
     if (slab_feat > 0) {
         // feature slabs (blockIdx.y): this wave owns columns [c0, c0 + slab_feat) of its row.  A row of a
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
         feat = (feat - c0) < slab_feat ? (feat - c0) : slab_feat;
     }
     const int nslots = feat >> 2;
-    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    const int64_t beg = rowptr[rg], end = rowptr[rg + 1];
     if (skip_above > 0 && end - beg > skip_above) return;
     EpiPre<VPL> pre;
     pre.valid = false;
@@ -519,16 +521,19 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
 // longer serialises on one wave.  Then mean / epilogue / store.
 __global__ __launch_bounds__(256) void csr_agg_finalize_kernel(const int64_t* __restrict__ rowptr, int feat,
                                                                int mean, SplitArgs sp, float* __restrict__ out,
-                                                               int64_t ldo, Epi epi) {
+                                                               int64_t ldo, Epi epi,
+                                                               const int32_t* __restrict__ out_map) {
     __shared__ float4 part[3][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t l = blockIdx.x;
     if (l >= sp.n_long) return;
-    const int64_t r = sp.long_rows[l];
-    if (r < 0) return;                                   // idle slot (block-uniform)
+    const int64_t rg = sp.long_rows[l];
+    if (rg < 0) return;                                  // idle slot (block-uniform)
+    const int64_t r = out_map ? (int64_t)out_map[rg] : rg;   // result row of this CSR row (row-indexed launches)
+    if (r < 0) return;                                   // not among the produced rows
     const int64_t c0 = sp.chunk_beg[l], c1 = c0 + sp.chunk_cnt[l];
-    const int64_t deg = rowptr[r + 1] - rowptr[r];
+    const int64_t deg = rowptr[rg + 1] - rowptr[rg];
     const int nslots = feat >> 2;
     for (int s0 = 0; s0 < nslots; s0 += 64) {
         const int s = s0 + lane;
@@ -577,12 +582,13 @@ __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
-    int64_t n_rows, int feat, int mean, Epi epi, int64_t row_base) {
+    int64_t n_rows, int feat, int mean, Epi epi, int64_t row_base, const int32_t* __restrict__ row_index) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t r = row_base + (int64_t)blockIdx.x * 4 + wave;
     if (r >= n_rows) return;
-    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    const int64_t rg = row_index ? (int64_t)row_index[r] : r;
+    const int64_t beg = rowptr[rg], end = rowptr[rg + 1];
     for (int f0 = 0; f0 < feat; f0 += 64 * 4) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int64_t e = beg; e < end; ++e) {
@@ -616,14 +622,15 @@ __global__ __launch_bounds__(256) void csr_agg_scalar_kernel(
 template <int VPL, int LPR>
 static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
                         const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
-                        int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp);
+                        int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp,
+                        const int32_t* out_map = nullptr);
 
 template <int VPL, int LPR, int CHX = 0, bool NT = false>
 static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* rowptr, const int32_t* col,
                       const float* val, const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x,
                       int64_t ldx, float* out,
                       int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e, const SplitArgs* sp,
-                      int slab_feat = 0) {
+                      int slab_feat = 0, const int32_t* row_index = nullptr, const int32_t* out_map = nullptr) {
     const int64_t skip = sp ? sp->threshold : 0;
     // a launch may not exceed 2^32 threads: beyond 2^22 blocks (16 Mi rows) the rows go in slices
     const int n_slabs = slab_feat > 0 ? (feat + slab_feat - 1) / slab_feat : 1;
@@ -634,20 +641,20 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
         if (weighted)
             hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true, CHX, NT>), g, dim3(256), 0, s, rowptr, col, val,
                                val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4,
-                               slab_feat);
+                               slab_feat, row_index);
         else
             hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false, CHX, NT>), g, dim3(256), 0, s, rowptr, col, val,
                                val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4,
-                               slab_feat);
+                               slab_feat, row_index);
         if (int rc = launch_status()) return rc;
     }
     if (slab_feat > 0) {      // the long rows' chunk / finalize passes run on the full width
-        if (feat <= 256) return launch_split<1, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
-        if (feat <= 512) return launch_split<2, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
-        return launch_split<4, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
+        if (feat <= 256) return launch_split<1, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp, out_map);
+        if (feat <= 512) return launch_split<2, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp, out_map);
+        return launch_split<4, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp, out_map);
     }
     return launch_split<VPL, LPR>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean,
-                                  e, sp);
+                                  e, sp, out_map);
 }
 
 template <int VPL, int LPR>
@@ -674,7 +681,7 @@ static int launch_multirow(bool weighted, hipStream_t s, const int64_t* rowptr, 
 template <int VPL, int LPR>
 static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
                         const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
-                        int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp) {
+                        int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp, const int32_t* out_map) {
     if (!sp || sp->n_long == 0 || sp->n_chunks == 0) return 0;
     dim3 cgrid((unsigned)((sp->n_chunks + 3) / 4));
     if (weighted)
@@ -685,14 +692,15 @@ static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, con
                            val_index, src_scale, src_map, x, ldx, feat, *sp);
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)sp->n_long), dim3(256), 0, s, rowptr,
-                       feat, mean, *sp, out, ldo, e);
+                       feat, mean, *sp, out, ldo, e, out_map);
     return launch_status();
 }
 
 }  // namespace plnlp
 
 extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col, const float* val,
-                                       const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x,
+                                       const int32_t* val_index, const float* src_scale, const int32_t* src_map,
+                                       const int32_t* row_index, const int32_t* split_out_map, const float* x,
                                        int64_t ldx, float* out,
                                        int64_t ldo, int64_t n_rows, int64_t n_src, int64_t feat, int reduce,
                                        int flags, const plnlp_epilogue* epi, const plnlp_row_split* split,
@@ -733,16 +741,20 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
             const dim3 g((unsigned)(((int64_t)grid.x - b0) < MAX_BLOCKS ? ((int64_t)grid.x - b0) : MAX_BLOCKS));
             if (weighted)
                 hipLaunchKernelGGL((csr_agg_scalar_kernel<true>), g, dim3(256), 0, s, rowptr, col, val, val_index,
-                                   src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, b0 * 4);
+                                   src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, b0 * 4, row_index);
             else
                 hipLaunchKernelGGL((csr_agg_scalar_kernel<false>), g, dim3(256), 0, s, rowptr, col, val, val_index,
-                                   src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, b0 * 4);
+                                   src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, b0 * 4, row_index);
             if (int rc = launch_status()) return rc;
         }
         return 0;
     }
     const int nslots = (int)(feat / 4);
-    if (src_map) flags = 0;      // the mapped gather exists on the one-row-per-wave forms only
+    if (src_map) flags &= ~(PLNLP_AGG_SHORT_ROWS | PLNLP_AGG_LDS_STAGE);   // the mapped gather exists on the one-row-per-wave forms only
+    if (row_index) {
+        flags &= ~(PLNLP_AGG_SHORT_ROWS | PLNLP_AGG_LDS_STAGE);     // row-indexed launches: one-row-per-wave forms
+        if (sp && !split_out_map) return PLNLP_E_NULL;
+    }
     if ((flags & PLNLP_AGG_LDS_STAGE) && n_src > 0 && n_src * 16 <= PLNLP_AGG_LDS_BUDGET) {
         // widest slab that fits the LDS budget
         if (n_src * 128 <= PLNLP_AGG_LDS_BUDGET && feat >= 32)
@@ -764,17 +776,17 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
                                       n_rows, (int)feat, mean, e, sp);
     }
 #define PLNLP_AGG(VPL, LPR) \
-    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp)
+    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp, 0, row_index, split_out_map)
 #define PLNLP_AGGX(VPL, LPR, CHX, NT) \
-    return launch_vec<VPL, LPR, CHX, NT>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp)
+    return launch_vec<VPL, LPR, CHX, NT>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp, 0, row_index, split_out_map)
     // feature slabs: 128 or 256 columns per wave (see csr_agg_vec_kernel); rows and slabs fill the grid
     if ((flags & (PLNLP_AGG_SLABS_128 | PLNLP_AGG_SLABS_256)) && nslots > 32 && !(e.flags & PLNLP_EPI_DROPOUT)) {
         if ((flags & PLNLP_AGG_SLABS_128))
             return launch_vec<1, 32>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
-                                     n_rows, (int)feat, mean, e, sp, 128);
+                                     n_rows, (int)feat, mean, e, sp, 128, row_index, split_out_map);
         if (nslots > 64)
             return launch_vec<1, 64>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
-                                     n_rows, (int)feat, mean, e, sp, 256);
+                                     n_rows, (int)feat, mean, e, sp, 256, row_index, split_out_map);
     }
     // tuning variants of the full-wave forms (flags): streaming-hint row loads, fewer rows in flight
     if (nslots > 32 && nslots <= 64 && (flags & PLNLP_AGG_NT_LOADS)) PLNLP_AGGX(1, 64, 0, true);

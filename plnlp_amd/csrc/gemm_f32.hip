@@ -45,6 +45,7 @@ struct Seg {
     int k;
     int a_vec, b_vec;  // 16-byte path usable
     const int32_t* b_index;   // B's row for reduction index j (row-contiguous B only), nullable
+    const int32_t* a_index;   // A's row for result row i (K-contiguous A only), nullable
 };
 
 struct GemmArgs {
@@ -61,6 +62,7 @@ struct GemmArgs {
     int z0;               // first split-K slice this launch writes
     float* c2; int64_t ldc2; int n_split;   // columns >= n_split go to c2[:, col - n_split] (n_split = n: unused)
     const float* b2; int64_t ldb2; int nb_split;   // B columns >= nb_split come from b2 (segment 0; nb_split = n: unused)
+    int bidx_mask;        // b_index applies to: bit 0 = the first B buffer, bit 1 = b2
     int vec_store;        // output rows are 16-byte storable (n, ldc, n_split, pointers all 4-float aligned)
 };
 
@@ -69,9 +71,11 @@ struct GemmArgs {
 // float4 at (row0 + (t>>3) + 32p, k0 + 4*(t&7)), p = 0..3.
 // FAST: 16-byte loads, no branches.  RAGGED (the segment's last K-tile may be partial; needs kdim % 4 == 0):
 // a float4 whose k lies past kdim is loaded from the last valid group instead and zeroed by a select.
+// ridx (nullable): the operand's row for tile row i is ridx[i] (rows gathered in the loader)
 template <bool FAST, bool RAGGED = false>
 __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
-                                        int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t) {
+                                        int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t,
+                                        const int32_t* __restrict__ ridx = nullptr) {
     const int kq = (t & 7) * 4 + k0;
     if constexpr (FAST) {
         // 4 independent 16-byte loads, no guards, nothing the compiler must wait on between them.
@@ -84,6 +88,7 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
         for (int p = 0; p < 4; ++p) {
             int64_t row = row0 + (t >> 3) + 32 * p;
             row = row < nrows ? row : nrows - 1;
+            if (ridx) row = ridx[row];
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + row * ld + kc);
             r[p] = kin ? v : zero;
         }
@@ -96,7 +101,9 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
     for (int p = 0; p < 4; ++p) {
         const int64_t row = row0 + (t >> 3) + 32 * p;
         const bool rok = row < nrows;
-        const float* q = base + (rok ? row : nrows - 1) * ld;
+        int64_t rr = rok ? row : nrows - 1;
+        if (ridx) rr = ridx[rr];
+        const float* q = base + rr * ld;
         f32x4 v;
         if (vec && kq + 3 < kdim) {            // whole 16-byte group inside: one wide load
             v = *reinterpret_cast<const f32x4*>(q + kq);
@@ -129,8 +136,10 @@ __device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__
             ks[p] = (!RAGGED || k < kdim) ? k : kdim - 1;            // a k row past the end: reload the last one
         }
         if constexpr (INDEXED) {
+            if (kidx) {                      // block-uniform: the index may apply to one of two B buffers only
 #pragma unroll
-            for (int p = 0; p < 4; ++p) ks[p] = kidx[ks[p]];
+                for (int p = 0; p < 4; ++p) ks[p] = kidx[ks[p]];
+            }
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -144,7 +153,7 @@ __device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__
         const int k = k0 + (t >> 5) + 8 * p;
         const bool kok = k < kdim;
         const int kc = kok ? k : kdim - 1;
-        const float* q = base + (int64_t)(INDEXED ? kidx[kc] : kc) * ld;
+        const float* q = base + (int64_t)((INDEXED && kidx) ? kidx[kc] : kc) * ld;
         f32x4 v;
         if (vec && rq + 3 < nrows) {
             v = *reinterpret_cast<const f32x4*>(q + rq);
@@ -174,9 +183,10 @@ __device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (
 // runtime-indexed struct access: that sent the staging registers to scratch).
 // MODE 0: guarded loads everywhere (unaligned operands); 1: fast loads, every K-tile full;
 // 2: fast loads, a segment's last K-tile may be partial (k % 4 == 0): out-of-range groups zeroed by selects
-template <bool A_T, bool B_T, int MODE, bool BIDX>
+template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
 __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[4], f32x4 (&rb)[4],
                                           int64_t m0, int n0, int t) {
+    static_assert(!AIDX || !A_T, "gathered A rows exist for the K-contiguous layout only");
     static_assert(!BIDX || !B_T, "gathered B rows exist for the row-contiguous layout only");
     const bool s1 = (g.nseg > 1) && (tile >= g.tiles0);
     const float* a = s1 ? g.seg[1].a : g.seg[0].a;
@@ -187,10 +197,14 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
     const int avec = s1 ? g.seg[1].a_vec : g.seg[0].a_vec;
     const int bvec = s1 ? g.seg[1].b_vec : g.seg[0].b_vec;
     const int32_t* bidx = s1 ? g.seg[1].b_index : g.seg[0].b_index;
+    const int32_t* aidx = nullptr;
+    if constexpr (AIDX) aidx = s1 ? g.seg[1].a_index : g.seg[0].a_index;
     const int k0 = (tile - (s1 ? g.tiles0 : 0)) * BK;
     int nb = g.n;                         // extent of the B operand along N as seen by this tile
+    if (BIDX && !(g.bidx_mask & 1) && (g.nb_split >= g.n || n0 < g.nb_split)) bidx = nullptr;
     if (g.nb_split < g.n) {               // N-concatenated B: [b | b2], tiles never straddle the seam
         const bool second = n0 >= g.nb_split;
+        if (BIDX && second && !(g.bidx_mask & 2)) bidx = nullptr;
         b = second ? g.b2 : b;
         ldb = second ? g.ldb2 : ldb;
         nb = second ? g.n - g.nb_split : g.nb_split;
@@ -202,12 +216,12 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
     if constexpr (MODE != 0) {
         constexpr bool RG = MODE == 2;
         if constexpr (A_T) load_rc<true, false, RG>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-        else               load_kc<true, RG>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+        else               load_kc<true, RG>(ra, a, lda, m0, g.m, k0, kdim, avec, t, aidx);
         if constexpr (B_T) load_kc<true, RG>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
         else               load_rc<true, BIDX, RG>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
     } else {
         if constexpr (A_T) load_rc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-        else               load_kc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
+        else               load_kc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t, aidx);
         if constexpr (B_T) load_kc<false>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
         else               load_rc<false, BIDX>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
     }
@@ -274,7 +288,7 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, con
 #define PLNLP_GEMM_PF 2
 #endif
 #ifndef ABL_CLAMPED_LOOP
-template <bool A_T, bool B_T, int MODE, bool BIDX>
+template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
                                        int h) {
@@ -288,7 +302,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
     // look-ahead.  Branch-free, it knows PF-1 sets are still in flight and waits for vmcnt(8 (PF-1)).
     if (te - tb >= 2 * PF) {
 #pragma unroll
-        for (int d = 0; d < PF; ++d) load_tile<A_T, B_T, MODE, BIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
+        for (int d = 0; d < PF; ++d) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
         do {
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
@@ -299,7 +313,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                 __syncthreads();
 #endif
 #ifndef ABL_NOGLOAD
-                load_tile<A_T, B_T, MODE, BIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t);
+                load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t);
 #endif
                 mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
             }
@@ -308,7 +322,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
     } else {
 #pragma unroll
         for (int d = 0; d < PF; ++d)
-            if (tb + d < te) load_tile<A_T, B_T, MODE, BIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
+            if (tb + d < te) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
     }
     // drain: the last < 2 PF tiles
     for (; base < te; base += PF) {
@@ -322,7 +336,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                 __syncthreads();
 #endif
 #ifndef ABL_NOGLOAD
-                if (tile + PF < te) load_tile<A_T, B_T, MODE, BIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t);
+                if (tile + PF < te) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t);
 #endif
                 mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
             }
@@ -335,7 +349,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 // look-ahead load unconditional with its tile index clamped to the slice's last tile.  1-3 % SLOWER than the
 // steady + drain form above on the 8..16-tile shapes of this path (the two `if (live)` regions cost more
 // than the two conditional loads of the drain), so it is not the default.
-template <bool A_T, bool B_T, int MODE, bool BIDX>
+template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
                                        int h) {
@@ -352,7 +366,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
         const int tl = tb + d < last ? tb + d : last;
-        load_tile<A_T, B_T, MODE, BIDX>(g, tl, ra[d], rb[d], m0, n0, t);
+        load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tl, ra[d], rb[d], m0, n0, t);
     }
     for (int base = tb; base < te; base += PF) {
 #pragma unroll
@@ -369,7 +383,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 #ifndef ABL_NOGLOAD
             {
                 const int tn = tile + PF < last ? tile + PF : last;
-                load_tile<A_T, B_T, MODE, BIDX>(g, tn, ra[d], rb[d], m0, n0, t);
+                load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tn, ra[d], rb[d], m0, n0, t);
             }
 #endif
             if (live) mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
@@ -380,7 +394,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 #endif
 // MODE (see load_tile): separate kernels so the hot loop of the aligned case carries no guarded
 // code at all (pure dwordx4 loads, nothing between their issue and the MFMAs).
-template <bool A_T, bool B_T, int MODE, bool BIDX = false>
+template <bool A_T, bool B_T, int MODE, bool BIDX = false, bool AIDX = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
 
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    k_loop<A_T, B_T, MODE, BIDX>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
+    k_loop<A_T, B_T, MODE, BIDX, AIDX>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
 
     // ---- write back.  The MFMA C/D map (col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)) would
     // give 64 scattered 4-byte stores per lane; instead the block tile is transposed through LDS
@@ -508,7 +522,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split_k,
                                                             int64_t stride, float* __restrict__ c, int64_t ldc,
                                                             int64_t m, int n, Epi epi, float* __restrict__ c2,
-                                                            int64_t ldc2, int n_split) {
+                                                            int64_t ldc2, int n_split, int64_t row0) {
+    // row0: the workspace holds rows [row0, row0 + m) of the result (the tail rows of a launch whose
+    // last, partly filled round of tiles was cut along K instead -- see gemm_impl)
     const int64_t total = m * (int64_t)n;
     const bool vec = (n % 4 == 0) && (stride % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)ws % 16 == 0) &&
                      ((uintptr_t)c % 16 == 0) &&
@@ -528,8 +544,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             }
             for (; zz < split_k; ++zz) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)zz * stride);
             const int64_t i = i4 * 4;
-            const int64_t row = i / n;
-            const int col = (int)(i - row * n);
+            const int64_t row = row0 + i / n;
+            const int col = (int)(i - (i / n) * n);
             float4 y = make_float4(acc.x, acc.y, acc.z, acc.w);
             if (c2 && col >= n_split) {
                 *reinterpret_cast<float4*>(c2 + row * ldc2 + (col - n_split)) = y;
@@ -544,8 +560,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int zz = 0; zz < split_k; ++zz) v += ws[(int64_t)zz * stride + i];
-        const int64_t row = i / n;
-        const int col = (int)(i - row * n);
+        const int64_t row = row0 + i / n;
+        const int col = (int)(i - (i / n) * n);
         if (c2 && col >= n_split) { c2[row * ldc2 + (col - n_split)] = v; continue; }
         float* p = c + row * ldc + col;
         if (epi.flags) {
@@ -561,7 +577,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c, int64_t ldc,
                      int64_t m, int64_t n, float* c2, int64_t ldc2, int64_t n_split, const plnlp_epilogue* epi,
                      int split_k, float* workspace, int64_t workspace_floats, void* stream,
-                     const float* b2 = nullptr, int64_t ldb2 = 0, int64_t nb_split = -1);
+                     const float* b2 = nullptr, int64_t ldb2 = 0, int64_t nb_split = -1, int bidx_mask = 3);
 
 extern "C" int plnlp_gemm_concat_b_f32(const plnlp_gemm_operand* seg, const float* b2, int64_t ldb2,
                                        int64_t nb_split, int a_trans, int b_trans, float* c, int64_t ldc,
@@ -575,7 +591,7 @@ extern "C" int plnlp_gemm_concat_b_f32(const plnlp_gemm_operand* seg, const floa
 }
 
 extern "C" int plnlp_gemm_pair_f32(const plnlp_gemm_operand* seg, const float* b2, int64_t ldb2, int64_t nb_split,
-                                   int a_trans, int b_trans, float* c, int64_t ldc, float* c2, int64_t ldc2,
+                                   int b_index_on, int a_trans, int b_trans, float* c, int64_t ldc, float* c2, int64_t ldc2,
                                    int64_t n_split, int64_t m, int64_t n, int split_k, float* workspace,
                                    int64_t workspace_floats, void* stream) {
     if (!seg || !c2) return PLNLP_E_NULL;
@@ -584,8 +600,9 @@ extern "C" int plnlp_gemm_pair_f32(const plnlp_gemm_operand* seg, const float* b
         if (nb_split <= 0 || nb_split >= n || nb_split % 128 != 0) return PLNLP_E_SHAPE;
         if (ldb2 < (b_trans ? seg->k : n - nb_split)) return PLNLP_E_SHAPE;
     }
+    if (b_index_on < 1 || b_index_on > 3) return PLNLP_E_SHAPE;
     return gemm_impl(seg, 1, a_trans, b_trans, c, ldc, m, n, c2, ldc2, n_split, nullptr, split_k, workspace,
-                     workspace_floats, stream, b2, ldb2, b2 ? nb_split : -1);
+                     workspace_floats, stream, b2, ldb2, b2 ? nb_split : -1, b_index_on);
 }
 
 extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c,
@@ -608,7 +625,7 @@ extern "C" int plnlp_gemm_split_out_f32(const plnlp_gemm_operand* segs, int n_se
 static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c, int64_t ldc,
                      int64_t m, int64_t n, float* c2, int64_t ldc2, int64_t n_split, const plnlp_epilogue* epi,
                      int split_k, float* workspace, int64_t workspace_floats, void* stream, const float* b2,
-                     int64_t ldb2, int64_t nb_split) {
+                     int64_t ldb2, int64_t nb_split, int bidx_mask) {
     using namespace plnlp;
     if (!segs || !c) return PLNLP_E_NULL;
     if (n_seg < 1 || n_seg > 2 || m < 0 || n < 0 || n > 0x7FFFFFF0) return PLNLP_E_SHAPE;
@@ -626,7 +643,9 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         Seg& d = g.seg[s];
         d.a = o.a; d.lda = o.lda; d.b = o.b; d.ldb = o.ldb; d.k = (int)o.k;
         d.b_index = o.b_index;
+        d.a_index = o.a_index;
         if (o.b_index && !(a_trans && !b_trans && n_seg == 1)) return PLNLP_E_UNSUPPORTED;
+        if (o.a_index && !(!a_trans && b_trans)) return PLNLP_E_UNSUPPORTED;
         d.a_vec = ((uintptr_t)o.a % 16 == 0) && (o.lda % 4 == 0);
         d.b_vec = ((uintptr_t)o.b % 16 == 0) && (o.ldb % 4 == 0);
         tiles[s] = (int)((o.k + BK - 1) / BK);
@@ -637,6 +656,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     g.m = m; g.n = (int)n; g.split_k = split_k; g.ws_stride = m * n;
     g.c2 = c2; g.ldc2 = ldc2; g.n_split = (int)n_split;
     g.b2 = b2; g.ldb2 = ldb2; g.nb_split = b2 ? (int)nb_split : (int)n;
+    g.bidx_mask = bidx_mask;
     g.vec_store = (n % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)c % 16 == 0) &&
                   (!c2 || ((n_split % 4 == 0) && (ldc2 % 4 == 0) && ((uintptr_t)c2 % 16 == 0))) &&
                   (split_k <= 1 || ((uintptr_t)workspace % 16 == 0));
@@ -669,13 +689,20 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     int mode = !aligned ? 0 : (ragged ? 2 : 1);
     const int reduce_slices = split_k;
     g.mt0 = 0; g.nt0 = 0; g.gm = gm; g.gn = (int)gn; g.z0 = 0;
-    auto launch = [&](const GemmArgs& ga, int md, int slices) -> int {
-        dim3 grid((unsigned)(gm * gn), 1, (unsigned)slices);
+    auto launch_grid = [&](const GemmArgs& ga, int md, dim3 grid) -> int {
 #define PLNLP_GEMM_M(AT, BT)                                                                              \
         switch (md) {                                                                                    \
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 1>), grid, dim3(256), 0, s, ga, e); break;   \
             case 2: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 2>), grid, dim3(256), 0, s, ga, e); break;   \
             default: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 0>), grid, dim3(256), 0, s, ga, e); break;  \
+        }
+        if (ga.seg[0].a_index || (ga.nseg > 1 && ga.seg[1].a_index)) {     // (!a_trans, b_trans) checked above
+            switch (md) {
+                case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, false, true>), grid, dim3(256), 0, s, ga, e); break;
+                case 2: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, false, true>), grid, dim3(256), 0, s, ga, e); break;
+                default: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 0, false, true>), grid, dim3(256), 0, s, ga, e); break;
+            }
+            return launch_status();
         }
         if (ga.seg[0].b_index) {      // (a_trans, !b_trans) checked above
             switch (md) {
@@ -690,6 +717,34 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
 #undef PLNLP_GEMM_M
         return launch_status();
     };
+    // ---- tail of the tile grid.  Tiles run in rounds of 512 (256 CUs x 2 workgroups); a last round that
+    // is only partly filled costs (nearly) a whole round: measured on the collab forward shape, 3686 tiles
+    // = 7.2 rounds run 24 % slower per FLOP than 3584 tiles = 7 rounds (profiles/r02_gemm_microbench).
+    // When the caller lends a workspace, the row panels of that last round are cut along K instead: the
+    // same tiles times `tail_slices` K-slices fill the round, and the reduce kernel applies the epilogue.
+    int64_t main_panels = gm, tail_rows = 0;
+    int tail_slices = 1;
+    if (split_k == 1 && workspace && g.tiles_total >= 4) {
+        const int64_t tiles = gm * gn, slots = 512;
+        const int64_t rounds = tiles / slots, rem = tiles % slots;
+        if (rounds >= 1 && rem > 0 && rem < 320) {
+            const int64_t mp = (rounds * slots) / gn;              // whole row panels inside the full rounds
+            const int64_t tp = gm - mp;                            // row panels of the last round
+            int sl = (int)(slots / (tp * gn));
+            if (sl > g.tiles_total / 2) sl = g.tiles_total / 2;    // at least 2 K-tiles per slice
+            const int64_t trows = m - mp * BM;
+            if (sl >= 2 && trows > 0 && workspace_floats >= (int64_t)sl * trows * n &&
+                ((uintptr_t)workspace % 16 == 0)) {
+                main_panels = mp; tail_rows = trows; tail_slices = sl;
+            }
+        }
+    }
+    auto launch = [&](const GemmArgs& ga, int md, int slices) -> int {
+        GemmArgs gq = ga;
+        gq.gm = main_panels;                                       // (== gm unless a tail was cut off)
+        dim3 grid((unsigned)(main_panels * gn), 1, (unsigned)slices);
+        return launch_grid(gq, md, grid);
+    };
     if (int rc = launch(g, mode, split_k)) return rc;
     if (split_k > 1) {
         const int64_t total = m * n;
@@ -697,7 +752,25 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, reduce_slices,
-                           g.ws_stride, c, ldc, m, (int)n, e, c2, ldc2, (int)n_split);
+                           g.ws_stride, c, ldc, m, (int)n, e, c2, ldc2, (int)n_split, (int64_t)0);
+        return launch_status();
+    }
+    if (tail_slices > 1) {
+        // the tail rows: partial products over `tail_slices` K-slices, then the reduce kernel with the epilogue
+        GemmArgs tg = g;
+        tg.mt0 = main_panels; tg.gm = gm - main_panels;
+        tg.split_k = tail_slices;
+        tg.ws_stride = tail_rows * n;
+        tg.c = workspace - main_panels * BM * n;       // the kernel indexes the workspace with GLOBAL rows
+        tg.ldc = n;
+        dim3 grid((unsigned)(tg.gm * gn), 1, (unsigned)tail_slices);
+        if (int rc = launch_grid(tg, mode, grid)) return rc;
+        const int64_t total = tail_rows * n;
+        int64_t blocks = (total / 4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, tail_slices,
+                           tg.ws_stride, c, ldc, tail_rows, (int)n, e, c2, ldc2, (int)n_split, main_panels * BM);
         return launch_status();
     }
     return 0;

@@ -48,14 +48,14 @@ class SAGEConv(torch.nn.Module):
         self.lin_l.reset_parameters()
         self.lin_r.reset_parameters()
 
-    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, sink=None, channel=None):
+    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, sink=None, channel=None, out_rows=None):
         act = act if act is not None else _Act(False, 0.0, False)
         if self.aggr != "mean":
             agg = ops.AggregateFn.apply(x, _require_graph(adj_t), "sum" if self.aggr == "add" else self.aggr, False)
             return ops.LinearFn.apply(torch.cat([agg, x], dim=1),
                                       torch.cat([self.lin_l.weight, self.lin_r.weight], dim=1), self.lin_l.bias, act)
         return ops.SAGEConvFn.apply(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight,
-                                    _require_graph(adj_t), act, in_act, sink, channel)
+                                    _require_graph(adj_t), act, in_act, sink, channel, out_rows)
 
 
     def forward_block(self, x_full, adj_block, row_lo: int, act: _Act = None):
@@ -86,7 +86,7 @@ class GCNConv(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.lin.weight)
         torch.nn.init.zeros_(self.bias)
 
-    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, channel=None):
+    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, channel=None, out_rows=None):
         act = act if act is not None else _Act(False, 0.0, False)
         parts = getattr(x, "_plnlp_parts", None)
         if parts is not None and channel is None and in_act is None and ops.GCN_INPUT_FUSION["enabled"]:
@@ -94,7 +94,7 @@ class GCNConv(torch.nn.Module):
             emb_weight, feats, cache = parts
             return ops.GCNInputConvFn.apply(emb_weight, self.lin.weight, self.bias, _require_graph(adj_t), act, feats,
                                             cache)
-        return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act, in_act, channel)
+        return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act, in_act, channel, out_rows)
 
 
 # --------------------------------------------------------------- encoders ------
@@ -131,8 +131,10 @@ class BaseGNN(torch.nn.Module):
         return x
 
     def forward(self, x, adj_t, fuse_output_gate: bool = False, input_grad_sink=None,
-                output_grad_channel=None, shard=None):
+                output_grad_channel=None, shard=None, output_rows=None):
         """shard: a plnlp_amd.shard.ShardContext -> row-sharded pass (see _forward_sharded).
+        output_rows: an ops.CompactIncidence -- the last conv produces only those rows, as a compact
+        matrix (ops.SPARSE_FORWARD / "OutputRows"); needs output_grad_channel and native convs.
         input_grad_sink: an ops.GradSink for the gradient of `x` (first conv must be a SAGEConv).
         output_grad_channel: an ops.SparseGradChannel through which the (single) consumer of the
         returned h hands back its gradient row-sparse; only honoured by the native convs.
@@ -159,9 +161,10 @@ class BaseGNN(torch.nn.Module):
                         raise ValueError("gradient sinks / channels need the fused (mean) SAGEConv")
                     x = conv(x, adj_t, act)
                 elif i == 0 and input_grad_sink is not None and isinstance(conv, SAGEConv):
-                    x = conv(x, adj_t, act, None, input_grad_sink, ch)
+                    x = conv(x, adj_t, act, None, input_grad_sink, ch, out_rows=output_rows if i == last else None)
                 else:
-                    x = conv(x, adj_t, act, prev_act if torch.is_grad_enabled() else None, channel=ch)
+                    x = conv(x, adj_t, act, prev_act if torch.is_grad_enabled() else None, channel=ch,
+                             out_rows=output_rows if (i == last and ch is not None) else None)
                 prev_act = act
             else:  # foreign conv module: un-fused reference order
                 x = conv(x, adj_t)
@@ -262,8 +265,8 @@ class MLPPredictor(_LinsPredictor):
     def forward(self, x_i, x_j):
         return self._stack(x_i * x_j)
 
-    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None, incidence=None):
-        return self._stack(ops.EdgeHadamardFn.apply(h, src, dst, gate_scale, channel, incidence))
+    def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None, incidence=None, compact: bool = False):
+        return self._stack(ops.EdgeHadamardFn.apply(h, src, dst, gate_scale, channel, incidence, compact))
 
 
 class MLPCatPredictor(_LinsPredictor):
@@ -327,8 +330,8 @@ class DotPredictor(torch.nn.Module):
         return torch.sum(x_i * x_j, dim=-1)
 
     def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None, compute_forward: bool = True,
-                    incidence=None):
-        return ops.EdgeDotFn.apply(h, src, dst, gate_scale, channel, compute_forward, incidence)
+                    incidence=None, compact: bool = False):
+        return ops.EdgeDotFn.apply(h, src, dst, gate_scale, channel, compute_forward, incidence, compact)
 
 
 class BilinearPredictor(torch.nn.Module):

@@ -309,10 +309,13 @@ class BaseModel(object):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
         return bool(torch.equal(lo, hi))
 
-    def _encode(self, data, pos_edge, neg_flat, use_sink, edges_ready):
+    def _encode(self, data, pos_edge, neg_flat, use_sink, edges_ready, rows_only=False):
         """encoder forward of a training step with the fusions the scorer allows; pos_edge [n,2] and
         neg_flat [n*k,2] are ALL edges whose scores will be back-propagated.  Returns (h, gate_scale,
-        channel, fused, batch) with batch an ops.EdgeBatch (src, dst, incidence) -- see train_step"""
+        channel, fused, batch) with batch an ops.EdgeBatch (src, dst, incidence) -- see train_step.
+        rows_only: the caller reads h ONLY through the fused scorer on exactly these edges, so the last
+        conv may produce just the touched rows (ops.SPARSE_FORWARD); h is then compact (batch.src_c /
+        dst_c address it) -- tell by `batch.src_c is not None`."""
         n_edges = pos_edge.size(0) + neg_flat.size(0)
         n_endpoints = 2 * n_edges
         native = isinstance(self.encoder, BaseGNN)
@@ -336,9 +339,15 @@ class BaseModel(object):
         # them (sort, touched-node compaction, its count read-back) NOW -- on the side stream, in the
         # shadow of the previous step's tail -- and join before the scorer
         build = n_edges > 0 and fused and x_in.is_cuda and ops.EDGE_BACKWARD["mode"] == "segment"
+        sparse_fwd = rows_only and build and channel is not None and ops.SPARSE_FORWARD["enabled"]
         batch = ops.EdgeBatch([pos_edge[:, 0], neg_flat[:, 0]], [pos_edge[:, 1], neg_flat[:, 1]], x_in.shape[0],
                               build=build, compact=channel is not None, overlap=x_in.is_cuda,
-                              inputs_ready=edges_ready)
+                              inputs_ready=edges_ready, compact_endpoints=sparse_fwd)
+        if sparse_fwd:
+            # the last conv needs the touched-row list (and its count, on the host) before it is launched:
+            # the lists were started on the side stream at the top of the step, in the shadow of the
+            # previous step's tail
+            kw["output_rows"] = batch.join().incidence
         if fuse_gate:
             h, gate_scale = self.encoder(x_in, data.adj_t, fuse_output_gate=True, **kw)
         else:
@@ -362,12 +371,16 @@ class BaseModel(object):
         self.optimizer.zero_grad(set_to_none=True)
         local = pos_edge.size(0)
         h, gate_scale, channel, fused, batch = self._encode(data, pos_edge, neg_edge.reshape(-1, 2), True,
-                                                             edges_ready)
+                                                             edges_ready, rows_only=True)
         src, dst, incidence = batch.src, batch.dst, batch.incidence
         if local > 0:
-            out = (self.predictor.score_edges(h, src, dst, gate_scale=gate_scale, channel=channel,
-                                              incidence=incidence) if fused
-                   else self._score(h, src, dst))
+            if batch.src_c is not None:          # h holds only the touched rows (ops.SPARSE_FORWARD)
+                out = self.predictor.score_edges(h, batch.src_c, batch.dst_c, gate_scale=gate_scale, channel=channel,
+                                                 incidence=incidence, compact=True)
+            else:
+                out = (self.predictor.score_edges(h, src, dst, gate_scale=gate_scale, channel=channel,
+                                                  incidence=incidence) if fused
+                       else self._score(h, src, dst))
             loss = self._loss_of_scores(out, local, num_neg, weight_margin)
             scale = self._slice_loss_scale(local, global_count)
             if scale != 1.0:

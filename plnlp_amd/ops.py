@@ -83,14 +83,66 @@ def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
             and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0)
 
 
+AGG_AUTOTUNE = {"enabled": os.environ.get("PLNLP_AGG_AUTOTUNE", "1") != "0", "min_feat": 256,
+                "candidates": (0, L.AGG_SLABS_128, L.AGG_SLABS_256)}
+
+
+def _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, feat, row_index=None) -> int:
+    """which form of the aggregation kernel to run on a STATIC graph at this feature width: one wave per
+    row, or one per (row, 128- / 256-column slab).  Which one wins depends on whether the source matrix
+    is cache-resident and on the degree skew (measured on MI355X, uniform 2.9 M-node graph, F = 512:
+    0.72 -> 0.79 of the HBM peak with 128-column slabs; R-MAT and the cache-resident collab graph lose
+    10-25 % with them), so it is MEASURED once per (graph, width, form) -- three timed launches on the
+    first eligible call -- and remembered on the graph object.  Per-batch structures (incidence lists)
+    and calls whose epilogue accumulates into `out` are never used for timing."""
+    if (not AGG_AUTOTUNE["enabled"] or not isinstance(graph, Graph) or feat < AGG_AUTOTUNE["min_feat"]
+            or not _vector_path(x, out, feat)):
+        return 0
+    flags = 0 if epilogue is None else int(epilogue.flags)
+    if flags & L.EPI_DROPOUT:
+        return 0
+    cache = getattr(graph, "_agg_tune", None)
+    if cache is None:
+        cache = graph._agg_tune = {}
+    key = (feat, bool((use_values and graph.val is not None) or src_scale is not None))      # width, weighted kernel
+    if key in cache:
+        return cache[key]
+    if flags & (L.EPI_ACCUM | L.EPI_ADDEND | L.EPI_GATE) or src_map is not None or row_index is not None:
+        return 0                      # not a call to time on; an earlier or later plain call decides
+    best, best_t = 0, None
+    for cand in AGG_AUTOTUNE["candidates"]:
+        times = []
+        for it in range(3):
+            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_ev.record()
+            csr_aggregate(graph, x, reduce, use_values, src_scale=src_scale, out=out, epilogue=epilogue, tune=cand)
+            e_ev.record()
+            e_ev.synchronize()
+            times.append(s_ev.elapsed_time(e_ev))
+        t = min(times[1:])
+        if best_t is None or t < 0.97 * best_t:         # a slab form must win clearly
+            best, best_t = cand, t
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        # replicated data-parallel ranks must run the SAME form (their replicas agree bit for bit only
+        # then): rank 0's measurement decides
+        pick = torch.tensor([best], dtype=torch.int64, device=x.device)
+        torch.distributed.broadcast(pick, 0)
+        best = int(pick.item())
+    cache[key] = best
+    return best
+
+
 def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
                   src_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                   epilogue: Optional[L.Epilogue] = None, split="auto", short_rows="auto",
-                  lds_stage="auto", src_map: Optional[torch.Tensor] = None, tune: int = 0) -> torch.Tensor:
+                  lds_stage="auto", src_map: Optional[torch.Tensor] = None, tune="auto",
+                  row_index: Optional[torch.Tensor] = None, out_map: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[r] = red_{e in row r} w_e x[col[e]]  (plnlp_csr_aggregate_f32).
     `graph` needs rowptr/col/val/n_rows/n_cols (+ row_split() when split == 'auto').
     src_map (int32 [n_cols]): x holds only some source rows; entry e reads x[src_map[col[e]]] and
-    is skipped where that is negative."""
+    is skipped where that is negative.
+    row_index (int32 [R]): only R result rows are produced, out[i] = the aggregate of CSR row
+    row_index[i]; out_map (int32 [n_rows]) is the inverse map (-1 = not produced) the long-row pass needs."""
     lib = L.load()
     L.require_device(x, graph.col, src_map)
     x = _f32c(x)
@@ -99,8 +151,13 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
     else:
         assert src_map.dtype == torch.int32 and src_map.numel() == graph.n_cols
     feat = x.shape[1]
+    n_out = graph.n_rows
+    if row_index is not None:
+        assert row_index.dtype == torch.int32 and out_map is not None and out_map.dtype == torch.int32
+        n_out = row_index.numel()
+        short_rows, lds_stage = False, False
     if out is None:
-        out = torch.empty(graph.n_rows, feat, dtype=torch.float32, device=x.device)
+        out = torch.empty(n_out, feat, dtype=torch.float32, device=x.device)
     val = graph.val if use_values else None
     val_index = getattr(graph, "val_index", None) if use_values else None
     if short_rows == "auto":     # several rows per wave when the average row has only a few entries
@@ -108,6 +165,8 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
     if lds_stage == "auto":      # small AND dense (ddi-like): feature slabs of x fit in LDS and are reused
         lds_stage = (LDS_STAGE_AUTO and graph.n_cols * 16 <= LDS_STAGE_BUDGET
                      and graph.col.numel() >= LDS_STAGE_MIN_DEG * graph.n_cols and feat % 4 == 0)
+    if tune == "auto":
+        tune = _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, feat, row_index)
     flags = (L.AGG_SHORT_ROWS if short_rows else 0) | (L.AGG_LDS_STAGE if lds_stage else 0) | int(tune)
     if lds_stage:
         split = None             # the staged form walks whole rows
@@ -121,8 +180,8 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
                         ws.numel())
     rc = lib.plnlp_csr_aggregate_f32(
         graph.rowptr.data_ptr(), graph.col.data_ptr() or graph.rowptr.data_ptr(), L.ptr(val), L.ptr(val_index),
-        L.ptr(src_scale), L.ptr(src_map),
-        x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), graph.n_rows, x.shape[0], feat,
+        L.ptr(src_scale), L.ptr(src_map), L.ptr(row_index), L.ptr(out_map),
+        x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), n_out, x.shape[0], feat,
         L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM, flags,
         C.byref(epilogue) if epilogue is not None else None,
         C.byref(sp) if sp is not None else None, L.stream_ptr())
@@ -185,13 +244,29 @@ def _pick_split_k(m: int, n: int, ktiles: int) -> int:
     return max(1, min(ktiles, 512 // blocks))
 
 
+_tail_ws = {}
+TAIL_WS_FLOATS = 512 * 128 * 128          # one round of tiles: the most the tail of a launch can need
+
+
+def _tail_workspace(device) -> torch.Tensor:
+    """scratch the GEMM may use to cut the last, partly filled round of its tile grid along K
+    (gemm_f32.hip::gemm_impl); one buffer per device, reused by every launch (stream-ordered)"""
+    key = torch.device(device)
+    if key not in _tail_ws:
+        _tail_ws[key] = torch.empty(TAIL_WS_FLOATS, dtype=torch.float32, device=key)
+    return _tail_ws[key]
+
+
 def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_trans: bool,
          out: Optional[torch.Tensor] = None, epilogue: Optional[L.Epilogue] = None,
-         split_k: Optional[int] = None, b_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+         split_k: Optional[int] = None, b_index: Optional[torch.Tensor] = None,
+         a_index: Optional[Sequence[Optional[torch.Tensor]]] = None) -> torch.Tensor:
     """C = EPI(sum_s op(A_s) op(B_s))  (plnlp_gemm_f32).  A_s: [M,K] or [K,M] if
     a_trans; B_s: [N,K] if b_trans (nn.Linear weight layout) else [K,N].
     b_index (int32 [K], one segment, a_trans and not b_trans): B's row for reduction index j
-    is b_index[j] -- B is gathered in place."""
+    is b_index[j] -- B is gathered in place.
+    a_index (per segment, int32 [M] or None; not a_trans, b_trans): A_s' row for result row i is
+    a_index[s][i] -- A_s is gathered in the loader (a layer evaluated at some rows only)."""
     lib = L.load()
     ops = (L.GemmOperand * len(segs))()
     m = n = None
@@ -203,6 +278,10 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
         keep += [a, b]
         ma, ka = (a.shape[1], a.shape[0]) if a_trans else a.shape
         nb, kb = b.shape if b_trans else (b.shape[1], b.shape[0])
+        if a_index is not None and a_index[i] is not None:
+            assert a_index[i].dtype == torch.int32 and not a_trans and b_trans
+            ma = a_index[i].numel()
+            ops[i].a_index = a_index[i].data_ptr()
         if b_index is not None:
             assert b_index.dtype == torch.int32 and len(segs) == 1 and a_trans and not b_trans
             kb = b_index.numel()
@@ -217,9 +296,10 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     if split_k is None:
         split_k = _pick_split_k(m, n, ktiles)
     split_k = max(1, min(split_k, ktiles))
-    ws = None
     if split_k > 1:
-        ws = torch.empty((split_k + 1) * m * n, dtype=torch.float32, device=out.device)   # +1: ragged-K tail slice
+        ws = torch.empty(split_k * m * n, dtype=torch.float32, device=out.device)
+    else:
+        ws = _tail_workspace(out.device)
     rc = lib.plnlp_gemm_f32(ops, len(segs), int(a_trans), int(b_trans), out.data_ptr(), _ld(out), m, n,
                             C.byref(epilogue) if epilogue is not None else None, split_k,
                             L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr())
@@ -227,14 +307,16 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     return out
 
 
-def wgrad_pair(dz: torch.Tensor, x1: torch.Tensor, x2: torch.Tensor, rows: Optional[torch.Tensor] = None):
+def wgrad_pair(dz: torch.Tensor, x1: torch.Tensor, x2: torch.Tensor, rows: Optional[torch.Tensor] = None,
+               x1_compact: bool = False):
     """(dW1, dW2) = dz^T x1, dz^T x2 in one split-K GEMM that reads dz once (gemm_pair); two products when
     the seam would cut a 128-column tile.
     rows (int32 [K]): dz holds only those rows of a row-sparse gradient; x1 / x2 are read at
-    rows[j] (gathered inside the GEMM's loader)."""
-    out = gemm_pair(dz, x1, x2, True, rows=rows)
+    rows[j] (gathered inside the GEMM's loader); x1_compact: x1 already holds just those rows."""
+    out = gemm_pair(dz, x1, x2, True, rows=rows, rows_on=2 if (x1_compact and rows is not None) else 3)
     if out is None:
-        return (gemm([(dz, x1)], True, False, b_index=rows), gemm([(dz, x2)], True, False, b_index=rows))
+        return (gemm([(dz, x1)], True, False, b_index=None if x1_compact else rows),
+                gemm([(dz, x2)], True, False, b_index=rows))
     return out
 
 
@@ -248,13 +330,14 @@ def dgrad_pair(dz: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, out1: Optio
 
 
 def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool, out1: Optional[torch.Tensor] = None,
-              rows: Optional[torch.Tensor] = None):
+              rows: Optional[torch.Tensor] = None, rows_on: int = 3):
     """(c1, c2) = op(a) @ b1, op(a) @ b2 in ONE launch (plnlp_gemm_pair_f32): `a` is read once, B comes
     from the two buffers as they are (no concatenated copy) and the two results are two contiguous
     tensors (no strided halves to copy out).  b1 / b2: [K, n1] / [K, n2] (row-contiguous).
       a_trans=False: a [M, K]   -- the two data gradients of SAGEConv  [gx | gagg] = dz [Wr | Wl]
       a_trans=True : a [K, M]   -- its two weight gradients  [dWl | dWr] = dz^T [agg | x]  (split-K;
-                                  rows (int32 [K]): b1 / b2 are read at rows[j], gathered in the loader)
+                                  rows (int32 [K]): b1 / b2 are read at rows[j], gathered in the loader;
+                                  rows_on = 2: only b2 is gathered, b1 is already compact)
     None when the seam would cut a 128-column tile (the caller falls back to two products)."""
     n1, n2 = b1.shape[1], b2.shape[1]
     if n1 % 128 != 0:
@@ -271,13 +354,15 @@ def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool
         ops[0].b_index = rows.data_ptr()
     else:
         assert b1.shape[0] == k and b2.shape[0] == k, (a.shape, b1.shape, b2.shape)
+    if rows is not None and rows_on == 2:
+        assert b1.shape[0] == k
     ktiles = (k + 31) // 32
     split_k = max(1, min(_pick_split_k(m, n, ktiles), ktiles)) if a_trans else 1
     c1 = out1 if out1 is not None else torch.empty(m, n1, dtype=torch.float32, device=a.device)
     assert c1.shape == (m, n1) and c1.is_contiguous()
     c2 = torch.empty(m, n2, dtype=torch.float32, device=a.device)
-    ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device) if split_k > 1 else None
-    L.check(lib.plnlp_gemm_pair_f32(ops, b2.data_ptr(), _ld(b2), n1, int(a_trans), 0, c1.data_ptr(), _ld(c1),
+    ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device) if split_k > 1 else _tail_workspace(a.device)
+    L.check(lib.plnlp_gemm_pair_f32(ops, b2.data_ptr(), _ld(b2), n1, int(rows_on), int(a_trans), 0, c1.data_ptr(), _ld(c1),
                                     c2.data_ptr(), _ld(c2), n1, m, n, split_k, L.ptr(ws),
                                     0 if ws is None else ws.numel(), L.stream_ptr()), "plnlp_gemm_pair_f32")
     return c1, c2
@@ -513,6 +598,40 @@ class CompactIncidence:
             from .graph import RowSplit
             self._split = RowSplit(self._rowptr_cap, self.item_edge.numel(), threshold)
         return self._split
+
+    def prepare_compact_columns(self) -> None:
+        """item_other translated to COMPACT row ids (node_map[other]; every endpoint of the batch is a
+        touched node, so all are >= 0): the column list of these same lists over a matrix that holds only
+        the touched rows (a row-restricted encoder output).  One gather, built with the lists."""
+        if getattr(self, "_other_c", None) is None:
+            self._other_c = self.node_map.index_select(0, self.item_other.long())
+
+    def compact_view(self) -> "_CompactCols":
+        self.prepare_compact_columns()
+        return _CompactCols(self)
+
+
+class _CompactCols:
+    """a CompactIncidence seen over the compact matrix: same rows / segments / weights, columns in
+    compact row ids"""
+
+    def __init__(self, ci: CompactIncidence):
+        self._ci = ci
+        self.col = self.item_other = ci._other_c
+        self.val_index = self.item_edge = ci.item_edge
+        self.val = None
+        self.node_map = ci.node_map
+
+    count = property(lambda self: self._ci.count)
+    n_rows = property(lambda self: self._ci.n_rows)
+    n_cols = property(lambda self: self._ci.n_rows)
+    n_nodes = n_cols
+    rows = property(lambda self: self._ci.rows)
+    rowptr = property(lambda self: self._ci.rowptr)
+    seg_ptr = rowptr
+
+    def row_split(self, threshold: int):
+        return self._ci.row_split(threshold)
 
 
 class RowSparseGrad:
@@ -813,6 +932,42 @@ class AggregateFn(torch.autograd.Function):
         return gx, None, None, None
 
 
+SPARSE_FORWARD = {"enabled": os.environ.get("PLNLP_SPARSE_FORWARD", "1") != "0"}
+"""OutputRows -- the LAST conv of an encoder evaluated only at the rows the step reads.
+
+The reference computes h = encoder(x, adj_t) for every node (model.py:150-151) and then reads h only at
+the endpoints of the batch's edges (model.py:155-156); the other rows are never used and their gradient is
+exactly zero.  When the scorer is fused (it gathers through an index map anyway) the last conv therefore
+produces just the touched rows, as a compact [T, out] matrix in the order of `CompactIncidence.rows`:
+
+  * SAGE: the mean aggregation walks only those CSR rows (row_index), the GEMM runs on T rows with the
+    root operand x gathered in its loader (a_index); GCN: the weighted aggregation walks only those rows;
+  * dropout masks are drawn at the ORIGINAL row positions (dropout_row_index), so every produced value is
+    bit-identical to the corresponding row of the full matrix;
+  * the backward is the row-sparse backward that already existed (same T rows), with the saved
+    aggregate now compact.
+Loss, every gradient and the update are those of the full-matrix step; on the collab-shaped workload
+T ~ 0.55 N, on citation2 ~ 0.09 N (one layer of aggregation out of four nearly disappears)."""
+
+
+def _compact_grad(out_rows, sg, gy, y, act: "_Act", n_rows: int):
+    """the gradient of a row-restricted conv output as a RowSparseGrad over out_rows, already taken
+    w.r.t. the pre-activation: from the channel (the fused scorers fold the activation derivative in
+    when act.gate_in_consumer) and / or from autograd (a [T, out] tensor); None when there is none"""
+    vals = None
+    if sg is not None:
+        vals = sg.values
+    if gy is not None:
+        vals = gy.contiguous() if vals is None else vals + gy
+    if vals is None:
+        return None
+    if act.active and not act.gate_in_consumer:
+        vals = _act_backward(vals, y, act)
+    elif gy is not None and act.active and sg is not None:
+        raise RuntimeError("a row-restricted conv output got a folded and an unfolded gradient at once")
+    return RowSparseGrad(out_rows.rows, out_rows.node_map, vals, n_rows, out_rows.count)
+
+
 class SAGEConvFn(torch.autograd.Function):
     """One SAGEConv (+ optional relu/dropout of BaseGNN.forward, layer.py:20-26):
         y = act( mean_agg(x) @ Wl^T + bl + x @ Wr^T )
@@ -822,20 +977,30 @@ class SAGEConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_l, b_l, w_r, graph: Graph, act: _Act, in_act: Optional[_Act] = None,
-                sink: Optional[GradSink] = None, channel: Optional[SparseGradChannel] = None):
+                sink: Optional[GradSink] = None, channel: Optional[SparseGradChannel] = None, out_rows=None):
         """in_act: the relu/dropout that PRODUCED x (previous layer).  When given, backward
         returns the gradient w.r.t. that layer's pre-activation (its derivative rides in the
         epilogue of the last kernel that touches gx) and in_act.gate_in_consumer is set.
         sink: see GradSink (the input gradient is delivered there, autograd gets None).
-        channel: the gradient of y may arrive row-sparse through it (see SparseGradChannel)."""
+        channel: the gradient of y may arrive row-sparse through it (see SparseGradChannel).
+        out_rows (a CompactIncidence: rows, node_map): produce ONLY those rows of y, as a compact
+        [len(rows), out] matrix (see OutputRows below); needs `channel`."""
         ctx.sink = sink
         ctx.channel = channel
+        ctx.out_rows = out_rows
         if channel is not None:
             ctx.set_materialize_grads(False)
         x = _f32c(x)
-        agg = csr_aggregate(graph, x, "mean", use_values=False)
-        epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
-        y = gemm([(agg, w_l), (x, w_r)], False, True, epilogue=epi)
+        if out_rows is not None:
+            assert channel is not None, "a row-restricted forward hands its gradient back through the channel"
+            rows = out_rows.rows
+            agg = csr_aggregate(graph, x, "mean", use_values=False, row_index=rows, out_map=out_rows.node_map)
+            epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_rows=rows)
+            y = gemm([(agg, w_l), (x, w_r)], False, True, epilogue=epi, a_index=[None, rows])
+        else:
+            agg = csr_aggregate(graph, x, "mean", use_values=False)
+            epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+            y = gemm([(agg, w_l), (x, w_r)], False, True, epilogue=epi)
         ctx.graph, ctx.act = graph, act
         ctx.in_act = in_act if (in_act is not None and in_act.active) else None
         if ctx.in_act is not None:
@@ -848,6 +1013,13 @@ class SAGEConvFn(torch.autograd.Function):
         x, agg, w_l, w_r, y = ctx.saved_tensors
         graph, act = ctx.graph, ctx.act
         sg = ctx.channel.take() if ctx.channel is not None else None
+        if ctx.out_rows is not None:
+            # the forward produced compact rows: the gradient is compact too (through the channel, or as
+            # a [T, out] tensor from a consumer that used the compact matrix directly)
+            sg = _compact_grad(ctx.out_rows, sg, gy, y, act, x.shape[0])
+            if sg is None:
+                return (None,) * 10
+            return SAGEConvFn._backward_sparse(ctx, sg)
         if sg is not None and (gy is not None or (act.active and not act.gate_in_consumer)):
             # a dense gradient arrived as well (second consumer), or the activation derivative
             # was not folded in by the producer: fall back to the dense form
@@ -856,7 +1028,7 @@ class SAGEConvFn(torch.autograd.Function):
         if sg is not None:
             return SAGEConvFn._backward_sparse(ctx, sg)
         if gy is None:
-            return (None,) * 9
+            return (None,) * 10
         dz = _act_backward(gy.contiguous(), y, act)
         need = ctx.needs_input_grad
         gx = gwl = gbl = gwr = None
@@ -900,7 +1072,7 @@ class SAGEConvFn(torch.autograd.Function):
             gbl = colsum(dz)
         if need[0] and OVERLAP_BACKWARD["enabled"] and joined is not None:
             torch.cuda.current_stream().wait_event(joined)
-        return gx, gwl, gbl, gwr, None, None, None, None, None
+        return gx, gwl, gbl, gwr, None, None, None, None, None, None
 
     @staticmethod
     def _backward_sparse(ctx, sg: RowSparseGrad):
@@ -924,7 +1096,8 @@ class SAGEConvFn(torch.autograd.Function):
                 else:
                     gx = zero(x)
             return (gx, zero(w_l) if need[1] else None, torch.zeros(w_l.shape[0], device=x.device) if need[2] else None,
-                    zero(w_r) if need[3] else None, None, None, None, None, None)
+                    zero(w_r) if need[3] else None, None, None, None, None, None, None)
+        compact_fwd = ctx.out_rows is not None          # agg holds only the rows sg.rows
         if need[0]:
             cin = w_r.shape[1]
             gx_c, gagg_c = dgrad_pair(dz, w_r, w_l)
@@ -941,15 +1114,15 @@ class SAGEConvFn(torch.autograd.Function):
             else:
                 gx = out
         if need[1] and need[3]:
-            gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows)
+            gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows, x1_compact=compact_fwd)
         else:
             if need[1]:
-                gwl = gemm([(dz, agg)], True, False, b_index=sg.rows)
+                gwl = gemm([(dz, agg)], True, False, b_index=None if compact_fwd else sg.rows)
             if need[3]:
                 gwr = gemm([(dz, x)], True, False, b_index=sg.rows)
         if need[2]:
             gbl = colsum(dz)
-        return gx, gwl, gbl, gwr, None, None, None, None, None
+        return gx, gwl, gbl, gwr, None, None, None, None, None, None
 
 
 def _root_map(graph: Graph, row_lo: int) -> torch.Tensor:
@@ -1137,8 +1310,10 @@ class GCNConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, graph: Graph, act: _Act, in_act: Optional[_Act] = None,
-                channel: Optional[SparseGradChannel] = None):
+                channel: Optional[SparseGradChannel] = None, out_rows=None):
+        """out_rows: produce only those rows of y, compact (OutputRows above); needs `channel`"""
         ctx.channel = channel
+        ctx.out_rows = out_rows
         if channel is not None:
             ctx.set_materialize_grads(False)
         kin = x.shape[1]
@@ -1151,8 +1326,15 @@ class GCNConvFn(torch.autograd.Function):
         else:
             xp, wp = _f32c(x), w
         xw = gemm([(xp, wp)], False, True)
-        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
-        y = csr_aggregate(graph, xw, "sum", use_values=True, epilogue=epi)
+        if out_rows is not None:
+            assert channel is not None, "a row-restricted forward hands its gradient back through the channel"
+            epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed,
+                                  dropout_rows=out_rows.rows)
+            y = csr_aggregate(graph, xw, "sum", use_values=True, epilogue=epi, row_index=out_rows.rows,
+                              out_map=out_rows.node_map)
+        else:
+            epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+            y = csr_aggregate(graph, xw, "sum", use_values=True, epilogue=epi)
         ctx.graph, ctx.act, ctx.kin = graph, act, kin
         ctx.in_act = in_act if (in_act is not None and in_act.active) else None
         if ctx.in_act is not None:
@@ -1165,12 +1347,15 @@ class GCNConvFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         graph, act = ctx.graph, ctx.act
         sg = ctx.channel.take() if ctx.channel is not None else None
-        if sg is not None and (gy is not None or (act.active and not act.gate_in_consumer)
-                               or sg.values.shape[0] == 0):
+        if ctx.out_rows is not None:
+            sg = _compact_grad(ctx.out_rows, sg, gy, y, act, x.shape[0])
+            gy = None
+        elif sg is not None and (gy is not None or (act.active and not act.gate_in_consumer)
+                                 or sg.values.shape[0] == 0):
             gy = sg.to_dense() if gy is None else gy + sg.to_dense()
             sg = None
         if sg is None and gy is None:
-            return (None,) * 7
+            return (None,) * 8
         # row-sparse dz (zero outside sg.rows): the bias gradient sums the touched rows and the
         # transposed aggregation gathers mapped source rows only; its result is dense again
         dz = sg.values if sg is not None else _act_backward(gy.contiguous(), y, act)
@@ -1192,7 +1377,7 @@ class GCNConvFn(torch.autograd.Function):
                           epilogue=L.make_epilogue(gate=x, gate_scale=ia.scale) if ia is not None else None)
                 if gx.shape[1] != kin:
                     gx = gx[:, :kin]
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -1312,7 +1497,10 @@ class EdgeBatch:
     stream passes True."""
 
     def __init__(self, src_parts, dst_parts, n_nodes: int, build: bool, compact: bool, overlap: bool,
-                 inputs_ready: bool = False):
+                 inputs_ready: bool = False, compact_endpoints: bool = False):
+        """compact_endpoints: also src_c / dst_c = the endpoints as rows of a matrix that holds only the
+        touched nodes, and the incidence's compact column list (a row-restricted encoder output)"""
+        self._compact_endpoints = compact_endpoints and compact
         dev = src_parts[0].device
         overlap = overlap and PROLOGUE_OVERLAP["enabled"] and dev.type == "cuda"
         self._done = None
@@ -1334,12 +1522,20 @@ class EdgeBatch:
         self.src = torch.cat(src_parts) if len(src_parts) > 1 else src_parts[0].contiguous()
         self.dst = torch.cat(dst_parts) if len(dst_parts) > 1 else dst_parts[0].contiguous()
         self.incidence = None
+        self.src_c = self.dst_c = None
         if build and self.src.numel() > 0:
             self.incidence = prepare_edge_backward(self.src, self.dst, n_nodes, compact)
+            if self._compact_endpoints:
+                inc = self.incidence
+                inc.prepare_compact_columns()
+                self.src_c = inc.node_map.index_select(0, self.src).long()
+                self.dst_c = inc.node_map.index_select(0, self.dst).long()
 
     def _tensors(self):
         out = [self.src, self.dst]
         inc = self.incidence
+        if self.src_c is not None:
+            out += [self.src_c, self.dst_c, inc._other_c]
         if inc is not None:
             for name in ("item_edge", "item_other", "seg_ptr", "_rows_cap", "node_map", "_rowptr_cap", "_count_dev"):
                 t = getattr(inc, name, None)
@@ -1361,9 +1557,16 @@ class EdgeBatch:
         return self
 
 
-def _sparse_edge_backward(h, src, dst, g, gate_scale: float, ci=None) -> RowSparseGrad:
+def _sparse_edge_backward(h, src, dst, g, gate_scale: float, ci=None, compact: bool = False) -> RowSparseGrad:
     """gradient of the gathered matrix h over the touched nodes only (scalar g: DOT, matrix g:
-    Hadamard), with the producing layer's relu/dropout derivative folded in when gate_scale > 0"""
+    Hadamard), with the producing layer's relu/dropout derivative folded in when gate_scale > 0.
+    compact: h already holds only the touched rows (row i = node ci.rows[i]) and src / dst are compact."""
+    if compact:
+        assert ci is not None
+        cv = ci.compact_view() if isinstance(ci, CompactIncidence) else ci
+        epi = L.make_epilogue(gate=h, gate_scale=gate_scale) if gate_scale > 0.0 else None
+        vals = edge_segment_bwd(h, cv, g, epilogue=epi)
+        return RowSparseGrad(cv.rows, cv.node_map, vals, cv.node_map.numel(), cv.count)
     if ci is None:
         ci = Incidence(src, dst, h.shape[0]).compact()
     epi = L.make_epilogue(gate=h, gate_scale=gate_scale, gate_index=ci.rows) if gate_scale > 0.0 else None
@@ -1377,19 +1580,21 @@ class EdgeDotFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None,
-                compute_forward: bool = True, incidence=None):
+                compute_forward: bool = True, incidence=None, compact: bool = False):
         """gate_scale > 0: h is the output of relu(+dropout, scale = 1/(1-p)) and the returned
         gradient is taken w.r.t. the pre-activation (h > 0 ? g * gate_scale : 0), folding the
         activation backward into the gather-reduce epilogue (no separate pass over [N, F]).
         channel: deliver the gradient of h row-sparse through it (see SparseGradChannel).
         compute_forward=False: the scores are not needed (the caller already has them and only
         wants this node in the graph for its backward); the returned tensor is uninitialised.
-        incidence: prepare_edge_backward(src, dst, ...) of the same edges, built ahead of time."""
+        incidence: prepare_edge_backward(src, dst, ...) of the same edges, built ahead of time.
+        compact: h holds only the touched rows, src / dst are rows of it (OutputRows above)."""
         h = _f32c(h)
         ctx.save_for_backward(h, src, dst)
         ctx.gate_scale = float(gate_scale)
         ctx.channel = channel
         ctx.incidence = incidence
+        ctx.compact = bool(compact)
         if not compute_forward:
             L.require_device(h, src, dst)
             return torch.empty(src.numel(), dtype=torch.float32, device=h.device)
@@ -1402,9 +1607,48 @@ class EdgeDotFn(torch.autograd.Function):
         gs = ctx.gate_scale
         inc = ctx.incidence
         if ctx.channel is not None and EDGE_BACKWARD["mode"] == "segment":
-            ci = inc if isinstance(inc, CompactIncidence) else None
-            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs, ci)
+            ci = inc if isinstance(inc, (CompactIncidence, _CompactCols)) else None
+            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs, ci, compact=ctx.compact)
+            return None, None, None, None, None, None, None, None
+        assert not ctx.compact, "a compact encoder output needs the row-sparse channel"
+        if EDGE_BACKWARD["mode"] == "segment":
+            epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
+            if not isinstance(inc, Incidence):
+                inc = Incidence(src, dst, h.shape[0])
+            gh = edge_segment_bwd(h, inc, g, epilogue=epi)
+        else:
+            gh = edge_scatter_bwd(h, src, dst, g)
+            if gs > 0.0:
+                gh = gate(gh, h, gs)
+        return gh, None, None, None, None, None, None, None
+
+
+class EdgeHadamardFn(torch.autograd.Function):
+    """x[e,:] = h[src[e],:] * h[dst[e],:]  (model.py:155-156 + layer.py:81)."""
+
+    @staticmethod
+    def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None, incidence=None,
+                compact: bool = False):
+        """gate_scale / channel / incidence / compact: as in EdgeDotFn"""
+        h = _f32c(h)
+        ctx.save_for_backward(h, src, dst)
+        ctx.gate_scale = float(gate_scale)
+        ctx.channel = channel
+        ctx.incidence = incidence
+        ctx.compact = bool(compact)
+        return edge_hadamard_fwd(h, src, dst)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, src, dst = ctx.saved_tensors
+        g = _f32c(g)
+        gs = ctx.gate_scale
+        inc = ctx.incidence
+        if ctx.channel is not None and EDGE_BACKWARD["mode"] == "segment":
+            ci = inc if isinstance(inc, (CompactIncidence, _CompactCols)) else None
+            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs, ci, compact=ctx.compact)
             return None, None, None, None, None, None, None
+        assert not ctx.compact, "a compact encoder output needs the row-sparse channel"
         if EDGE_BACKWARD["mode"] == "segment":
             epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
             if not isinstance(inc, Incidence):
@@ -1415,41 +1659,6 @@ class EdgeDotFn(torch.autograd.Function):
             if gs > 0.0:
                 gh = gate(gh, h, gs)
         return gh, None, None, None, None, None, None
-
-
-class EdgeHadamardFn(torch.autograd.Function):
-    """x[e,:] = h[src[e],:] * h[dst[e],:]  (model.py:155-156 + layer.py:81)."""
-
-    @staticmethod
-    def forward(ctx, h, src, dst, gate_scale=0.0, channel: Optional[SparseGradChannel] = None, incidence=None):
-        """gate_scale / channel / incidence: as in EdgeDotFn"""
-        h = _f32c(h)
-        ctx.save_for_backward(h, src, dst)
-        ctx.gate_scale = float(gate_scale)
-        ctx.channel = channel
-        ctx.incidence = incidence
-        return edge_hadamard_fwd(h, src, dst)
-
-    @staticmethod
-    def backward(ctx, g):
-        h, src, dst = ctx.saved_tensors
-        g = _f32c(g)
-        gs = ctx.gate_scale
-        inc = ctx.incidence
-        if ctx.channel is not None and EDGE_BACKWARD["mode"] == "segment":
-            ci = inc if isinstance(inc, CompactIncidence) else None
-            ctx.channel.grad = _sparse_edge_backward(h, src, dst, g, gs, ci)
-            return None, None, None, None, None, None
-        if EDGE_BACKWARD["mode"] == "segment":
-            epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
-            if not isinstance(inc, Incidence):
-                inc = Incidence(src, dst, h.shape[0])
-            gh = edge_segment_bwd(h, inc, g, epilogue=epi)
-        else:
-            gh = edge_scatter_bwd(h, src, dst, g)
-            if gs > 0.0:
-                gh = gate(gh, h, gs)
-        return gh, None, None, None, None, None
 
 
 _unit_grads = {}

@@ -36,7 +36,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.plnlp_abi_version() == 2
+    assert lib.plnlp_abi_version() == 3
     assert lib.plnlp_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5):
         assert lib.plnlp_error_string(code).startswith(b"plnlp:")
@@ -44,7 +44,7 @@ def test_abi_version_and_error_strings(lib):
 
 def test_argument_validation_without_launch(lib):
     # NULL pointers / bad shapes are rejected before any HIP call
-    assert lib.plnlp_csr_aggregate_f32(None, None, None, None, None, None, None, 4, None, 4, 1, 1, 4, 0, 0, None, None, None) == -1
+    assert lib.plnlp_csr_aggregate_f32(None, None, None, None, None, None, None, None, None, 4, None, 4, 1, 1, 4, 0, 0, None, None, None) == -1
     assert lib.plnlp_gemm_f32(None, 1, 0, 1, None, 4, 4, 4, None, 1, None, 0, None) == -1
     assert lib.plnlp_adam_step_f32(None, None, None, None, -1, 0.1, 0.9, 0.999, 1e-8, 0.0, 0, 1, None, 0.0, 1.0, None) == -2
     assert lib.plnlp_dropout_f32(None, None, 4, 4, 1.5, 0, None) == -2

@@ -908,9 +908,14 @@ def test_csr_aggregate_src_map_equals_dense_with_zero_rows(P, feat, weighted):
     scale = torch.rand(n, generator=gen) + 0.5
     for reduce in ("sum", "mean"):
         for sc in (None, scale):
-            dense = P.ops.csr_aggregate(g, dev(xz), reduce, weighted, src_scale=dev(sc))
+            # tune=0: the one-wave-per-row form (the autotuner may pick a feature-slab form at this width,
+            # whose lane groups split a row by position like the narrow forms below)
+            dense = P.ops.csr_aggregate(g, dev(xz), reduce, weighted, src_scale=dev(sc), tune=0)
             comp = P.ops.csr_aggregate(g, dev(x[rows].contiguous()), reduce, weighted, src_scale=dev(sc),
+                                       src_map=dev(nmap), tune=0)
+            auto = P.ops.csr_aggregate(g, dev(x[rows].contiguous()), reduce, weighted, src_scale=dev(sc),
                                        src_map=dev(nmap))
+            close(auto, dense, rtol=2e-6, msg=f"auto {feat} {weighted} {reduce}")
             if feat > 128 or feat % 4:      # one neighbour per wave instruction: the order of the sum is kept
                 assert torch.equal(dense, comp), (feat, weighted, reduce, sc is not None)
             else:                           # lane groups split the row by position, which the squeeze shifts

@@ -483,3 +483,70 @@ def test_csr_aggregate_feature_slab_forms_match_oracle(P, feat, tune):
     want[::3] += add.double()
     want = torch.where(gate > 0, want * 1.5, torch.zeros_like(want))
     close(out, want)
+
+
+# ------------------------------------------- last conv at the touched rows only ----
+@pytest.mark.parametrize("enc,layers,pred,in_feats", [("SAGE", 1, "DOT", 0), ("SAGE", 1, "MLP", 0), ("SAGE", 2, "DOT", 0),
+                                                     ("GCN", 1, "DOT", 0), ("GCN", 2, "MLP", 50), ("GCN", 3, "MLP", 0)])
+def test_row_restricted_last_conv_equals_full_forward(P, enc, layers, pred, in_feats):
+    """ops.SPARSE_FORWARD: the last conv produces only the rows the batch's edges touch (row-indexed
+    aggregation, gathered root operand, dropout drawn at the original row positions).  Against the full
+    forward with the same row-sparse backward: identical loss bits over several steps (every produced
+    row is the same arithmetic), gradients and updated weights equal to fp32 round-off."""
+    from plnlp_amd import ops
+    from gpu_util import rand_csr
+    n, feat, batch, k = 3000, 64, 512, 2
+    csr = rand_csr(n, 8 * n, 31, weighted=False, hub=900)
+    r, c, _ = csr.coo()
+    adj = P.Graph.from_coo(torch.cat([r, c]), torch.cat([c, r]), None, n, n).to("cuda")
+    if enc == "GCN":
+        adj = P.gcn_normalization(adj)
+
+    class D:
+        pass
+    data = D()
+    data.adj_t = adj
+    if in_feats:
+        data.x = torch.randn(n, in_feats, generator=torch.Generator().manual_seed(8)).cuda()
+    gen = torch.Generator().manual_seed(9)
+    steps = 3
+    pos = torch.randint(0, n, (steps * batch, 2), generator=gen).cuda()
+    pos[:40, 0] = 3                                   # a hub of the graph is a hot node of the batch too
+    neg = torch.randint(0, n, (steps * batch, k, 2), generator=gen).cuda()
+    w = torch.rand(steps * batch, generator=gen).cuda()
+    res = {}
+    old_f, old_b = dict(ops.SPARSE_FORWARD), dict(ops.SPARSE_BACKWARD)
+    try:
+        ops.SPARSE_BACKWARD["max_expected_fraction"] = 1.0
+        for mode in (False, True):
+            ops.SPARSE_FORWARD["enabled"] = mode
+            torch.manual_seed(77)
+            P.manual_seed(77)
+            m = P.BaseModel(lr=1e-3, dropout=0.3, grad_clip_norm=1.0, gnn_num_layers=layers, mlp_num_layers=2,
+                            emb_hidden_channels=feat, gnn_hidden_channels=feat, mlp_hidden_channels=feat,
+                            num_nodes=n, num_node_feats=in_feats, gnn_encoder_name=enc, predictor_name=pred,
+                            loss_func="WeightedHingeAUC", optimizer_name="Adam", device="cuda",
+                            use_node_feats=in_feats > 0, train_node_emb=True)
+            m.param_init()
+            m.encoder.train()
+            m.predictor.train()
+            losses, first_grads = [], None
+            for i in range(steps):
+                sl = slice(i * batch, (i + 1) * batch)
+                losses.append(float(m.train_step(data, pos[sl], neg[sl], k, w[sl])))
+                if i == 0:
+                    first_grads = [p.grad.clone() for p in m.para_list]
+            res[mode] = (losses, first_grads, [p.detach().clone() for p in m.para_list])
+    finally:
+        ops.SPARSE_FORWARD.update(old_f)
+        ops.SPARSE_BACKWARD.update(old_b)
+    (lf, gf, wf), (lr_, gr, wr) = res[False], res[True]
+    assert lf[0] == lr_[0], (lf, lr_)
+    close(np.array(lr_), np.array(lf), rtol=1e-6)
+    for a, b in zip(gf, gr):
+        scale = max(1e-6, float(a.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-6 * scale + 1e-7
+    for a, b in zip(wf, wr):
+        # Adam: a coordinate whose gradient is round-off around zero may move by lr in either direction
+        assert float((a - b).abs().max()) <= 3 * 1e-3 + 1e-6
+        assert float(((a - b).abs() <= 1e-6).float().mean()) >= 0.999
