@@ -437,7 +437,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        import datetime
+        torch.distributed.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
         pg = torch.distributed.group.WORLD
 
     import plnlp_amd as P
@@ -554,7 +555,7 @@ def main():
     edges_per_step = B * (1 + k) * world
 
     extra = {}
-    if world > 1 and not args.no_strong:
+    if world > 1 and not args.no_strong and K * B * world <= pos_all.size(0):
         # the same job at the reference's FIXED global batch (B positives in total, B / N per rank): what N GPUs
         # buy for the reference's own step; and, on rank 0 alone, ONE GPU fed the N-fold batch (what the
         # weak-scaling number would be without any second GPU)

@@ -486,11 +486,18 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
-    const float* __restrict__ x, int64_t ldx, int feat, SplitArgs sp) {
+    const float* __restrict__ x, int64_t ldx, int feat, SplitArgs sp, int slab_feat) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t c = (int64_t)blockIdx.x * 4 + wave;
     if (c >= sp.n_chunks) return;
+    const int feat_full = feat;
+    int c0 = 0;
+    if (slab_feat > 0) {          // feature slab of this block (see csr_agg_vec_kernel): columns [c0, c0 + slab_feat)
+        c0 = blockIdx.y * slab_feat;
+        x += c0;
+        feat = (feat - c0) < slab_feat ? (feat - c0) : slab_feat;
+    }
     const int l = sp.chunk_long[c];
     if (l < 0) return;                 // idle chunk slot
     const int64_t r = sp.long_rows[l];
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
-    float* w = sp.ws + c * (int64_t)feat;
+    float* w = sp.ws + c * (int64_t)feat_full + c0;
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
         int s = sub + k * LPR;
@@ -623,7 +630,7 @@ template <int VPL, int LPR>
 static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
                         const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
                         int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp,
-                        const int32_t* out_map = nullptr);
+                        const int32_t* out_map = nullptr, int slab_feat = 0);
 
 template <int VPL, int LPR, int CHX = 0, bool NT = false>
 static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* rowptr, const int32_t* col,
@@ -648,11 +655,9 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
                                slab_feat, row_index);
         if (int rc = launch_status()) return rc;
     }
-    if (slab_feat > 0) {      // the long rows' chunk / finalize passes run on the full width
-        if (feat <= 256) return launch_split<1, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp, out_map);
-        if (feat <= 512) return launch_split<2, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp, out_map);
-        return launch_split<4, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp, out_map);
-    }
+    if (slab_feat > 0)        // the long rows' chunks run per slab too (same geometry); the finalize pass is full width
+        return launch_split<VPL, LPR>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean,
+                                      e, sp, out_map, slab_feat);
     return launch_split<VPL, LPR>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean,
                                   e, sp, out_map);
 }
@@ -681,15 +686,17 @@ static int launch_multirow(bool weighted, hipStream_t s, const int64_t* rowptr, 
 template <int VPL, int LPR>
 static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
                         const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
-                        int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp, const int32_t* out_map) {
+                        int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp, const int32_t* out_map,
+                        int slab_feat) {
     if (!sp || sp->n_long == 0 || sp->n_chunks == 0) return 0;
-    dim3 cgrid((unsigned)((sp->n_chunks + 3) / 4));
+    const int n_slabs = slab_feat > 0 ? (feat + slab_feat - 1) / slab_feat : 1;
+    dim3 cgrid((unsigned)((sp->n_chunks + 3) / 4), (unsigned)n_slabs);
     if (weighted)
         hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, true>), cgrid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, src_map, x, ldx, feat, *sp);
+                           val_index, src_scale, src_map, x, ldx, feat, *sp, slab_feat);
     else
         hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, false>), cgrid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, src_map, x, ldx, feat, *sp);
+                           val_index, src_scale, src_map, x, ldx, feat, *sp, slab_feat);
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)sp->n_long), dim3(256), 0, s, rowptr,
                        feat, mean, *sp, out, ldo, e, out_map);

@@ -71,11 +71,12 @@ struct GemmArgs {
 // float4 at (row0 + (t>>3) + 32p, k0 + 4*(t&7)), p = 0..3.
 // FAST: 16-byte loads, no branches.  RAGGED (the segment's last K-tile may be partial; needs kdim % 4 == 0):
 // a float4 whose k lies past kdim is loaded from the last valid group instead and zeroed by a select.
-// ridx (nullable): the operand's row for tile row i is ridx[i] (rows gathered in the loader)
+// rsel (nullable): the operand's rows for this thread's 4 tile rows, already looked up (rows gathered in
+// the loader: the ids do not depend on the K-tile, so the kernel fetches them once)
 template <bool FAST, bool RAGGED = false>
 __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t,
-                                        const int32_t* __restrict__ ridx = nullptr) {
+                                        const int* __restrict__ rsel = nullptr) {
     const int kq = (t & 7) * 4 + k0;
     if constexpr (FAST) {
         // 4 independent 16-byte loads, no guards, nothing the compiler must wait on between them.
@@ -88,7 +89,7 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
         for (int p = 0; p < 4; ++p) {
             int64_t row = row0 + (t >> 3) + 32 * p;
             row = row < nrows ? row : nrows - 1;
-            if (ridx) row = ridx[row];
+            if (rsel) row = rsel[p];
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + row * ld + kc);
             r[p] = kin ? v : zero;
         }
@@ -102,7 +103,7 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
         const int64_t row = row0 + (t >> 3) + 32 * p;
         const bool rok = row < nrows;
         int64_t rr = rok ? row : nrows - 1;
-        if (ridx) rr = ridx[rr];
+        if (rsel) rr = rsel[p];
         const float* q = base + rr * ld;
         f32x4 v;
         if (vec && kq + 3 < kdim) {            // whole 16-byte group inside: one wide load
@@ -183,9 +184,12 @@ __device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (
 // runtime-indexed struct access: that sent the staging registers to scratch).
 // MODE 0: guarded loads everywhere (unaligned operands); 1: fast loads, every K-tile full;
 // 2: fast loads, a segment's last K-tile may be partial (k % 4 == 0): out-of-range groups zeroed by selects
+// arow0 / arow1 (AIDX): this thread's gathered A rows for segment 0 / 1, looked up once per block
+// (entries are the plain row ids where a segment has no index)
 template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
 __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[4], f32x4 (&rb)[4],
-                                          int64_t m0, int n0, int t) {
+                                          int64_t m0, int n0, int t, const int* arow0 = nullptr,
+                                          const int* arow1 = nullptr) {
     static_assert(!AIDX || !A_T, "gathered A rows exist for the K-contiguous layout only");
     static_assert(!BIDX || !B_T, "gathered B rows exist for the row-contiguous layout only");
     const bool s1 = (g.nseg > 1) && (tile >= g.tiles0);
@@ -197,8 +201,8 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
     const int avec = s1 ? g.seg[1].a_vec : g.seg[0].a_vec;
     const int bvec = s1 ? g.seg[1].b_vec : g.seg[0].b_vec;
     const int32_t* bidx = s1 ? g.seg[1].b_index : g.seg[0].b_index;
-    const int32_t* aidx = nullptr;
-    if constexpr (AIDX) aidx = s1 ? g.seg[1].a_index : g.seg[0].a_index;
+    const int* aidx = nullptr;
+    if constexpr (AIDX) aidx = s1 ? arow1 : arow0;
     const int k0 = (tile - (s1 ? g.tiles0 : 0)) * BK;
     int nb = g.n;                         // extent of the B operand along N as seen by this tile
     if (BIDX && !(g.bidx_mask & 1) && (g.nb_split >= g.n || n0 < g.nb_split)) bidx = nullptr;
@@ -294,6 +298,16 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                                        int h) {
     constexpr int PF = PLNLP_GEMM_PF;
     f32x4 ra[PF][4], rb[PF][4];
+    int arow0[4], arow1[4];
+    if constexpr (AIDX) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int64_t row = m0 + (t >> 3) + 32 * p;
+            row = row < g.m ? row : g.m - 1;
+            arow0[p] = g.seg[0].a_index ? g.seg[0].a_index[row] : (int)row;
+            arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
+        }
+    }
     int base = tb;
     // steady state: entered with all PF sets loaded and every tile of a round reloading its set,
     // UNCONDITIONALLY.  With any of those loads under a branch (`if (tile + PF < te)`, or a guarded
@@ -302,7 +316,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
     // look-ahead.  Branch-free, it knows PF-1 sets are still in flight and waits for vmcnt(8 (PF-1)).
     if (te - tb >= 2 * PF) {
 #pragma unroll
-        for (int d = 0; d < PF; ++d) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
+        for (int d = 0; d < PF; ++d) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb + d, ra[d], rb[d], m0, n0, t, arow0, arow1);
         do {
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
@@ -313,7 +327,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                 __syncthreads();
 #endif
 #ifndef ABL_NOGLOAD
-                load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t);
+                load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t, arow0, arow1);
 #endif
                 mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
             }
@@ -322,7 +336,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
     } else {
 #pragma unroll
         for (int d = 0; d < PF; ++d)
-            if (tb + d < te) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb + d, ra[d], rb[d], m0, n0, t);
+            if (tb + d < te) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb + d, ra[d], rb[d], m0, n0, t, arow0, arow1);
     }
     // drain: the last < 2 PF tiles
     for (; base < te; base += PF) {
@@ -336,7 +350,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                 __syncthreads();
 #endif
 #ifndef ABL_NOGLOAD
-                if (tile + PF < te) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t);
+                if (tile + PF < te) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t, arow0, arow1);
 #endif
                 mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
             }
@@ -355,6 +369,16 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                                        int h) {
     constexpr int PF = PLNLP_GEMM_PF;
     f32x4 ra[PF][4], rb[PF][4];
+    int arow0[4], arow1[4];
+    if constexpr (AIDX) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int64_t row = m0 + (t >> 3) + 32 * p;
+            row = row < g.m ? row : g.m - 1;
+            arow0[p] = g.seg[0].a_index ? g.seg[0].a_index[row] : (int)row;
+            arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
+        }
+    }
     // Every global load of the loop is UNCONDITIONAL: a load under a branch (`if (tile + PF < te)`) makes
     // the compiler assume the younger register sets may never have been issued and wait for vmcnt(0)
     // before staging the oldest one -- i.e. for the younger sets too, which halves the look-ahead.  The
@@ -366,7 +390,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
         const int tl = tb + d < last ? tb + d : last;
-        load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tl, ra[d], rb[d], m0, n0, t);
+        load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tl, ra[d], rb[d], m0, n0, t, arow0, arow1);
     }
     for (int base = tb; base < te; base += PF) {
 #pragma unroll
@@ -383,7 +407,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 #ifndef ABL_NOGLOAD
             {
                 const int tn = tile + PF < last ? tile + PF : last;
-                load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tn, ra[d], rb[d], m0, n0, t);
+                load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tn, ra[d], rb[d], m0, n0, t, arow0, arow1);
             }
 #endif
             if (live) mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);

@@ -76,6 +76,8 @@ class Graph:
         self._t: Optional["Graph"] = None
         self._inv_deg: Optional[torch.Tensor] = None
         self._split: Optional[RowSplit] = None
+        self._agg_tune = {}      # measured choice of aggregation kernel form per feature width (ops._agg_tune);
+                                 # shared with the transposed views: the backward passes cannot be timed themselves
 
     def row_split(self, threshold: int = 256) -> RowSplit:
         """long-row tables of this (static) graph, built once"""
@@ -213,6 +215,7 @@ class Graph:
             r, c, v = self.coo()
             self._t = Graph.from_coo(c, r, v, self.n_cols, self.n_rows)
             self._t._t = self
+            self._t._agg_tune = self._agg_tune
         return self._t
 
     def t_pos(self) -> torch.Tensor:
@@ -234,6 +237,7 @@ class Graph:
         if getattr(self, "_t_mean", None) is None:
             gt = self.t()
             g = Graph(gt.rowptr, gt.col, self.inv_degree()[gt.col.long()].contiguous(), gt.n_rows, gt.n_cols)
+            g._agg_tune = self._agg_tune
             self._t_mean = g
         return self._t_mean
 

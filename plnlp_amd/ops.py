@@ -101,10 +101,8 @@ def _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, f
     flags = 0 if epilogue is None else int(epilogue.flags)
     if flags & L.EPI_DROPOUT:
         return 0
-    cache = getattr(graph, "_agg_tune", None)
-    if cache is None:
-        cache = graph._agg_tune = {}
-    key = (feat, bool((use_values and graph.val is not None) or src_scale is not None))      # width, weighted kernel
+    cache = graph._agg_tune
+    key = feat                        # one choice per width, shared by the weighted / transposed passes
     if key in cache:
         return cache[key]
     if flags & (L.EPI_ACCUM | L.EPI_ADDEND | L.EPI_GATE) or src_map is not None or row_index is not None:
@@ -248,9 +246,17 @@ _tail_ws = {}
 TAIL_WS_FLOATS = 512 * 128 * 128          # one round of tiles: the most the tail of a launch can need
 
 
-def _tail_workspace(device) -> torch.Tensor:
+# off by default: measured on MI355X (profiles/r02_gemm_tail_ab.jsonl, interleaved A/B after a clock warm-up)
+# cutting the partly filled last round of tiles along K is 0-3 % SLOWER on every shape of this path -- the
+# blocks of a short last round run alone on their CUs at nearly twice the speed, so the round is cheap
+GEMM_TAIL = {"enabled": os.environ.get("PLNLP_GEMM_TAIL", "0") == "1"}
+
+
+def _tail_workspace(device) -> Optional[torch.Tensor]:
     """scratch the GEMM may use to cut the last, partly filled round of its tile grid along K
     (gemm_f32.hip::gemm_impl); one buffer per device, reused by every launch (stream-ordered)"""
+    if not GEMM_TAIL["enabled"]:
+        return None
     key = torch.device(device)
     if key not in _tail_ws:
         _tail_ws[key] = torch.empty(TAIL_WS_FLOATS, dtype=torch.float32, device=key)

@@ -661,7 +661,7 @@ def test_csr_aggregate_short_row_form_matches(P, feat):
             a = P.ops.csr_aggregate(g, dev(x), reduce, use_values, short_rows=True)
             b = P.ops.csr_aggregate(g, dev(x), reduce, use_values, short_rows=False)
             close(a, ref, atol=3e-4)
-            close(a, b, atol=1e-5)
+            close(a, b, atol=4e-5)       # two valid summation orders of a 600-term hub row (the forms group lanes differently)
     assert torch.equal(P.ops.csr_aggregate(g, dev(x), "sum", True, short_rows=True),
                        P.ops.csr_aggregate(g, dev(x), "sum", True, short_rows=True))
 

@@ -51,6 +51,9 @@ def argument(argv=None):
                           ('eval_last_best', False), ('random_walk_augment', False)):
         p.add_argument(f'--{name}', type=str2bool, default=default)
     p.add_argument('--data_scale', type=float, default=1.0, help='shrink the synthetic dataset')
+    p.add_argument('--dp_exchange', type=str, default='auto',
+                   help="under torch.distributed.run: what the ranks exchange per step (BaseModel docstring): "
+                        "auto | grads | scores | shard")
     p.add_argument('--seed', type=int, default=None, help='seed torch + the dropout stream (the reference never seeds)')
     return p.parse_args(argv)
 
@@ -157,8 +160,17 @@ def prepare_graph(args, data, split_edge, num_nodes):
 
 def main(argv=None):
     args = argument(argv)
+    group = None
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:      # one process per GPU (torch.distributed.run)
+        args.device = int(os.environ.get('LOCAL_RANK', '0'))
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     device = torch.device(f'cuda:{args.device}')
     torch.cuda.set_device(device)      # kernels launch on the current device's stream
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        torch.distributed.init_process_group('nccl', device_id=device)
+        group = torch.distributed.group.WORLD
+        if args.seed is None:          # every rank must draw the same negatives / permutations
+            args.seed = 0
     if args.seed is not None:
         torch.manual_seed(args.seed)
         P.manual_seed(args.seed)
@@ -186,7 +198,8 @@ def main(argv=None):
         gnn_hidden_channels=args.gnn_hidden_channels, mlp_hidden_channels=args.mlp_hidden_channels,
         num_nodes=num_nodes, num_node_feats=num_node_feats, gnn_encoder_name=args.encoder,
         predictor_name=args.predictor, loss_func=args.loss_func, optimizer_name=args.optimizer, device=device,
-        use_node_feats=args.use_node_feats, train_node_emb=args.train_node_emb, pretrain_emb=args.pretrain_emb)
+        use_node_feats=args.use_node_feats, train_node_emb=args.train_node_emb, pretrain_emb=args.pretrain_emb,
+        process_group=group, dp_scaling='strong', dp_exchange=args.dp_exchange)
     total_params = sum(p.numel() for p in model.para_list)
     msg = f'Total number of model parameters is {total_params}'
     print(msg)
