@@ -26,10 +26,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+    # gemm_f32.hip is compiled twice: K-tile depth 32 (with the host entry points) and 16 (kernels only)
+    units = [(src, src.replace(".hip", ".o"), []) for src in SOURCES]
+    units.append(("gemm_f32.hip", "gemm_f32_bk16.o", ["-DPLNLP_GEMM_BK=16"]))
+    for src, oname, extra in units:
+        obj = os.path.join(HERE, "build", oname)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+               os.path.join(CSRC, src), "-o", obj] + extra
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

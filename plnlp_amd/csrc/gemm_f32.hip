@@ -34,11 +34,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // kept the staged tile in scratch memory instead of VGPRs
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDK = BK + 4;   // K-contiguous tile row stride (floats)
-constexpr int LDR = 128;      // row-contiguous tile row stride (floats)
-constexpr int TILE_FLOATS = 128 * LDK;  // >= 32*128
-
+// This file is compiled TWICE (plnlp_amd/build.py): with K-tile depth 32 -- the translation unit that also
+// holds the host entry points -- and with depth 16 (-DPLNLP_GEMM_BK=16: kernels + their launcher only, in
+// their own namespace).  Depth 16 halves the LDS and staging-register footprint, so THREE workgroups share a
+// CU instead of two: measured (profiles/r02_gemm_bk16_ab.txt) +2..5 % on the forward / data-gradient shapes,
+// +15 % on the short reductions of citation2 (K = 180 / 200), -3 % on the weight gradients, which keep 32.
+#ifndef PLNLP_GEMM_BK
+#define PLNLP_GEMM_BK 32
+#endif
+#if PLNLP_GEMM_BK == 16
+#define GEMM_NS g16
+#else
+#define GEMM_NS g32
+#endif
+constexpr int BM = 128, BN = 128;
 struct Seg {
     const float* a; int64_t lda;
     const float* b; int64_t ldb;
@@ -66,6 +75,18 @@ struct GemmArgs {
     int vec_store;        // output rows are 16-byte storable (n, ldc, n_split, pointers all 4-float aligned)
 };
 
+namespace GEMM_NS {
+constexpr int BK = PLNLP_GEMM_BK;     // 32 or 16
+static_assert(BK == 32 || BK == 16, "K-tile depth");
+constexpr int NP = BK / 8;                 // 16-byte loads per thread per operand per K-tile
+constexpr int KQ = BK / 4;                 // 16-byte groups per K-contiguous tile row
+constexpr int KQ_SHIFT = BK == 32 ? 3 : 2;
+constexpr int KC_ROWS = 256 / KQ;          // K-contiguous tile rows covered by one pass of the 256 threads
+constexpr int LDK = BK + 4;   // K-contiguous tile row stride (floats)
+constexpr int LDR = 128;      // row-contiguous tile row stride (floats)
+constexpr int TILE_FLOATS = 128 * LDK;  // >= BK*128
+
+
 // ---- global -> registers ------------------------------------------------------
 // K-contiguous operand: rows [row0, row0+128) x k [k0, k0+32); thread t loads
 // float4 at (row0 + (t>>3) + 32p, k0 + 4*(t&7)), p = 0..3.
@@ -74,10 +95,10 @@ struct GemmArgs {
 // rsel (nullable): the operand's rows for this thread's 4 tile rows, already looked up (rows gathered in
 // the loader: the ids do not depend on the K-tile, so the kernel fetches them once)
 template <bool FAST, bool RAGGED = false>
-__device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
+__device__ __forceinline__ void load_kc(f32x4 (&r)[NP], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t,
                                         const int* __restrict__ rsel = nullptr) {
-    const int kq = (t & 7) * 4 + k0;
+    const int kq = (t & (KQ - 1)) * 4 + k0;
     if constexpr (FAST) {
         // 4 independent 16-byte loads, no guards, nothing the compiler must wait on between them.
         // Rows past the matrix edge are CLAMPED to the last row: they read valid memory and only
@@ -86,8 +107,8 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
         const int kc = (!RAGGED || kq < kdim) ? kq : kdim - 4;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int64_t row = row0 + (t >> 3) + 32 * p;
+        for (int p = 0; p < NP; ++p) {
+            int64_t row = row0 + (t >> KQ_SHIFT) + KC_ROWS * p;
             row = row < nrows ? row : nrows - 1;
             if (rsel) row = rsel[p];
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + row * ld + kc);
@@ -99,8 +120,8 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
     // out-of-range elements are zeroed by selects, so the 16 loads of a thread are all in flight
     // together instead of waiting on each other across divergent branches
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int64_t row = row0 + (t >> 3) + 32 * p;
+    for (int p = 0; p < NP; ++p) {
+        const int64_t row = row0 + (t >> KQ_SHIFT) + KC_ROWS * p;
         const bool rok = row < nrows;
         int64_t rr = rok ? row : nrows - 1;
         if (rsel) rr = rsel[p];
@@ -123,34 +144,34 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[4], const float* __restrict__
 // thread t loads float4 at (k0 + (t>>5) + 8p, row0 + 4*(t&31)).
 // INDEXED: the operand's row for reduction index k is kidx[k] (rows gathered in place).
 template <bool FAST, bool INDEXED = false, bool RAGGED = false>
-__device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__ base, int64_t ld,
+__device__ __forceinline__ void load_rc(f32x4 (&r)[NP], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t,
                                         const int32_t* __restrict__ kidx = nullptr) {
     const int64_t rq = row0 + (t & 31) * 4;
     if constexpr (FAST) {   // needs nrows % 4 == 0 (checked on the host): clamp whole float4 groups
         const int64_t rc = rq < nrows ? rq : nrows - 4;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        int ks[4];
+        int ks[NP];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int k = k0 + (t >> 5) + 8 * p;
             ks[p] = (!RAGGED || k < kdim) ? k : kdim - 1;            // a k row past the end: reload the last one
         }
         if constexpr (INDEXED) {
             if (kidx) {                      // block-uniform: the index may apply to one of two B buffers only
 #pragma unroll
-                for (int p = 0; p < 4; ++p) ks[p] = kidx[ks[p]];
+                for (int p = 0; p < NP; ++p) ks[p] = kidx[ks[p]];
             }
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)ks[p] * ld + rc);
             r[p] = (!RAGGED || k0 + (t >> 5) + 8 * p < kdim) ? v : zero;
         }
         return;
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int k = k0 + (t >> 5) + 8 * p;
         const bool kok = k < kdim;
         const int kc = kok ? k : kdim - 1;
@@ -169,14 +190,14 @@ __device__ __forceinline__ void load_rc(f32x4 (&r)[4], const float* __restrict__
         r[p] = kok ? v : zero;
     }
 }
-__device__ __forceinline__ void store_kc(float* __restrict__ tile, const f32x4 (&r)[4], int t) {
+__device__ __forceinline__ void store_kc(float* __restrict__ tile, const f32x4 (&r)[NP], int t) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-        *reinterpret_cast<f32x4*>(tile + ((t >> 3) + 32 * p) * LDK + (t & 7) * 4) = r[p];
+    for (int p = 0; p < NP; ++p)
+        *reinterpret_cast<f32x4*>(tile + ((t >> KQ_SHIFT) + KC_ROWS * p) * LDK + (t & (KQ - 1)) * 4) = r[p];
 }
-__device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (&r)[4], int t) {
+__device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (&r)[NP], int t) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < NP; ++p)
         *reinterpret_cast<f32x4*>(tile + ((t >> 5) + 8 * p) * LDR + (t & 31) * 4) = r[p];
 }
 
@@ -187,7 +208,7 @@ __device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (
 // arow0 / arow1 (AIDX): this thread's gathered A rows for segment 0 / 1, looked up once per block
 // (entries are the plain row ids where a segment has no index)
 template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
-__device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[4], f32x4 (&rb)[4],
+__device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[NP], f32x4 (&rb)[NP],
                                           int64_t m0, int n0, int t, const int* arow0 = nullptr,
                                           const int* arow1 = nullptr) {
     static_assert(!AIDX || !A_T, "gathered A rows exist for the K-contiguous layout only");
@@ -236,7 +257,7 @@ template <bool A_T, bool B_T>
 __device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][2], const float* __restrict__ at,
                                          const float* __restrict__ bt, int wm, int wn, int l31, int h) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < BK / 8; ++q) {
         float a[2][4], b[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -271,13 +292,13 @@ __device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][2], const float* __res
 }
 
 template <bool A_T, bool B_T>
-__device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, const f32x4 (&ra)[4],
-                                           const f32x4 (&rb)[4], int t) {
+__device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, const f32x4 (&ra)[NP],
+                                           const f32x4 (&rb)[NP], int t) {
     float* at = lds + buf * TILE_FLOATS;
     float* bt = lds + (2 + buf) * TILE_FLOATS;
 #ifdef ABL_NOSTAGE
     // ablation: consume the loaded registers without the LDS writes (an impossible condition keeps them live)
-    if (ra[0].x == 123.456f && rb[3].w == 654.321f) { at[t] = ra[1].y + ra[2].z + ra[3].w; bt[t] = rb[0].x + rb[1].y + rb[2].z; }
+    if (ra[0].x == 123.456f && rb[NP - 1].w == 654.321f) { at[t] = ra[1].y + ra[NP - 1].w; bt[t] = rb[0].x + rb[1].y; }
     return;
 #endif
     if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
@@ -297,12 +318,12 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
                                        int h) {
     constexpr int PF = PLNLP_GEMM_PF;
-    f32x4 ra[PF][4], rb[PF][4];
-    int arow0[4], arow1[4];
+    f32x4 ra[PF][NP], rb[PF][NP];
+    int arow0[NP], arow1[NP];
     if constexpr (AIDX) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int64_t row = m0 + (t >> 3) + 32 * p;
+        for (int p = 0; p < NP; ++p) {
+            int64_t row = m0 + (t >> KQ_SHIFT) + KC_ROWS * p;
             row = row < g.m ? row : g.m - 1;
             arow0[p] = g.seg[0].a_index ? g.seg[0].a_index[row] : (int)row;
             arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
@@ -368,12 +389,12 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
                                        int h) {
     constexpr int PF = PLNLP_GEMM_PF;
-    f32x4 ra[PF][4], rb[PF][4];
-    int arow0[4], arow1[4];
+    f32x4 ra[PF][NP], rb[PF][NP];
+    int arow0[NP], arow1[NP];
     if constexpr (AIDX) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int64_t row = m0 + (t >> 3) + 32 * p;
+        for (int p = 0; p < NP; ++p) {
+            int64_t row = m0 + (t >> KQ_SHIFT) + KC_ROWS * p;
             row = row < g.m ? row : g.m - 1;
             arow0[p] = g.seg[0].a_index ? g.seg[0].a_index[row] : (int)row;
             arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
@@ -419,7 +440,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 // MODE (see load_tile): separate kernels so the hot loop of the aligned case carries no guarded
 // code at all (pure dwordx4 loads, nothing between their issue and the MFMAs).
 template <bool A_T, bool B_T, int MODE, bool BIDX = false, bool AIDX = false>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
+__global__ __launch_bounds__(256, BK == 16 ? 3 : 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
 
     const int t = threadIdx.x;
@@ -466,25 +487,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     // (free after the last K-tile) and leaves as 16-byte row stores, with the epilogue applied on
     // float4 (one wide load each for bias / gate / accumulate operands).
     constexpr int CS = BN + 4;                       // LDS row stride of the staged C tile (floats)
-    static_assert(BM * CS <= 4 * TILE_FLOATS, "C tile must fit the operand buffers");
+    // the whole 128-row tile when the operand buffers are large enough (BK = 32), else in two 64-row halves
+    constexpr bool SPLIT_C = BM * CS > 4 * TILE_FLOATS;
+    static_assert((BM / 2) * CS <= 4 * TILE_FLOATS, "half a C tile must fit the operand buffers");
     float* cbase = g.c;
     int64_t ldc = g.ldc;
     const bool raw = g.split_k > 1;
     if (raw) { cbase = g.c + (int64_t)(z + g.z0) * g.ws_stride; ldc = g.n; }
-    __syncthreads();
+    if constexpr (!SPLIT_C) {
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                lds[(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + wn * 64 + j * 32 + l31] = acc[i][j][q];
-    __syncthreads();
+                for (int q = 0; q < 16; ++q)
+                    lds[(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + wn * 64 + j * 32 + l31] = acc[i][j][q];
+        __syncthreads();
+    }
     const bool vec_out = g.vec_store;
     // thread t owns column group c4 of rows rl0 + 8u: the column is the same for all 16 rows
     const int c4 = (t & 31) * 4, rl0 = t >> 5;
     const int col = n0 + c4;
-    if (col >= g.n) return;
+    const bool col_live = col < g.n;                 // (no early return: the split form has barriers below)
+    if (!SPLIT_C && !col_live) return;
     const bool colvec = vec_out && col + 3 < g.n;
     // epilogue operands as float4 registers: bias once per thread, gate / accumulate rows 8 at a time
     // ahead of the loop that uses them (their global-load latency used to sit between the LDS read
@@ -495,34 +521,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     if (pre && (epi.flags & PLNLP_EPI_BIAS)) bias4 = *reinterpret_cast<const float4*>(epi.bias + col);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        float4 g4[8], p4[8];
+        if constexpr (SPLIT_C) {                     // rows [64 half, 64 half + 64): the waves wm == half own them
+            __syncthreads();
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            lds[(i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + wn * 64 + j * 32 + l31] = acc[i][j][q];
+            }
+            __syncthreads();
+            if (!col_live) continue;
+        }
+        // gate / accumulate operands are fetched EPF rows ahead of the loop that uses them (fewer at BK = 16,
+        // whose register budget is 168 for three waves per SIMD)
+        constexpr int EPF = BK == 16 ? 4 : 8;
+#pragma unroll
+        for (int u0 = 0; u0 < 8; u0 += EPF) {
+        float4 g4[EPF], p4[EPF];
         if (pre && (epi.flags & (PLNLP_EPI_GATE | PLNLP_EPI_ACCUM))) {
 #pragma unroll
-            for (int uu = 0; uu < 8; ++uu) {
+            for (int ue = 0; ue < EPF; ++ue) {
+                const int uu = u0 + ue;
                 int64_t row = m0 + rl0 + 8 * (half * 8 + uu);
                 row = row < g.m ? row : g.m - 1;
                 if (epi.flags & PLNLP_EPI_GATE) {
                     const int64_t gr = epi.gate_index ? (int64_t)epi.gate_index[row] : row;
-                    g4[uu] = *reinterpret_cast<const float4*>(epi.gate + gr * epi.ld_gate + col);
+                    g4[ue] = *reinterpret_cast<const float4*>(epi.gate + gr * epi.ld_gate + col);
                 }
                 if (epi.flags & PLNLP_EPI_ACCUM) {
                     const float* prow = second_col ? g.c2 + row * g.ldc2 - g.n_split : cbase + row * ldc;
-                    p4[uu] = *reinterpret_cast<const float4*>(prow + col);
+                    p4[ue] = *reinterpret_cast<const float4*>(prow + col);
                 }
             }
         }
 #pragma unroll
-        for (int uu = 0; uu < 8; ++uu) {
+        for (int ue = 0; ue < EPF; ++ue) {
+            const int uu = u0 + ue;
             const int rl = rl0 + 8 * (half * 8 + uu);
             const int64_t row = m0 + rl;
             if (row >= g.m) continue;
-            float4 v = *reinterpret_cast<const float4*>(lds + rl * CS + c4);
+            float4 v = *reinterpret_cast<const float4*>(lds + (SPLIT_C ? rl - 64 * half : rl) * CS + c4);
             float* orow = second_col ? g.c2 + row * g.ldc2 - g.n_split : cbase + row * ldc;   // index with the global column
 #ifdef ABL_NOSTORE
             if (v.x != 123.456f) continue;
 #endif
             if (colvec) {
-                if (pre) v = epi_apply4_pre(epi, v, row, col, g.n, bias4, g4[uu], p4[uu]);
+                if (pre) v = epi_apply4_pre(epi, v, row, col, g.n, bias4, g4[ue], p4[ue]);
                 else if (!raw) v = epi_apply4(epi, v, row, col, g.n, orow);
                 *reinterpret_cast<float4*>(orow + col) = v;
             } else {
@@ -538,7 +585,46 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
                 }
             }
         }
+        }
     }
+}
+
+// every kernel variant of this K-tile depth behind one function (called from gemm_impl)
+int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_trans, hipStream_t s, const Epi& e) {
+#define PLNLP_GEMM_M(AT, BT)                                                                              \
+    switch (md) {                                                                                        \
+        case 1: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 1>), grid, dim3(256), 0, s, ga, e); break;       \
+        case 2: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 2>), grid, dim3(256), 0, s, ga, e); break;       \
+        default: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 0>), grid, dim3(256), 0, s, ga, e); break;      \
+    }
+    if (ga.seg[0].a_index || (ga.nseg > 1 && ga.seg[1].a_index)) {     // (!a_trans, b_trans) checked by the caller
+        switch (md) {
+            case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, false, true>), grid, dim3(256), 0, s, ga, e); break;
+            case 2: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, false, true>), grid, dim3(256), 0, s, ga, e); break;
+            default: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 0, false, true>), grid, dim3(256), 0, s, ga, e); break;
+        }
+        return launch_status();
+    }
+    if (ga.seg[0].b_index) {      // (a_trans, !b_trans) checked by the caller
+        switch (md) {
+            case 1: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1, true>), grid, dim3(256), 0, s, ga, e); break;
+            case 2: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2, true>), grid, dim3(256), 0, s, ga, e); break;
+            default: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 0, true>), grid, dim3(256), 0, s, ga, e); break;
+        }
+        return launch_status();
+    }
+    if (a_trans) { if (b_trans) { PLNLP_GEMM_M(true, true) } else { PLNLP_GEMM_M(true, false) } }
+    else         { if (b_trans) { PLNLP_GEMM_M(false, true) } else { PLNLP_GEMM_M(false, false) } }
+#undef PLNLP_GEMM_M
+    return launch_status();
+}
+}  // namespace GEMM_NS
+
+#if PLNLP_GEMM_BK != 32
+}  // namespace plnlp
+#else
+namespace g16 {      // the depth-16 translation unit
+int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_trans, hipStream_t s, const Epi& e);
 }
 
 // sum split-K slices in slice order, apply the epilogue.  16 bytes per thread, 8 slices in flight.
@@ -655,6 +741,9 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     if (n_seg < 1 || n_seg > 2 || m < 0 || n < 0 || n > 0x7FFFFFF0) return PLNLP_E_SHAPE;
     if (m == 0 || n == 0) return 0;
     if (split_k < 1) split_k = 1;
+    // K-tile depth of this launch: the weight gradients (row-contiguous A, a reduction over 10^5 .. 10^6 rows cut
+    // along K) keep 32; everything else runs the depth-16 kernels, three workgroups per CU
+    const int BK = a_trans ? 32 : 16;
     GemmArgs g{};
     g.nseg = n_seg;
     int tiles[2] = {0, 0};
@@ -714,32 +803,8 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     const int reduce_slices = split_k;
     g.mt0 = 0; g.nt0 = 0; g.gm = gm; g.gn = (int)gn; g.z0 = 0;
     auto launch_grid = [&](const GemmArgs& ga, int md, dim3 grid) -> int {
-#define PLNLP_GEMM_M(AT, BT)                                                                              \
-        switch (md) {                                                                                    \
-            case 1: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 1>), grid, dim3(256), 0, s, ga, e); break;   \
-            case 2: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 2>), grid, dim3(256), 0, s, ga, e); break;   \
-            default: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 0>), grid, dim3(256), 0, s, ga, e); break;  \
-        }
-        if (ga.seg[0].a_index || (ga.nseg > 1 && ga.seg[1].a_index)) {     // (!a_trans, b_trans) checked above
-            switch (md) {
-                case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, false, true>), grid, dim3(256), 0, s, ga, e); break;
-                case 2: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, false, true>), grid, dim3(256), 0, s, ga, e); break;
-                default: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 0, false, true>), grid, dim3(256), 0, s, ga, e); break;
-            }
-            return launch_status();
-        }
-        if (ga.seg[0].b_index) {      // (a_trans, !b_trans) checked above
-            switch (md) {
-                case 1: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1, true>), grid, dim3(256), 0, s, ga, e); break;
-                case 2: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2, true>), grid, dim3(256), 0, s, ga, e); break;
-                default: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 0, true>), grid, dim3(256), 0, s, ga, e); break;
-            }
-            return launch_status();
-        }
-        if (a_trans) { if (b_trans) { PLNLP_GEMM_M(true, true) } else { PLNLP_GEMM_M(true, false) } }
-        else         { if (b_trans) { PLNLP_GEMM_M(false, true) } else { PLNLP_GEMM_M(false, false) } }
-#undef PLNLP_GEMM_M
-        return launch_status();
+        return BK == 16 ? g16::launch_kernels(ga, md, grid, a_trans, b_trans, s, e)
+                        : g32::launch_kernels(ga, md, grid, a_trans, b_trans, s, e);
     };
     // ---- tail of the tile grid.  Tiles run in rounds of 512 (256 CUs x 2 workgroups); a last round that
     // is only partly filled costs (nearly) a whole round: measured on the collab forward shape, 3686 tiles
@@ -799,3 +864,4 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     }
     return 0;
 }
+#endif   // PLNLP_GEMM_BK == 32

@@ -1257,7 +1257,9 @@ class GCNInputConvFn(torch.autograd.Function):
     per (graph, features) and kept, so a step aggregates e = 50 columns instead of 200, forward and
     backward (only the embedding needs a gradient: A_hat^T (dz W)[:, :e]), and the data-gradient GEMM
     shrinks to those columns.  Same value as the reference order up to fp32 reassociation.
-    Layout of the aggregated operand: [A emb (e, padded to 4) | A x (f, padded to 4)]."""
+    Layout of the aggregated operand: [A emb (e, padded to 4) | A x (f, padded to 4) | zeros up to a multiple
+    of 16 columns] -- the reduction then has no ragged K-tile (citation2: 52 + 128 = 180 -> 192 columns:
+    0.48 -> 0.56 of the MFMA peak on the forward product, profiles/r02_gemm_microbench_v8.jsonl)."""
 
     @staticmethod
     def forward(ctx, emb_weight, w, b, graph: Graph, act: _Act, feats, cache: dict):
@@ -1267,16 +1269,17 @@ class GCNInputConvFn(torch.autograd.Function):
         st = cache.get("gcn_input")
         # the entry holds the graph and the feature tensor themselves (compared by identity): an id() or a
         # data pointer alone can be reused by a different object once the old one is freed
+        kp = (ep + fp + 15) // 16 * 16
         if st is None or st["key"] != key or st["graph"] is not graph or st["feats"] is not feats:
-            ax = torch.zeros(n, ep + fp, dtype=torch.float32, device=emb_weight.device)
+            ax = torch.zeros(n, kp, dtype=torch.float32, device=emb_weight.device)
             fpad = torch.zeros(n, fp, dtype=torch.float32, device=emb_weight.device)
             fpad[:, :f].copy_(feats)
-            csr_aggregate(graph, fpad, "sum", use_values=True, out=ax[:, ep:])        # A_hat x, once
+            csr_aggregate(graph, fpad, "sum", use_values=True, out=ax[:, ep:ep + fp])  # A_hat x, once
             st = {"key": key, "graph": graph, "feats": feats, "ax": ax,
                   "emb_pad": torch.zeros(n, ep, dtype=torch.float32, device=ax.device),
                   # W in the aggregated operand's layout; the pad columns stay zero, the two blocks are
                   # refreshed per step (two copies instead of a fresh zero-filled matrix)
-                  "wa": torch.zeros(w.shape[0], ep + fp, dtype=torch.float32, device=w.device)}
+                  "wa": torch.zeros(w.shape[0], kp, dtype=torch.float32, device=w.device)}
             cache["gcn_input"] = st
         ax, emb_pad = st["ax"], st["emb_pad"]
         emb_pad[:, :e].copy_(emb_weight.detach())
