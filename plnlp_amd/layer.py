@@ -96,6 +96,11 @@ class GCNConv(torch.nn.Module):
                                             cache)
         return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act, in_act, channel, out_rows)
 
+    def forward_block(self, x_full, adj_block, row_lo: int, act: _Act = None):
+        """this conv on one destination-row block of a row-sharded encoder (ops.GCNConvBlockFn)"""
+        act = act if act is not None else _Act(False, 0.0, False)
+        return ops.GCNConvBlockFn.apply(x_full, self.lin.weight, self.bias, _require_graph(adj_block), act)
+
 
 # --------------------------------------------------------------- encoders ------
 class BaseGNN(torch.nn.Module):
@@ -118,8 +123,8 @@ class BaseGNN(torch.nn.Module):
         all-gathered into the next layer's source matrix (its backward reduce-scatters the gradient)."""
         last = len(self.convs) - 1
         for i, conv in enumerate(self.convs):
-            if not isinstance(conv, SAGEConv):
-                raise NotImplementedError("row-sharded encoder: SAGE layers (GCN recipes use dp_exchange='grads')")
+            if not isinstance(conv, (SAGEConv, GCNConv)):
+                raise NotImplementedError("row-sharded encoder: SAGE / GCN layers")
             activated = i < last or self.num_layers == 1
             act = _Act(True, self.dropout, self.training) if activated else None
             if act is not None and act.p > 0.0:

@@ -121,9 +121,9 @@ class BaseModel(object):
         state_dict, eval and the reference-style surface see what they always saw) but is no longer
         trained directly: the optimiser owns `_emb_shard`, the view of this rank's S rows."""
         from . import shard
-        if self.emb is None or self.use_node_feats or not self.train_node_emb:
-            raise NotImplementedError("dp_exchange='shard' needs a trainable embedding table as the encoder's only "
-                                      "input (the ddi / collab recipes); use 'grads' otherwise")
+        if self.emb is None or not self.train_node_emb:
+            raise NotImplementedError("dp_exchange='shard' needs a trainable embedding table in the encoder's input "
+                                      "(alone: ddi / collab; next to node features: citation2); use 'grads' otherwise")
         rank, world = self._world()
         part = shard.RowPartition(self.num_nodes, world, rank)
         self._shard = shard.ShardContext(self.process_group, part)
@@ -143,6 +143,20 @@ class BaseModel(object):
         if getattr(self, "_table_work", None) is not None:
             self._table_work.wait()
             self._table_work = None
+
+    def _shard_concat_feats(self, emb_full, data):
+        """[emb | data.x] over the padded row range of the sharded layout (rows >= num_nodes are zero)"""
+        key = id(data.x)
+        hit = getattr(self, "_feat_pad", None)
+        if hit is None or hit[0] is not data.x:
+            feats = data.x.to(self.device).to(emb_full.dtype)
+            pad = torch.zeros(self._shard.part.padded, feats.shape[1], dtype=feats.dtype, device=self.device)
+            pad[:feats.shape[0]].copy_(feats)
+            self._feat_pad = hit = (data.x, pad, {})
+        feats_pad, cache = hit[1], hit[2]
+        if emb_full.is_cuda and isinstance(self.encoder, BaseGNN):
+            return ops.concat_features(emb_full, feats_pad, cache)      # persistent 16-byte-aligned buffer
+        return torch.cat([emb_full, feats_pad], dim=-1)
 
     def _adj_block(self, data):
         """this rank's destination-row slice of data.adj_t (built once per graph object)"""
@@ -485,6 +499,8 @@ class BaseModel(object):
         lo, hi, local = plan.lo, plan.hi, plan.local
         self._table_wait()
         x_full = sc.leaf(self._emb_shard, self._emb_full)
+        if self.use_node_feats:               # model.py:98-105 on the padded row range: [emb | x]
+            x_full = self._shard_concat_feats(x_full, data)
         h_block = self.encoder(x_full, self._adj_block(data), shard=sc)
         plan.join()
         hq = shard.ExchangeRows.apply(h_block, plan, sc.group)             # [rows my slice touches, h]

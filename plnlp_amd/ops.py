@@ -1193,6 +1193,51 @@ class SAGEConvBlockFn(torch.autograd.Function):
         return gx, gwl, gbl, gwr, None, None, None
 
 
+class GCNConvBlockFn(torch.autograd.Function):
+    """GCNConv(normalize=False) on ONE destination-row block of a row-sharded encoder:
+        y[S, out] = act( (A_hat_block x_full) W^T + b )
+    aggregate-FIRST (GCNConv itself transforms first): the transform of all N source rows would have to
+    be repeated on every rank, the aggregate of the block's S rows is not -- same value up to fp32
+    reassociation.  The gradient of x_full is the partial sum over this block's rows (all n_cols rows)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, graph: Graph, act: _Act):
+        kin = x.shape[1]
+        if kin % 4 != 0:
+            xp, _ = _padded_operand(x if x.dtype == torch.float32 else x.float())
+            wp = torch.zeros(w.shape[0], xp.shape[1], dtype=torch.float32, device=w.device)
+            wp[:, :kin].copy_(w)
+        else:
+            xp, wp = _f32c(x), w
+        assert xp.shape[0] == graph.n_cols, (xp.shape, graph)
+        agg = csr_aggregate(graph, xp, "sum", use_values=True)
+        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+        y = gemm([(agg, wp)], False, True, epilogue=epi)
+        ctx.graph, ctx.act, ctx.kin = graph, act, kin
+        ctx.save_for_backward(agg, wp, y if act.active else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        agg, wp, y = ctx.saved_tensors
+        graph, act, kin = ctx.graph, ctx.act, ctx.kin
+        dz = _act_backward(gy.contiguous(), y, act)
+        need = ctx.needs_input_grad
+        gx = gw = gb = None
+        if need[0]:
+            gagg = gemm([(dz, wp)], False, False)
+            gx = csr_aggregate(graph.t(), gagg, "sum", use_values=True)
+            if gx.shape[1] != kin:
+                gx = gx[:, :kin]
+        if need[1]:
+            gw = gemm([(dz, agg)], True, False)
+            if gw.shape[1] != kin:
+                gw = gw[:, :kin].contiguous()
+        if need[2]:
+            gb = colsum(dz)
+        return gx, gw, gb, None, None
+
+
 def _pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 

@@ -411,6 +411,88 @@ def test_sage_block_conv_equals_full_conv(P, feat, out):
         close(got, want, rtol=3e-5, msg=name)
 
 
+@pytest.mark.parametrize("feat,out", [(178, 64), (256, 256)])
+def test_gcn_block_conv_equals_full_conv(P, feat, out):
+    """ops.GCNConvBlockFn (aggregate first) over 3 destination-row blocks == GCNConvFn (transform first)
+    on the whole normalised graph, to fp32 reassociation; input width 178 = the citation2 [emb | x] case
+    (not a multiple of 4: padded operand)."""
+    from plnlp_amd import shard
+    from plnlp_amd.ops import GCNConvBlockFn, GCNConvFn, _Act
+    n, W = 301, 3
+    csr = rand_csr(n, 4000, 29, weighted=True, hub=400)
+    g = to_graph(P, csr)
+    part = [shard.RowPartition(n, W, r) for r in range(W)]
+    S, npad = part[0].rows, part[0].padded
+    gen = torch.Generator().manual_seed(2)
+    x = torch.zeros(npad, feat)
+    x[:n] = torch.randn(n, feat, generator=gen)
+    w = torch.randn(out, feat, generator=gen) * 0.1
+    b = torch.randn(out, generator=gen)
+    gy = torch.randn(npad, out, generator=gen)
+
+    def leaves():
+        return [dev(t).requires_grad_(True) for t in (x, w, b)]
+
+    xf, wf, bf = leaves()
+    gpad = P.Graph(torch.cat([g.rowptr, g.rowptr[-1:].expand(npad - n)]), g.col, g.val, npad, npad)
+    y_full = GCNConvFn.apply(xf, wf, bf, gpad, _Act(True, 0.0, True), None, None, None)
+    y_full.backward(dev(gy))
+    want = torch.relu(O.spmm(csr, x[:n].double(), "sum", True) @ w.double().T + b.double())
+    acc, ys = None, []
+    for r in range(W):
+        xb, wb, bb = leaves()
+        blk = g.row_block(part[r].lo, S, npad)
+        yb = GCNConvBlockFn.apply(xb, wb, bb, blk, _Act(True, 0.0, True))
+        yb.backward(dev(gy)[part[r].lo:part[r].lo + S])
+        ys.append(yb.detach())
+        grads = [xb.grad, wb.grad, bb.grad]
+        assert xb.grad.shape == x.shape and wb.grad.shape == w.shape
+        acc = grads if acc is None else [a + c for a, c in zip(acc, grads)]
+    close(torch.cat(ys)[:n], want, msg="vs oracle")
+    close(torch.cat(ys)[:n], y_full.detach()[:n], rtol=3e-5, msg="vs transform-first")
+    for got, ref, name in zip(acc, (xf.grad, wf.grad, bf.grad), ("x", "w", "b")):
+        close(got, ref, rtol=5e-5, msg=name)
+
+
+def test_sharded_gcn_feature_step_on_one_rank_rccl_group_matches_plain_step(P):
+    """the citation2 recipe's shape through dp_exchange='shard' on a 1-rank RCCL group: GCN x2 on
+    [embedding | features] (width 40 + 18 = 58, padded operand), MLP predictor, AUC loss"""
+    import torch.distributed as dist
+    from test_sharded_encoder import _free_port
+    from plnlp_amd import synthetic
+    n, h, B, k = 2000, 64, 1024, 1
+    g = synthetic.make_graph("collab", seed=5, device="cpu", num_nodes=n, num_edges=12000, weighted=False)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        def make(pg, exchange):
+            m = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=1.0, gnn_num_layers=2, mlp_num_layers=2,
+                            emb_hidden_channels=40, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n,
+                            num_node_feats=18, gnn_encoder_name="GCN", predictor_name="MLP",
+                            loss_func="AUC", optimizer_name="Adam", device="cuda",
+                            use_node_feats=True, train_node_emb=True, process_group=pg, dp_exchange=exchange)
+            torch.manual_seed(37)
+            m.param_init()
+            return m
+        plain, sharded = make(None, "auto"), make(dist.group.WORLD, "shard")
+        data = g["data"]
+        data.adj_t = P.gcn_normalization(g["adj_t"].to("cuda"))
+        data.x = torch.randn(n, 18, generator=torch.Generator().manual_seed(8)).cuda()
+        split = {"train": {"edge": g["edges"]}}
+        la, lb = [], []
+        for epoch in range(2):
+            torch.manual_seed(60 + epoch)
+            la.append(plain.train(data, split, B, "global", k))
+            torch.manual_seed(60 + epoch)
+            lb.append(sharded.train(data, split, B, "global", k))
+        close(np.array(lb), np.array(la), rtol=3e-4)
+        close(sharded.emb.weight, plain.emb.weight, rtol=1e-3, atol=2e-2)
+        assert sharded.check_replicas()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_sharded_step_on_one_rank_rccl_group_matches_plain_step(P):
     """BaseModel(dp_exchange='shard') driven through a 1-rank RCCL group on the GPU: every collective of
     the sharded step runs (all-gather, all-to-all, reduce-scatter, all-reduce), on the HIP kernels, and

@@ -39,7 +39,7 @@ def _problem():
 
 
 class ShardableGNNRef(torch.nn.Module):
-    """oracle SAGE encoder; with shard= it computes one destination-row block the way
+    """oracle SAGE / GCN encoder; with shard= it computes one destination-row block the way
     plnlp_amd.BaseGNN._forward_sharded does, on the oracle's own conv arithmetic"""
 
     def __init__(self, ref: O.GNNRef):
@@ -50,12 +50,16 @@ class ShardableGNNRef(torch.nn.Module):
         self.ref.reset_parameters()
 
     def forward(self, x, adj, shard=None):
-        csr = O.CSR(adj.rowptr, adj.col.to(torch.int64), None, adj.n_cols)
+        val = None if adj.val is None else adj.val.to(x.dtype)
+        csr = O.CSR(adj.rowptr, adj.col.to(torch.int64), val, adj.n_cols)
         if shard is None:
             return self.ref(x, csr)
         n = len(self.ref.convs)
         for i, conv in enumerate(self.ref.convs):
-            y = conv.lin_l(O.spmm(csr, x, "mean", use_values=False)) + conv.lin_r(x[shard.lo:shard.lo + shard.rows])
+            if isinstance(conv, O.GCNConvRef):        # aggregate first, like ops.GCNConvBlockFn
+                y = conv.lin(O.spmm(csr, x, "sum", use_values=True)) + conv.bias
+            else:
+                y = conv.lin_l(O.spmm(csr, x, "mean", use_values=False)) + conv.lin_r(x[shard.lo:shard.lo + shard.rows])
             if i < n - 1 or self.ref.num_layers == 1:
                 y = F.relu(y)
             x = shard.all_gather(y) if i < n - 1 else y
@@ -66,7 +70,7 @@ class _Data:
     pass
 
 
-def _run(rank, world, port, batch, scaling, loss_name, predictor, layers, out_q):
+def _run(rank, world, port, batch, scaling, loss_name, predictor, layers, out_q, kind="SAGE", feats=0):
     import plnlp_amd as P
     pg = None
     if world > 1:
@@ -75,12 +79,12 @@ def _run(rank, world, port, batch, scaling, loss_name, predictor, layers, out_q)
     torch.set_num_threads(1)
     torch.manual_seed(100)
     row, col, pos, w = _problem()
-    enc = ShardableGNNRef(O.GNNRef("SAGE", H, H, H, layers, 0.0)).double()
+    enc = ShardableGNNRef(O.GNNRef(kind, H + feats, H, H, layers, 0.0)).double()
     pred = (O.DotPredictorRef() if predictor == "DOT" else O.MLPPredictorRef(H, H, 1, 2, 0.0)).double()
     m = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=1.0, gnn_num_layers=layers, mlp_num_layers=2,
                     emb_hidden_channels=H, gnn_hidden_channels=H, mlp_hidden_channels=H, num_nodes=N,
-                    num_node_feats=0, gnn_encoder_name="SAGE", predictor_name=predictor, loss_func=loss_name,
-                    optimizer_name="Adam", device="cpu", use_node_feats=False, train_node_emb=True,
+                    num_node_feats=feats, gnn_encoder_name=kind, predictor_name=predictor, loss_func=loss_name,
+                    optimizer_name="Adam", device="cpu", use_node_feats=feats > 0, train_node_emb=True,
                     modules=(enc, pred, lambda p_, n_, k_, w_: O.LOSSES[O.select_loss(loss_name, w_ is not None)](
                         p_, n_, k_, w_)),
                     process_group=pg, dp_scaling=scaling, dp_exchange="shard" if world > 1 else "auto")
@@ -96,6 +100,10 @@ def _run(rank, world, port, batch, scaling, loss_name, predictor, layers, out_q)
     m.param_init()
     data = _Data()
     data.adj_t = P.Graph.from_coo(row, col, None, N, N)
+    if kind == "GCN":
+        data.adj_t = P.gcn_normalization(data.adj_t)
+    if feats:
+        data.x = torch.randn(N, feats, generator=torch.Generator().manual_seed(12)).double()
     data.edge_index = torch.stack([col, row])
     split = {"train": {"edge": pos, "weight": w.double()}}
     torch.manual_seed(200)
@@ -112,11 +120,11 @@ def _run(rank, world, port, batch, scaling, loss_name, predictor, layers, out_q)
     return losses, small.double().numpy(), table.double().numpy()
 
 
-def _spawn(world, *args):
+def _spawn(world, *args, **kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port) + args + (q,)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port) + args + (q,), kwargs=kw) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -140,6 +148,20 @@ def test_sharded_two_ranks_equal_one_process(scaling, loss_name, predictor, laye
         np.testing.assert_allclose(table, ref_table, rtol=1e-6, atol=1e-9)
     np.testing.assert_array_equal(res[0][2], res[1][2])        # small weights: bit-identical replicas
     np.testing.assert_array_equal(res[0][3], res[1][3])        # and every rank holds the same full table
+
+
+def test_sharded_gcn_with_node_features_equals_one_process():
+    """the citation2 recipe's shape: GCN x2 on [emb | features], MLP predictor -- GCN blocks aggregate first
+    (ops.GCNConvBlockFn), the input is [table all-gathered | features] over the padded row range"""
+    B = 64
+    ref_losses, ref_small, ref_table = _run(0, 1, 0, B, "strong", "AUC", "MLP", 2, None, kind="GCN", feats=5)
+    res = _spawn(2, B, "strong", "AUC", "MLP", 2, kind="GCN", feats=5)
+    for rank, losses, small, table in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-9, err_msg=f"rank {rank}")
+        np.testing.assert_allclose(small, ref_small, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(table, ref_table, rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][3], res[1][3])
 
 
 def test_sharded_uneven_last_batch_and_empty_slice():
