@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PLNLP_ABI_VERSION 3
+#define PLNLP_ABI_VERSION 4
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -184,7 +184,18 @@ typedef struct plnlp_gemm_operand {
     const int32_t* a_index;   /* nullable, a_trans = 0 and b_trans = 1 only: A's row for result row i is
                                  a_index[i] (a layer evaluated only at the rows an edge batch reads: the
                                  root operand x is gathered in the loader)                              */
+    int32_t math;             /* PLNLP_GEMM_MATH_* of the launch (read from segs[0])                     */
+    int32_t reserved;         /* 0 */
 } plnlp_gemm_operand;
+
+/* how the products are formed.  Both take and return fp32 and accumulate in fp32:
+ *   F32    -- v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain over k (157 TFLOP/s peak)
+ *   BF16X3 -- every operand element split in the loader into three bf16 terms (x = hi + mid + lo, residuals
+ *             exact), six bf16 MFMAs per product block (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi): each
+ *             product reproduced to <= 2^-25 relative (the f32 MFMA rounds it at 2^-24), 16/6 of the f32 MFMA rate.
+ *             Operands must be finite and below 2^127 in magnitude (an infinity would split into inf - inf). */
+#define PLNLP_GEMM_MATH_F32    0
+#define PLNLP_GEMM_MATH_BF16X3 1
 
 int plnlp_gemm_f32(const plnlp_gemm_operand* segs /* HOST ptr */, int n_seg,
                    int a_trans, int b_trans,

@@ -38,7 +38,8 @@ class RowSplit(C.Structure):
 class GemmOperand(C.Structure):
     """mirror of plnlp_gemm_operand"""
     _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64),
-                ("k", C.c_int64), ("b_index", C.c_void_p), ("a_index", C.c_void_p)]
+                ("k", C.c_int64), ("b_index", C.c_void_p), ("a_index", C.c_void_p),
+                ("math", C.c_int32), ("reserved", C.c_int32)]
 
 
 class AdamTensor(C.Structure):
@@ -48,6 +49,7 @@ class AdamTensor(C.Structure):
 
 
 MULTI_MAX = 16
+GEMM_MATH_F32, GEMM_MATH_BF16X3 = 0, 1
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND = 1, 2, 4, 8, 16, 32
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 AGG_SHORT_ROWS = 1
@@ -149,7 +151,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.plnlp_abi_version() != 3:
+    if lib.plnlp_abi_version() != 4:
         raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

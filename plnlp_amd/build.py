@@ -26,9 +26,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    # gemm_f32.hip is compiled twice: K-tile depth 32 (with the host entry points) and 16 (kernels only)
+    # gemm_f32.hip is compiled three times: K-tile depth 32 (with the host entry points), depth 16 (kernels
+    # only) and depth 16 with the operands split into bf16 terms (kernels only)
     units = [(src, src.replace(".hip", ".o"), []) for src in SOURCES]
     units.append(("gemm_f32.hip", "gemm_f32_bk16.o", ["-DPLNLP_GEMM_BK=16"]))
+    # (-fno-slp-vectorize: packed f32 adds formed from the operand split cost issue slots beside the MFMAs and
+    # sent the split's residuals through scratch memory)
+    units.append(("gemm_f32.hip", "gemm_f32_x3.o", ["-DPLNLP_GEMM_BK=16", "-DPLNLP_GEMM_X3=1", "-fno-slp-vectorize"]))
     for src, oname, extra in units:
         obj = os.path.join(HERE, "build", oname)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",

@@ -26,6 +26,7 @@
 // result): grid.z slices write raw partial tiles to a workspace and a second
 // kernel adds them in slice order -- deterministic, no atomics.
 #include "common.hip.h"
+#include <utility>
 
 namespace plnlp {
 
@@ -33,6 +34,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // staging registers use the native vector type: HIP's float4 struct is copied with memcpy, which
 // kept the staged tile in scratch memory instead of VGPRs
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // This file is compiled TWICE (plnlp_amd/build.py): with K-tile depth 32 -- the translation unit that also
 // holds the host entry points -- and with depth 16 (-DPLNLP_GEMM_BK=16: kernels + their launcher only, in
@@ -42,7 +45,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef PLNLP_GEMM_BK
 #define PLNLP_GEMM_BK 32
 #endif
-#if PLNLP_GEMM_BK == 16
+// ... and a THIRD time with -DPLNLP_GEMM_BK=16 -DPLNLP_GEMM_X3=1: the same tiling on the bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate) with every f32 operand element split, on its way into
+// LDS, into three bf16 terms  x = hi + mid + lo  (round-to-nearest each, the residuals exact in f32, so the
+// three carry 24+ significant bits) and the product formed from the six terms that matter:
+//     a b ~= hi hi + (hi mid + mid hi) + (mid mid + hi lo + lo hi),     dropped: mid lo, lo mid, lo lo <= 2^-26 |a b|
+// i.e. each product is reproduced to 2^-25..2^-26 relative -- tighter than the one f32 rounding (2^-24) the
+// f32 MFMA applies to it -- and accumulated in f32 like before.  Six bf16 MFMAs of K = 16 replace eight f32
+// MFMAs of K = 2 per 32x32x16 block: 6 x 32 = 192 cycles instead of 512.  Which form a launch uses is the
+// caller's choice (plnlp_gemm_operand.math); tests/test_hip_round2.py measures both against fp64.
+#ifndef PLNLP_GEMM_X3
+#define PLNLP_GEMM_X3 0
+#endif
+#if PLNLP_GEMM_X3
+#if PLNLP_GEMM_BK != 16
+#error "the split-bf16 form is built at K-tile depth 16"
+#endif
+#define GEMM_NS x16
+#elif PLNLP_GEMM_BK == 16
 #define GEMM_NS g16
 #else
 #define GEMM_NS g32
@@ -84,7 +104,26 @@ constexpr int KQ_SHIFT = BK == 32 ? 3 : 2;
 constexpr int KC_ROWS = 256 / KQ;          // K-contiguous tile rows covered by one pass of the 256 threads
 constexpr int LDK = BK + 4;   // K-contiguous tile row stride (floats)
 constexpr int LDR = 128;      // row-contiguous tile row stride (floats)
-constexpr int TILE_FLOATS = 128 * LDK;  // >= BK*128
+constexpr bool X3 = PLNLP_GEMM_X3 != 0;
+// split-bf16 LDS image of one operand tile (128 x 16), in 16-byte units:
+//   K-contiguous operand: [term 3][k-group 2][row 128] x (8 bf16 = k 8g .. 8g+7 of that row) -- exactly one lane's
+//       MFMA fragment per unit (ds_read_b128, lanes 0-31 / 32-63 each on 512 contiguous bytes); the k-group
+//       stride is 132 units = 2112 bytes = 64 (mod 128): LDS WRITES are banked modulo 32 dwords, and the
+//       even / odd lanes of a ds_write_b128 (k-group 0 / 1 of the same rows) must fall on different halves
+//       of that 128-byte row (at 136 units, = 0 mod 128, every write was a 2-way conflict:
+//       SQ_LDS_BANK_CONFLICT = a third of the LDS-busy cycles, profiles/r02_gemm_x3_pmc.json)
+//   row-contiguous operand: [term 3][k-pair 8][128 rows] x (one dword = bf16 k 2p, bf16 k 2p+1 of that row):
+//       a lane's fragment is 4 ds_read_b32 (consecutive rows on consecutive banks), a staging thread's
+//       4 rows x 2 k are one ds_write_b128
+constexpr int X3_KG = 132, X3_TERM = 2 * X3_KG;
+constexpr int TILE_FLOATS = X3 ? 3 * X3_TERM * 4 : 128 * LDK;  // floats per operand tile buffer
+
+// staging thread t -> tile element of its p-th 16-byte load.  f32 form: K-contiguous rows (t >> KQ_SHIFT) + KC_ROWS p
+// at k-quad (t & (KQ-1)); row-contiguous k rows (t >> 5) + 8 p.  Split form: a thread owns 8 consecutive k of ONE
+// row (one LDS unit) resp. two consecutive k rows (one bf16 pair per column).
+__device__ __forceinline__ int kc_row(int t, int p) { return X3 ? (t >> 1) : (t >> KQ_SHIFT) + KC_ROWS * p; }
+__device__ __forceinline__ int kc_k(int t, int p) { return X3 ? (t & 1) * 8 + 4 * p : (t & (KQ - 1)) * 4; }
+__device__ __forceinline__ int rc_k(int t, int p) { return X3 ? 2 * (t >> 5) + p : (t >> 5) + 8 * p; }
 
 
 // ---- global -> registers ------------------------------------------------------
@@ -98,17 +137,17 @@ template <bool FAST, bool RAGGED = false>
 __device__ __forceinline__ void load_kc(f32x4 (&r)[NP], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t,
                                         const int* __restrict__ rsel = nullptr) {
-    const int kq = (t & (KQ - 1)) * 4 + k0;
     if constexpr (FAST) {
         // 4 independent 16-byte loads, no guards, nothing the compiler must wait on between them.
         // Rows past the matrix edge are CLAMPED to the last row: they read valid memory and only
         // feed output rows that the (guarded) store discards.
-        const bool kin = !RAGGED || kq < kdim;
-        const int kc = (!RAGGED || kq < kdim) ? kq : kdim - 4;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            int64_t row = row0 + (t >> KQ_SHIFT) + KC_ROWS * p;
+            const int kq = kc_k(t, p) + k0;
+            const bool kin = !RAGGED || kq < kdim;
+            const int kc = (!RAGGED || kq < kdim) ? kq : kdim - 4;
+            int64_t row = row0 + kc_row(t, p);
             row = row < nrows ? row : nrows - 1;
             if (rsel) row = rsel[p];
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + row * ld + kc);
@@ -121,7 +160,8 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[NP], const float* __restrict_
     // together instead of waiting on each other across divergent branches
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int64_t row = row0 + (t >> KQ_SHIFT) + KC_ROWS * p;
+        const int kq = kc_k(t, p) + k0;
+        const int64_t row = row0 + kc_row(t, p);
         const bool rok = row < nrows;
         int64_t rr = rok ? row : nrows - 1;
         if (rsel) rr = rsel[p];
@@ -154,7 +194,7 @@ __device__ __forceinline__ void load_rc(f32x4 (&r)[NP], const float* __restrict_
         int ks[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int k = k0 + (t >> 5) + 8 * p;
+            const int k = k0 + rc_k(t, p);
             ks[p] = (!RAGGED || k < kdim) ? k : kdim - 1;            // a k row past the end: reload the last one
         }
         if constexpr (INDEXED) {
@@ -166,13 +206,13 @@ __device__ __forceinline__ void load_rc(f32x4 (&r)[NP], const float* __restrict_
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)ks[p] * ld + rc);
-            r[p] = (!RAGGED || k0 + (t >> 5) + 8 * p < kdim) ? v : zero;
+            r[p] = (!RAGGED || k0 + rc_k(t, p) < kdim) ? v : zero;
         }
         return;
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int k = k0 + (t >> 5) + 8 * p;
+        const int k = k0 + rc_k(t, p);
         const bool kok = k < kdim;
         const int kc = kok ? k : kdim - 1;
         const float* q = base + (int64_t)((INDEXED && kidx) ? kidx[kc] : kc) * ld;
@@ -193,12 +233,126 @@ __device__ __forceinline__ void load_rc(f32x4 (&r)[NP], const float* __restrict_
 __device__ __forceinline__ void store_kc(float* __restrict__ tile, const f32x4 (&r)[NP], int t) {
 #pragma unroll
     for (int p = 0; p < NP; ++p)
-        *reinterpret_cast<f32x4*>(tile + ((t >> KQ_SHIFT) + KC_ROWS * p) * LDK + (t & (KQ - 1)) * 4) = r[p];
+        *reinterpret_cast<f32x4*>(tile + kc_row(t, p) * LDK + kc_k(t, p)) = r[p];
 }
 __device__ __forceinline__ void store_rc(float* __restrict__ tile, const f32x4 (&r)[NP], int t) {
 #pragma unroll
     for (int p = 0; p < NP; ++p)
-        *reinterpret_cast<f32x4*>(tile + ((t >> 5) + 8 * p) * LDR + (t & 31) * 4) = r[p];
+        *reinterpret_cast<f32x4*>(tile + rc_k(t, p) * LDR + (t & 31) * 4) = r[p];
+}
+
+// ---- the split-bf16 form: registers -> three bf16 terms -> LDS -----------------------------------------
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // (bf16(lo), bf16(hi)), round to nearest even
+    typedef float f32x2 __attribute__((ext_vector_type(2)));      // selects v_cvt_pk_bf16_f32 (no inline asm: the
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));    // scheduler must see a VALU instruction)
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// x = hi + mid + lo for two values at once; each residual is exact in f32 (the rounded term shares its leading bits)
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    mid = cvt_pk_bf16(r0, r1);
+    r0 -= __uint_as_float(mid << 16);
+    r1 -= __uint_as_float(mid & 0xffff0000u);
+    lo = cvt_pk_bf16(r0, r1);
+}
+// K-contiguous: r[0], r[1] = k 8g .. 8g+7 of row t >> 1 (g = t & 1)
+__device__ __forceinline__ void store_kc_x3(float* __restrict__ tile, const f32x4 (&r)[NP], int t) {
+    static_assert(!X3 || NP == 2, "one LDS unit per thread");
+    unsigned h[4], m[4], l[4];
+    split3(r[0].x, r[0].y, h[0], m[0], l[0]);
+    split3(r[0].z, r[0].w, h[1], m[1], l[1]);
+    split3(r[1 % NP].x, r[1 % NP].y, h[2], m[2], l[2]);
+    split3(r[1 % NP].z, r[1 % NP].w, h[3], m[3], l[3]);
+    const u32x4 hi = {h[0], h[1], h[2], h[3]}, mid = {m[0], m[1], m[2], m[3]}, lo = {l[0], l[1], l[2], l[3]};
+    u32x4* u = reinterpret_cast<u32x4*>(tile) + (t & 1) * X3_KG + (t >> 1);
+    u[0] = hi; u[X3_TERM] = mid; u[2 * X3_TERM] = lo;
+}
+// row-contiguous: r[0] = k row 2P, r[1] = k row 2P+1 (P = t >> 5), rows 4 (t & 31) .. +3
+__device__ __forceinline__ void store_rc_x3(float* __restrict__ tile, const f32x4 (&r)[NP], int t) {
+    unsigned h[4], m[4], l[4];
+    split3(r[0].x, r[1 % NP].x, h[0], m[0], l[0]);
+    split3(r[0].y, r[1 % NP].y, h[1], m[1], l[1]);
+    split3(r[0].z, r[1 % NP].z, h[2], m[2], l[2]);
+    split3(r[0].w, r[1 % NP].w, h[3], m[3], l[3]);
+    const u32x4 hi = {h[0], h[1], h[2], h[3]}, mid = {m[0], m[1], m[2], m[3]}, lo = {l[0], l[1], l[2], l[3]};
+    u32x4* u = reinterpret_cast<u32x4*>(tile) + (t >> 5) * 32 + (t & 31);
+    u[0] = hi; u[X3_TERM] = mid; u[2 * X3_TERM] = lo;
+}
+// the same split in three stages per element pair (5 + 5 + 1 instructions), so that the K loop can place one
+// stage behind each MFMA.  ROWC: the operand is row-contiguous (pairs run down two k rows) or K-contiguous
+struct X3Split {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    f32x2 r[4];                      // the pair's running residual (kept as the 2-vector the conversion consumes)
+    unsigned hi[4], mid[4], lo[4];
+    static __device__ __forceinline__ unsigned pk(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+    template <bool ROWC, int Q>
+    __device__ __forceinline__ void first(const f32x4 (&x)[NP]) {
+        f32x2 v;
+        if constexpr (ROWC) { v.x = x[0][Q]; v.y = x[1 % NP][Q]; }
+        else { v.x = x[(Q >> 1) % NP][2 * (Q & 1)]; v.y = x[(Q >> 1) % NP][2 * (Q & 1) + 1]; }
+        hi[Q] = pk(v);
+        r[Q].x = v.x - __uint_as_float(hi[Q] << 16);
+        r[Q].y = v.y - __uint_as_float(hi[Q] & 0xffff0000u);
+    }
+    template <int Q>
+    __device__ __forceinline__ void second() {
+        mid[Q] = pk(r[Q]);
+        r[Q].x -= __uint_as_float(mid[Q] << 16);
+        r[Q].y -= __uint_as_float(mid[Q] & 0xffff0000u);
+    }
+    __device__ __forceinline__ void third() {
+        lo[0] = pk(r[0]); lo[1] = pk(r[1]); lo[2] = pk(r[2]); lo[3] = pk(r[3]);
+    }
+    template <bool ROWC>
+    __device__ __forceinline__ void store(float* __restrict__ tile, int t) const {
+        u32x4* u = reinterpret_cast<u32x4*>(tile) + (ROWC ? (t >> 5) * 32 + (t & 31) : (t & 1) * X3_KG + (t >> 1));
+        const u32x4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]},
+                    l4 = {lo[0], lo[1], lo[2], lo[3]};
+        u[0] = h4; u[X3_TERM] = m4; u[2 * X3_TERM] = l4;
+    }
+};
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// one lane's fragment (8 bf16: k 8h .. 8h+7 of `row`) of term s
+template <bool ROWC>
+__device__ __forceinline__ bf16x8 frag_x3(const float* __restrict__ tile, int s, int row, int h) {
+    u32x4 v;
+    if constexpr (ROWC) {
+        const unsigned* d = reinterpret_cast<const unsigned*>(tile) + s * (X3_TERM * 4) + (4 * h) * 128 + row;
+        v.x = d[0]; v.y = d[128]; v.z = d[256]; v.w = d[384];
+    } else {
+        v = reinterpret_cast<const u32x4*>(tile)[s * X3_TERM + h * X3_KG + row];
+    }
+    return __builtin_bit_cast(bf16x8, v);
+}
+// one K-tile (16) of the split product: 6 bf16 MFMAs per 32x32 block, small terms first
+template <bool A_T, bool B_T>
+__device__ __forceinline__ void mma_tile_x3(f32x16 (&acc)[2][2], const float* __restrict__ at,
+                                            const float* __restrict__ bt, int wm, int wn, int l31, int h) {
+    bf16x8 a[2][3], b[2][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i][s] = frag_x3<A_T>(at, s, wm * 64 + i * 32 + l31, h);
+            b[i][s] = frag_x3<!B_T>(bt, s, wn * 64 + i * 32 + l31, h);
+        }
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[u]], b[j][TB[u]], acc[i][j], 0, 0, 0);
 }
 
 // one K-tile of both operands, global -> registers.  The segment is picked with selects (no
@@ -256,6 +410,7 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
 template <bool A_T, bool B_T>
 __device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][2], const float* __restrict__ at,
                                          const float* __restrict__ bt, int wm, int wn, int l31, int h) {
+    if constexpr (X3) { mma_tile_x3<A_T, B_T>(acc, at, bt, wm, wn, l31, h); return; }
 #pragma unroll
     for (int q = 0; q < BK / 8; ++q) {
         float a[2][4], b[2][4];
@@ -301,6 +456,11 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, con
     if (ra[0].x == 123.456f && rb[NP - 1].w == 654.321f) { at[t] = ra[1].y + ra[NP - 1].w; bt[t] = rb[0].x + rb[1].y; }
     return;
 #endif
+    if constexpr (X3) {
+        if constexpr (A_T) store_rc_x3(at, ra, t); else store_kc_x3(at, ra, t);
+        if constexpr (B_T) store_kc_x3(bt, rb, t); else store_rc_x3(bt, rb, t);
+        return;
+    }
     if constexpr (A_T) store_rc(at, ra, t); else store_kc(at, ra, t);
     if constexpr (B_T) store_kc(bt, rb, t); else store_rc(bt, rb, t);
 }
@@ -323,7 +483,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
     if constexpr (AIDX) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            int64_t row = m0 + (t >> KQ_SHIFT) + KC_ROWS * p;
+            int64_t row = m0 + kc_row(t, p);
             row = row < g.m ? row : g.m - 1;
             arow0[p] = g.seg[0].a_index ? g.seg[0].a_index[row] : (int)row;
             arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
@@ -394,7 +554,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
     if constexpr (AIDX) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            int64_t row = m0 + (t >> KQ_SHIFT) + KC_ROWS * p;
+            int64_t row = m0 + kc_row(t, p);
             row = row < g.m ? row : g.m - 1;
             arow0[p] = g.seg[0].a_index ? g.seg[0].a_index[row] : (int)row;
             arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
@@ -437,10 +597,101 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 }
 
 #endif
+// K loop of the split-bf16 form.  A K-tile is only 24 MFMAs (768 cycles) next to ~110 VALU instructions of
+// operand splitting and addressing, so the two must overlap INSIDE a wave: the registers of tile i+1 (loaded one
+// iteration earlier) are split and written to the other LDS buffer while the MFMAs of tile i run -- one basic
+// block per tile (every look-ahead load unconditional, its tile index clamped to the slice's last tile; the junk
+// it stages past the end is never read), the instruction mix pinned with sched_group_barrier: MFMA, then a few
+// VALU, ... (a bf16 32x32x16 MFMA leaves ~7 issue slots before the next one can start).  One barrier per tile.
+#if PLNLP_GEMM_X3 && !defined(ABL_X3_PLAIN_LOOP)
+#define PLNLP_X3_PIPELINED 1
+template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX, int D>
+__device__ __forceinline__ void x3_step(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
+                                        f32x4 (&ra)[2][NP], f32x4 (&rb)[2][NP], int next_tile, int64_t m0, int n0,
+                                        int t, int wm, int wn, int l31, int h, const int* arow0, const int* arow1) {
+    const float* at = lds + D * TILE_FLOATS;
+    const float* bt = lds + (2 + D) * TILE_FLOATS;
+    // fragments: both 32-column halves of B (3 terms each) and the first 32-row half of A; the second half of A
+    // replaces the first after its 12 MFMAs (all twelve at once would not fit three waves per SIMD)
+    bf16x8 a[3], b[2][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        a[s] = frag_x3<A_T>(at, s, wm * 64 + l31, h);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j][s] = frag_x3<!B_T>(bt, s, wn * 64 + j * 32 + l31, h);
+    }
+    // the set staged one step ago is free: fetch the tile two ahead into it
+    load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, next_tile, ra[D], rb[D], m0, n0, t, arow0, arow1);
+    // the other set holds the next tile: it is split into the other LDS buffer BETWEEN the MFMAs -- region q of
+    // the block = MFMA q + one 5-instruction stage of the split of one element pair (nothing crosses a
+    // sched_barrier, so the wave always has VALU work to issue while the matrix pipe runs the MFMA)
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int TA2[6] = {2, 1, 1, 0, 0, 0}, TB2[6] = {0, 1, 0, 2, 1, 0};
+    X3Split sa, sb;
+    float* nat = lds + (D ^ 1) * TILE_FLOATS;
+    float* nbt = lds + (2 + (D ^ 1)) * TILE_FLOATS;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<24>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int i = q / 12, u = (q % 12) >> 1, j = q & 1;
+        // the A fragment of the second 32 rows replaces the first term by term, each as soon as the first half
+        // has issued its last MFMA on that term (lo after q = 3, mid after q = 9, hi after q = 11); the second
+        // half runs its six products in the order that needs them in that sequence
+        if constexpr (q == 4)  a[2] = frag_x3<A_T>(at, 2, wm * 64 + 32 + l31, h);
+        if constexpr (q == 10) a[1] = frag_x3<A_T>(at, 1, wm * 64 + 32 + l31, h);
+        if constexpr (q == 12) a[0] = frag_x3<A_T>(at, 0, wm * 64 + 32 + l31, h);
+        constexpr int ta = i == 0 ? TA[u] : TA2[u], tb = i == 0 ? TB[u] : TB2[u];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta], b[j][tb], acc[i][j], 0, 0, 0);
+        if constexpr (q < 4)        sa.template first<A_T, q & 3>(ra[D ^ 1]);
+        else if constexpr (q < 8)   sa.template second<q & 3>();
+        else if constexpr (q == 8)  { sa.third(); sa.template store<A_T>(nat, t); }
+        else if constexpr (q < 13)  sb.template first<!B_T, (q - 9) & 3>(rb[D ^ 1]);
+        else if constexpr (q < 17)  sb.template second<(q - 13) & 3>();
+        else if constexpr (q == 17) { sb.third(); sb.template store<!B_T>(nbt, t); }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+}
+template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
+__device__ __forceinline__ void k_loop_x3(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
+                                          int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
+                                          int h) {
+    if (te <= tb) return;                       // an empty split-K slice (block-uniform)
+    f32x4 ra[2][NP], rb[2][NP];
+    int arow0[NP], arow1[NP];
+    if constexpr (AIDX) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            int64_t row = m0 + kc_row(t, p);
+            row = row < g.m ? row : g.m - 1;
+            arow0[p] = g.seg[0].a_index ? g.seg[0].a_index[row] : (int)row;
+            arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
+        }
+    }
+    const int last = te - 1;
+    load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb, ra[0], rb[0], m0, n0, t, arow0, arow1);
+    load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb + 1 < last ? tb + 1 : last, ra[1], rb[1], m0, n0, t, arow0, arow1);
+    stage_tile<A_T, B_T>(lds, 0, ra[0], rb[0], t);
+    __syncthreads();
+    int i = tb;
+    for (; i + 2 <= te; i += 2) {
+        x3_step<A_T, B_T, MODE, BIDX, AIDX, 0>(g, acc, lds, ra, rb, i + 2 < last ? i + 2 : last, m0, n0, t, wm, wn,
+                                               l31, h, arow0, arow1);
+        x3_step<A_T, B_T, MODE, BIDX, AIDX, 1>(g, acc, lds, ra, rb, i + 3 < last ? i + 3 : last, m0, n0, t, wm, wn,
+                                               l31, h, arow0, arow1);
+    }
+    if (i < te)
+        x3_step<A_T, B_T, MODE, BIDX, AIDX, 0>(g, acc, lds, ra, rb, last, m0, n0, t, wm, wn, l31, h, arow0, arow1);
+}
+#endif
+
 // MODE (see load_tile): separate kernels so the hot loop of the aligned case carries no guarded
 // code at all (pure dwordx4 loads, nothing between their issue and the MFMAs).
 template <bool A_T, bool B_T, int MODE, bool BIDX = false, bool AIDX = false>
-__global__ __launch_bounds__(256, BK == 16 ? 3 : 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
+// workgroups per CU: 3 at K-tile depth 16 (<= 168 registers), except the split-bf16 kernels whose guarded or
+// ragged loaders with a row-contiguous operand do not fit that budget without spilling
+__global__ __launch_bounds__(256, (BK == 16 && !(X3 && (MODE == 0 || (MODE == 2 && (A_T || !B_T))))) ? 3 : 2)
+void gemm_f32_kernel(GemmArgs g, Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
 
     const int t = threadIdx.x;
@@ -480,7 +731,11 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 2) void gemm_f32_kernel(GemmArg
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+#ifdef PLNLP_X3_PIPELINED
+    k_loop_x3<A_T, B_T, MODE, BIDX, AIDX>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
+#else
     k_loop<A_T, B_T, MODE, BIDX, AIDX>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
+#endif
 
     // ---- write back.  The MFMA C/D map (col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)) would
     // give 64 scattered 4-byte stores per lane; instead the block tile is transposed through LDS
@@ -626,6 +881,9 @@ int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_tra
 namespace g16 {      // the depth-16 translation unit
 int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_trans, hipStream_t s, const Epi& e);
 }
+namespace x16 {      // the split-bf16 translation unit
+int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_trans, hipStream_t s, const Epi& e);
+}
 
 // sum split-K slices in slice order, apply the epilogue.  16 bytes per thread, 8 slices in flight.
 // c2 != nullptr: result columns >= n_split go to c2[:, col - n_split] (the pair form; no epilogue there)
@@ -743,7 +1001,9 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     if (split_k < 1) split_k = 1;
     // K-tile depth of this launch: the weight gradients (row-contiguous A, a reduction over 10^5 .. 10^6 rows cut
     // along K) keep 32; everything else runs the depth-16 kernels, three workgroups per CU
-    const int BK = a_trans ? 32 : 16;
+    const int math = segs[0].math;
+    if (math != PLNLP_GEMM_MATH_F32 && math != PLNLP_GEMM_MATH_BF16X3) return PLNLP_E_UNSUPPORTED;
+    const int BK = (math == PLNLP_GEMM_MATH_BF16X3) ? 16 : (a_trans ? 32 : 16);
     GemmArgs g{};
     g.nseg = n_seg;
     int tiles[2] = {0, 0};
@@ -803,6 +1063,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     const int reduce_slices = split_k;
     g.mt0 = 0; g.nt0 = 0; g.gm = gm; g.gn = (int)gn; g.z0 = 0;
     auto launch_grid = [&](const GemmArgs& ga, int md, dim3 grid) -> int {
+        if (math == PLNLP_GEMM_MATH_BF16X3) return x16::launch_kernels(ga, md, grid, a_trans, b_trans, s, e);
         return BK == 16 ? g16::launch_kernels(ga, md, grid, a_trans, b_trans, s, e)
                         : g32::launch_kernels(ga, md, grid, a_trans, b_trans, s, e);
     };

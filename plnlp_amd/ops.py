@@ -263,6 +263,21 @@ def _tail_workspace(device) -> Optional[torch.Tensor]:
     return _tail_ws[key]
 
 
+# how every dense product of the path is formed (include/plnlp_hip.h, PLNLP_GEMM_MATH_*): 'f32' = the f32-input
+# MFMA (an fmaf chain), 'bf16x3' = operands split into three bf16 terms in the loader, six bf16 MFMAs per block
+# -- the same fp32-in / fp32-out contract, per-product error below the f32 rounding, 2.67x the MFMA rate
+GEMM_MATH = {"mode": os.environ.get("PLNLP_GEMM_MATH", "bf16x3")}
+
+
+def _gemm_math() -> int:
+    mode = GEMM_MATH["mode"]
+    if mode == "bf16x3":
+        return L.GEMM_MATH_BF16X3
+    if mode == "f32":
+        return L.GEMM_MATH_F32
+    raise ValueError(f"GEMM_MATH mode {mode!r}: 'f32' or 'bf16x3'")
+
+
 def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_trans: bool,
          out: Optional[torch.Tensor] = None, epilogue: Optional[L.Epilogue] = None,
          split_k: Optional[int] = None, b_index: Optional[torch.Tensor] = None,
@@ -275,6 +290,7 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     a_index[s][i] -- A_s is gathered in the loader (a layer evaluated at some rows only)."""
     lib = L.load()
     ops = (L.GemmOperand * len(segs))()
+    ops[0].math = _gemm_math()
     m = n = None
     ktiles = 0
     keep = []
@@ -354,6 +370,7 @@ def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool
     k, m = (a.shape[0], a.shape[1]) if a_trans else (a.shape[1], a.shape[0])
     n = n1 + n2
     ops = (L.GemmOperand * 1)()
+    ops[0].math = _gemm_math()
     ops[0].a, ops[0].lda, ops[0].b, ops[0].ldb, ops[0].k = a.data_ptr(), _ld(a), b1.data_ptr(), _ld(b1), k
     if rows is not None:
         assert rows.dtype == torch.int32 and rows.numel() == k and a_trans
@@ -384,6 +401,7 @@ def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool
     m, k = a.shape
     n = b.shape[0] if b_trans else b.shape[1]
     ops = (L.GemmOperand * 1)()
+    ops[0].math = _gemm_math()
     ops[0].a, ops[0].lda, ops[0].b, ops[0].ldb, ops[0].k = a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), k
     c1 = out1 if out1 is not None else torch.empty(m, n_split, dtype=torch.float32, device=a.device)
     assert c1.shape == (m, n_split) and c1.is_contiguous()

@@ -36,6 +36,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="timed blocks per shape; the median is reported")
     ap.add_argument("--tail", default="env", choices=["env", "0", "1", "ab"],
                     help="cut the last partly filled round of tiles along K (ops.GEMM_TAIL); ab = measure both")
+    ap.add_argument("--math", default="env", choices=["env", "f32", "bf16x3", "ab"],
+                    help="how the products are formed (ops.GEMM_MATH); ab = measure both, interleaved")
+    ap.add_argument("--error", action="store_true",
+                    help="also report max |C - C_fp64| / sum_k |a||b| over 64 sampled result rows (no epilogue)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     # bring the clocks up first: the first shape of a cold process measured 10-15 % low
@@ -59,19 +63,43 @@ def main():
             e = _lib.make_epilogue(bias=bias, relu=True, dropout_p=0.3, dropout_seed=1)
         out = torch.empty(m, n, device=dev)
         flop = 2.0 * m * n * sum(ks)
-        modes = {"env": [None], "0": [False], "1": [True], "ab": [False, True]}[args.tail]
+        tails = {"env": [None], "0": [False], "1": [True], "ab": [False, True]}[args.tail]
+        maths = {"env": [None], "f32": ["f32"], "bf16x3": ["bf16x3"], "ab": ["f32", "bf16x3"]}[args.math]
+        modes = [(mt, tl) for mt in maths for tl in tails]
         ts = {md: [] for md in modes}
-        for _ in range(args.repeats):                     # interleaved: both arms see the same clocks
+
+        def arm(md):
+            if md[0] is not None:
+                P.ops.GEMM_MATH["mode"] = md[0]
+            if md[1] is not None:
+                P.ops.GEMM_TAIL["enabled"] = md[1]
+        for _ in range(args.repeats):                     # interleaved: every arm sees the same clocks
             for md in modes:
-                if md is not None:
-                    P.ops.GEMM_TAIL["enabled"] = md
+                arm(md)
                 ts[md].append(time_kernel(lambda: P.ops.gemm(segs, at, bt, out=out, epilogue=e), iters=args.iters))
         for md in modes:
             t = sorted(ts[md])[len(ts[md]) // 2]
             rec = {"shape": name, "M": m, "N": n, "K": ks, "ms": round(t * 1e3, 4),
-                   "TFLOPs": round(flop / t / 1e12, 2), "frac_of_157": round(flop / t / 157.3e12, 3)}
-            if md is not None:
-                rec["tail_cut"] = md
+                   "TFLOPs": round(flop / t / 1e12, 2), "frac_of_157": round(flop / t / 157.3e12, 3),
+                   "math": md[0] or P.ops.GEMM_MATH["mode"]}
+            if md[0] == "bf16x3" or (md[0] is None and P.ops.GEMM_MATH["mode"] == "bf16x3"):
+                rec["bf16_TFLOPs_executed"] = round(6 * flop / t / 1e12, 1)
+                rec["frac_of_2500"] = round(6 * flop / t / 2.5e15, 3)
+            if md[1] is not None:
+                rec["tail_cut"] = md[1]
+            if args.error:
+                arm(md)
+                got = P.ops.gemm(segs, at, bt)
+                rows = torch.randperm(m, device=dev)[:64]
+                ref = torch.zeros(rows.numel(), n, dtype=torch.float64, device=dev)
+                mag = torch.zeros_like(ref)
+                for a, b in segs:
+                    a64 = (a[:, rows].T if at else a[rows]).double()
+                    b64 = (b.T if bt else b).double()
+                    ref += a64 @ b64
+                    mag += a64.abs() @ b64.abs()
+                rec["max_err_over_sum_abs"] = float(((got[rows].double() - ref).abs() / mag).max())
+                rec["rms_err_over_sum_abs"] = float((((got[rows].double() - ref) / mag) ** 2).mean().sqrt())
             print(json.dumps(rec), flush=True)
         del segs, out
 

@@ -22,6 +22,16 @@ def P():
     return plnlp_amd
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def math(request, P):
+    """both ways the dense products are formed (include/plnlp_hip.h PLNLP_GEMM_MATH_*); every other GPU test
+    runs on the default (ops.GEMM_MATH, bf16x3 unless PLNLP_GEMM_MATH says otherwise)"""
+    old = P.ops.GEMM_MATH["mode"]
+    P.ops.GEMM_MATH["mode"] = request.param
+    yield request.param
+    P.ops.GEMM_MATH["mode"] = old
+
+
 def dev(t):
     return t.cuda() if t is not None else None
 
@@ -124,7 +134,7 @@ def test_dropout_mask_bit_exact(P):
 # ----------------------------------------------------------------------- GEMM ----
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 256, 256), (257, 200, 178), (1000, 1, 512),
                                    (65, 130, 50), (4267, 512, 512), (33, 7, 5)])
-def test_gemm_nt_matches_fp64(P, m, n, k):
+def test_gemm_nt_matches_fp64(P, m, n, k, math):
     g = torch.Generator().manual_seed(m + n + k)
     a = torch.randn(m, k, generator=g)
     w = torch.randn(n, k, generator=g)
@@ -135,7 +145,7 @@ def test_gemm_nt_matches_fp64(P, m, n, k):
     close(out2, ref, atol=2e-5 * np.sqrt(k))
 
 
-def test_gemm_layout_variants_and_segments(P):
+def test_gemm_layout_variants_and_segments(P, math):
     g = torch.Generator().manual_seed(7)
     m, n, k1, k2 = 500, 192, 96, 50
     a1, a2 = torch.randn(m, k1, generator=g), torch.randn(m, k2, generator=g)
@@ -163,7 +173,7 @@ def test_gemm_layout_variants_and_segments(P):
     close(out, base.double() + dy.double() @ w1.double(), atol=1e-4)
 
 
-def test_gemm_is_exact_fma_chain_determinism(P):
+def test_gemm_is_exact_fma_chain_determinism(P, math):
     a = torch.randn(777, 300)
     w = torch.randn(130, 300)
     x = P.ops.gemm([(dev(a), dev(w))], False, True)
@@ -259,7 +269,7 @@ def _copy_params(dst_mod, src_mod):
 
 
 @pytest.mark.parametrize("kind,layers,feat", [("SAGE", 1, 64), ("SAGE", 2, 128), ("GCN", 2, 200), ("SAGE", 3, 32)])
-def test_encoder_forward_backward_matches_oracle(P, kind, layers, feat):
+def test_encoder_forward_backward_matches_oracle(P, kind, layers, feat, math):
     torch.manual_seed(11)
     n = 500
     csr = rand_csr(n, 6000, 21, weighted=True)
@@ -312,7 +322,7 @@ def test_encoder_dropout_matches_oracle_with_same_counter_mask(P):
 
 
 @pytest.mark.parametrize("L", [1, 2, 3])
-def test_mlp_predictor_matches_golden_fixture(P, golden, L):
+def test_mlp_predictor_matches_golden_fixture(P, golden, L, math):
     g = golden("g2_predictors")
     m = P.MLPPredictor(16, 16, 1, L, 0.0)
     m.load_state_dict({k[len(f"mlp{L}_sd_"):]: torch.from_numpy(g[k]) for k in g.files
@@ -408,7 +418,14 @@ def test_training_trajectory_matches_reference_fixture(P, golden):
         ref64 = _oracle_f64_losses(g, name, adj, N, lo, hi, w)
         close(losses[0], ref32[0], rtol=2e-5, msg=name)
         drift = np.abs(ref32 - ref64)
-        assert (np.abs(losses - ref64) <= 4 * drift + 2e-5 * np.abs(ref64)).all(), (name, losses, ref32, ref64)
+        print(f"{name}: |HIP - f64| / |f64| per epoch {np.abs(losses - ref64) / np.abs(ref64)}, "
+              f"reference fp32 run {drift / np.abs(ref64)}")
+        # epochs 2, 3: free-running fp32 trajectories are chaotic here (measured, profiles/r02_trajectory_drift.txt:
+        # the reference's own fp32 run is 1e-3 / 4e-3 off exact arithmetic on sage_mlp_auc; this path 1e-4 / 7e-4
+        # with either GEMM form; on sage_mlp_whinge_noweight 1e-5 / 1e-4 with the f32 MFMA, 5e-5 / 2e-4 with the
+        # split-bf16 one, the reference 8e-9 / 5e-5).  The sharp per-step statement is the teacher-forced loop
+        # of tests/test_hip_round2.py (every step within 1e-6 of the fp64 oracle from the oracle's weights).
+        assert (np.abs(losses - ref64) <= 4 * drift + 5e-4 * np.abs(ref64)).all(), (name, losses, ref32, ref64)
 
 
 def test_single_step_gradients_match_oracle(P, golden):
@@ -581,7 +598,7 @@ def test_edge_backward_hot_node_dot(P):
     assert torch.equal(a, P.ops.edge_segment_bwd(dev(h), P.ops.Incidence(dev(src), dev(dst), n), dev(go)))
 
 
-def test_gemm_split_out_and_colsum_shapes(P):
+def test_gemm_split_out_and_colsum_shapes(P, math):
     g = torch.Generator().manual_seed(12)
     a = torch.randn(1000, 96, generator=g)
     b = torch.randn(96, 320, generator=g)
@@ -624,7 +641,7 @@ def test_driver_runs_citation2_gcn_recipe(P, tmp_path):
 
 @pytest.mark.parametrize("m,n,k,at,bt", [(200, 256, 65536, True, False), (192, 200, 65536, True, False),
                                          (235868 // 8 + 5, 256, 512, False, True), (4100, 200, 2048, False, False)])
-def test_gemm_edge_tiles_never_read_past_the_operands(P, m, n, k, at, bt):
+def test_gemm_edge_tiles_never_read_past_the_operands(P, m, n, k, at, bt, math):
     """operands whose byte size is a multiple of the 2 MiB allocation granule end exactly at an
     unmapped page: any over-read of an edge tile faults instead of passing by luck"""
     g = torch.Generator().manual_seed(m + n)
@@ -758,7 +775,7 @@ def test_csr_aggregate_lds_staged_form_matches(P, n, feat):
 
 @pytest.mark.parametrize("kind,dims", [("SAGE", (30, 50, 18)), ("GCN", (30, 50, 18)), ("SAGE", (7, 9, 5)),
                                         ("GCN", (129, 130, 131)), ("SAGE", (200, 200, 200))])
-def test_encoders_with_awkward_widths(P, kind, dims):
+def test_encoders_with_awkward_widths(P, kind, dims, math):
     """feature widths that are not multiples of 4 / 32 / 128: every unaligned and ragged code path of
     the aggregation and the GEMM (guarded loads, scalar stores, split outputs off a tile seam)"""
     cin, hid, cout = dims
@@ -966,7 +983,7 @@ def _sub_rows(csr, rows):
 
 @pytest.mark.parametrize("k,m,n1,n2", [(5000, 256, 256, 256), (4097, 128, 128, 64), (333, 64, 200, 200),
                                        (70001, 256, 256, 256), (31, 8, 12, 12)])
-def test_wgrad_over_gathered_rows_equals_gather_then_gemm(P, k, m, n1, n2):
+def test_wgrad_over_gathered_rows_equals_gather_then_gemm(P, k, m, n1, n2, math):
     """dz^T [x1 | x2][rows] with the gather inside the GEMM loader == the same GEMM on materialised
     gathered operands, bit for bit (same tiles, same split-K partition)"""
     gen = torch.Generator().manual_seed(k)
