@@ -293,17 +293,27 @@ struct X3Split {
         f32x2 v;
         if constexpr (ROWC) { v.x = x[0][Q]; v.y = x[1 % NP][Q]; }
         else { v.x = x[(Q >> 1) % NP][2 * (Q & 1)]; v.y = x[(Q >> 1) % NP][2 * (Q & 1) + 1]; }
+#ifdef ABL_X3_NOSPLIT      // ablation: timing without the split arithmetic (wrong numbers)
+        hi[Q] = __float_as_uint(v.x); mid[Q] = __float_as_uint(v.y); lo[Q] = hi[Q]; r[Q] = v;
+        return;
+#endif
         hi[Q] = pk(v);
         r[Q].x = v.x - __uint_as_float(hi[Q] << 16);
         r[Q].y = v.y - __uint_as_float(hi[Q] & 0xffff0000u);
     }
     template <int Q>
     __device__ __forceinline__ void second() {
+#ifdef ABL_X3_NOSPLIT
+        return;
+#endif
         mid[Q] = pk(r[Q]);
         r[Q].x -= __uint_as_float(mid[Q] << 16);
         r[Q].y -= __uint_as_float(mid[Q] & 0xffff0000u);
     }
     __device__ __forceinline__ void third() {
+#ifdef ABL_X3_NOSPLIT
+        return;
+#endif
         lo[0] = pk(r[0]); lo[1] = pk(r[1]); lo[2] = pk(r[2]); lo[3] = pk(r[3]);
     }
     template <bool ROWC>
@@ -311,6 +321,9 @@ struct X3Split {
         u32x4* u = reinterpret_cast<u32x4*>(tile) + (ROWC ? (t >> 5) * 32 + (t & 31) : (t & 1) * X3_KG + (t >> 1));
         const u32x4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]},
                     l4 = {lo[0], lo[1], lo[2], lo[3]};
+#ifdef ABL_X3_NOSTORE      // ablation: no LDS writes (an impossible condition keeps three of the terms live)
+        if (hi[0] != 0x12345678u || lo[3] != 0x9abcdef0u || mid[1] != 0x0fedcba9u) return;
+#endif
         u[0] = h4; u[X3_TERM] = m4; u[2 * X3_TERM] = l4;
     }
 };
@@ -621,7 +634,9 @@ __device__ __forceinline__ void x3_step(const GemmArgs& g, f32x16 (&acc)[2][2], 
         for (int j = 0; j < 2; ++j) b[j][s] = frag_x3<!B_T>(bt, s, wn * 64 + j * 32 + l31, h);
     }
     // the set staged one step ago is free: fetch the tile two ahead into it
+#ifndef ABL_X3_NOGLOAD     // ablation: the staging registers keep the first tiles (no loads, no address arithmetic)
     load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, next_tile, ra[D], rb[D], m0, n0, t, arow0, arow1);
+#endif
     // the other set holds the next tile: it is split into the other LDS buffer BETWEEN the MFMAs -- region q of
     // the block = MFMA q + one 5-instruction stage of the split of one element pair (nothing crosses a
     // sched_barrier, so the wave always has VALU work to issue while the matrix pipe runs the MFMA)
