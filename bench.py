@@ -284,13 +284,30 @@ def measure_gemm_roofline(P, n_rows, k_in, hidden, device, sage=True):
     bias = torch.zeros(hidden, device=device)
     out = torch.empty(n_rows, hidden, device=device)
     epi = _lib.make_epilogue(bias=bias, relu=True, dropout_p=0.3, dropout_seed=1)
-    t = time_kernel(lambda: P.ops.gemm(segs, False, True, out=out, epilogue=epi))
     flop = 2.0 * n_rows * hidden * k_in * len(segs)
-    return {"bound": "mfma", "kernel": "gemm_f32_kernel (M=%d, N=%d, K=%s, bias+relu+dropout epilogue)"
-                                       % (n_rows, hidden, "+".join([str(k_in)] * len(segs))),
-            "achieved": flop / t / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / t / 157.3e12,
-            "traffic": None, "flops": flop, "kernel_ms": t * 1e3,
-            "note": "v_mfma_f32_32x32x2_f32 (exact fp32; gfx950 has no TF32), peak = 256 CUs x 256 FLOP/clk x 2.4 GHz"}
+    kname = "M=%d, N=%d, K=%s, bias+relu+dropout epilogue" % (n_rows, hidden, "+".join([str(k_in)] * len(segs)))
+    mode0 = P.ops.GEMM_MATH["mode"]
+    times = {}
+    try:
+        for mode in ("f32", "bf16x3"):             # both forms of the product, the path's own one reported first
+            P.ops.GEMM_MATH["mode"] = mode
+            times[mode] = time_kernel(lambda: P.ops.gemm(segs, False, True, out=out, epilogue=epi))
+    finally:
+        P.ops.GEMM_MATH["mode"] = mode0
+    f32_form = {"kernel": "g16::gemm_f32_kernel (%s)" % kname, "achieved": flop / times["f32"] / 1e12, "peak": 157.3,
+                "unit": "TFLOP/s", "frac": flop / times["f32"] / 157.3e12, "kernel_ms": times["f32"] * 1e3,
+                "note": "v_mfma_f32_32x32x2_f32 (an fmaf chain; gfx950 has no TF32), peak = 256 CUs x 256 FLOP/clk x 2.4 GHz"}
+    t = times["bf16x3"]
+    x3_form = {"kernel": "x16::gemm_f32_kernel (%s)" % kname, "achieved": 6 * flop / t / 1e12, "peak": 2500.0,
+               "unit": "TFLOP/s", "frac": 6 * flop / t / 2.5e15, "kernel_ms": t * 1e3,
+               "f32_equivalent_TFLOPs": flop / t / 1e12, "f32_equivalent_over_f32_mfma_peak": flop / t / 157.3e12,
+               "note": "fp32 in / fp32 out; every operand element split in the loader into three bf16 terms, six "
+                       "v_mfma_f32_32x32x16_bf16 per 32x32x16 block (executed flops = 6 x algorithmic), f32 accumulate; "
+                       "per-product error <= the f32 MFMA's (tests/test_hip_round2.py, profiles/r02_gemm_bf16x3_error.jsonl); "
+                       "peak = dense bf16 MFMA at 2.4 GHz, the kernel itself runs power-limited at ~1.75 GHz"}
+    mine, other = (x3_form, f32_form) if mode0 == "bf16x3" else (f32_form, x3_form)
+    return dict({"bound": "mfma", "math": mode0, "traffic": None, "flops": flop}, **mine,
+                **{"other_form": dict({"math": "f32" if mode0 == "bf16x3" else "bf16x3"}, **other)})
 
 
 def cpu_baseline(cfg, g, pos, neg, w, steps):
@@ -576,6 +593,7 @@ def main():
         "metric": "pos+neg edges scored/sec", "value": edges_per_step * K / dt, "unit": "edges/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "gemm_math": P.ops.GEMM_MATH["mode"],
         "config": {"workload": "ogbl-%s-shaped synthetic graph (N=%d, nnz=%d), %s x%d h=%d, %s predictor, "
                                "%s loss, B=%d/GPU, num_neg=%d, dropout=%.1f, %s"
                                % (cfg["shape"], n, g["adj_t"].nnz, cfg["encoder"], cfg["gnn_layers"], cfg["hidden"],

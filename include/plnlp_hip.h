@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PLNLP_ABI_VERSION 4
+#define PLNLP_ABI_VERSION 5
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -186,6 +186,12 @@ typedef struct plnlp_gemm_operand {
                                  root operand x is gathered in the loader)                              */
     int32_t math;             /* PLNLP_GEMM_MATH_* of the launch (read from segs[0])                     */
     int32_t reserved;         /* 0 */
+    const int32_t* a_index2;  /* nullable, with a_index (one segment, BF16X3 only): A's row for result row i is the
+                                 ELEMENTWISE PRODUCT a[a_index[i], :] * a[a_index2[i], :] -- the Hadamard of the two
+                                 endpoint rows of edge i (plnlp/model.py:155-156 + layer.py:81) formed in the loader
+                                 of MLPPredictor's first linear instead of being written out and read back       */
+    const int32_t* b_index2;  /* nullable, with b_index: likewise for B's row of reduction index j (the weight
+                                 gradient of that linear, dz^T (h[src] * h[dst]))                                */
 } plnlp_gemm_operand;
 
 /* how the products are formed.  Both take and return fp32 and accumulate in fp32:

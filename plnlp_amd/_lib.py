@@ -39,7 +39,7 @@ class GemmOperand(C.Structure):
     """mirror of plnlp_gemm_operand"""
     _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64),
                 ("k", C.c_int64), ("b_index", C.c_void_p), ("a_index", C.c_void_p),
-                ("math", C.c_int32), ("reserved", C.c_int32)]
+                ("math", C.c_int32), ("reserved", C.c_int32), ("a_index2", C.c_void_p), ("b_index2", C.c_void_p)]
 
 
 class AdamTensor(C.Structure):
@@ -151,7 +151,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.plnlp_abi_version() != 4:
+    if lib.plnlp_abi_version() != 5:
         raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -75,6 +75,8 @@ struct Seg {
     int a_vec, b_vec;  // 16-byte path usable
     const int32_t* b_index;   // B's row for reduction index j (row-contiguous B only), nullable
     const int32_t* a_index;   // A's row for result row i (K-contiguous A only), nullable
+    const int32_t* a_index2;  // with a_index: the row is the elementwise product of rows a_index[i], a_index2[i]
+    const int32_t* b_index2;  // with b_index: likewise for B's row of reduction index j
 };
 
 struct GemmArgs {
@@ -248,6 +250,12 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // (b
     const f32x2 v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+// elementwise product that stays a rounded f32 product (never contracted into a consumer's subtraction)
+__device__ __forceinline__ f32x4 mul_rounded(f32x4 a, f32x4 b) {
+    f32x4 r = a * b;
+    asm("" : "+v"(r));          // opaque to the optimiser: what leaves here is the rounded value
+    return r;
+}
 // x = hi + mid + lo for two values at once; each residual is exact in f32 (the rounded term shares its leading bits)
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
     hi = cvt_pk_bf16(x0, x1);
@@ -288,11 +296,18 @@ struct X3Split {
     f32x2 r[4];                      // the pair's running residual (kept as the 2-vector the conversion consumes)
     unsigned hi[4], mid[4], lo[4];
     static __device__ __forceinline__ unsigned pk(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
-    template <bool ROWC, int Q>
-    __device__ __forceinline__ void first(const f32x4 (&x)[NP]) {
+    template <bool ROWC, int Q, bool PAIR = false>
+    __device__ __forceinline__ void first(const f32x4 (&x)[NP], const f32x4 (*y)[NP] = nullptr) {
+        // no contraction: with PAIR, x * y - hi as one fma would split the EXACT product instead of the f32 one
+        // the materialised Hadamard holds (a different, if no worse, rounding than the unfused path)
+#pragma clang fp contract(off)
         f32x2 v;
         if constexpr (ROWC) { v.x = x[0][Q]; v.y = x[1 % NP][Q]; }
         else { v.x = x[(Q >> 1) % NP][2 * (Q & 1)]; v.y = x[(Q >> 1) % NP][2 * (Q & 1) + 1]; }
+        if constexpr (PAIR) {          // the operand element is the product of the two gathered rows' elements
+            if constexpr (ROWC) { v.x *= (*y)[0][Q]; v.y *= (*y)[1 % NP][Q]; }
+            else { v.x *= (*y)[(Q >> 1) % NP][2 * (Q & 1)]; v.y *= (*y)[(Q >> 1) % NP][2 * (Q & 1) + 1]; }
+        }
 #ifdef ABL_X3_NOSPLIT      // ablation: timing without the split arithmetic (wrong numbers)
         hi[Q] = __float_as_uint(v.x); mid[Q] = __float_as_uint(v.y); lo[Q] = hi[Q]; r[Q] = v;
         return;
@@ -374,10 +389,13 @@ __device__ __forceinline__ void mma_tile_x3(f32x16 (&acc)[2][2], const float* __
 // 2: fast loads, a segment's last K-tile may be partial (k % 4 == 0): out-of-range groups zeroed by selects
 // arow0 / arow1 (AIDX): this thread's gathered A rows for segment 0 / 1, looked up once per block
 // (entries are the plain row ids where a segment has no index)
-template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
+// PAIR: the indexed operand's row is the elementwise product of TWO gathered rows; the second factor goes to r2
+// (A: its row ids arrive in arow1 -- one segment only, so the slot is free; B: seg[0].b_index2)
+template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false, bool PAIR = false>
 __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[NP], f32x4 (&rb)[NP],
                                           int64_t m0, int n0, int t, const int* arow0 = nullptr,
-                                          const int* arow1 = nullptr) {
+                                          const int* arow1 = nullptr, f32x4 (*r2)[NP] = nullptr) {
+    static_assert(!PAIR || (AIDX != BIDX), "the pair form belongs to exactly one gathered operand");
     static_assert(!AIDX || !A_T, "gathered A rows exist for the K-contiguous layout only");
     static_assert(!BIDX || !B_T, "gathered B rows exist for the row-contiguous layout only");
     const bool s1 = (g.nseg > 1) && (tile >= g.tiles0);
@@ -389,14 +407,16 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
     const int avec = s1 ? g.seg[1].a_vec : g.seg[0].a_vec;
     const int bvec = s1 ? g.seg[1].b_vec : g.seg[0].b_vec;
     const int32_t* bidx = s1 ? g.seg[1].b_index : g.seg[0].b_index;
+    const int32_t* bidx2 = g.seg[0].b_index2;
     const int* aidx = nullptr;
-    if constexpr (AIDX) aidx = s1 ? arow1 : arow0;
+    if constexpr (AIDX) aidx = (s1 && !PAIR) ? arow1 : arow0;
     const int k0 = (tile - (s1 ? g.tiles0 : 0)) * BK;
     int nb = g.n;                         // extent of the B operand along N as seen by this tile
     if (BIDX && !(g.bidx_mask & 1) && (g.nb_split >= g.n || n0 < g.nb_split)) bidx = nullptr;
+    if (!bidx) bidx2 = nullptr;
     if (g.nb_split < g.n) {               // N-concatenated B: [b | b2], tiles never straddle the seam
         const bool second = n0 >= g.nb_split;
-        if (BIDX && second && !(g.bidx_mask & 2)) bidx = nullptr;
+        if (BIDX && second && !(g.bidx_mask & 2)) { bidx = nullptr; bidx2 = nullptr; }
         b = second ? g.b2 : b;
         ldb = second ? g.ldb2 : ldb;
         nb = second ? g.n - g.nb_split : g.nb_split;
@@ -411,11 +431,15 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
         else               load_kc<true, RG>(ra, a, lda, m0, g.m, k0, kdim, avec, t, aidx);
         if constexpr (B_T) load_kc<true, RG>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
         else               load_rc<true, BIDX, RG>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
+        if constexpr (PAIR && AIDX) load_kc<true, RG>(*r2, a, lda, m0, g.m, k0, kdim, avec, t, arow1);
+        if constexpr (PAIR && BIDX) load_rc<true, true, RG>(*r2, b, ldb, n0, nb, k0, kdim, bvec, t, bidx2);
     } else {
         if constexpr (A_T) load_rc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
         else               load_kc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t, aidx);
         if constexpr (B_T) load_kc<false>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
         else               load_rc<false, BIDX>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
+        if constexpr (PAIR && AIDX) load_kc<false>(*r2, a, lda, m0, g.m, k0, kdim, avec, t, arow1);
+        if constexpr (PAIR && BIDX) load_rc<false, true>(*r2, b, ldb, n0, nb, k0, kdim, bvec, t, bidx2);
     }
 }
 
@@ -618,10 +642,11 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 // VALU, ... (a bf16 32x32x16 MFMA leaves ~7 issue slots before the next one can start).  One barrier per tile.
 #if PLNLP_GEMM_X3 && !defined(ABL_X3_PLAIN_LOOP)
 #define PLNLP_X3_PIPELINED 1
-template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX, int D>
+template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX, bool PAIR, int D>
 __device__ __forceinline__ void x3_step(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
-                                        f32x4 (&ra)[2][NP], f32x4 (&rb)[2][NP], int next_tile, int64_t m0, int n0,
-                                        int t, int wm, int wn, int l31, int h, const int* arow0, const int* arow1) {
+                                        f32x4 (&ra)[2][NP], f32x4 (&rb)[2][NP], f32x4 (&r2)[2][NP], int next_tile,
+                                        int64_t m0, int n0, int t, int wm, int wn, int l31, int h, const int* arow0,
+                                        const int* arow1) {
     const float* at = lds + D * TILE_FLOATS;
     const float* bt = lds + (2 + D) * TILE_FLOATS;
     // fragments: both 32-column halves of B (3 terms each) and the first 32-row half of A; the second half of A
@@ -635,7 +660,7 @@ __device__ __forceinline__ void x3_step(const GemmArgs& g, f32x16 (&acc)[2][2], 
     }
     // the set staged one step ago is free: fetch the tile two ahead into it
 #ifndef ABL_X3_NOGLOAD     // ablation: the staging registers keep the first tiles (no loads, no address arithmetic)
-    load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, next_tile, ra[D], rb[D], m0, n0, t, arow0, arow1);
+    load_tile<A_T, B_T, MODE, BIDX, AIDX, PAIR>(g, next_tile, ra[D], rb[D], m0, n0, t, arow0, arow1, &r2[D]);
 #endif
     // the other set holds the next tile: it is split into the other LDS buffer BETWEEN the MFMAs -- region q of
     // the block = MFMA q + one 5-instruction stage of the split of one element pair (nothing crosses a
@@ -657,22 +682,23 @@ __device__ __forceinline__ void x3_step(const GemmArgs& g, f32x16 (&acc)[2][2], 
         if constexpr (q == 12) a[0] = frag_x3<A_T>(at, 0, wm * 64 + 32 + l31, h);
         constexpr int ta = i == 0 ? TA[u] : TA2[u], tb = i == 0 ? TB[u] : TB2[u];
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta], b[j][tb], acc[i][j], 0, 0, 0);
-        if constexpr (q < 4)        sa.template first<A_T, q & 3>(ra[D ^ 1]);
+        if constexpr (q < 4)        sa.template first<A_T, q & 3, PAIR && AIDX>(ra[D ^ 1], &r2[D ^ 1]);
         else if constexpr (q < 8)   sa.template second<q & 3>();
         else if constexpr (q == 8)  { sa.third(); sa.template store<A_T>(nat, t); }
-        else if constexpr (q < 13)  sb.template first<!B_T, (q - 9) & 3>(rb[D ^ 1]);
+        else if constexpr (q < 13)  sb.template first<!B_T, (q - 9) & 3, PAIR && BIDX>(rb[D ^ 1], &r2[D ^ 1]);
         else if constexpr (q < 17)  sb.template second<(q - 13) & 3>();
         else if constexpr (q == 17) { sb.third(); sb.template store<!B_T>(nbt, t); }
         __builtin_amdgcn_sched_barrier(0);
     });
     __syncthreads();
 }
-template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
+template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false, bool PAIR = false>
 __device__ __forceinline__ void k_loop_x3(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                           int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
                                           int h) {
     if (te <= tb) return;                       // an empty split-K slice (block-uniform)
     f32x4 ra[2][NP], rb[2][NP];
+    f32x4 r2[PAIR ? 2 : 1][NP];                 // PAIR: the second factor of the gathered operand's rows
     int arow0[NP], arow1[NP];
     if constexpr (AIDX) {
 #pragma unroll
@@ -680,33 +706,46 @@ __device__ __forceinline__ void k_loop_x3(const GemmArgs& g, f32x16 (&acc)[2][2]
             int64_t row = m0 + kc_row(t, p);
             row = row < g.m ? row : g.m - 1;
             arow0[p] = g.seg[0].a_index ? g.seg[0].a_index[row] : (int)row;
-            arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
+            if constexpr (PAIR) arow1[p] = g.seg[0].a_index2[row];         // (one segment: see load_tile)
+            else arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
         }
     }
     const int last = te - 1;
-    load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb, ra[0], rb[0], m0, n0, t, arow0, arow1);
-    load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tb + 1 < last ? tb + 1 : last, ra[1], rb[1], m0, n0, t, arow0, arow1);
+    f32x4 (&q2)[2][NP] = reinterpret_cast<f32x4 (&)[2][NP]>(r2);     // (only indexed past 0 when PAIR)
+    load_tile<A_T, B_T, MODE, BIDX, AIDX, PAIR>(g, tb, ra[0], rb[0], m0, n0, t, arow0, arow1, &q2[0]);
+    load_tile<A_T, B_T, MODE, BIDX, AIDX, PAIR>(g, tb + 1 < last ? tb + 1 : last, ra[1], rb[1], m0, n0, t, arow0, arow1,
+                                                &q2[PAIR ? 1 : 0]);
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {           // (the split below must see the f32 product: see X3Split::first)
+            if constexpr (AIDX) ra[0][p] = mul_rounded(ra[0][p], q2[0][p]);
+            else rb[0][p] = mul_rounded(rb[0][p], q2[0][p]);
+        }
+    }
     stage_tile<A_T, B_T>(lds, 0, ra[0], rb[0], t);
     __syncthreads();
     int i = tb;
     for (; i + 2 <= te; i += 2) {
-        x3_step<A_T, B_T, MODE, BIDX, AIDX, 0>(g, acc, lds, ra, rb, i + 2 < last ? i + 2 : last, m0, n0, t, wm, wn,
-                                               l31, h, arow0, arow1);
-        x3_step<A_T, B_T, MODE, BIDX, AIDX, 1>(g, acc, lds, ra, rb, i + 3 < last ? i + 3 : last, m0, n0, t, wm, wn,
-                                               l31, h, arow0, arow1);
+        x3_step<A_T, B_T, MODE, BIDX, AIDX, PAIR, 0>(g, acc, lds, ra, rb, q2, i + 2 < last ? i + 2 : last, m0, n0, t, wm,
+                                                     wn, l31, h, arow0, arow1);
+        x3_step<A_T, B_T, MODE, BIDX, AIDX, PAIR, 1>(g, acc, lds, ra, rb, q2, i + 3 < last ? i + 3 : last, m0, n0, t, wm,
+                                                     wn, l31, h, arow0, arow1);
     }
     if (i < te)
-        x3_step<A_T, B_T, MODE, BIDX, AIDX, 0>(g, acc, lds, ra, rb, last, m0, n0, t, wm, wn, l31, h, arow0, arow1);
+        x3_step<A_T, B_T, MODE, BIDX, AIDX, PAIR, 0>(g, acc, lds, ra, rb, q2, last, m0, n0, t, wm, wn, l31, h, arow0,
+                                                     arow1);
 }
 #endif
 
 // MODE (see load_tile): separate kernels so the hot loop of the aligned case carries no guarded
 // code at all (pure dwordx4 loads, nothing between their issue and the MFMAs).
-template <bool A_T, bool B_T, int MODE, bool BIDX = false, bool AIDX = false>
 // workgroups per CU: 3 at K-tile depth 16 (<= 168 registers), except the split-bf16 kernels whose guarded or
-// ragged loaders with a row-contiguous operand do not fit that budget without spilling
-__global__ __launch_bounds__(256, (BK == 16 && !(X3 && (MODE == 0 || (MODE == 2 && (A_T || !B_T))))) ? 3 : 2)
+// ragged loaders with a row-contiguous operand, or the second factor of a pair-gathered operand, do not fit
+// that budget without spilling
+template <bool A_T, bool B_T, int MODE, bool BIDX = false, bool AIDX = false, bool PAIR = false>
+__global__ __launch_bounds__(256, (BK == 16 && !(X3 && (PAIR || MODE == 0 || (MODE == 2 && (A_T || !B_T))))) ? 3 : 2)
 void gemm_f32_kernel(GemmArgs g, Epi epi) {
+    static_assert(!PAIR || X3, "pair-gathered operands exist in the split-bf16 build only");
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
 
     const int t = threadIdx.x;
@@ -747,7 +786,7 @@ void gemm_f32_kernel(GemmArgs g, Epi epi) {
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
 #ifdef PLNLP_X3_PIPELINED
-    k_loop_x3<A_T, B_T, MODE, BIDX, AIDX>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
+    k_loop_x3<A_T, B_T, MODE, BIDX, AIDX, PAIR>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
 #else
     k_loop<A_T, B_T, MODE, BIDX, AIDX>(g, acc, lds, m0, n0, tb, te, t, wm, wn, l31, h);
 #endif
@@ -867,6 +906,26 @@ int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_tra
         case 2: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 2>), grid, dim3(256), 0, s, ga, e); break;       \
         default: hipLaunchKernelGGL((gemm_f32_kernel<AT, BT, 0>), grid, dim3(256), 0, s, ga, e); break;      \
     }
+#if PLNLP_GEMM_X3 && defined(PLNLP_X3_PIPELINED)
+    if (ga.seg[0].a_index2) {         // rows of A = products of two gathered rows ((!a_trans, b_trans, one segment) checked by the caller)
+        switch (md) {
+            case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, false, true, true>), grid, dim3(256), 0, s, ga, e); break;
+            case 2: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, false, true, true>), grid, dim3(256), 0, s, ga, e); break;
+            default: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 0, false, true, true>), grid, dim3(256), 0, s, ga, e); break;
+        }
+        return launch_status();
+    }
+    if (ga.seg[0].b_index2) {         // rows of B likewise ((a_trans, !b_trans, one segment) checked by the caller)
+        switch (md) {
+            case 1: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1, true, false, true>), grid, dim3(256), 0, s, ga, e); break;
+            case 2: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2, true, false, true>), grid, dim3(256), 0, s, ga, e); break;
+            default: hipLaunchKernelGGL((gemm_f32_kernel<true, false, 0, true, false, true>), grid, dim3(256), 0, s, ga, e); break;
+        }
+        return launch_status();
+    }
+#else
+    if (ga.seg[0].a_index2 || ga.seg[0].b_index2) return PLNLP_E_UNSUPPORTED;
+#endif
     if (ga.seg[0].a_index || (ga.nseg > 1 && ga.seg[1].a_index)) {     // (!a_trans, b_trans) checked by the caller
         switch (md) {
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, false, true>), grid, dim3(256), 0, s, ga, e); break;
@@ -1032,6 +1091,11 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         d.a = o.a; d.lda = o.lda; d.b = o.b; d.ldb = o.ldb; d.k = (int)o.k;
         d.b_index = o.b_index;
         d.a_index = o.a_index;
+        d.a_index2 = o.a_index2;
+        d.b_index2 = o.b_index2;
+        if ((o.a_index2 && (!o.a_index || n_seg != 1)) || (o.b_index2 && (!o.b_index || n_seg != 1 || b2)))
+            return PLNLP_E_UNSUPPORTED;
+        if ((o.a_index2 || o.b_index2) && segs[0].math != PLNLP_GEMM_MATH_BF16X3) return PLNLP_E_UNSUPPORTED;
         if (o.b_index && !(a_trans && !b_trans && n_seg == 1)) return PLNLP_E_UNSUPPORTED;
         if (o.a_index && !(!a_trans && b_trans)) return PLNLP_E_UNSUPPORTED;
         d.a_vec = ((uintptr_t)o.a % 16 == 0) && (o.lda % 4 == 0);

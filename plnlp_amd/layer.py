@@ -271,6 +271,12 @@ class MLPPredictor(_LinsPredictor):
         return self._stack(x_i * x_j)
 
     def score_edges(self, h, src, dst, gate_scale: float = 0.0, channel=None, incidence=None, compact: bool = False):
+        params = []
+        for lin in self.lins:
+            params += [lin.weight, lin.bias]
+        if ops.edge_mlp_fusable(h, params):       # the Hadamard formed inside the first linear's loaders
+            return ops.EdgeMLPFn.apply(h, src, dst, gate_scale, channel, incidence, compact, float(self.dropout),
+                                       self.training, *params)
         return self._stack(ops.EdgeHadamardFn.apply(h, src, dst, gate_scale, channel, incidence, compact))
 
 

@@ -239,9 +239,12 @@ def _pick_split_k(m: int, n: int, ktiles: int) -> int:
     blocks = ((m + 127) // 128) * ((n + 127) // 128)
     if blocks >= 384 or ktiles <= 1:
         return 1
-    return max(1, min(ktiles, 512 // blocks))
+    return max(1, min(ktiles, SPLIT_K_SLOTS["slots"] // blocks))
 
 
+# workgroup slots one round of a split-K launch should fill (256 CUs x 2; the split-bf16 kernels run 3 per CU, but
+# 768 slots measured +5 % on ddi's 512x512 weight gradient and -6 % on collab's 256x256 -- profiles/r02_gemm_x3_splitk.txt)
+SPLIT_K_SLOTS = {"slots": int(os.environ.get("PLNLP_SPLIT_K_SLOTS", "512"))}
 _tail_ws = {}
 TAIL_WS_FLOATS = 512 * 128 * 128          # one round of tiles: the most the tail of a launch can need
 
@@ -281,16 +284,28 @@ def _gemm_math() -> int:
 def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_trans: bool,
          out: Optional[torch.Tensor] = None, epilogue: Optional[L.Epilogue] = None,
          split_k: Optional[int] = None, b_index: Optional[torch.Tensor] = None,
-         a_index: Optional[Sequence[Optional[torch.Tensor]]] = None) -> torch.Tensor:
+         a_index: Optional[Sequence[Optional[torch.Tensor]]] = None, a_index2: Optional[torch.Tensor] = None,
+         b_index2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = EPI(sum_s op(A_s) op(B_s))  (plnlp_gemm_f32).  A_s: [M,K] or [K,M] if
     a_trans; B_s: [N,K] if b_trans (nn.Linear weight layout) else [K,N].
     b_index (int32 [K], one segment, a_trans and not b_trans): B's row for reduction index j
     is b_index[j] -- B is gathered in place.
     a_index (per segment, int32 [M] or None; not a_trans, b_trans): A_s' row for result row i is
-    a_index[s][i] -- A_s is gathered in the loader (a layer evaluated at some rows only)."""
+    a_index[s][i] -- A_s is gathered in the loader (a layer evaluated at some rows only).
+    a_index2 / b_index2 (int32, with a_index[0] / b_index, one segment, bf16x3 only): the gathered row is the
+    elementwise PRODUCT of rows index[i] and index2[i] -- the Hadamard of an edge's endpoint rows formed in
+    the loader (MLPPredictor's first linear and its weight gradient)."""
     lib = L.load()
     ops = (L.GemmOperand * len(segs))()
     ops[0].math = _gemm_math()
+    if a_index2 is not None:
+        assert a_index is not None and a_index[0] is not None and len(segs) == 1 and a_index2.dtype == torch.int32
+        assert a_index2.numel() == a_index[0].numel()
+        ops[0].a_index2 = a_index2.data_ptr()
+    if b_index2 is not None:
+        assert b_index is not None and len(segs) == 1 and b_index2.dtype == torch.int32
+        assert b_index2.numel() == b_index.numel()
+        ops[0].b_index2 = b_index2.data_ptr()
     m = n = None
     ktiles = 0
     keep = []
@@ -1731,6 +1746,97 @@ class EdgeHadamardFn(torch.autograd.Function):
             if gs > 0.0:
                 gh = gate(gh, h, gs)
         return gh, None, None, None, None, None, None
+
+
+# MLPPredictor.score_edges as ONE autograd node with the Hadamard formed inside the first linear's loaders
+# (needs the split-bf16 GEMM form; off: EdgeHadamardFn + MLPStackFn, the product written out and read back).
+# OFF by default -- measured on the ddi recipe (profiles/r02_fused_edge_mlp_ab.txt): the step is 4 % SLOWER with
+# it.  The 183 us Hadamard kernel and the 268 MB it writes do disappear, but a K-tile of the GEMM touches only 64
+# bytes of each gathered row, so the two loaders issue 32 scattered 64-byte gathers per instruction where the
+# stand-alone kernel reads whole 2 KB rows: the first linear's forward goes 0.39 -> 0.90 ms, its weight
+# gradient 0.78 -> 1.05 ms.
+FUSE_EDGE_MLP = {"enabled": os.environ.get("PLNLP_FUSE_EDGE_MLP", "0") == "1"}
+
+
+def edge_mlp_fusable(h: torch.Tensor, params) -> bool:
+    return (FUSE_EDGE_MLP["enabled"] and GEMM_MATH["mode"] == "bf16x3" and h.is_cuda and h.dtype == torch.float32
+            and len(params) >= 4 and params[0].shape[0] > 1)
+
+
+class EdgeMLPFn(torch.autograd.Function):
+    """MLPPredictor on the edges (src, dst) of h (model.py:155-156 + layer.py:81-86):
+        y = lins[-1]( ... dropout(relu(lins[0](h[src] * h[dst]))) ... )
+    The [E, K] Hadamard is never materialised: the first linear's GEMM gathers the two endpoint rows and
+    multiplies them in its A loader (a_index / a_index2), its weight gradient dz^T (h[src] * h[dst]) does the
+    same in its B loader (b_index / b_index2).  Only the data gradient d(Hadamard) = dz W exists as a matrix --
+    the input of the edge backward (gate_scale / channel / incidence / compact: as in EdgeHadamardFn)."""
+
+    @staticmethod
+    def forward(ctx, h, src, dst, gate_scale, channel, incidence, compact, dropout_p: float, training: bool, *params):
+        h = _f32c(h)
+        s32, d32 = src.to(torch.int32), dst.to(torch.int32)
+        n_layers = len(params) // 2
+        xs, acts = [], []
+        x = None
+        for i in range(n_layers):
+            w, b = params[2 * i], params[2 * i + 1]
+            last = i == n_layers - 1
+            act = _Act(not last, 0.0 if last else dropout_p, training)
+            acts.append(act)
+            epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+            if i == 0:
+                y = gemm([(h, w)], False, True, epilogue=epi, a_index=[s32], a_index2=d32)
+            elif last and w.shape[0] == 1:
+                y = matvec(x, w, b).reshape(-1, 1)
+            else:
+                y = gemm([(x, w)], False, True, epilogue=epi)
+            xs.append(y)
+            x = y
+        ctx.acts, ctx.n_layers = acts, n_layers
+        ctx.gate_scale, ctx.channel, ctx.incidence, ctx.compact = float(gate_scale), channel, incidence, bool(compact)
+        ctx.save_for_backward(h, src, dst, s32, d32, *xs[:-1], *params)
+        return xs[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        nl = ctx.n_layers
+        saved = ctx.saved_tensors
+        h, src, dst, s32, d32 = saved[:5]
+        xs, params = saved[5:5 + nl - 1], saved[5 + nl - 1:]       # xs[i] = output of layer i = input of layer i+1
+        need = ctx.needs_input_grad
+        grads = [None] * (2 * nl)
+        d = _f32c(g)
+        for i in range(nl - 1, -1, -1):
+            w, b = params[2 * i], params[2 * i + 1]
+            head = (i == nl - 1) and w.shape[0] == 1
+            if need[9 + 2 * i]:
+                if i == 0:
+                    grads[0] = gemm([(d, h)], True, False, b_index=s32, b_index2=d32)
+                else:
+                    grads[2 * i] = (colsum(xs[i - 1], row_weight=d).reshape(1, -1) if head
+                                    else gemm([(d, xs[i - 1])], True, False))
+            if b is not None and need[10 + 2 * i]:
+                grads[2 * i + 1] = colsum(d.reshape(-1, 1)) if head else colsum(d)
+            epi = L.make_epilogue(gate=xs[i - 1], gate_scale=ctx.acts[i - 1].scale) if i > 0 else None
+            d = outer(d, w, epilogue=epi) if head else gemm([(d, w)], False, False, epilogue=epi)
+        # d = gradient of the Hadamard; the gathers' backward as in EdgeHadamardFn
+        gs, inc = ctx.gate_scale, ctx.incidence
+        if ctx.channel is not None and EDGE_BACKWARD["mode"] == "segment":
+            ci = inc if isinstance(inc, (CompactIncidence, _CompactCols)) else None
+            ctx.channel.grad = _sparse_edge_backward(h, src, dst, d, gs, ci, compact=ctx.compact)
+            gh = None
+        else:
+            assert not ctx.compact, "a compact encoder output needs the row-sparse channel"
+            if EDGE_BACKWARD["mode"] == "segment":
+                epi = L.make_epilogue(gate=h, gate_scale=gs) if gs > 0.0 else None
+                if not isinstance(inc, Incidence):
+                    inc = Incidence(src, dst, h.shape[0])
+                gh = edge_segment_bwd(h, inc, d, epilogue=epi)
+            else:
+                gh = edge_scatter_bwd(h, src, dst, d)
+                if gs > 0.0:
+                    gh = gate(gh, h, gs)
+        return (gh, None, None, None, None, None, None, None, None, *grads)
 
 
 _unit_grads = {}

@@ -593,6 +593,109 @@ def test_split_bf16_products_exact_cases(P):
     assert torch.equal(_gemm_err(P, x, w, False, True, "bf16x3")[2], _gemm_err(P, x, w, False, True, "bf16x3")[2])
 
 
+# ------------------------------- Hadamard of the endpoint rows inside the GEMM loaders ----
+@pytest.mark.parametrize("n,k,e,nout", [(500, 64, 3000, 64), (4267, 512, 20000, 512), (300, 200, 1000, 200), (64, 36, 129, 50)])
+def test_gemm_pair_gathered_operands_equal_materialised_hadamard(P, n, k, e, nout):
+    """a_index/a_index2 (forward: (h[src] * h[dst]) W^T) and b_index/b_index2 (weight gradient:
+    dz^T (h[src] * h[dst])) against the same products on the materialised Hadamard -- the same f32 product
+    enters the same split, so the bits agree -- and against fp64."""
+    gen = torch.Generator().manual_seed(n + e)
+    h = torch.randn(n, k, generator=gen)
+    w = torch.randn(nout, k, generator=gen) * 0.1
+    src = torch.randint(0, n, (e,), generator=gen)
+    dst = torch.randint(0, n, (e,), generator=gen)
+    dz = torch.randn(e, nout, generator=gen)
+    had = dev(h)[dev(src)] * dev(h)[dev(dst)]
+    s32, d32 = dev(src).to(torch.int32), dev(dst).to(torch.int32)
+    old = P.ops.GEMM_MATH["mode"]
+    P.ops.GEMM_MATH["mode"] = "bf16x3"
+    try:
+        y = P.ops.gemm([(dev(h), dev(w))], False, True, a_index=[s32], a_index2=d32)
+        y_ref = P.ops.gemm([(had, dev(w))], False, True)
+        gw = P.ops.gemm([(dev(dz), dev(h))], True, False, b_index=s32, b_index2=d32)
+        gw_ref = P.ops.gemm([(dev(dz), had)], True, False)
+        P.ops.GEMM_MATH["mode"] = "f32"
+        with pytest.raises(Exception):          # the f32-MFMA form has no pair loader: it must refuse, not ignore
+            P.ops.gemm([(dev(h), dev(w))], False, True, a_index=[s32], a_index2=d32)
+    finally:
+        P.ops.GEMM_MATH["mode"] = old
+    assert torch.equal(y, y_ref) and torch.equal(gw, gw_ref)
+    had64 = h.double()[src] * h.double()[dst]
+    close(y, had64 @ w.double().T, atol=2e-5 * np.sqrt(k))
+    close(gw, dz.double().T @ had64, atol=3e-5 * np.sqrt(e))
+
+
+@pytest.mark.parametrize("layers,hidden", [(2, 64), (3, 128)])
+def test_fused_edge_mlp_equals_hadamard_then_stack(P, layers, hidden):
+    """MLPPredictor.score_edges with ops.FUSE_EDGE_MLP on (ops.EdgeMLPFn) and off (EdgeHadamardFn +
+    MLPStackFn): same scores bit for bit in eval mode, every gradient (h and all weights) to fp32 round-off;
+    and against the oracle predictor in fp64."""
+    from plnlp_amd import ops
+    n, e = 700, 5000
+    gen = torch.Generator().manual_seed(layers)
+    h0 = torch.randn(n, hidden, generator=gen)
+    src, dst = torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)
+    gy = torch.randn(e, 1, generator=gen)
+    pred = P.layer.MLPPredictor(hidden, hidden, 1, layers, 0.0).cuda()
+    torch.manual_seed(3)
+    pred.reset_parameters()
+    outs = {}
+    for fused in (True, False):
+        ops.FUSE_EDGE_MLP["enabled"] = fused
+        try:
+            h = dev(h0).requires_grad_(True)
+            pred.zero_grad()
+            y = pred.score_edges(h, dev(src), dev(dst))
+            assert (type(y.grad_fn).__name__ == "EdgeMLPFnBackward") == fused
+            y.backward(dev(gy))
+            outs[fused] = [y.detach(), h.grad] + [p.grad.clone() for p in pred.parameters()]
+        finally:
+            ops.FUSE_EDGE_MLP["enabled"] = False
+    assert torch.equal(outs[True][0], outs[False][0])
+    for a, b in zip(outs[True][1:], outs[False][1:]):
+        close(a, b, rtol=2e-6)
+    ref = O.MLPPredictorRef(hidden, hidden, 1, layers, 0.0).double()
+    ref.load_state_dict({k_: v.detach().cpu().double() for k_, v in pred.state_dict().items()})
+    h64 = h0.double().requires_grad_(True)
+    y64 = ref(h64[src], h64[dst])
+    y64.backward(gy.double())
+    close(outs[True][0], y64.detach())
+    close(outs[True][1], h64.grad, rtol=3e-5)
+    for got, p64 in zip(outs[True][2:], ref.parameters()):
+        close(got, p64.grad, rtol=3e-5)
+
+
+def test_fused_edge_mlp_in_the_training_step(P):
+    """the ddi recipe's shape (SAGE x2 + MLP predictor, row-sparse backward, touched-rows forward) trained
+    3 epochs with the fused predictor and with the unfused one from the same weights: same losses"""
+    from plnlp_amd import ops, synthetic
+    n, h, B, k = 3000, 64, 2048, 3
+    g = synthetic.make_graph("ddi", seed=6, device="cpu", num_nodes=n, num_edges=30000)
+    data = g["data"]
+    data.adj_t = g["adj_t"].to("cuda")
+    split = {"train": {"edge": g["edges"]}}
+    losses = {}
+    for fused in (True, False):
+        ops.FUSE_EDGE_MLP["enabled"] = fused
+        try:
+            m = P.BaseModel(lr=0.005, dropout=0.3, grad_clip_norm=2.0, gnn_num_layers=2, mlp_num_layers=3,
+                            emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n,
+                            num_node_feats=0, gnn_encoder_name="SAGE", predictor_name="MLP", loss_func="AUC",
+                            optimizer_name="Adam", device="cuda", use_node_feats=False, train_node_emb=True)
+            torch.manual_seed(11)
+            P.manual_seed(11)
+            m.param_init()
+            out = []
+            for ep in range(3):
+                torch.manual_seed(100 + ep)
+                out.append(m.train(data, split, B, "global", k))
+            losses[fused] = np.array(out)
+        finally:
+            ops.FUSE_EDGE_MLP["enabled"] = False
+    close(losses[True], losses[False], rtol=1e-4)
+    close(losses[True][:1], losses[False][:1], rtol=2e-6)
+
+
 # ------------------------------------------------- aggregation: feature slabs ----
 @pytest.mark.parametrize("feat", [256, 512, 384])
 @pytest.mark.parametrize("tune", [16, 32])
