@@ -217,13 +217,31 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(MultiAdam a, float lr, 
     int64_t done = 0;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0) {
         const int64_t n4 = n >> 2;
+        // the gradient and the two moments are touched once per step: streaming hints on them, so that what the
+        // caches keep after this kernel is the parameter itself -- the table the next step's first aggregation gathers
+        typedef float f32x4n __attribute__((ext_vector_type(4)));
         for (int64_t i = tid; i < n4; i += nthreads) {
             float4 p4 = reinterpret_cast<float4*>(p)[i];
+#ifndef PLNLP_ADAM_PLAIN_ACCESS
+            const f32x4n gn = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(g) + i);
+            const f32x4n mn = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(m) + i);
+            const f32x4n vn = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(v) + i);
+            const float4 g4 = make_float4(gn.x, gn.y, gn.z, gn.w);
+            float4 m4 = make_float4(mn.x, mn.y, mn.z, mn.w), v4 = make_float4(vn.x, vn.y, vn.z, vn.w);
+#else
             const float4 g4 = reinterpret_cast<const float4*>(g)[i];
             float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+#endif
             update(p4.x, g4.x, m4.x, v4.x); update(p4.y, g4.y, m4.y, v4.y);
             update(p4.z, g4.z, m4.z, v4.z); update(p4.w, g4.w, m4.w, v4.w);
-            reinterpret_cast<float4*>(p)[i] = p4; reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4;
+            reinterpret_cast<float4*>(p)[i] = p4;
+#ifndef PLNLP_ADAM_PLAIN_ACCESS
+            const f32x4n mo = {m4.x, m4.y, m4.z, m4.w}, vo = {v4.x, v4.y, v4.z, v4.w};
+            __builtin_nontemporal_store(mo, reinterpret_cast<f32x4n*>(m) + i);
+            __builtin_nontemporal_store(vo, reinterpret_cast<f32x4n*>(v) + i);
+#else
+            reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4;
+#endif
         }
         done = n4 << 2;
     }
