@@ -193,7 +193,10 @@ def run_rmat_stress(args, P, world, rank, device, pg):
         "roofline": {"bound": "hbm", "kernel": "csr_agg_vec_kernel (mean, F=512) on this rank's row block",
                      "achieved": by / t_agg / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by / t_agg / 8.0e12,
                      "traffic": None, "algorithmic_bytes": by, "kernel_ms": t_agg * 1e3,
-                     "source_MiB": npad * F * 4 / 2 ** 20},
+                     "source_MiB": npad * F * 4 / 2 ** 20,
+                     "note": "gather-model bytes on a SKEWED graph: the hub rows of R-MAT are re-read from the caches, "
+                             "so this is an effective rate, not a no-reuse HBM fraction (that one: the uniform graph "
+                             "of the default workload's `roofline`)"},
         "graph_build_s": t_graph, "output_checksum": checksum,
         "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 1,
     }
@@ -268,7 +271,10 @@ def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
             "kernel_ms": t * 1e3, "source_MiB": src_mib,
             "note": ("source fits the 256 MiB Infinity Cache: cache-bound, frac is compulsory bytes over the HBM "
                      "peak; effective_GBps is the gather-model rate (not a roofline fraction)") if cached else
-                    "source exceeds the 256 MiB Infinity Cache: HBM-bound, gather-model bytes"}
+                    ("source exceeds the 256 MiB Infinity Cache: HBM-bound, gather-model bytes" +
+                     ("" if shape.startswith("uniform") else
+                      "; the graph is SKEWED (hub rows are re-read from the caches), so this is an effective rate, not a "
+                      "no-reuse HBM fraction -- that one is taken on the uniform graph (default workload's `roofline`)"))}
 
 
 def measure_gemm_roofline(P, n_rows, k_in, hidden, device, sage=True):

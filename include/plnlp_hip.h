@@ -162,7 +162,7 @@ int plnlp_csr_aggregate_max_bwd_f32(const int64_t* rowptr_t, const int32_t* col_
                                     const int32_t* arg, int64_t ld_arg, float* gx, int64_t ldgx,
                                     int64_t n_src, int64_t feat, void* stream);
 
-/* ---- K4: dense fp32 linear on the f32-input MFMA ---------------------------
+/* ---- K4: dense fp32 linear on the MFMA (f32-input form or three-term bf16 split: see PLNLP_GEMM_MATH_*) --
  * C[M,N] = EPI( sum_s  op(A_s)[M,K_s] * op(B_s)[K_s,N] )     s = 0 .. n_seg-1 (<= 2)
  *   a_trans = 0: A_s stored [M,K_s] (lda = row stride)   1: stored [K_s,M]
  *   b_trans = 1: B_s stored [N,K_s] (nn.Linear weight)   0: stored [K_s,N]

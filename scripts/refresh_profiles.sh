@@ -1,7 +1,7 @@
 # round-2 measurement set: everything DESIGN.md / profiles/ quote, in one pass on one MI355X
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=gpurun_out/r02f; mkdir -p $R
+R=gpurun_out/r02g; mkdir -p $R
 python bench.py > $R/bench_collab.json 2> $R/bench_collab.err; tail -c 400 $R/bench_collab.json
 rocprofv3 --kernel-trace --stats -f csv -d $R/prof -o collab -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-stress > $R/bench_collab_under_rocprof.json 2>/dev/null
 f=$(find $R/prof -name "*kernel_stats.csv" | head -1); cp $f $R/kernel_stats_collab.csv
@@ -16,7 +16,9 @@ done
 python bench.py --force-dist --no-cpu-baseline --no-parity --no-stress --no-roofline > $R/bench_collab_shard_1rank.json 2>/dev/null
 python bench.py --force-dist --dp-exchange scores --no-cpu-baseline --no-parity --no-stress --no-roofline > $R/bench_collab_scores_1rank.json 2>/dev/null
 python bench.py --workload rmat --scale 0.25 --steps 3 --warmup 1 > $R/bench_rmat_s025.json 2>/dev/null; cat $R/bench_rmat_s025.json
-python scripts/bench_gemm.py > $R/gemm_microbench.jsonl 2>/dev/null
+python scripts/bench_gemm.py --math ab --error > $R/gemm_microbench.jsonl 2>/dev/null
+python bench.py --workload citation2 --force-dist --dp-exchange shard --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-stress --no-roofline > $R/bench_citation2_shard_1rank.json 2>/dev/null
+PLNLP_GEMM_MATH=f32 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-stress > $R/bench_collab_f32_mfma.json 2>/dev/null
 python scripts/bench_agg.py --cases collab,uniform,uniform_big,ddi --feat 256,512 --tune 0,16,32 > $R/agg_microbench.jsonl 2>/dev/null
 python scripts/bench_agg.py --cases rmat25 --feat 512 --tune 0,16,32 >> $R/agg_microbench.jsonl 2>/dev/null
 ls -la $R
