@@ -146,13 +146,12 @@ class BaseModel(object):
 
     def _shard_concat_feats(self, emb_full, data):
         """[emb | data.x] over the padded row range of the sharded layout (rows >= num_nodes are zero)"""
-        key = id(data.x)
-        hit = getattr(self, "_feat_pad", None)
-        if hit is None or hit[0] is not data.x:
+        hit = getattr(self, "_feat_pad", None)      # (feature tensor itself, padded copy, concat cache): compared by identity
+        if hit is None or hit[0] is not data.x or hit[3] != data.x._version:
             feats = data.x.to(self.device).to(emb_full.dtype)
             pad = torch.zeros(self._shard.part.padded, feats.shape[1], dtype=feats.dtype, device=self.device)
             pad[:feats.shape[0]].copy_(feats)
-            self._feat_pad = hit = (data.x, pad, {})
+            self._feat_pad = hit = (data.x, pad, {}, data.x._version)
         feats_pad, cache = hit[1], hit[2]
         if emb_full.is_cuda and isinstance(self.encoder, BaseGNN):
             return ops.concat_features(emb_full, feats_pad, cache)      # persistent 16-byte-aligned buffer
