@@ -912,8 +912,10 @@ def _act_backward(gy: torch.Tensor, y: torch.Tensor, act: _Act) -> torch.Tensor:
 
 
 _side_streams = {}
-OVERLAP_BACKWARD = {"enabled": False}   # measured on MI355X: no gain at collab, -4 % at ddi (the two kernels
-                                         # fight for the same CUs); kept as an option
+OVERLAP_BACKWARD = {"enabled": os.environ.get("PLNLP_OVERLAP_BACKWARD", "0") == "1"}
+# off: measured on MI355X in round 1 (dense backward): no gain at collab, -4 % at ddi (the two kernels fight for the
+# same CUs); measured again in round 2 with the split-bf16 GEMMs and the row-sparse backward
+# (profiles/r02_overlap_backward_ab.txt); kept as an option
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -1145,12 +1147,30 @@ class SAGEConvFn(torch.autograd.Function):
                                   gate_scale=ia.scale if ia is not None else 1.0)
             out = sink.buffer if sink is not None else torch.empty(x.shape[0], cin, dtype=torch.float32,
                                                                    device=x.device)
-            csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=out,
-                          epilogue=epi)
-            if sink is not None:
-                if sink.on_ready is not None:
-                    sink.on_ready()
+            joined = None
+            if OVERLAP_BACKWARD["enabled"] and OVERLAP_BACKWARD.get("sparse", True):
+                # as in the dense form: the cache- / HBM-bound transposed aggregation on the side stream, the
+                # MFMA-bound weight gradients on the main stream
+                main = torch.cuda.current_stream()
+                side = side_stream(dz.device)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=out,
+                                  epilogue=epi)
+                    if sink is not None and sink.on_ready is not None:
+                        sink.on_ready()
+                    joined = torch.cuda.Event()
+                    joined.record(side)
+                for t_ in (gagg_c, gx_c, out):          # allocated on the main stream, consumed on the side stream
+                    t_.record_stream(side)
             else:
+                csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=out,
+                              epilogue=epi)
+                if sink is not None and sink.on_ready is not None:
+                    sink.on_ready()
+            if sink is None:
                 gx = out
         if need[1] and need[3]:
             gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows, x1_compact=compact_fwd)
@@ -1161,6 +1181,8 @@ class SAGEConvFn(torch.autograd.Function):
                 gwr = gemm([(dz, x)], True, False, b_index=sg.rows)
         if need[2]:
             gbl = colsum(dz)
+        if need[0] and joined is not None:
+            torch.cuda.current_stream().wait_event(joined)
         return gx, gwl, gbl, gwr, None, None, None, None, None, None
 
 
