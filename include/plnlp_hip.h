@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PLNLP_ABI_VERSION 5
+#define PLNLP_ABI_VERSION 6
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -50,6 +50,8 @@ const char* plnlp_error_string(int code);
 #define PLNLP_EPI_ADDEND   32u   /* result += addend[a, f], a = addend_index ? addend_index[r] : r,
                                     skipped when a < 0 (a row-sparse term joining a dense result);
                                     applied where PLNLP_EPI_ACCUM is */
+#define PLNLP_EPI_ADAM     64u   /* the result is the gradient of the parameter `out`: one Adam step on it instead of
+                                    a store (see the adam_* fields; plnlp_csr_aggregate_f32 only) */
 
 typedef struct plnlp_epilogue {
     uint32_t     flags;
@@ -67,6 +69,14 @@ typedef struct plnlp_epilogue {
     const int32_t* dropout_row_index; /* nullable: the dropout counter of result row r is taken at row
                                     dropout_row_index[r] (the result holds only SOME rows of the full matrix
                                     and must draw the mask the full matrix would)                     */
+    /* PLNLP_EPI_ADAM (plnlp_csr_aggregate_f32, vector path only): the result is the GRADIENT of `out`, which is
+     * a parameter -- it is not stored; out, adam_m, adam_v (same leading dimension as out) take one Adam step
+     * (torch.optim.Adam, no weight decay, no clipping: the embedding table of plnlp/model.py:163-167) with
+     * exactly the arithmetic of plnlp_adam_multi_f32.  Not combinable with PLNLP_EPI_ACCUM.               */
+    float*       adam_m;
+    float*       adam_v;
+    int64_t      adam_step;      /* step count AFTER this update (>= 1): bias corrections 1 - beta^step     */
+    float        adam_lr, adam_beta1, adam_beta2, adam_eps;
 } plnlp_epilogue;
 
 /* ---- K1/K2: CSR neighbour gather-and-reduce --------------------------------

@@ -25,7 +25,9 @@ class Epilogue(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
                 ("bias", C.c_void_p), ("gate", C.c_void_p), ("ld_gate", C.c_int64),
                 ("gate_scale", C.c_float), ("gate_index", C.c_void_p), ("addend", C.c_void_p),
-                ("ld_addend", C.c_int64), ("addend_index", C.c_void_p), ("dropout_row_index", C.c_void_p)]
+                ("ld_addend", C.c_int64), ("addend_index", C.c_void_p), ("dropout_row_index", C.c_void_p),
+                ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_step", C.c_int64),
+                ("adam_lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float)]
 
 
 class RowSplit(C.Structure):
@@ -50,7 +52,7 @@ class AdamTensor(C.Structure):
 
 MULTI_MAX = 16
 GEMM_MATH_F32, GEMM_MATH_BF16X3 = 0, 1
-EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND, EPI_ADAM = 1, 2, 4, 8, 16, 32, 64
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 AGG_SHORT_ROWS = 1
 AGG_LDS_STAGE = 2
@@ -151,7 +153,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.plnlp_abi_version() != 5:
+    if lib.plnlp_abi_version() != 6:
         raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
@@ -193,7 +195,9 @@ def require_device(*tensors: Optional[torch.Tensor]) -> None:
 
 def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accumulate=False,
                   gate=None, gate_scale=1.0, gate_index=None, addend=None,
-                  addend_index=None, dropout_rows=None) -> Optional[Epilogue]:
+                  addend_index=None, dropout_rows=None, adam=None) -> Optional[Epilogue]:
+    """adam = (exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps): PLNLP_EPI_ADAM -- the launch's `out` is the
+    parameter, the result its gradient (plnlp_csr_aggregate_f32 only)"""
     flags = 0
     e = Epilogue()
     if bias is not None:
@@ -225,8 +229,14 @@ def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accum
         if addend_index is not None:
             assert addend_index.dtype == torch.int32
             e.addend_index = addend_index.data_ptr()
+    if adam is not None:
+        m, v, step, lr, b1, b2, eps = adam
+        assert m.is_contiguous() and v.is_contiguous() and m.dtype == torch.float32 and v.dtype == torch.float32
+        flags |= EPI_ADAM
+        e.adam_m, e.adam_v, e.adam_step = m.data_ptr(), v.data_ptr(), int(step)
+        e.adam_lr, e.adam_beta1, e.adam_beta2, e.adam_eps = float(lr), float(b1), float(b2), float(eps)
     if flags == 0:
         return None
     e.flags = flags
-    e._keepalive = (bias, gate, gate_index, addend, addend_index, dropout_rows)      # the struct holds raw pointers; keep the tensors alive with it
+    e._keepalive = (bias, gate, gate_index, addend, addend_index, dropout_rows, adam)      # the struct holds raw pointers; keep the tensors alive with it
     return e

@@ -1,5 +1,6 @@
 // Shared device helpers for libplnlp_hip.so (gfx950 only; wave64 hard-coded).
 #pragma once
+#include <cmath>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/plnlp_hip.h"
@@ -80,14 +81,42 @@ struct Epi {
     const int32_t* addend_index;
     const int32_t* drop_row;    // dropout counter row of result row r (nullable: r itself)
     int          vec4;          // bias / gate / addend may be read 16 bytes at a time (f % 4 == 0 callers only)
+    // PLNLP_EPI_ADAM
+    float*       adam_m;
+    float*       adam_v;
+    float        adam_lr, adam_b1, adam_b2, adam_eps, adam_bc1, adam_bc2_sqrt;
 };
 
-inline int make_epi(const plnlp_epilogue* e, Epi* out) {
+// bias corrections of step t, as plnlp_adam_multi_f32 forms them
+inline void adam_bias_corrections(float beta1, float beta2, int64_t step, float* bc1, float* bc2_sqrt) {
+    *bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    *bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+}
+
+// one element of torch.optim.Adam (amsgrad=False) given the clipped / decayed gradient -- the ONE place this
+// arithmetic lives: the optimiser kernels and the PLNLP_EPI_ADAM epilogue must produce the same bits
+__device__ __forceinline__ void adam_update(float& pi, float gi, float& mi, float& vi, float step, float b1,
+                                            float b2, float eps, float bc2_sqrt) {
+    mi = mi + (1.f - b1) * (gi - mi);
+    vi = fmaf(1.f - b2, gi * gi, b2 * vi);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step * (mi / denom);
+}
+
+inline int make_epi(const plnlp_epilogue* e, Epi* out, bool allow_adam = false) {
     Epi d{};
     d.keep_scale = 1.f;
     d.gate_scale = 1.f;
     if (e) {
         d.flags = e->flags;
+        if (d.flags & PLNLP_EPI_ADAM) {
+            if (!allow_adam || (d.flags & PLNLP_EPI_ACCUM)) return PLNLP_E_UNSUPPORTED;
+            if (!e->adam_m || !e->adam_v) return PLNLP_E_NULL;
+            if (e->adam_step < 1 || ((uintptr_t)e->adam_m % 16) || ((uintptr_t)e->adam_v % 16)) return PLNLP_E_SHAPE;
+            d.adam_m = e->adam_m; d.adam_v = e->adam_v;
+            d.adam_lr = e->adam_lr; d.adam_b1 = e->adam_beta1; d.adam_b2 = e->adam_beta2; d.adam_eps = e->adam_eps;
+            adam_bias_corrections(e->adam_beta1, e->adam_beta2, e->adam_step, &d.adam_bc1, &d.adam_bc2_sqrt);
+        }
         if (d.flags & PLNLP_EPI_BIAS) { if (!e->bias) return PLNLP_E_NULL; d.bias = e->bias; }
         if (d.flags & PLNLP_EPI_GATE) {
             if (!e->gate) return PLNLP_E_NULL;
@@ -193,6 +222,25 @@ __device__ __forceinline__ float4 epi_apply4_pre(const Epi& e, float4 v, int64_t
         v.z = y.z > 0.f ? v.z * e.gate_scale : 0.f; v.w = y.w > 0.f ? v.w * e.gate_scale : 0.f;
     }
     return v;
+}
+
+// PLNLP_EPI_ADAM: g = the finished gradient of out[r, f .. f+3]; p = &out[r, f], off = r * ldo + f (m, v share
+// out's leading dimension).  The moments are touched once per step: streaming hints on them.
+__device__ __forceinline__ void epi_adam4(const Epi& e, float4 g, float* __restrict__ p, int64_t off) {
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    float4 p4 = *reinterpret_cast<float4*>(p);
+    const f32x4n mn = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(e.adam_m + off));
+    const f32x4n vn = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(e.adam_v + off));
+    float4 m4 = make_float4(mn.x, mn.y, mn.z, mn.w), v4 = make_float4(vn.x, vn.y, vn.z, vn.w);
+    const float step = e.adam_lr / e.adam_bc1;
+    adam_update(p4.x, g.x, m4.x, v4.x, step, e.adam_b1, e.adam_b2, e.adam_eps, e.adam_bc2_sqrt);
+    adam_update(p4.y, g.y, m4.y, v4.y, step, e.adam_b1, e.adam_b2, e.adam_eps, e.adam_bc2_sqrt);
+    adam_update(p4.z, g.z, m4.z, v4.z, step, e.adam_b1, e.adam_b2, e.adam_eps, e.adam_bc2_sqrt);
+    adam_update(p4.w, g.w, m4.w, v4.w, step, e.adam_b1, e.adam_b2, e.adam_eps, e.adam_bc2_sqrt);
+    *reinterpret_cast<float4*>(p) = p4;
+    const f32x4n mo = {m4.x, m4.y, m4.z, m4.w}, vo = {v4.x, v4.y, v4.z, v4.w};
+    __builtin_nontemporal_store(mo, reinterpret_cast<f32x4n*>(e.adam_m + off));
+    __builtin_nontemporal_store(vo, reinterpret_cast<f32x4n*>(e.adam_v + off));
 }
 
 inline int launch_status() {

@@ -240,6 +240,7 @@ __device__ __forceinline__ void finish_row(float4 (&acc)[VPL], int64_t r, int64_
             // streaming hint on the result rows: they are not read again by this launch, the gathered table is
             // (measured, profiles/r02_agg_nt_store.txt: -5 % on the collab launch whose 230 MiB table competes with
             // the 230 MiB result for the 256 MiB Infinity Cache, -1 % where the table is far larger than the cache)
+            if (epi.flags & PLNLP_EPI_ADAM) { epi_adam4(epi, y, orow + s * 4, r * ldo + (int64_t)s * 4); continue; }
             const f32x4n yv = {y.x, y.y, y.z, y.w};
             __builtin_nontemporal_store(yv, reinterpret_cast<f32x4n*>(orow + s * 4));
         }
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
         if (epi.bias) epi.bias += c0;
         if (epi.gate) epi.gate += c0;
         if (epi.addend) epi.addend += c0;
+        if (epi.adam_m) { epi.adam_m += c0; epi.adam_v += c0; }
         feat = (feat - c0) < slab_feat ? (feat - c0) : slab_feat;
     }
     const int nslots = feat >> 2;
@@ -440,7 +442,8 @@ __global__ __launch_bounds__(LDS_THREADS) void csr_agg_lds_kernel(
             }
             float* orow = out + r * ldo;
             const float4 y = epi_apply4(epi, acc, r, f, feat, orow);
-            *reinterpret_cast<float4*>(orow + f) = y;
+            if (epi.flags & PLNLP_EPI_ADAM) epi_adam4(epi, y, orow + f, r * ldo + f);
+            else *reinterpret_cast<float4*>(orow + f) = y;
         }
     }
 }
@@ -580,7 +583,8 @@ __global__ __launch_bounds__(256) void csr_agg_finalize_kernel(const int64_t* __
             }
             float* orow = out + r * ldo;
             const float4 y = epi_apply4(epi, acc, r, (int64_t)s * 4, feat, orow);
-            *reinterpret_cast<float4*>(orow + s * 4) = y;
+            if (epi.flags & PLNLP_EPI_ADAM) epi_adam4(epi, y, orow + s * 4, r * ldo + (int64_t)s * 4);
+            else *reinterpret_cast<float4*>(orow + s * 4) = y;
         }
         __syncthreads();
     }
@@ -723,7 +727,7 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
     if (n_rows == 0) return 0;
     if (!col) return PLNLP_E_NULL;
     Epi e;
-    if (int rc = make_epi(epi, &e)) return rc;
+    if (int rc = make_epi(epi, &e, /*allow_adam=*/true)) return rc;
     if (n_rows > (int64_t)4 * 0x7FFFFFFF) return PLNLP_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((n_rows + 3) / 4));
@@ -746,6 +750,8 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
         sa.ws = split->workspace;
         sp = &sa;
     }
+    // the Adam epilogue updates every result row exactly once: the vector path over ALL rows (no row subset)
+    if ((e.flags & PLNLP_EPI_ADAM) && (!vec_ok || row_index)) return PLNLP_E_UNSUPPORTED;
     if (!vec_ok) {
         constexpr int64_t MAX_BLOCKS = (int64_t)1 << 22;          // < 2^32 threads per launch
         for (int64_t b0 = 0; b0 < (int64_t)grid.x; b0 += MAX_BLOCKS) {

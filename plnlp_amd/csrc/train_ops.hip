@@ -110,10 +110,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     auto update = [&](float& pi, float gi, float& mi, float& vi) {
         gi *= coef;
         if (wd != 0.f) { if (decoupled) pi *= (1.f - lr * wd); else gi = fmaf(wd, pi, gi); }
-        mi = mi + (1.f - b1) * (gi - mi);            // lerp, as torch.optim.Adam
-        vi = fmaf(1.f - b2, gi * gi, b2 * vi);
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi = pi - step * (mi / denom);
+        adam_update(pi, gi, mi, vi, step, b1, b2, eps, bc2_sqrt);      // (common.hip.h: shared with PLNLP_EPI_ADAM)
     };
     int64_t done = 0;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0) {   // 16 bytes per lane
@@ -207,10 +204,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(MultiAdam a, float lr, 
     auto update = [&](float& pi, float gi, float& mi, float& vi) {
         gi *= coef;
         if (wd != 0.f) { if (decoupled) pi *= (1.f - lr * wd); else gi = fmaf(wd, pi, gi); }
-        mi = mi + (1.f - b1) * (gi - mi);
-        vi = fmaf(1.f - b2, gi * gi, b2 * vi);
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi = pi - step * (mi / denom);
+        adam_update(pi, gi, mi, vi, step, b1, b2, eps, bc2_sqrt);      // (common.hip.h: shared with PLNLP_EPI_ADAM)
     };
     const int64_t tid = (int64_t)((int)blockIdx.x - fb) * 256 + threadIdx.x;
     const int64_t nthreads = (int64_t)(nb - fb) * 256;
@@ -506,8 +500,7 @@ extern "C" int plnlp_adam_multi_f32(const plnlp_adam_tensor* tensors, int n_tens
         if (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) return PLNLP_E_NULL;
         a.p[i] = t.param; a.g[i] = t.grad; a.m[i] = t.exp_avg; a.v[i] = t.exp_avg_sq; a.n[i] = t.n;
         a.sqnorm[i] = t.sqnorm; a.max_norm[i] = t.max_norm;
-        a.bc1[i] = (float)(1.0 - pow((double)beta1, (double)t.step));
-        a.bc2_sqrt[i] = (float)sqrt(1.0 - pow((double)beta2, (double)t.step));
+        adam_bias_corrections(beta1, beta2, t.step, &a.bc1[i], &a.bc2_sqrt[i]);
         a.first_block[i] = blocks;
         blocks += (int)ew_grid((t.n + 3) / 4);          // 16 bytes per lane
     }

@@ -26,8 +26,14 @@ from . import loss as loss_mod
 from . import ops
 from .layer import (GCN, SAGE, WSAGE, BaseGNN, BilinearPredictor, DotPredictor, GCNConv, MLPBilPredictor,
                     MLPCatPredictor, MLPDotPredictor, MLPPredictor, SAGEConv, Transformer)
-from .optim import FusedAdam, group_sqnorm
+from .optim import FusedAdam, fused_adam_state, group_sqnorm
 from .utils import batch_permutation, evaluate_hits, evaluate_mrr, get_pos_neg_edges
+
+import os
+
+# single process, SAGE on the raw embedding table: the table's Adam step rides in the epilogue of the kernel that
+# finishes its gradient (BaseModel._embedding_grad_sink); PLNLP_FUSE_EMBEDDING_ADAM=0 keeps gradient and update apart
+FUSE_EMBEDDING_ADAM = {"enabled": os.environ.get("PLNLP_FUSE_EMBEDDING_ADAM", "1") != "0"}
 
 
 class BaseModel(object):
@@ -243,12 +249,26 @@ class BaseModel(object):
         from .layer import SAGEConv
         from .ops import GradSink
         self._early_work = None
-        if (self.process_group is None or self.emb is None or x_in is not self.emb.weight
+        self._adam_sink = None
+        if (self.emb is None or x_in is not self.emb.weight
                 or not self.emb.weight.requires_grad or not x_in.is_cuda
                 or not isinstance(self.encoder.convs[0], SAGEConv) or self.encoder.convs[0].aggr != "mean"):
             return None
+        adam = None
+        if self.process_group is None:
+            # One process: nothing to reduce over ranks, and the reference clips the encoder and the predictor but
+            # NOT the embedding (model.py:163-165) -- Adam is the only consumer of the table's gradient, so the
+            # kernel that finishes that gradient may apply the update itself (ops.GradSink.adam, PLNLP_EPI_ADAM)
+            if not (self._fused_step and FUSE_EMBEDDING_ADAM["enabled"]):
+                return None
+            adam = fused_adam_state(self.optimizer, self.emb.weight)
+            if adam is None:
+                return None
         if getattr(self, "_emb_grad_buf", None) is None:
             self._emb_grad_buf = torch.empty_like(self.emb.weight)
+        if adam is not None:
+            self._adam_sink = GradSink(self._emb_grad_buf, None, adam=adam)
+            return self._adam_sink
         self.emb.weight.grad = self._emb_grad_buf
 
         def start_reduce():
@@ -277,6 +297,13 @@ class BaseModel(object):
     def _clip_and_step(self):
         """model.py:163-167: encoder and predictor clipped as separate groups, the
         embedding not at all; then the optimiser."""
+        sink = getattr(self, "_adam_sink", None)
+        if sink is not None:
+            if sink.adam_applied:       # the table was stepped inside the backward pass; its .grad stays None
+                self.optimizer.state[self.emb.weight]["step"] += 1
+            else:                       # the backward took a path without the fused update: the gradient is in the buffer
+                self.emb.weight.grad = sink.buffer
+            self._adam_sink = None
         if self._fused_step:
             clip = {}
             if self.clip_norm >= 0:

@@ -105,7 +105,7 @@ def _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, f
     key = feat                        # one choice per width, shared by the weighted / transposed passes
     if key in cache:
         return cache[key]
-    if flags & (L.EPI_ACCUM | L.EPI_ADDEND | L.EPI_GATE) or src_map is not None or row_index is not None:
+    if flags & (L.EPI_ACCUM | L.EPI_ADDEND | L.EPI_GATE | L.EPI_ADAM) or src_map is not None or row_index is not None:
         return 0                      # not a call to time on; an earlier or later plain call decides
     best, best_t = 0, None
     for cand in AGG_AUTOTUNE["candidates"]:
@@ -942,8 +942,13 @@ class GradSink:
     `param.grad`), calls `on_ready()` -- the caller starts the asynchronous all-reduce there --
     and only then queues its weight-gradient GEMMs, which run while the reduction is in flight."""
 
-    def __init__(self, buffer: torch.Tensor, on_ready=None):
+    def __init__(self, buffer: torch.Tensor, on_ready=None, adam=None):
         self.buffer, self.on_ready = buffer, on_ready
+        # adam = dict(param, exp_avg, exp_avg_sq, step, lr, betas, eps): the input IS a parameter that is neither
+        # clipped nor reduced over ranks -- the backward may then apply its Adam step in the epilogue of the kernel
+        # that finishes the gradient (PLNLP_EPI_ADAM) instead of writing the gradient out; it sets
+        # `adam_applied` when it did (else the gradient is in `buffer` as usual)
+        self.adam, self.adam_applied = adam, False
 
 
 class AggregateFn(torch.autograd.Function):
@@ -1145,6 +1150,30 @@ class SAGEConvFn(torch.autograd.Function):
             ia = ctx.in_act
             epi = L.make_epilogue(addend=gx_c, addend_index=sg.node_map, gate=x if ia is not None else None,
                                   gate_scale=ia.scale if ia is not None else 1.0)
+            fuse_adam = (sink is not None and sink.adam is not None and ia is None and x.is_contiguous()
+                         and sink.adam["param"].data_ptr() == x.data_ptr() and sink.adam["param"].shape == x.shape
+                         and _vector_path(gagg_c, x, cin))
+            if fuse_adam:
+                # the input is the embedding table and nothing but Adam consumes its gradient: update it in the
+                # epilogue of the aggregation that finishes that gradient (no 242 MB gradient written and read
+                # back).  The weight gradients read the OLD table, so they go first.
+                if need[1] and need[3]:
+                    gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows, x1_compact=compact_fwd)
+                else:
+                    if need[1]:
+                        gwl = gemm([(dz, agg)], True, False, b_index=None if compact_fwd else sg.rows)
+                    if need[3]:
+                        gwr = gemm([(dz, x)], True, False, b_index=sg.rows)
+                ad = sink.adam
+                epi = L.make_epilogue(addend=gx_c, addend_index=sg.node_map,
+                                      adam=(ad["exp_avg"], ad["exp_avg_sq"], ad["step"], ad["lr"], ad["betas"][0],
+                                            ad["betas"][1], ad["eps"]))
+                csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=x.data,
+                              epilogue=epi)
+                sink.adam_applied = True
+                if need[2]:
+                    gbl = colsum(dz)
+                return None, gwl, gbl, gwr, None, None, None, None, None, None
             out = sink.buffer if sink is not None else torch.empty(x.shape[0], cin, dtype=torch.float32,
                                                                    device=x.device)
             joined = None

@@ -42,6 +42,24 @@ class FusedAdam(torch.optim.Optimizer):
                            grad_scale=grad_scale)
 
 
+def fused_adam_state(opt: "FusedAdam", p: torch.nn.Parameter) -> Optional[dict]:
+    """Adam state and hyper-parameters of `p` for an update applied OUTSIDE opt.step() (ops.GradSink.adam: the
+    PLNLP_EPI_ADAM epilogue).  None when the group's settings are not plain Adam.  The caller advances
+    state['step'] itself once the update has really been applied."""
+    for group in opt.param_groups:
+        if any(q is p for q in group["params"]):
+            if group["weight_decay"] != 0.0 or group["decoupled"]:
+                return None
+            st = opt.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            return dict(param=p, exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], step=st["step"] + 1,
+                        lr=group["lr"], betas=group["betas"], eps=group["eps"])
+    return None
+
+
 def group_sqnorm(params: Sequence[torch.nn.Parameter]) -> Optional[torch.Tensor]:
     """squared total gradient norm of a clip group as a device scalar"""
     grads = [p.grad for p in params if p.grad is not None]

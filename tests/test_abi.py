@@ -36,7 +36,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.plnlp_abi_version() == 5
+    assert lib.plnlp_abi_version() == 6
     assert lib.plnlp_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5):
         assert lib.plnlp_error_string(code).startswith(b"plnlp:")

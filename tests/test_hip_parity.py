@@ -1022,6 +1022,9 @@ def _sparse_vs_dense_step(P, enc, layers, pred, n=4000, feat=64, batch=300, k=2,
     w = torch.rand(batch, generator=gen).cuda()
     res = {}
     old = dict(ops.SPARSE_BACKWARD)
+    from plnlp_amd import model as model_mod
+    fuse_old = model_mod.FUSE_EMBEDDING_ADAM["enabled"]
+    model_mod.FUSE_EMBEDDING_ADAM["enabled"] = False       # this comparison reads the embedding's gradient tensor
     try:
         for mode in ("dense", "sparse"):
             ops.SPARSE_BACKWARD["enabled"] = mode == "sparse"
@@ -1043,6 +1046,7 @@ def _sparse_vs_dense_step(P, enc, layers, pred, n=4000, feat=64, batch=300, k=2,
             res[mode] = (float(loss), grads)
     finally:
         ops.SPARSE_BACKWARD.update(old)
+        model_mod.FUSE_EMBEDDING_ADAM["enabled"] = fuse_old
     return res
 
 

@@ -696,6 +696,49 @@ def test_fused_edge_mlp_in_the_training_step(P):
     close(losses[True][:1], losses[False][:1], rtol=2e-6)
 
 
+# ------------------------------- embedding update in the gradient kernel's epilogue ----
+@pytest.mark.parametrize("pred,layers,feat", [("DOT", 1, 64), ("MLP", 1, 256), ("DOT", 2, 64)])
+def test_embedding_adam_in_the_aggregation_epilogue_gives_the_same_bits(P, pred, layers, feat):
+    """model.FUSE_EMBEDDING_ADAM: the table's Adam step applied by the transposed aggregation that finishes its
+    gradient (PLNLP_EPI_ADAM; hub rows through the finalize pass) instead of a gradient tensor + the optimiser
+    kernel -- the same arithmetic on the same values: parameters, Adam moments and losses after 3 epochs are
+    bit-identical.  (2 layers: the first conv's backward is dense, the path falls back to the gradient tensor.)"""
+    from plnlp_amd import model as M, synthetic
+    n, B, k = 3000, 1024, 1
+    g = synthetic.make_graph("collab", seed=9, device="cpu", num_nodes=n, num_edges=20000, weighted=True)
+    data = g["data"]
+    data.adj_t = g["adj_t"].to("cuda")
+    assert int((data.adj_t.rowptr[1:] - data.adj_t.rowptr[:-1]).max()) > 256       # a hub row: chunk + finalize passes
+    split = {"train": {"edge": g["edges"], "weight": g["weight"] / 5.0}}
+    res = {}
+    for fused in (True, False):
+        M.FUSE_EMBEDDING_ADAM["enabled"] = fused
+        try:
+            m = P.BaseModel(lr=0.01, dropout=0.3, grad_clip_norm=1.0, gnn_num_layers=layers, mlp_num_layers=2,
+                            emb_hidden_channels=feat, gnn_hidden_channels=feat, mlp_hidden_channels=feat, num_nodes=n,
+                            num_node_feats=0, gnn_encoder_name="SAGE", predictor_name=pred,
+                            loss_func="WeightedHingeAUC" if pred == "DOT" else "AUC", optimizer_name="Adam",
+                            device="cuda", use_node_feats=False, train_node_emb=True)
+            torch.manual_seed(21)
+            P.manual_seed(21)
+            m.param_init()
+            losses = []
+            for ep in range(3):
+                torch.manual_seed(70 + ep)
+                losses.append(m.train(data, split, B, "local", k))
+            torch.cuda.synchronize()
+            st = m.optimizer.state[m.emb.weight]
+            res[fused] = (losses, [p.detach().clone() for p in m.para_list], st["exp_avg"].clone(),
+                          st["exp_avg_sq"].clone(), st["step"])
+        finally:
+            M.FUSE_EMBEDDING_ADAM["enabled"] = True
+    assert res[True][0] == res[False][0]
+    assert res[True][4] == res[False][4]
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+
+
 # ------------------------------------------------- aggregation: feature slabs ----
 @pytest.mark.parametrize("feat", [256, 512, 384])
 @pytest.mark.parametrize("tune", [16, 32])
