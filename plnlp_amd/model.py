@@ -349,7 +349,40 @@ class BaseModel(object):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
         return bool(torch.equal(lo, hi))
 
-    def _encode(self, data, pos_edge, neg_flat, use_sink, edges_ready, rows_only=False):
+    def _edge_flags(self, n_edges: int, on_gpu: bool, rows_only: bool):
+        """what the scorer's fusions allow for a batch of n_edges scored edges -- a function of the model and the
+        batch size alone, so a batch can be prepared before the step that uses it (prepare_edges):
+        (fused scorer, row-sparse gradient channel, build the gather-backward index structures, touched-rows forward)"""
+        n_endpoints = 2 * n_edges
+        native = isinstance(self.encoder, BaseGNN)
+        fused = native and type(self.predictor) in (DotPredictor, MLPPredictor)   # gather fused into the scorer
+        use_channel = (n_edges > 0 and fused and all(isinstance(c, (SAGEConv, GCNConv)) for c in self.encoder.convs)
+                       and getattr(self.encoder.convs[-1], "aggr", "mean") == "mean"
+                       and ops.sparse_backward_pays(n_endpoints, self.num_nodes))
+        build = n_edges > 0 and fused and on_gpu and ops.EDGE_BACKWARD["mode"] == "segment"
+        sparse_fwd = rows_only and build and use_channel and ops.SPARSE_FORWARD["enabled"]
+        return fused, use_channel, build, sparse_fwd
+
+    def prepare_edges(self, pos_edge, neg_edge, edges_ready=True, rows_only=True):
+        """Start the edge-only pre-processing of a FUTURE training step (ops.EdgeBatch: endpoint lists, the sort
+        behind the deterministic gather backward, the touched-node compaction and its count read-back) on the
+        side stream and return the handle to pass as train_step(..., prepared=).  A training loop that calls this
+        for batch i+1 before it enqueues step i never waits for that read-back: without the look-ahead the host
+        blocks on it at the top of every step while the main stream drains (a ~70 us hole per 1.7 ms collab step).
+        pos_edge [b,2], neg_edge [b,k,2] as for train_step (this rank's slice)."""
+        neg_flat = neg_edge.reshape(-1, 2)
+        n_edges = pos_edge.size(0) + neg_flat.size(0)
+        on_gpu = pos_edge.is_cuda
+        fused, use_channel, build, sparse_fwd = self._edge_flags(n_edges, on_gpu, rows_only)
+        batch = ops.EdgeBatch([pos_edge[:, 0], neg_flat[:, 0]], [pos_edge[:, 1], neg_flat[:, 1]], self.num_nodes,
+                              build=build, compact=use_channel, overlap=on_gpu,
+                              inputs_ready=edges_ready, compact_endpoints=sparse_fwd,
+                              record_streams=not self._throttled())
+        batch._flags = (n_edges, fused, use_channel, build, sparse_fwd)
+        return batch
+
+    def _encode(self, data, pos_edge, neg_flat, use_sink, edges_ready, rows_only=False, prepared=None,
+                keep_alive=False):
         """encoder forward of a training step with the fusions the scorer allows; pos_edge [n,2] and
         neg_flat [n*k,2] are ALL edges whose scores will be back-propagated.  Returns (h, gate_scale,
         channel, fused, batch) with batch an ops.EdgeBatch (src, dst, incidence) -- see train_step.
@@ -357,13 +390,12 @@ class BaseModel(object):
         conv may produce just the touched rows (ops.SPARSE_FORWARD); h is then compact (batch.src_c /
         dst_c address it) -- tell by `batch.src_c is not None`."""
         n_edges = pos_edge.size(0) + neg_flat.size(0)
-        n_endpoints = 2 * n_edges
         native = isinstance(self.encoder, BaseGNN)
-        fused = native and type(self.predictor) in (DotPredictor, MLPPredictor)   # gather fused into the scorer
+        x_in = self.create_input_feat(data)
+        fused, use_channel, build, sparse_fwd = self._edge_flags(n_edges, x_in.is_cuda, rows_only)
         # a 1-layer encoder ends in relu+dropout (layer.py:24-26); with a fused scorer as the only
         # consumer of h, that activation's backward rides in the scorer's gather-reduce epilogue
         fuse_gate = n_edges > 0 and fused and self.encoder.num_layers == 1
-        x_in = self.create_input_feat(data)
         kw = {}
         sink = self._embedding_grad_sink(x_in) if (native and use_sink) else None
         if sink is not None:
@@ -371,18 +403,20 @@ class BaseModel(object):
         # the batch touches at most n_endpoints nodes: the gradient of h is zero in every other row,
         # and the scorer hands it to the last conv's backward in row-sparse form
         channel = None
-        if (n_edges > 0 and fused and all(isinstance(c, (SAGEConv, GCNConv)) for c in self.encoder.convs)
-                and getattr(self.encoder.convs[-1], "aggr", "mean") == "mean"
-                and ops.sparse_backward_pays(n_endpoints, x_in.shape[0])):
+        if use_channel:
             channel = kw["output_grad_channel"] = ops.SparseGradChannel()
-        # src / dst and the index structures of the gather backward depend on the edges alone: build
-        # them (sort, touched-node compaction, its count read-back) NOW -- on the side stream, in the
-        # shadow of the previous step's tail -- and join before the scorer
-        build = n_edges > 0 and fused and x_in.is_cuda and ops.EDGE_BACKWARD["mode"] == "segment"
-        sparse_fwd = rows_only and build and channel is not None and ops.SPARSE_FORWARD["enabled"]
-        batch = ops.EdgeBatch([pos_edge[:, 0], neg_flat[:, 0]], [pos_edge[:, 1], neg_flat[:, 1]], x_in.shape[0],
-                              build=build, compact=channel is not None, overlap=x_in.is_cuda,
-                              inputs_ready=edges_ready, compact_endpoints=sparse_fwd)
+        # src / dst and the index structures of the gather backward depend on the edges alone: they were
+        # started one step ahead (prepare_edges), or are built NOW -- on the side stream, in the shadow of the
+        # previous step's tail -- and joined before the scorer
+        if prepared is not None:
+            if prepared._flags != (n_edges, fused, use_channel, build, sparse_fwd) or x_in.shape[0] != self.num_nodes:
+                raise ValueError("prepare_edges() was called for a different batch shape or model configuration")
+            batch = prepared
+        else:
+            batch = ops.EdgeBatch([pos_edge[:, 0], neg_flat[:, 0]], [pos_edge[:, 1], neg_flat[:, 1]], x_in.shape[0],
+                                  build=build, compact=channel is not None, overlap=x_in.is_cuda,
+                                  inputs_ready=edges_ready, compact_endpoints=sparse_fwd,
+                                  record_streams=not (self._throttled() and keep_alive))
         if sparse_fwd:
             # the last conv needs the touched-row list (and its count, on the host) before it is launched:
             # the lists were started on the side stream at the top of the step, in the shadow of the
@@ -400,7 +434,7 @@ class BaseModel(object):
         return self.predictor(h[src], h[dst])
 
     def train_step(self, data, pos_edge, neg_edge, num_neg, weight_margin=None, edges_ready=False,
-                   global_count=None):
+                   global_count=None, prepared=None):
         """One iteration of the hot loop, model.py:148-167, on this rank's slice:
         pos_edge [b,2], neg_edge [b,k,2] (device).  Returns the detached local loss -- this rank's
         SHARE of the global batch's loss (global_count = positives in the global batch; only the
@@ -411,7 +445,8 @@ class BaseModel(object):
         self.optimizer.zero_grad(set_to_none=True)
         local = pos_edge.size(0)
         h, gate_scale, channel, fused, batch = self._encode(data, pos_edge, neg_edge.reshape(-1, 2), True,
-                                                             edges_ready, rows_only=True)
+                                                             edges_ready, rows_only=True, prepared=prepared,
+                                                             keep_alive=True)
         src, dst, incidence = batch.src, batch.dst, batch.incidence
         if local > 0:
             if batch.src_c is not None:          # h holds only the touched rows (ops.SPARSE_FORWARD)
@@ -433,7 +468,21 @@ class BaseModel(object):
             loss.backward()
         self._allreduce_grads()
         self._clip_and_step()
+        self._throttle(keep=(batch, pos_edge, neg_edge, weight_margin))
         return loss.detach().reshape(())
+
+    def _throttled(self) -> bool:
+        return self.device.type == "cuda" and ops.STEP_THROTTLE["depth"] > 0
+
+    def _throttle(self, keep=None):
+        """bound how far the host runs ahead of the device, and hold `keep` (what this step borrowed from the
+        side stream) until the step has finished there (ops.StepThrottle)"""
+        if not self._throttled():
+            return
+        th = getattr(self, "_step_throttle", None)
+        if th is None or th.depth != ops.STEP_THROTTLE["depth"]:
+            th = self._step_throttle = ops.StepThrottle(ops.STEP_THROTTLE["depth"])
+        th.tick(keep)
 
     def train_step_global(self, data, pos_edge, neg_edge, num_neg, weight_margin=None, edges_ready=False):
         """One iteration in dp_exchange='scores' mode.  Every rank passes the GLOBAL batch
@@ -487,6 +536,7 @@ class BaseModel(object):
             out = self._score(h, src, dst)
         out.backward(g_all.reshape(out.shape))
         self._clip_and_step()
+        self._throttle()
         return loss.detach().reshape(())
 
     def shard_plan(self, pos_edge, neg_edge, num_neg):
@@ -555,6 +605,7 @@ class BaseModel(object):
             self._emb_shard.grad = torch.zeros_like(self._emb_shard)
         self._clip_and_step()
         self._table_work = sc.sync_table(self._emb_full, self._emb_shard)
+        self._throttle()
         return loss.detach().reshape(())
 
     # ------------------------------------------------------------------ train ---
@@ -611,9 +662,10 @@ class BaseModel(object):
             with torch.cuda.stream(side):
                 out = (pos_train_edge[perm], neg_train_edge[perm],
                        edge_weight_margin[perm] if edge_weight_margin is not None else None)
-            for t in out:
-                if t is not None:
-                    t.record_stream(main)
+            if not (self._throttled() and mode != "scores"):     # (train_step hands them to the step throttle instead)
+                for t in out:
+                    if t is not None:
+                        t.record_stream(main)
             return out
 
         pending = None
@@ -658,14 +710,26 @@ class BaseModel(object):
                 loss_acc += loss.double() * n_b
                 total_examples += n_b
                 continue
-            if world > 1:
-                per = (n_b + world - 1) // world
-                perm = perm_all[rank * per:(rank + 1) * per]
-            else:
-                perm = perm_all
-            pos_b, neg_b, weight_margin = take(perm)
+            def my_slice(perm_of_batch):
+                if world > 1:
+                    per = (perm_of_batch.numel() + world - 1) // world
+                    return perm_of_batch[rank * per:(rank + 1) * per]
+                return perm_of_batch
+
+            def gather_and_prepare(perm_of_batch):
+                got = take(my_slice(perm_of_batch))
+                pb = self.prepare_edges(got[0], got[1], edges_ready=side is not None) if side is not None else None
+                return got + (pb,)
+            # one batch of look-ahead, as in the sharded mode: the next batch's gathers and index structures are
+            # started before this step is enqueued, so their count read-back never stalls the host
+            if pending is None:
+                pending = gather_and_prepare(perm_all)
+            pos_b, neg_b, weight_margin, prepared = pending
+            pending = None
+            if bi + 1 < len(batches):
+                pending = gather_and_prepare(order[start:start + batches[bi + 1].numel()])
             loss = self.train_step(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None,
-                                   global_count=n_b)
+                                   global_count=n_b, prepared=prepared)
             loss_acc += loss.double() * n_b
             total_examples += n_b
 

@@ -1620,6 +1620,38 @@ def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, co
 PROLOGUE_OVERLAP = {"enabled": os.environ.get("PLNLP_PROLOGUE_OVERLAP", "1") != "0"}
 
 
+JOIN_STATS = {"waited": 0, "skipped": 0}        # EdgeBatch.join: stream waits enqueued / found unnecessary
+
+
+class StepThrottle:
+    """Keeps the host at most `depth` training steps ahead of the GPU, and carries the lifetime of what a step
+    borrowed from another stream.
+
+    The host enqueues a collab step in ~1.0 ms, the GPU runs it in ~1.7 ms: unthrottled, the distance grows by
+    0.7 ms per step and every step in flight pins memory (measured 1.7 hipMalloc calls per step in a 30-step run).
+    Two steps of look-ahead hide every launch latency; beyond that the host only hoards memory.
+
+    `keep` (tick) is released only once the step's event has been waited for.  That replaces
+    Tensor.record_stream for the side-stream-built edge structures: the caching allocator implements
+    record_stream by recording one event on the consuming stream per block when the block is freed -- ~15 marker
+    packets at the head of the next step's forward pass (profiles/r02_step_gap.txt)."""
+
+    def __init__(self, depth: int = 2):
+        import collections
+        self.depth, self.events = depth, collections.deque()
+
+    def tick(self, keep=None) -> None:
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events.append((ev, keep))
+        if len(self.events) > self.depth:
+            old, _ = self.events.popleft()
+            old.synchronize()
+
+
+STEP_THROTTLE = {"depth": int(os.environ.get("PLNLP_STEP_THROTTLE", "2"))}
+
+
 class EdgeBatch:
     """The scored edges of one training step -- src / dst (positives then negatives) -- and the index
     structures of their backward pass (prepare_edge_backward).
@@ -1635,7 +1667,7 @@ class EdgeBatch:
     stream passes True."""
 
     def __init__(self, src_parts, dst_parts, n_nodes: int, build: bool, compact: bool, overlap: bool,
-                 inputs_ready: bool = False, compact_endpoints: bool = False):
+                 inputs_ready: bool = False, compact_endpoints: bool = False, record_streams: bool = True):
         """compact_endpoints: also src_c / dst_c = the endpoints as rows of a matrix that holds only the
         touched nodes, and the incidence's compact column list (a row-restricted encoder output)"""
         self._compact_endpoints = compact_endpoints and compact
@@ -1651,8 +1683,12 @@ class EdgeBatch:
                 self._produce(src_parts, dst_parts, n_nodes, build, compact)
                 self._done = torch.cuda.Event()
                 self._done.record(side)
-            for t in self._tensors():          # allocated under the side stream, consumed on the main one
-                t.record_stream(main)
+            # allocated under the side stream, consumed on the main one: either the allocator is told
+            # (record_stream), or the caller keeps this object alive until the consuming step has finished on
+            # the device (StepThrottle.tick(keep=...)) -- see StepThrottle for why the latter is cheaper
+            if record_streams:
+                for t in self._tensors():
+                    t.record_stream(main)
         else:
             self._produce(src_parts, dst_parts, n_nodes, build, compact)
 
@@ -1690,7 +1726,14 @@ class EdgeBatch:
 
     def join(self) -> "EdgeBatch":
         if self._done is not None:
-            torch.cuda.current_stream().wait_event(self._done)
+            # prepared a step ahead (BaseModel.prepare_edges) the work has usually finished: then there is nothing
+            # for the stream to wait on -- a cross-queue wait packet at the head of the forward pass measured
+            # ~60 us of idle GPU per step on MI355X even when its event had long fired
+            if not self._done.query():
+                torch.cuda.current_stream().wait_event(self._done)
+                JOIN_STATS["waited"] += 1
+            else:
+                JOIN_STATS["skipped"] += 1
             self._done = None
         return self
 

@@ -1,0 +1,4 @@
+#!/bin/bash
+for w in collab ddi; do
+python bench.py --workload $w --steps 40 --warmup 5 --no-cpu-baseline --no-parity --no-stress --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', d['ms_per_step'], 'host enqueue ms/step', d['host_enqueue_ms_per_step'])"
+done

@@ -1,0 +1,2 @@
+#!/bin/bash
+python scripts/probe_gap.py 2>&1 | tail -8
