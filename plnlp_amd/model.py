@@ -578,7 +578,7 @@ class BaseModel(object):
         if self.use_node_feats:               # model.py:98-105 on the padded row range: [emb | x]
             x_full = self._shard_concat_feats(x_full, data)
         h_block = self.encoder(x_full, self._adj_block(data), shard=sc)
-        plan.join()
+        plan.join(record_streams=not self._throttled())          # (kept alive by the step throttle below instead)
         hq = shard.ExchangeRows.apply(h_block, plan, sc.group)             # [rows my slice touches, h]
         if local > 0:
             if want_inc:
@@ -605,7 +605,7 @@ class BaseModel(object):
             self._emb_shard.grad = torch.zeros_like(self._emb_shard)
         self._clip_and_step()
         self._table_work = sc.sync_table(self._emb_full, self._emb_shard)
-        self._throttle()
+        self._throttle(keep=(plan, pos_edge, neg_edge, weight_margin))
         return loss.detach().reshape(())
 
     # ------------------------------------------------------------------ train ---
@@ -678,9 +678,10 @@ class BaseModel(object):
                     sd.wait_stream(cur)                 # the epoch tensors were produced on the current stream
                 with torch.cuda.stream(sd):
                     got = take(perm)
-                for t in got:
-                    if t is not None:
-                        t.record_stream(cur)
+                if not self._throttled():                   # (else train_step_sharded hands them to the step throttle)
+                    for t in got:
+                        if t is not None:
+                            t.record_stream(cur)
             else:
                 got = take(perm)
             return got + (self.shard_plan(got[0], got[1], num_neg),)

@@ -231,19 +231,24 @@ class ShardPlan:
         self._finished = True
         return self
 
-    def join(self) -> "ShardPlan":
-        """the current stream waits for the lists (no-op when they were built on it)"""
+    def join(self, record_streams: bool = True) -> "ShardPlan":
+        """the current stream waits for the lists (no-op when they were built on it, or when they are already
+        complete -- started a batch ahead they usually are).  record_streams=False: the caller keeps this plan
+        alive until the consuming step has finished on the device (ops.StepThrottle) instead of telling the
+        allocator, which would record one event per tensor on the consuming stream when the plan dies."""
         if self._joined is not None:
             cur = torch.cuda.current_stream(self._dev)
-            cur.wait_event(self._joined)
-            for t in (self.send_rows, self.src_c, self.dst_c, self.rows):
-                t.record_stream(cur)
-            inc = self.incidence
-            if inc is not None:
-                for name in ("item_edge", "item_other", "seg_ptr"):
-                    getattr(inc, name).record_stream(cur)
-                if getattr(inc, "_split", None) is not None:
-                    inc._split._buf.record_stream(cur)
+            if not self._joined.query():
+                cur.wait_event(self._joined)
+            if record_streams:
+                for t in (self.send_rows, self.src_c, self.dst_c, self.rows):
+                    t.record_stream(cur)
+                inc = self.incidence
+                if inc is not None:
+                    for name in ("item_edge", "item_other", "seg_ptr"):
+                        getattr(inc, name).record_stream(cur)
+                    if getattr(inc, "_split", None) is not None:
+                        inc._split._buf.record_stream(cur)
             self._joined = None
         return self
 
