@@ -298,9 +298,11 @@ class BaseModel(object):
         """model.py:163-167: encoder and predictor clipped as separate groups, the
         embedding not at all; then the optimiser."""
         sink = getattr(self, "_adam_sink", None)
+        joined = None
         if sink is not None:
             if sink.adam_applied:       # the table was stepped inside the backward pass; its .grad stays None
                 self.optimizer.state[self.emb.weight]["step"] += 1
+                joined = sink.joined
             else:                       # the backward took a path without the fused update: the gradient is in the buffer
                 self.emb.weight.grad = sink.buffer
             self._adam_sink = None
@@ -312,6 +314,8 @@ class BaseModel(object):
                     if sq is not None:
                         clip.update({id(p): (sq, float(self.clip_norm)) for p in group})
             self.optimizer.step(clip=clip)
+            if joined is not None:      # the table's update was queued on the side stream: the next forward reads it
+                torch.cuda.current_stream().wait_event(joined)
             return
         if self.clip_norm >= 0:
             for module in (self.encoder, self.predictor):

@@ -912,16 +912,21 @@ def _act_backward(gy: torch.Tensor, y: torch.Tensor, act: _Act) -> torch.Tensor:
 
 
 _side_streams = {}
+# off: measured on MI355X (collab, bench.py --steps 40, twice): 1.643 / 1.650 ms with the table's update on its own
+# stream beside the small weights' clip + Adam (~60 us of short kernels), 1.625 / 1.626 ms in line -- the two
+# cross-stream hand-overs cost more than the overlap returns
+FUSED_ADAM_SIDE_STREAM = {"enabled": os.environ.get("PLNLP_FUSED_ADAM_SIDE_STREAM", "0") == "1"}
 OVERLAP_BACKWARD = {"enabled": os.environ.get("PLNLP_OVERLAP_BACKWARD", "0") == "1"}
 # off: measured on MI355X in round 1 (dense backward): no gain at collab, -4 % at ddi (the two kernels fight for the
 # same CUs); measured again in round 2 with the split-bf16 GEMMs and the row-sparse backward
 # (profiles/r02_overlap_backward_ab.txt); kept as an option
 
 
-def side_stream(device) -> "torch.cuda.Stream":
+def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
     """second HIP stream per device: bandwidth-bound backward kernels (transposed aggregation) run
-    there next to the MFMA-bound weight-gradient GEMMs instead of after them"""
-    key = torch.device(device).index or 0
+    there next to the MFMA-bound weight-gradient GEMMs instead of after them.  which = 1: a further one (the
+    embedding's update), so that it does not queue behind the next batch's index preparation"""
+    key = (torch.device(device).index or 0, which)
     if key not in _side_streams:
         # high priority: HIP hands out hardware queues per priority class, so this stream does not end
         # up multiplexed onto the main stream's hardware queue once a process group has created its own
@@ -949,6 +954,7 @@ class GradSink:
         # that finishes the gradient (PLNLP_EPI_ADAM) instead of writing the gradient out; it sets
         # `adam_applied` when it did (else the gradient is in `buffer` as usual)
         self.adam, self.adam_applied = adam, False
+        self.joined = None        # event after which the update is complete, when it was queued on another stream
 
 
 class AggregateFn(torch.autograd.Function):
@@ -1164,15 +1170,31 @@ class SAGEConvFn(torch.autograd.Function):
                         gwl = gemm([(dz, agg)], True, False, b_index=None if compact_fwd else sg.rows)
                     if need[3]:
                         gwr = gemm([(dz, x)], True, False, b_index=sg.rows)
+                if need[2]:
+                    gbl = colsum(dz)
                 ad = sink.adam
                 epi = L.make_epilogue(addend=gx_c, addend_index=sg.node_map,
                                       adam=(ad["exp_avg"], ad["exp_avg_sq"], ad["step"], ad["lr"], ad["betas"][0],
                                             ad["betas"][1], ad["eps"]))
-                csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=x.data,
-                              epilogue=epi)
+                if FUSED_ADAM_SIDE_STREAM["enabled"]:
+                    # nothing else of this step depends on the table's update: it runs on the side stream while
+                    # the main stream clips and steps the small weights; the caller joins (sink.joined) before the
+                    # next forward pass
+                    main, side = torch.cuda.current_stream(), side_stream(dz.device, 1)
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map,
+                                      out=x.data, epilogue=epi)
+                        sink.joined = torch.cuda.Event()
+                        sink.joined.record(side)
+                    for t_ in (gagg_c, gx_c, sg.node_map):        # main-stream temporaries read on the side stream
+                        t_.record_stream(side)
+                else:
+                    csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=x.data,
+                                  epilogue=epi)
                 sink.adam_applied = True
-                if need[2]:
-                    gbl = colsum(dz)
                 return None, gwl, gbl, gwr, None, None, None, None, None, None
             out = sink.buffer if sink is not None else torch.empty(x.shape[0], cin, dtype=torch.float32,
                                                                    device=x.device)
