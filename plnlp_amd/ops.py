@@ -66,7 +66,18 @@ def _ld(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------- raw kernels ------
-SPLIT_THRESHOLD = 256   # rows longer than this are cut into chunks (one wave each)
+# rows longer than this are cut into chunks of this many edges (one wave each).  0 = by the size of the matrix the
+# rows gather from: 128 up to a million source rows, 256 beyond.  Measured on MI355X (profiles/r02_split_threshold.txt):
+# on the cache-resident graphs the hub pass is latency-bound and short of waves (collab: 735 rows hold 31 % of the
+# edges = 2 900 chunks of 256 for 256 CUs) -- 128-edge chunks: collab step -2.7 %, ddi step -3.4 %, ddi aggregation
+# -23 %; on citation2 / R-MAT-23 (sources far beyond the caches) 128 costs 1 %, 64 costs 6 %.
+SPLIT_THRESHOLD = int(os.environ.get("PLNLP_SPLIT_THRESHOLD", "0"))
+
+
+def split_threshold(n_source_rows: int) -> int:
+    if SPLIT_THRESHOLD > 0:
+        return SPLIT_THRESHOLD
+    return 128 if n_source_rows <= (1 << 20) else 256
 LDS_STAGE_BUDGET = 152 * 1024   # bytes of LDS a staged feature slab may take (n_src * 16 B at the narrowest)
 LDS_STAGE_MIN_DEG = 32          # average row length from which staging x in LDS could pay for itself
 LDS_STAGE_AUTO = False          # measured on MI355X (ddi-shaped, F=512): LDS-staged 0.44 ms vs streaming 0.32 ms --
@@ -170,7 +181,7 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
         split = None             # the staged form walks whole rows
     sp = None
     if split == "auto":
-        split = graph.row_split(SPLIT_THRESHOLD) if _vector_path(x, out, feat) else None
+        split = graph.row_split(split_threshold(graph.n_cols)) if _vector_path(x, out, feat) else None
     if split is not None and split.active and _vector_path(x, out, feat):
         ws = torch.empty(split.n_chunks * feat, dtype=torch.float32, device=x.device)
         sp = L.RowSplit(split.threshold, split.n_long, split.long_rows.data_ptr(), split.chunk_beg.data_ptr(),
@@ -201,7 +212,7 @@ def csr_aggregate_max(graph, x: torch.Tensor, use_values: bool = True, split="au
     val = graph.val if use_values else None
     sp = ws_arg = None
     if split == "auto":
-        split = graph.row_split(SPLIT_THRESHOLD) if _vector_path(x, out, feat) else None
+        split = graph.row_split(split_threshold(graph.n_cols)) if _vector_path(x, out, feat) else None
     if split is not None and split.active and _vector_path(x, out, feat):
         ws = torch.empty(split.n_chunks * feat, dtype=torch.float32, device=x.device)
         ws_arg = torch.empty(split.n_chunks * feat, dtype=torch.int32, device=x.device)
@@ -1635,7 +1646,7 @@ def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, co
     inc = Incidence(src, dst, n_nodes)
     if compact:
         inc = inc.compact()
-    inc.row_split(SPLIT_THRESHOLD)
+    inc.row_split(split_threshold(n_nodes))
     return inc
 
 

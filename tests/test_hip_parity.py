@@ -561,7 +561,8 @@ def test_row_split_hub_rows_match_oracle_and_unsplit(P, feat):
     csr = O.CSR.from_coo(r, c, v, n)
     gr = to_graph(P, csr)
     x = torch.randn(n, feat, generator=g)
-    sp = gr.row_split(256)
+    th = P.ops.split_threshold(gr.n_cols)             # what csr_aggregate's split="auto" uses for this graph
+    sp = gr.row_split(th)
     assert sp.n_long >= 3 and sp.n_chunks >= 12 + 2 + 5
     for reduce in ("sum", "mean"):
         for use_values in (True, False):
@@ -569,7 +570,7 @@ def test_row_split_hub_rows_match_oracle_and_unsplit(P, feat):
             a = P.ops.csr_aggregate(gr, dev(x), reduce, use_values)                 # static split
             b = P.ops.csr_aggregate(gr, dev(x), reduce, use_values, split=None)     # no split
             d = P.ops.csr_aggregate(gr, dev(x), reduce, use_values,
-                                    split=RowSplit(gr.rowptr, gr.nnz, 256))      # upper-bound sized tables
+                                    split=RowSplit(gr.rowptr, gr.nnz, th))       # upper-bound sized tables
             close(a, ref, atol=2e-4)
             close(b, ref, atol=3e-3)      # unsplit: one sequential fp32 chain over 3000 terms
             assert torch.equal(a, d)
