@@ -67,17 +67,18 @@ def _ld(t: torch.Tensor) -> int:
 
 # ------------------------------------------------------------- raw kernels ------
 # rows longer than this are cut into chunks of this many edges (one wave each).  0 = by the size of the matrix the
-# rows gather from: 128 up to a million source rows, 256 beyond.  Measured on MI355X (profiles/r02_split_threshold.txt):
+# rows gather from: 128 up to a million source rows, 1024 beyond.  Measured on MI355X (profiles/r02_split_threshold.txt):
 # on the cache-resident graphs the hub pass is latency-bound and short of waves (collab: 735 rows hold 31 % of the
 # edges = 2 900 chunks of 256 for 256 CUs) -- 128-edge chunks: collab step -2.7 %, ddi step -3.4 %, ddi aggregation
-# -23 %; on citation2 / R-MAT-23 (sources far beyond the caches) 128 costs 1 %, 64 costs 6 %.
+# -23 %; on citation2 / R-MAT-23 (sources far beyond the caches) there are waves enough and fewer, longer chunks
+# save partial sums: 1024 vs 256: citation2 step -1.1 %, R-MAT-23 aggregation -5.7 %; 128 costs 1 %, 64 costs 6 %.
 SPLIT_THRESHOLD = int(os.environ.get("PLNLP_SPLIT_THRESHOLD", "0"))
 
 
 def split_threshold(n_source_rows: int) -> int:
     if SPLIT_THRESHOLD > 0:
         return SPLIT_THRESHOLD
-    return 128 if n_source_rows <= (1 << 20) else 256
+    return 128 if n_source_rows <= (1 << 20) else 1024
 LDS_STAGE_BUDGET = 152 * 1024   # bytes of LDS a staged feature slab may take (n_src * 16 B at the narrowest)
 LDS_STAGE_MIN_DEG = 32          # average row length from which staging x in LDS could pay for itself
 LDS_STAGE_AUTO = False          # measured on MI355X (ddi-shaped, F=512): LDS-staged 0.44 ms vs streaming 0.32 ms --
