@@ -269,6 +269,9 @@ def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
             "algorithmic_bytes": alg, "bytes_model": "compulsory" if cached else "gather",
             "gather_model_bytes": by, "compulsory_bytes": by_min, "effective_GBps": by / t / 1e9,
             "kernel_ms": t * 1e3, "source_MiB": src_mib,
+            "kernel_form": {0: "one wave per row", 16: "one wave per (row, 128-column slab)",
+                            32: "one wave per (row, 256-column slab)"}.get(
+                                getattr(graph, "_agg_tune", {}).get(feat, 0), "?") + " (measured choice, ops._agg_tune)",
             "note": ("source fits the 256 MiB Infinity Cache: cache-bound, frac is compulsory bytes over the HBM "
                      "peak; effective_GBps is the gather-model rate (not a roofline fraction)") if cached else
                     ("source exceeds the 256 MiB Infinity Cache: HBM-bound, gather-model bytes" +
