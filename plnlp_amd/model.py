@@ -243,7 +243,7 @@ class BaseModel(object):
         return (torch.distributed.get_rank(self.process_group),
                 torch.distributed.get_world_size(self.process_group))
 
-    def _embedding_grad_sink(self, x_in):
+    def _embedding_grad_sink(self, x_in, replicated_update=False):
         """Data parallel + SAGE on the raw embedding table: deliver the (large) embedding gradient
         early so its all-reduce overlaps the encoder's weight-gradient GEMMs (ops.GradSink)."""
         from .layer import SAGEConv
@@ -255,7 +255,9 @@ class BaseModel(object):
                 or not isinstance(self.encoder.convs[0], SAGEConv) or self.encoder.convs[0].aggr != "mean"):
             return None
         adam = None
-        if self.process_group is None:
+        if self.process_group is None or replicated_update:
+            # (replicated_update: dp_exchange='scores' -- every rank back-propagates the whole global batch, so every
+            # rank holds the complete gradient and applies the same deterministic update: nothing to reduce either)
             # One process: nothing to reduce over ranks, and the reference clips the encoder and the predictor but
             # NOT the embedding (model.py:163-165) -- Adam is the only consumer of the table's gradient, so the
             # kernel that finishes that gradient may apply the update itself (ops.GradSink.adam, PLNLP_EPI_ADAM)
@@ -401,7 +403,9 @@ class BaseModel(object):
         # consumer of h, that activation's backward rides in the scorer's gather-reduce epilogue
         fuse_gate = n_edges > 0 and fused and self.encoder.num_layers == 1
         kw = {}
-        sink = self._embedding_grad_sink(x_in) if (native and use_sink) else None
+        sink = None
+        if native and use_sink:
+            sink = self._embedding_grad_sink(x_in, replicated_update=(use_sink == "replicated"))
         if sink is not None:
             kw["input_grad_sink"] = sink
         # the batch touches at most n_endpoints nodes: the gradient of h is zero in every other row,
@@ -502,8 +506,8 @@ class BaseModel(object):
         per = (n + world - 1) // world
         lo, hi = min(rank * per, n), min((rank + 1) * per, n)
         local = hi - lo
-        h, gate_scale, channel, fused, batch = self._encode(data, pos_edge, neg_edge.reshape(-1, 2), False,
-                                                             edges_ready)
+        h, gate_scale, channel, fused, batch = self._encode(data, pos_edge, neg_edge.reshape(-1, 2), "replicated",
+                                                             edges_ready, keep_alive=True)
         src, dst, incidence = batch.src, batch.dst, batch.incidence
         # 1. local slice: scores (outside the encoder's graph), loss, d loss / d score
         g_pad = torch.zeros(per * (1 + k), dtype=h.dtype, device=h.device)
@@ -540,7 +544,7 @@ class BaseModel(object):
             out = self._score(h, src, dst)
         out.backward(g_all.reshape(out.shape))
         self._clip_and_step()
-        self._throttle()
+        self._throttle(keep=(batch, pos_edge, neg_edge, weight_margin))
         return loss.detach().reshape(())
 
     def shard_plan(self, pos_edge, neg_edge, num_neg):
@@ -666,7 +670,7 @@ class BaseModel(object):
             with torch.cuda.stream(side):
                 out = (pos_train_edge[perm], neg_train_edge[perm],
                        edge_weight_margin[perm] if edge_weight_margin is not None else None)
-            if not (self._throttled() and mode != "scores"):     # (train_step hands them to the step throttle instead)
+            if not self._throttled():        # (else the step hands them to the step throttle instead)
                 for t in out:
                     if t is not None:
                         t.record_stream(main)
