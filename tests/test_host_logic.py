@@ -262,3 +262,75 @@ def test_driver_graph_prep_matches_oracle_restatement(year, valedges, coalesce):
     np.testing.assert_allclose(split["train"]["weight"].numpy(), ref["train_weight"].numpy(), rtol=2e-6)
     if year > 0:
         np.testing.assert_array_equal(split["train"]["year"].numpy(), ref["train_year"].numpy())
+
+
+def test_hub_chunk_threshold_follows_the_source_size(monkeypatch):
+    """ops.split_threshold: 128-edge chunks while the gathered matrix has up to 2^20 rows (cache-resident graphs),
+    1024 beyond; PLNLP_SPLIT_THRESHOLD (ops.SPLIT_THRESHOLD) pins it"""
+    from plnlp_amd import ops
+    monkeypatch.setattr(ops, "SPLIT_THRESHOLD", 0)
+    assert ops.split_threshold(4267) == 128 and ops.split_threshold(1 << 20) == 128
+    assert ops.split_threshold((1 << 20) + 1) == 1024 and ops.split_threshold(50_000_000) == 1024
+    monkeypatch.setattr(ops, "SPLIT_THRESHOLD", 256)
+    assert ops.split_threshold(100) == 256 and ops.split_threshold(10 ** 8) == 256
+
+
+def test_fused_adam_state_only_for_plain_adam():
+    """optim.fused_adam_state: the state an update applied outside optimizer.step() needs -- created on first use,
+    step reported as the count AFTER the pending update, refused when the group decays weights"""
+    from plnlp_amd.optim import FusedAdam, fused_adam_state
+    p, q = torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(2))
+    opt = FusedAdam([{"params": [p], "lr": 0.02}, {"params": [q], "weight_decay": 0.1}], lr=0.01)
+    st = fused_adam_state(opt, p)
+    assert st["step"] == 1 and st["lr"] == 0.02 and st["betas"] == (0.9, 0.999) and st["exp_avg"].shape == p.shape
+    assert st["exp_avg"] is opt.state[p]["exp_avg"] and opt.state[p]["step"] == 0      # the caller advances it
+    opt.state[p]["step"] = 7
+    assert fused_adam_state(opt, p)["step"] == 8
+    assert fused_adam_state(opt, q) is None
+    assert fused_adam_state(opt, torch.nn.Parameter(torch.zeros(1))) is None           # not one of the optimiser's
+
+
+def test_prepared_edges_must_match_the_step():
+    """BaseModel.prepare_edges / train_step(prepared=): a handle prepared for another batch shape is refused, the
+    right one gives the same loss as building the structures inside the step (CPU, oracle modules injected)"""
+    n, h = 60, 8
+    gen = torch.Generator().manual_seed(3)
+    row, col = torch.randint(0, n, (300,), generator=gen), torch.randint(0, n, (300,), generator=gen)
+
+    class D:
+        pass
+    data = D()
+    data.adj_t = P.Graph.from_coo(row, col, None, n, n)
+
+    def make():
+        torch.manual_seed(5)
+        enc, pred = O.GNNRef("SAGE", h, h, h, 1, 0.0), O.DotPredictorRef()
+        m = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=1.0, gnn_num_layers=1, mlp_num_layers=2,
+                        emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n,
+                        num_node_feats=0, gnn_encoder_name="SAGE", predictor_name="DOT", loss_func="AUC",
+                        optimizer_name="Adam", device="cpu", use_node_feats=False, train_node_emb=True,
+                        modules=(_CsrEncoder(enc), pred, lambda p_, n_, k_, w_: O.LOSSES[O.select_loss("AUC", False)](p_, n_, k_, w_)))
+        m.param_init()
+        return m
+    pos = torch.randint(0, n, (16, 2), generator=gen)
+    neg = torch.randint(0, n, (16, 2, 2), generator=gen)
+    a, b = make(), make()
+    la = a.train_step(data, pos, neg, 2)
+    lb = b.train_step(data, pos, neg, 2, prepared=b.prepare_edges(pos, neg))
+    assert float(la) == float(lb)
+    with pytest.raises(ValueError):
+        b.train_step(data, pos, neg, 2, prepared=b.prepare_edges(pos[:8], neg[:8]))
+
+
+class _CsrEncoder(torch.nn.Module):
+    """oracle encoder behind the (x, adj_t) call BaseModel makes"""
+
+    def __init__(self, ref):
+        super().__init__()
+        self.ref = ref
+
+    def reset_parameters(self):
+        self.ref.reset_parameters()
+
+    def forward(self, x, adj):
+        return self.ref(x, O.CSR(adj.rowptr, adj.col.to(torch.int64), None, adj.n_cols))
