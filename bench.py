@@ -323,7 +323,9 @@ def cpu_baseline(cfg, g, pos, neg, w, steps):
     """the CPU oracle (port of the reference PyG CPU path) on the same workload"""
     import oracle as O
     n, h = g["num_nodes"], cfg["hidden"]
-    torch.set_num_threads(os.cpu_count())
+    from plnlp_amd.utils import host_cpu_budget
+    cores = host_cpu_budget()            # affinity mask capped by the cgroup quota (a 256-core box may grant 16 CPUs)
+    torch.set_num_threads(cores)
     adj = g["adj_t"]
     csr = O.CSR(adj.rowptr.cpu(), adj.col.cpu().to(torch.int64), None if adj.val is None else adj.val.cpu(), n)
     feats = cfg.get("feats", 0)
@@ -342,10 +344,11 @@ def cpu_baseline(cfg, g, pos, neg, w, steps):
         sl = slice((i % 2) * B, (i % 2) * B + B)
         tr.step(pos[sl], neg[sl], cfg["num_neg"], None if w is None else w[sl])
     dt = (time.perf_counter() - t0) / steps
-    return {"value": B * (1 + cfg["num_neg"]) / dt, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": B * (1 + cfg["num_neg"]) / dt, "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": "%d full training steps (B=%d, k=%d) of the CPU oracle on the same synthetic %s-shaped "
-                      "graph, torch %s CPU, %d threads; %.2f s/step" %
-                      (steps, B, cfg["num_neg"], cfg["shape"], torch.__version__, os.cpu_count(), dt)}
+                      "graph, torch %s CPU, %d threads (the host shows %d cores, the container's CPU quota grants %d); "
+                      "%.2f s/step" %
+                      (steps, B, cfg["num_neg"], cfg["shape"], torch.__version__, cores, os.cpu_count(), cores, dt)}
 
 
 def hits_parity(P, device, epochs=12, recipe="collab", with_f64=False, seed=0):
@@ -470,6 +473,8 @@ def main():
     import plnlp_amd as P
     from plnlp_amd import synthetic
     P._lib.load()
+    from plnlp_amd.utils import limit_host_threads
+    limit_host_threads(world)      # stay inside the container's CPU quota (utils.host_cpu_budget)
     if args.workload == "rmat":
         return run_rmat_stress(args, P, world, rank, device, pg)
 

@@ -107,3 +107,34 @@ def evaluate_mrr(evaluator, pos_val_pred, neg_val_pred, pos_test_pred, neg_test_
         out = evaluator.eval({'y_pred_pos': pos, 'y_pred_neg': neg.view(pos.shape[0], -1)})
         scores.append(out['mrr_list'].mean().item())
     return {'MRR': tuple(scores)}
+
+
+def host_cpu_budget() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota.  A container that
+    shows 256 cores behind a 16-CPU quota freezes the whole process for the rest of every 100 ms period once its
+    threads -- OpenMP workers spinning after a parallel region included -- have burnt the quota (measured on the
+    MI355X boxes of this project: 128 torch threads turned a steady 41 ms collab epoch into 45-100 ms)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                            # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:                                                        # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def limit_host_threads(share: int = 1) -> int:
+    """cap torch's intra-op threads at this process's share of host_cpu_budget() (share = ranks on the node);
+    returns the thread count in force.  Called by the drivers (train.py, bench.py), never by the library itself."""
+    import torch
+    t = max(1, min(torch.get_num_threads(), host_cpu_budget() // max(1, share)))
+    torch.set_num_threads(t)
+    return t

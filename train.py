@@ -166,6 +166,8 @@ def main(argv=None):
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     device = torch.device(f'cuda:{args.device}')
     torch.cuda.set_device(device)      # kernels launch on the current device's stream
+    from plnlp_amd.utils import limit_host_threads
+    limit_host_threads(int(os.environ.get('WORLD_SIZE', '1')))      # stay inside the container's CPU quota
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         torch.distributed.init_process_group('nccl', device_id=device)
         group = torch.distributed.group.WORLD
