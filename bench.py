@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the >>256 MiB HBM roofline measurement")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=6,
+                    help="timed steps of the CPU oracle (collab: ~1.8 s each on 16 CPUs -> ~13 s with the warm-up step)")
     ap.add_argument("--no-parity", action="store_true", help="skip the Hits@50 GPU-vs-oracle training parity run")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the DP path on 1 GPU)")
