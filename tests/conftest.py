@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle (and torch's CPU ops in general) must stay inside the container's CPU quota: with one thread
+    # per visible core the GPU boxes (256 cores shown, 16 granted) freeze the process for most of every 100 ms
+    from plnlp_amd.utils import limit_host_threads
+    limit_host_threads()
 
 
 def pytest_collection_modifyitems(config, items):
