@@ -1675,7 +1675,7 @@ class StepThrottle:
         self.depth, self.events = depth, collections.deque()
 
     def tick(self, keep=None) -> None:
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(blocking=True)      # the waiting host thread sleeps instead of spinning (CPU quota, §4)
         ev.record()
         self.events.append((ev, keep))
         if len(self.events) > self.depth:
