@@ -66,57 +66,117 @@ def parse():
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher check without GPUs: the ranks rendezvous over gloo, do one all-reduce and rank 0 "
                          "prints a JSON line (no kernels run; not a measurement)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--batch-mult", type=int, default=1,
                     help="multiply the per-GPU batch (debug: the per-rank cost of an N-rank 'scores' job is about the "
                          "1-GPU step at N times the batch; invalidates the number)")
     return ap.parse_args()
 
 
-def launch_ranks(n_ranks):
+def launch_ranks(n_ranks, deadline_s=None):
     """`python bench.py --gpus N` outside a launcher: start N rank processes of this same script (one
     per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line, return the worst exit code.  Runs before
     anything touches the GPU in this process, and starts CHILDREN -- a process that has initialised the
-    GPU must never exec another program on this pool."""
+    GPU must never exec another program on this pool.
+    The children are POLLED: the first one that exits non-zero (import error, out of memory, a kernel
+    fault) takes its siblings down with it -- they would otherwise sit in the rendezvous or in a collective
+    until the 10-minute RCCL timeout -- and an overall deadline bounds the whole job.  Every rank's stderr
+    is kept in its own file (gpurun_out/ranks/ when that directory can be made, else a temp dir) and the
+    failing rank's tail is relayed."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    procs = []
+    deadline_s = float(os.environ.get("PLNLP_BENCH_DEADLINE_S", "1500")) if deadline_s is None else deadline_s
+    log_dir = os.path.join(ROOT, "gpurun_out", "ranks")
+    try:
+        os.makedirs(log_dir, exist_ok=True)
+    except OSError:
+        log_dir = tempfile.mkdtemp(prefix="plnlp_ranks_")
+    procs, logs = [], []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        err = open(os.path.join(log_dir, "rank%d.stderr" % r), "w")
+        out = open(os.path.join(log_dir, "rank%d.stdout" % r), "w")
+        logs.append((out, err))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, abs(p.wait()))
+                                      stdout=out, stderr=err))
+    t0 = time.time()
+    rc, failed = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed, rc = bad[0], abs(codes[bad[0]]) or 1
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > deadline_s:
+            failed, rc = -1, 124
+            break
+        time.sleep(0.2)
+    if failed is not None:                      # end exactly the children started here (terminate, then kill)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.time()
+        while any(p.poll() is None for p in procs) and time.time() - t1 < 10:
+            time.sleep(0.1)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    for out, err in logs:
+        out.close()
+        err.close()
+
+    def tail(path, n=30):
+        try:
+            return "".join(open(path).readlines()[-n:])
+        except OSError:
+            return ""
+    if failed is not None:
+        which = "deadline of %.0f s exceeded" % deadline_s if failed < 0 else "rank %d exited with code %d" % (failed, rc)
+        print("bench.py --gpus %d: %s; the other ranks were stopped.  Logs: %s" % (n_ranks, which, log_dir), file=sys.stderr)
+        for r in range(n_ranks):
+            if failed < 0 or r == failed:
+                print("---- rank %d stderr (tail) ----\n%s" % (r, tail(os.path.join(log_dir, "rank%d.stderr" % r))),
+                      file=sys.stderr)
+        return rc
     line = None
-    for ln in (out or "").splitlines():
+    for ln in open(os.path.join(log_dir, "rank0.stdout")).read().splitlines():
         if ln.startswith("{") and ln.rstrip().endswith("}"):
             line = ln
         else:
             print(ln, file=sys.stderr)
+    sys.stderr.write(tail(os.path.join(log_dir, "rank0.stderr"), 15))
     if line is not None:
         print(line, flush=True)
-    return rc if line is not None or rc else 1
+    return 0 if line is not None else 1
 
 
-def dry_run_cpu(world, rank):
-    """the launcher path without GPUs (gloo): proves that N ranks start, meet and reduce"""
+def dry_run_cpu(world, rank, fail_rank=-1):
+    """the launcher path without GPUs (gloo): proves that N ranks start, meet and pass the start-up collective
+    self-test the real run performs (plnlp_amd.shard.collective_self_test).  fail_rank: that rank exits with an
+    error before the rendezvous (launcher test: the siblings must be stopped, not left waiting)."""
+    if rank == fail_rank:
+        sys.exit("dry run: rank %d fails on purpose" % rank)
+    from plnlp_amd import shard
     torch.distributed.init_process_group("gloo")
-    t = torch.tensor([float(rank + 1)])
-    torch.distributed.all_reduce(t)
-    ok = float(t.item()) == world * (world + 1) / 2
-    torch.distributed.barrier()
+    passed = shard.collective_self_test(torch.distributed.group.WORLD, torch.device("cpu"))
     ranks = torch.distributed.get_world_size()
+    print("rank %d: collective self-test ok: %s" % (rank, ", ".join(sorted(passed))), file=sys.stderr, flush=True)
     torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps({"dry_run": True, "backend": "gloo", "rccl_ranks": ranks, "n_gpus": world,
-                          "all_reduce_ok": ok, "note": "launcher check only; no kernel ran, not a measurement"}),
+                          "all_reduce_ok": True, "collective_self_test": sorted(passed),
+                          "note": "launcher check only; no kernel ran, not a measurement"}),
               flush=True)
-    return 0 if ok else 1
+    return 0
 
 
 def run_rmat_stress(args, P, world, rank, device, pg):
@@ -459,7 +519,7 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     if args.dry_run_cpu:
-        sys.exit(dry_run_cpu(world, rank))
+        sys.exit(dry_run_cpu(world, rank, args.dry_run_fail_rank))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None

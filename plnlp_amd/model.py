@@ -266,11 +266,13 @@ class BaseModel(object):
             adam = fused_adam_state(self.optimizer, self.emb.weight)
             if adam is None:
                 return None
+        if adam is not None:
+            # the fused update consumes the gradient in the kernel that finishes it: no [N, F] gradient buffer is
+            # allocated unless the backward takes a path without the fused update (GradSink.buffer is lazy)
+            self._adam_sink = GradSink(None, None, adam=adam, like=self.emb.weight)
+            return self._adam_sink
         if getattr(self, "_emb_grad_buf", None) is None:
             self._emb_grad_buf = torch.empty_like(self.emb.weight)
-        if adam is not None:
-            self._adam_sink = GradSink(self._emb_grad_buf, None, adam=adam)
-            return self._adam_sink
         self.emb.weight.grad = self._emb_grad_buf
 
         def start_reduce():
@@ -354,6 +356,27 @@ class BaseModel(object):
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
         return bool(torch.equal(lo, hi))
+
+    def _tune_graph(self, graph):
+        """once per (static) graph object: let the ranks of this model's group agree on the form of the
+        aggregation kernel at the widths this encoder aggregates (ops.tune_aggregation -- rank 0's measurement
+        is broadcast).  Every training-step entry point calls this first, i.e. at a point all ranks of the group
+        pass together; the aggregation op itself never communicates.  One process: the op measures lazily."""
+        if self.process_group is None or not isinstance(self.encoder, BaseGNN) or graph.device.type != "cuda":
+            return
+        seen = getattr(self, "_tuned_graphs", None)
+        if seen is None:
+            seen = self._tuned_graphs = {}
+        if seen.get(id(graph)) is graph:
+            return
+        feats = set()
+        for conv in self.encoder.convs:
+            if isinstance(conv, SAGEConv):
+                feats.add(conv.in_channels)
+            elif isinstance(conv, GCNConv):
+                feats.add(conv.out_channels)
+        ops.tune_aggregation(graph, feats, group=self.process_group)
+        seen[id(graph)] = graph
 
     def _edge_flags(self, n_edges: int, on_gpu: bool, rows_only: bool):
         """what the scorer's fusions allow for a batch of n_edges scored edges -- a function of the model and the
@@ -450,6 +473,7 @@ class BaseModel(object):
         edges_ready=True: the edge tensors are not the output of work still pending on the current
         stream (views of resident tensors, or produced on the side stream) -- their pre-processing
         may then overlap the previous step (ops.EdgeBatch)."""
+        self._tune_graph(data.adj_t)
         self.optimizer.zero_grad(set_to_none=True)
         local = pos_edge.size(0)
         h, gate_scale, channel, fused, batch = self._encode(data, pos_edge, neg_edge.reshape(-1, 2), True,
@@ -501,6 +525,7 @@ class BaseModel(object):
         one-process step on the global batch (the loss is a sum over pairs) and is the same
         bits on every rank.  Returns the detached loss of the local slice."""
         rank, world = self._world()
+        self._tune_graph(data.adj_t)
         self.optimizer.zero_grad(set_to_none=True)
         n, k = pos_edge.size(0), num_neg
         per = (n + world - 1) // world
@@ -571,6 +596,7 @@ class BaseModel(object):
         from . import shard
         sc = self._shard
         rank, world = sc.rank, sc.world
+        self._tune_graph(self._adj_block(data))
         self.optimizer.zero_grad(set_to_none=True)
         n, k = pos_edge.size(0), num_neg
         per = (n + world - 1) // world

@@ -99,14 +99,78 @@ AGG_AUTOTUNE = {"enabled": os.environ.get("PLNLP_AGG_AUTOTUNE", "1") != "0", "mi
                 "candidates": (0, L.AGG_SLABS_128, L.AGG_SLABS_256)}
 
 
+def _multi_rank() -> bool:
+    d = torch.distributed
+    return d.is_available() and d.is_initialized() and d.get_world_size() > 1
+
+
+def _time_agg_forms(graph, x, out, reduce, use_values, src_scale, epilogue) -> int:
+    """three timed launches per candidate form on this rank; a slab form must win clearly (3 %)"""
+    best, best_t = 0, None
+    for cand in AGG_AUTOTUNE["candidates"]:
+        times = []
+        for it in range(3):
+            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_ev.record()
+            csr_aggregate(graph, x, reduce, use_values, src_scale=src_scale, out=out, epilogue=epilogue, tune=cand)
+            e_ev.record()
+            e_ev.synchronize()
+            times.append(s_ev.elapsed_time(e_ev))
+        t = min(times[1:])
+        if best_t is None or t < 0.97 * best_t:
+            best, best_t = cand, t
+    return best
+
+
+def tune_aggregation(graph, feats, group=None, time_fn=None) -> dict:
+    """Decide -- by measurement -- which form of the aggregation kernel runs on the STATIC `graph` at each
+    feature width in `feats`, and remember it on the graph object (shared with its transposed views).
+
+    This is the ONLY place where ranks agree on a form: every rank of `group` must call it (a trainer does,
+    from BaseModel._tune_graph, at a point all its ranks pass together); rank 0's measurement is broadcast
+    so that replicated ranks run identical kernels (the forms differ in summation order, and replicas stay
+    bit-identical only on the same form).  group=None: this process decides alone, no collective.
+    The aggregation op itself never communicates (csr_aggregate -> _agg_tune).
+    time_fn(graph, feat) -> form: injectable measurement (CPU tests of the agreement logic)."""
+    picked = {}
+    if not AGG_AUTOTUNE["enabled"]:
+        return picked
+    for feat in sorted(set(int(f) for f in feats)):
+        if feat < AGG_AUTOTUNE["min_feat"] or feat % 4 != 0 or feat > 1024:
+            continue
+        cache = graph._agg_tune
+        best = cache.get(feat)
+        if best is None:
+            if time_fn is not None:
+                best = int(time_fn(graph, feat))
+            else:
+                x = torch.empty(graph.n_cols, feat, dtype=torch.float32, device=graph.device).normal_()
+                out = torch.empty(graph.n_rows, feat, dtype=torch.float32, device=graph.device)
+                best = _time_agg_forms(graph, x, out, "mean" if graph.val is None else "sum", graph.val is not None,
+                                       None, None)
+                del x, out
+        if group is not None and torch.distributed.get_world_size(group) > 1:
+            dev = graph.device if graph.device.type == "cuda" else torch.device("cpu")
+            pick = torch.tensor([best], dtype=torch.int64, device=dev)
+            torch.distributed.broadcast(pick, torch.distributed.get_global_rank(group, 0), group=group)
+            best = int(pick.item())
+        cache[feat] = best
+        picked[feat] = cache[feat]
+    return picked
+
+
 def _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, feat, row_index=None) -> int:
     """which form of the aggregation kernel to run on a STATIC graph at this feature width: one wave per
     row, or one per (row, 128- / 256-column slab).  Which one wins depends on whether the source matrix
     is cache-resident and on the degree skew (measured on MI355X, uniform 2.9 M-node graph, F = 512:
     0.72 -> 0.79 of the HBM peak with 128-column slabs; R-MAT and the cache-resident collab graph lose
-    10-25 % with them), so it is MEASURED once per (graph, width, form) -- three timed launches on the
-    first eligible call -- and remembered on the graph object.  Per-batch structures (incidence lists)
-    and calls whose epilogue accumulates into `out` are never used for timing."""
+    10-25 % with them), so it is MEASURED once per (graph, width, form) and remembered on the graph
+    object.  NO collective happens here: in a multi-rank job the choice is made by tune_aggregation()
+    (called by the trainer on all ranks of its group); an untuned graph then runs the default form --
+    a rank that aggregates on its own (a control model, a roofline measurement on rank 0) can never
+    leave its peers waiting in a broadcast.  In a single process the first plain call measures.
+    Per-batch structures (incidence lists) and calls whose epilogue accumulates into `out` are never
+    used for timing."""
     if (not AGG_AUTOTUNE["enabled"] or not isinstance(graph, Graph) or feat < AGG_AUTOTUNE["min_feat"]
             or not _vector_path(x, out, feat)):
         return 0
@@ -119,27 +183,10 @@ def _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, f
         return cache[key]
     if flags & (L.EPI_ACCUM | L.EPI_ADDEND | L.EPI_GATE | L.EPI_ADAM) or src_map is not None or row_index is not None:
         return 0                      # not a call to time on; an earlier or later plain call decides
-    best, best_t = 0, None
-    for cand in AGG_AUTOTUNE["candidates"]:
-        times = []
-        for it in range(3):
-            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s_ev.record()
-            csr_aggregate(graph, x, reduce, use_values, src_scale=src_scale, out=out, epilogue=epilogue, tune=cand)
-            e_ev.record()
-            e_ev.synchronize()
-            times.append(s_ev.elapsed_time(e_ev))
-        t = min(times[1:])
-        if best_t is None or t < 0.97 * best_t:         # a slab form must win clearly
-            best, best_t = cand, t
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        # replicated data-parallel ranks must run the SAME form (their replicas agree bit for bit only
-        # then): rank 0's measurement decides
-        pick = torch.tensor([best], dtype=torch.int64, device=x.device)
-        torch.distributed.broadcast(pick, 0)
-        best = int(pick.item())
-    cache[key] = best
-    return best
+    if _multi_rank():
+        return 0                      # the ranks agree in tune_aggregation(), never inside the op
+    cache[key] = _time_agg_forms(graph, x, out, reduce, use_values, src_scale, epilogue)
+    return cache[key]
 
 
 def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
@@ -959,14 +1006,22 @@ class GradSink:
     `param.grad`), calls `on_ready()` -- the caller starts the asynchronous all-reduce there --
     and only then queues its weight-gradient GEMMs, which run while the reduction is in flight."""
 
-    def __init__(self, buffer: torch.Tensor, on_ready=None, adam=None):
-        self.buffer, self.on_ready = buffer, on_ready
+    def __init__(self, buffer: Optional[torch.Tensor], on_ready=None, adam=None, like: Optional[torch.Tensor] = None):
+        """buffer=None with like=<the parameter>: the buffer is allocated on first use (a backward that applies
+        the fused update never touches it)"""
+        self._buffer, self._like, self.on_ready = buffer, like, on_ready
         # adam = dict(param, exp_avg, exp_avg_sq, step, lr, betas, eps): the input IS a parameter that is neither
         # clipped nor reduced over ranks -- the backward may then apply its Adam step in the epilogue of the kernel
         # that finishes the gradient (PLNLP_EPI_ADAM) instead of writing the gradient out; it sets
         # `adam_applied` when it did (else the gradient is in `buffer` as usual)
         self.adam, self.adam_applied = adam, False
         self.joined = None        # event after which the update is complete, when it was queued on another stream
+
+    @property
+    def buffer(self) -> torch.Tensor:
+        if self._buffer is None:
+            self._buffer = torch.empty_like(self._like)
+        return self._buffer
 
 
 class AggregateFn(torch.autograd.Function):

@@ -297,3 +297,48 @@ def allreduce_sum(tensors: List[torch.Tensor], group) -> None:
     works = [dist.all_reduce(t, group=group, async_op=True) for t in tensors]
     for w in works:
         w.wait()
+
+
+def collective_self_test(group, device) -> dict:
+    """Every collective the data-parallel forms use (all-reduce, broadcast, all-gather, reduce-scatter, uneven
+    all-to-all), once, on a tiny tensor with a known answer -- run at start-up, BEFORE the first training step,
+    so that a broken fabric / environment (HSA_ENABLE_IPC_MODE_LEGACY, a missing peer) shows up as a named
+    failure on every rank instead of as a hang inside step 1.  Returns {collective: True}; raises RuntimeError
+    naming the first collective whose result is wrong.  Cheap (six tiny collectives)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    f = torch.float32
+    done = {}
+
+    def check(name, ok):
+        if not bool(ok):
+            raise RuntimeError(f"collective self-test: {name} returned a wrong result on rank {rank} of {world}")
+        done[name] = True
+
+    t = torch.full((4,), float(rank + 1), dtype=f, device=device)
+    dist.all_reduce(t, group=group)
+    check("all_reduce_sum", torch.all(t == world * (world + 1) / 2))
+    t = torch.full((4,), float(rank + 1), dtype=f, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    check("all_reduce_max", torch.all(t == world))
+    t = torch.full((3,), 7.0 if rank == 0 else -1.0, dtype=f, device=device)
+    dist.broadcast(t, dist.get_global_rank(group, 0), group=group)
+    check("broadcast", torch.all(t == 7.0))
+    mine = torch.full((2, 3), float(rank), dtype=f, device=device)
+    full = torch.empty(2 * world, 3, dtype=f, device=device)
+    dist.all_gather_into_tensor(full, mine, group=group)
+    want = torch.arange(world, dtype=f, device=device).repeat_interleave(2).unsqueeze(1).expand(-1, 3)
+    check("all_gather_into_tensor", torch.equal(full, want))
+    part = torch.arange(world, dtype=f, device=device).repeat_interleave(2).unsqueeze(1).expand(-1, 3).contiguous() + rank
+    out = torch.empty(2, 3, dtype=f, device=device)
+    dist.reduce_scatter_tensor(out, part, group=group)
+    check("reduce_scatter_tensor", torch.all(out == world * rank + world * (world - 1) / 2))
+    # uneven all-to-all: rank r sends (q + 1) rows holding r * 100 + q to every rank q
+    send = torch.cat([torch.full((q + 1, 2), float(rank * 100 + q), dtype=f, device=device) for q in range(world)])
+    recv = torch.empty(world * (rank + 1), 2, dtype=f, device=device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[rank + 1] * world,
+                           input_split_sizes=[q + 1 for q in range(world)], group=group)
+    want = torch.cat([torch.full((rank + 1, 2), float(q * 100 + rank), dtype=f, device=device) for q in range(world)])
+    check("all_to_all_single_uneven", torch.equal(recv, want))
+    dist.barrier(group=group)
+    done["barrier"] = True
+    return done

@@ -24,6 +24,27 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["rccl_ranks"] == 2 and out["n_gpus"] == 2 and out["all_reduce_ok"] and out["dry_run"]
+    # the start-up self-test ran every collective the data-parallel forms use
+    assert {"all_reduce_sum", "broadcast", "all_gather_into_tensor", "reduce_scatter_tensor",
+            "all_to_all_single_uneven", "barrier"} <= set(out["collective_self_test"])
+
+
+def test_a_failing_rank_stops_its_siblings():
+    """rank 1 dies before the rendezvous: the launcher must notice, end rank 0 (which would otherwise wait in the
+    rendezvous for minutes) and return the failure -- quickly, with rank 1's message relayed"""
+    import time
+    t0 = time.time()
+    r = _run({}, ["--gpus", "2", "--dry-run-cpu", "--dry-run-fail-rank", "1"])
+    assert r.returncode != 0
+    assert time.time() - t0 < 120
+    assert "rank 1" in r.stderr and "fails on purpose" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_launcher_deadline():
+    """an overall deadline bounds the job: a rank that never finishes is stopped"""
+    r = _run({"PLNLP_BENCH_DEADLINE_S": "0.0"}, ["--gpus", "2", "--dry-run-cpu"])
+    assert r.returncode == 124 and "deadline" in r.stderr
 
 
 def test_bench_under_an_external_launcher_does_not_respawn():

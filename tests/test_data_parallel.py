@@ -129,3 +129,47 @@ def test_uneven_last_batch_and_empty_slice(exchange):
     for rank, losses, flat in res:
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-9)
     np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+def _tuner_rank(rank, world, port, out_q):
+    """the aggregation autotuner under a process group: the op never communicates; the ranks agree only in
+    ops.tune_aggregation (a rank-0-only aggregation used to broadcast into its idle peers)"""
+    import plnlp_amd as P
+    from plnlp_amd import ops
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    adj, _, _ = _problem()
+    g = P.Graph(adj.rowptr.clone(), adj.col.to(torch.int32), None, adj.n_rows, adj.n_cols)
+    x = torch.zeros(g.n_cols, 256)
+    out = torch.zeros(g.n_rows, 256)
+    alone = None
+    if rank == 1:
+        # ONE rank consults the tuner from inside the op while its peer does something else: it must return the
+        # default form at once, without a collective and without remembering it
+        alone = ops._agg_tune(g, x, out, "mean", False, None, None, None, 256)
+        assert alone == 0 and 256 not in g._agg_tune
+    # all ranks, explicitly: every rank "measures" a different winner, rank 0's is adopted everywhere
+    picked = ops.tune_aggregation(g, [256, 64, 512], group=dist.group.WORLD,
+                                  time_fn=lambda graph, feat: (16 if feat == 256 else 32) if rank == 0 else 0)
+    after = ops._agg_tune(g, x, out, "mean", False, None, None, None, 256)
+    # the transposed views share the choice (the backward passes cannot be timed themselves)
+    shared = g.t()._agg_tune is g._agg_tune
+    out_q.put((rank, alone, picked, after, shared))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_aggregation_tuner_never_communicates_inside_the_op():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tuner_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, alone, picked, after, shared in res:
+        assert picked == {256: 16, 512: 32}, (rank, picked)       # width 64 is below the tuned range
+        assert after == 16 and shared
+    assert res[1][1] == 0

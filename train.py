@@ -178,10 +178,28 @@ def main(argv=None):
         P.manual_seed(args.seed)
     data, split_edge, num_nodes = load_dataset(args, device)
     num_node_feats = getattr(data, 'num_features', 0) if data.x is not None else 0
-    print(args)
-    os.makedirs(args.res_dir or '.', exist_ok=True)
+    # under torch.distributed.run every rank runs this script: rank 0 alone prints and owns the log file (the
+    # others would interleave duplicates, or split across files whose names differ by a second).  Evaluation still
+    # runs on every rank -- test() draws from the CPU generator like the reference's loaders do, and the ranks'
+    # streams must stay in step for the next epoch's negatives and permutations.
+    is_main = int(os.environ.get('RANK', '0')) == 0
+    _print = print if is_main else (lambda *a, **k: None)
+
+    class _Log:
+        """`with open(log_file, 'a') as f` on rank 0, a sink elsewhere"""
+        def __enter__(self):
+            self.f = open(log_file, 'a') if is_main else open(os.devnull, 'w')
+            return self.f
+
+        def __exit__(self, *exc):
+            self.f.close()
+            return False
+
+    _print(args)
+    if is_main:
+        os.makedirs(args.res_dir or '.', exist_ok=True)
     log_file = os.path.join(args.res_dir, 'log_' + args.data_name + '_' + str(int(time.time())) + '.txt')
-    with open(log_file, 'a') as f:
+    with _Log() as f:
         f.write(str(args) + '\n')
 
     prepare_graph(args, data, split_edge, num_nodes)
@@ -204,8 +222,8 @@ def main(argv=None):
         process_group=group, dp_scaling='strong', dp_exchange=args.dp_exchange)
     total_params = sum(p.numel() for p in model.para_list)
     msg = f'Total number of model parameters is {total_params}'
-    print(msg)
-    with open(log_file, 'a') as f:
+    _print(msg)
+    with _Log() as f:
         f.write(msg + '\n')
 
     evaluator = Evaluator(name=args.data_name)
@@ -243,27 +261,29 @@ def main(argv=None):
                         line = (f'Run: {run + 1:02d}, Epoch: {epoch:02d}, Loss: {loss:.4f}, '
                                 f'Learning Rate: {cur_lr:.4f}, Valid: {100 * valid_res:.2f}%, '
                                 f'Test: {100 * test_res:.2f}%')
-                        print(key)
-                        print(line)
-                        with open(log_file, 'a') as f:
+                        _print(key)
+                        _print(line)
+                        with _Log() as f:
                             print(key, file=f)
                             print(line, file=f)
-                    print('---')
-                    print(f'Training Time Per Epoch: {spent_time / args.eval_steps: .4f} s')
-                    print('---')
+                    _print('---')
+                    _print(f'Training Time Per Epoch: {spent_time / args.eval_steps: .4f} s')
+                    _print('---')
                     start_time = time.time()
             if args.use_lr_decay:
                 cur_lr = P.adjust_lr(model.optimizer, epoch / args.epochs, args.lr)
         for key in loggers:
-            print(key)
-            loggers[key].print_statistics(run, last_best=args.eval_last_best)
-            with open(log_file, 'a') as f:
+            _print(key)
+            if is_main:
+                loggers[key].print_statistics(run, last_best=args.eval_last_best)
+            with _Log() as f:
                 print(key, file=f)
                 loggers[key].print_statistics(run, f=f, last_best=args.eval_last_best)
     for key in loggers:
-        print(key)
-        loggers[key].print_statistics(last_best=args.eval_last_best)
-        with open(log_file, 'a') as f:
+        _print(key)
+        if is_main:
+            loggers[key].print_statistics(last_best=args.eval_last_best)
+        with _Log() as f:
             print(key, file=f)
             loggers[key].print_statistics(f=f, last_best=args.eval_last_best)
     return loggers
