@@ -203,22 +203,15 @@ def run_rmat_stress(args, P, world, rank, device, pg):
         x[lo:lo + step_rows].normal_(generator=gen)
     ws = [torch.randn(F, F, device=device, generator=gen) * 0.03 for _ in range(4)]
     bs = [torch.zeros(F, device=device) for _ in range(2)]
-    agg = torch.empty(S, F, device=device)
-    y = torch.empty(S, F, device=device)
-    y2 = torch.empty(S, F, device=device)
-
-    def layer(src, out, wl, wr, b, relu):
-        P.ops.csr_aggregate(blk, src, "mean", False, out=agg)
-        P.ops.gemm([(agg, wl), (src[part.lo:part.lo + S], wr)], False, True, out=out,
-                   epilogue=_lib.make_epilogue(bias=b, relu=relu))
+    enc = shard.RowShardedSAGEForward(blk, part, [(ws[0], bs[0], ws[1]), (ws[2], bs[1], ws[3])], group=pg)
+    agg = enc.agg
+    if pg is not None:          # the ranks agree on the kernel form once, collectively (never inside the op)
+        P.ops.tune_aggregation(blk, [F], group=pg)
+    y2 = None
 
     def forward():
-        layer(x, y, ws[0], ws[1], bs[0], True)
-        if pg is not None:
-            torch.distributed.all_gather_into_tensor(x, y, group=pg)       # the layer's output replaces its input
-        else:
-            x[:S].copy_(y)
-        layer(x, y2, ws[2], ws[3], bs[1], False)
+        nonlocal y2
+        y2 = enc.forward(x)
 
     def sync():
         if pg is not None:
@@ -252,12 +245,15 @@ def run_rmat_stress(args, P, world, rank, device, pg):
                                "destination rows sharded over %d rank(s)" % (n, int(total_nnz.item()), world),
                    "scale": args.scale, "rows_per_rank": S, "parallelism": "row-sharded x%d, one all-gather between layers" % world},
         "roofline": {"bound": "hbm", "kernel": "csr_agg_vec_kernel (mean, F=512) on this rank's row block",
-                     "achieved": by / t_agg / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by / t_agg / 8.0e12,
+                     "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
+                     "effective_GBps": by / t_agg / 1e9,
                      "traffic": None, "algorithmic_bytes": by, "kernel_ms": t_agg * 1e3,
                      "source_MiB": npad * F * 4 / 2 ** 20,
-                     "note": "gather-model bytes on a SKEWED graph: the hub rows of R-MAT are re-read from the caches, "
-                             "so this is an effective rate, not a no-reuse HBM fraction (that one: the uniform graph "
-                             "of the default workload's `roofline`)"},
+                     "note": "SKEWED graph: the hub rows of R-MAT are re-read from the caches, so the gather-model byte "
+                             "count overstates what crosses the HBM pins and no roofline fraction is claimed from it "
+                             "(frac = null); effective_GBps = gather-model bytes / time.  The no-reuse HBM fraction of "
+                             "this kernel is the uniform graph of the default workload's `roofline`; measured HBM bytes "
+                             "of this launch: scripts/pmc_agg.sh -> profiles/"},
         "graph_build_s": t_graph, "output_checksum": checksum,
         "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 1,
     }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PLNLP_ABI_VERSION 6
+#define PLNLP_ABI_VERSION 7
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -317,6 +317,18 @@ int plnlp_compact_rows(const int64_t* rowptr, int64_t n_rows, int32_t* rows, int
 int plnlp_random_walk(const int64_t* rowptr, const int32_t* col, const int64_t* start,
                       int64_t n_walkers, int walk_length, uint64_t seed,
                       int64_t* walks /* [n_walkers, walk_length + 1] */, void* stream);
+
+/* R-MAT (a, b, c, d) edge stream -- the synthetic graph of BASELINE.json config 5 ("scale-26 R-MAT
+ * .57/.19/.19/.05, ids mod N, generated on-GPU in chunks"; the reference itself has no generator: it loads OGB
+ * files, main.py:74-95).  Edges [edge_lo, edge_lo + n_edges) of the stream defined by (scale, seed, thresholds):
+ * bit l of an edge's raw row / column id comes from the counter hash of (seed, edge * 64 + l) compared with the
+ * integer thresholds t_a = a * 2^32, t_ab = (a + b) * 2^32, t_abc = (a + b + c) * 2^32; relabel != 0 sends the raw
+ * ids through a seeded bijection of [0, 2^scale) first; ids are folded mod n_nodes.  Pure integer arithmetic: any
+ * rank replays any part of the stream bit-exactly (a row-sharded run keeps only the edges of its own rows), and
+ * oracle/reference_path.py::rmat_edges_ref restates it in numpy. */
+int plnlp_rmat_edges(int scale, int64_t n_nodes, int64_t edge_lo, int64_t n_edges, uint64_t seed,
+                     uint32_t t_a, uint32_t t_ab, uint32_t t_abc, int relabel,
+                     int32_t* rows /* [n_edges] */, int32_t* cols /* [n_edges] */, void* stream);
 
 /* deterministic variant over a node-sorted incidence list built once per batch:
  * for node slot s (seg_node[s] = node id, or s itself when seg_node is NULL), items

@@ -19,7 +19,7 @@ __all__ = [
     "CSR", "spmm", "spmm_max", "spmm_dense_check", "gcn_norm_csr",
     "SAGEConvRef", "GCNConvRef", "GNNRef", "MLPPredictorRef", "DotPredictorRef",
     "LOSSES", "pairwise_loss", "select_loss",
-    "dropout_keep_mask", "counter_dropout", "random_walk_ref",
+    "dropout_keep_mask", "counter_dropout", "random_walk_ref", "rmat_edges_ref", "rmat_thresholds",
     "batch_permutation", "local_neg_sample_ref", "pad_negatives_ref",
     "perm_copy_ref", "structured_negative_sampling_ref", "global_neg_sample_ref",
     "pos_neg_edges_ref", "hits_at_k", "mrr_list", "evaluate_hits_ref",
@@ -271,6 +271,55 @@ def random_walk_ref(adj: "CSR", start: torch.Tensor, walk_length: int, seed: int
         cur = np.where(deg > 0, nxt, cur)
         out[:, l + 1] = cur
     return torch.from_numpy(out)
+
+
+def rmat_thresholds(probs=(0.57, 0.19, 0.19, 0.05)):
+    """32-bit integer thresholds of the R-MAT quadrant draw: a, a + b, a + b + c as fractions of 2^32"""
+    a, b, c, _ = probs
+    return tuple(min(int(round(v * 4294967296.0)), 0xFFFFFFFF) for v in (a, a + b, a + b + c))
+
+
+def _rmat_relabel(x: np.ndarray, scale: int, seed: int) -> np.ndarray:
+    """the seeded bijection of [0, 2^scale) of plnlp_amd/csrc/incidence.hip::rmat_relabel"""
+    m64 = (1 << 64) - 1
+    M = np.uint64((1 << scale) - 1)
+    sh = np.uint64((scale + 1) // 2)
+    c1 = np.uint64(((seed * 0x9E3779B97F4A7C15) & m64) >> 7)
+    c2 = np.uint64(((seed ^ 0xD6E8FEB86659FD93) * 0xBF58476D1CE4E5B9) & m64)
+    with np.errstate(over="ignore"):
+        x = (x * np.uint64(0x9E3779B97F4A7C15) + c1) & M
+        x ^= x >> sh
+        x = (x * np.uint64(0xBF58476D1CE4E5B9)) & M
+        x ^= x >> sh
+        x = (x * np.uint64(0x94D049BB133111EB) + c2) & M
+        x ^= x >> sh
+    return x
+
+
+def rmat_edges_ref(scale: int, n_nodes: int, edge_lo: int, n_edges: int, seed: int,
+                   probs=(0.57, 0.19, 0.19, 0.05), relabel: bool = True):
+    """(rows, cols) int64 numpy arrays: edges [edge_lo, edge_lo + n_edges) of the R-MAT stream of BASELINE.json
+    config 5 (the reference has no generator of its own -- it loads OGB files, main.py:74-95).
+    Restates plnlp_amd/csrc/incidence.hip::rmat_edges_kernel bit for bit: `scale` quadrant draws per edge from
+    the counter hash of (seed, edge * 64 + level) against integer thresholds, a seeded relabelling bijection,
+    ids folded mod n_nodes."""
+    t_a, t_ab, t_abc = (np.uint64(v) for v in rmat_thresholds(probs))
+    s_lo, s_hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    e = np.arange(edge_lo, edge_lo + n_edges, dtype=np.uint64)
+    r = np.zeros(n_edges, dtype=np.uint64)
+    c = np.zeros(n_edges, dtype=np.uint64)
+    for l in range(scale):
+        idx = e * np.uint64(64) + np.uint64(l)
+        h = _lowbias32((idx & _M32) ^ s_lo)
+        h = _lowbias32((h + (((idx >> np.uint64(32)) * np.uint64(0x9E3779B9)) & _M32) + s_hi) & _M32)
+        right = ((h >= t_a) & (h < t_ab)) | (h >= t_abc)
+        down = h >= t_ab
+        r = (r << np.uint64(1)) | down.astype(np.uint64)
+        c = (c << np.uint64(1)) | right.astype(np.uint64)
+    if relabel:
+        r, c = _rmat_relabel(r, scale, seed), _rmat_relabel(c, scale, seed)
+    n = np.uint64(n_nodes)
+    return (r % n).astype(np.int64), (c % n).astype(np.int64)
 
 
 def counter_dropout(x: torch.Tensor, p: float, seed: int, training: bool = True) -> torch.Tensor:

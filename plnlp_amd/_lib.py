@@ -71,6 +71,8 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plnlp_random_walk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_uint64, C.c_void_p,
                                     C.c_void_p]),
+    "plnlp_rmat_edges": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "plnlp_incidence_temp_bytes": (c_i64, [c_i64]),
     "plnlp_incidence_build": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -153,7 +155,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.plnlp_abi_version() != 6:
+    if lib.plnlp_abi_version() != 7:
         raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -108,6 +108,50 @@ __global__ __launch_bounds__(256) void random_walk_kernel(const int64_t* __restr
     }
 }
 
+// ---- R-MAT edge stream (BASELINE.json config 5: the skewed HBM stress graph) ----------------------
+// Edge e of the stream (a global edge id, so any rank can replay any part of the stream without holding the
+// rest): `scale` quadrant draws, one per bit, each from the counter hash of (seed, e * 64 + level) compared
+// against 32-bit integer thresholds (a, a+b, a+b+c as fractions of 2^32 -- no floating point, so the numpy
+// restatement in oracle/reference_path.py::rmat_edges_ref is bit-exact); the raw 2^scale ids then go through a
+// seeded bijection of [0, 2^scale) (Graph500-style relabelling: raw R-MAT ids put every hub at a power-of-two
+// id) and are folded mod n_nodes.
+__host__ __device__ inline uint64_t rmat_relabel(uint64_t x, int scale, uint64_t seed) {
+    const uint64_t M = scale >= 64 ? ~0ull : ((1ull << scale) - 1ull);
+    const int sh = (scale + 1) / 2;
+    const uint64_t c1 = (seed * 0x9E3779B97F4A7C15ull) >> 7, c2 = (seed ^ 0xD6E8FEB86659FD93ull) * 0xBF58476D1CE4E5B9ull;
+    x = (x * 0x9E3779B97F4A7C15ull + c1) & M;      // odd multiplier: a bijection of the low `scale` bits
+    x ^= x >> sh;                                  // xor-shift: a bijection
+    x = (x * 0xBF58476D1CE4E5B9ull) & M;
+    x ^= x >> sh;
+    x = (x * 0x94D049BB133111EBull + c2) & M;
+    x ^= x >> sh;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void rmat_edges_kernel(int scale, int64_t n_nodes, int64_t edge_lo, int64_t n_edges,
+                                                         uint32_t seed_lo, uint32_t seed_hi, uint32_t t_a,
+                                                         uint32_t t_ab, uint32_t t_abc, int relabel,
+                                                         int32_t* __restrict__ rows, int32_t* __restrict__ cols) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_edges) return;
+    const uint64_t e = (uint64_t)(edge_lo + i);
+    uint64_t r = 0, c = 0;
+    for (int l = 0; l < scale; ++l) {
+        const uint32_t h = counter_hash(e * 64ull + (uint64_t)l, seed_lo, seed_hi);
+        const uint32_t right = ((h >= t_a) & (h < t_ab)) | (h >= t_abc);      // quadrants b, d -> column bit
+        const uint32_t down = h >= t_ab;                                       // quadrants c, d -> row bit
+        r = (r << 1) | down;
+        c = (c << 1) | right;
+    }
+    if (relabel) {
+        const uint64_t seed = ((uint64_t)seed_hi << 32) | seed_lo;
+        r = rmat_relabel(r, scale, seed);
+        c = rmat_relabel(c, scale, seed);
+    }
+    rows[i] = (int32_t)(r % (uint64_t)n_nodes);
+    cols[i] = (int32_t)(c % (uint64_t)n_nodes);
+}
+
 // ---- non-empty rows of a CSR, in order (three launches: block counts, scan of the counts, write) --
 constexpr int CB = 1024;
 
@@ -309,4 +353,28 @@ extern "C" int plnlp_random_walk(const int64_t* rowptr, const int32_t* col, cons
                        (hipStream_t)stream, rowptr, col, start, n_walkers, walk_length, (uint32_t)seed,
                        (uint32_t)(seed >> 32), walks);
     return launch_status();
+}
+
+extern "C" int plnlp_rmat_edges(int scale, int64_t n_nodes, int64_t edge_lo, int64_t n_edges, uint64_t seed,
+                                uint32_t t_a, uint32_t t_ab, uint32_t t_abc, int relabel, int32_t* rows,
+                                int32_t* cols, void* stream) {
+    using namespace plnlp;
+    if (scale < 1 || scale > 40 || n_nodes < 1 || n_nodes > 0x7FFFFFFF || edge_lo < 0 || n_edges < 0)
+        return PLNLP_E_SHAPE;
+    if (!(t_a <= t_ab && t_ab <= t_abc)) return PLNLP_E_SHAPE;
+    if (n_edges == 0) return 0;
+    if (!rows || !cols) return PLNLP_E_NULL;
+    if (n_edges > ((int64_t)1 << 38)) return PLNLP_E_SHAPE;
+    constexpr int64_t MAX_BLOCKS = (int64_t)1 << 22;            // < 2^32 threads per launch
+    const int64_t blocks = (n_edges + 255) / 256;
+    for (int64_t b0 = 0; b0 < blocks; b0 += MAX_BLOCKS) {
+        const int64_t nb = (blocks - b0) < MAX_BLOCKS ? (blocks - b0) : MAX_BLOCKS;
+        const int64_t off = b0 * 256;
+        const int64_t cnt = (n_edges - off) < nb * 256 ? (n_edges - off) : nb * 256;
+        hipLaunchKernelGGL(rmat_edges_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, scale, n_nodes,
+                           edge_lo + off, cnt, (uint32_t)seed, (uint32_t)(seed >> 32), t_a, t_ab, t_abc, relabel,
+                           rows + off, cols + off);
+        if (int rc = launch_status()) return rc;
+    }
+    return 0;
 }

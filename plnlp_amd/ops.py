@@ -796,6 +796,28 @@ def random_walk(graph, start: torch.Tensor, walk_length: int, seed: int) -> torc
     return walks
 
 
+def rmat_thresholds(probs=(0.57, 0.19, 0.19, 0.05)):
+    """a, a + b, a + b + c as fractions of 2^32: the integer thresholds of plnlp_rmat_edges' quadrant draw"""
+    a, b, c, _ = probs
+    return tuple(min(int(round(v * 4294967296.0)), 0xFFFFFFFF) for v in (a, a + b, a + b + c))
+
+
+def rmat_edges(scale: int, n_nodes: int, edge_lo: int, n_edges: int, seed: int, device,
+               probs=(0.57, 0.19, 0.19, 0.05), relabel: bool = True):
+    """(rows, cols) int32 [n_edges]: edges [edge_lo, edge_lo + n_edges) of the R-MAT stream (plnlp_rmat_edges;
+    BASELINE.json config 5).  A function of (scale, seed, probs, edge id) alone -- any rank replays any part."""
+    lib = L.load()
+    device = torch.device(device)
+    rows = torch.empty(n_edges, dtype=torch.int32, device=device)
+    cols = torch.empty(n_edges, dtype=torch.int32, device=device)
+    L.require_device(rows, cols)
+    t_a, t_ab, t_abc = rmat_thresholds(probs)
+    L.check(lib.plnlp_rmat_edges(int(scale), int(n_nodes), int(edge_lo), int(n_edges), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                 t_a, t_ab, t_abc, int(bool(relabel)), rows.data_ptr(), cols.data_ptr(),
+                                 L.stream_ptr()), "plnlp_rmat_edges")
+    return rows, cols
+
+
 def random_walk_pairs(graph, start: torch.Tensor, walk_length: int, seed: int):
     """main.py:241-253: pairs (start, j-th hop) for j = 1..L with weight 1/j, self pairs removed."""
     walk = random_walk(graph, start, walk_length, seed)

@@ -299,6 +299,54 @@ def allreduce_sum(tensors: List[torch.Tensor], group) -> None:
         w.wait()
 
 
+class RowShardedSAGEForward:
+    """Forward-only SAGE encoder over a destination-row partition -- the layout of BASELINE.json config 5
+    (R-MAT 50 M nodes / 1 B edges, h = 512: a training replica of it does not exist, X alone is 102 GB;
+    SURVEY.md 8e).  Rank r holds ONLY its CSR block (rows [lo, lo + S), sources anywhere) and a full replica of
+    the source matrix X [W * S, F]; every layer computes the rank's S output rows
+
+        y_r = act( mean_agg_block(X) @ Wl^T + b + X[lo : lo + S] @ Wr^T )        (plnlp/layer.py:18-36)
+
+    and between layers ONE all-gather writes the blocks back into X's own storage (the layer's output replaces
+    its input: no second 102 GB matrix).  relu after every layer but the last (layer.py:20-23; dropout is
+    inference-off).  Same kernels as the training path (ops.csr_aggregate, ops.gemm concat-K).
+    layers: [(Wl [out, in], b [out], Wr [out, in]), ...] with in == out == X's width."""
+
+    def __init__(self, block, part: RowPartition, layers, group=None):
+        from . import ops, _lib
+        self.block, self.part, self.layers, self.group = block, part, layers, group
+        self._ops, self._lib = ops, _lib
+        f = layers[0][0].shape[1]
+        for wl, b, wr in layers:
+            assert wl.shape == (f, f) and wr.shape == (f, f) and b.shape == (f,), "in == out == width of X"
+        dev = layers[0][0].device
+        self.agg = torch.empty(part.rows, f, dtype=torch.float32, device=dev)
+        self.out = [torch.empty(part.rows, f, dtype=torch.float32, device=dev) for _ in range(min(2, len(layers)))]
+
+    def layer(self, x_full, i: int, out: torch.Tensor) -> torch.Tensor:
+        ops, part = self._ops, self.part
+        wl, b, wr = self.layers[i]
+        last = i == len(self.layers) - 1
+        ops.csr_aggregate(self.block, x_full, "mean", False, out=self.agg)
+        return ops.gemm([(self.agg, wl), (x_full[part.lo:part.lo + part.rows], wr)], False, True, out=out,
+                        epilogue=self._lib.make_epilogue(bias=b, relu=not last))
+
+    def forward(self, x_full: torch.Tensor) -> torch.Tensor:
+        """x_full [W * S, F] is OVERWRITTEN by the intermediate layers' outputs; returns this rank's rows of
+        the last layer"""
+        part = self.part
+        assert x_full.shape[0] == part.padded and x_full.is_contiguous()
+        y = None
+        for i in range(len(self.layers)):
+            y = self.layer(x_full, i, self.out[i % len(self.out)])
+            if i + 1 < len(self.layers):
+                if self.group is not None:
+                    dist.all_gather_into_tensor(x_full, y, group=self.group)
+                else:
+                    x_full[part.lo:part.lo + part.rows].copy_(y)
+        return y
+
+
 def collective_self_test(group, device) -> dict:
     """Every collective the data-parallel forms use (all-reduce, broadcast, all-gather, reduce-scatter, uneven
     all-to-all), once, on a tiny tensor with a known answer -- run at start-up, BEFORE the first training step,

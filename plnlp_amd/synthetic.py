@@ -106,31 +106,19 @@ def uniform_graph(num_nodes: int, num_edges: int, device, seed: int = 0) -> Grap
 def rmat_graph(scale: int, num_edges: int, device, seed: int = 0, probs=(0.57, 0.19, 0.19, 0.05),
                num_nodes: Optional[int] = None, symmetric: bool = False, chunk: int = 1 << 26,
                permute: bool = True) -> Graph:
-    """R-MAT (a, b, c, d) edge generator on the device (BASELINE.json config 5: the skewed,
-    cache-hostile stress for the aggregation kernel).  2**scale ids, folded mod num_nodes; generated
-    in chunks; duplicates kept (a multigraph row just lists a source twice, like torch_sparse)."""
-    a, b, c, d = probs
+    """R-MAT (a, b, c, d) multigraph on the device (BASELINE.json config 5: the skewed, cache-hostile stress for
+    the aggregation kernel).  2**scale raw ids, relabelled by a seeded bijection (permute) and folded mod
+    num_nodes; duplicates kept (a multigraph row just lists a source twice, like torch_sparse).  The edge stream
+    is the counter-hash stream of plnlp_rmat_edges (ops.rmat_edges): a function of (scale, seed, probs, edge id)
+    alone, restated bit for bit by the CPU oracle and replayable per row block (rmat_row_block)."""
+    from . import ops
     n = int(num_nodes) if num_nodes is not None else 1 << scale
-    gen = torch.Generator(device=device).manual_seed(seed)
     rows, cols = [], []
-    done = 0
-    while done < num_edges:
-        m = min(chunk, num_edges - done)
-        r = torch.zeros(m, dtype=torch.int64, device=device)
-        cc = torch.zeros(m, dtype=torch.int64, device=device)
-        for _ in range(scale):
-            u = torch.rand(m, generator=gen, device=device)
-            right = ((u >= a) & (u < a + b)) | (u >= a + b + c)          # quadrants b, d -> column bit
-            down = u >= a + b                                             # quadrants c, d -> row bit
-            r = (r << 1) | down.to(torch.int64)
-            cc = (cc << 1) | right.to(torch.int64)
-        rows.append(r % n)
-        cols.append(cc % n)
-        done += m
+    for e0 in range(0, num_edges, chunk):
+        r, c = ops.rmat_edges(scale, n, e0, min(chunk, num_edges - e0), seed, device, probs, relabel=permute)
+        rows.append(r)
+        cols.append(c)
     r, cc = torch.cat(rows), torch.cat(cols)
-    if permute:      # Graph500-style vertex relabelling: raw R-MAT ids put every hub at a power-of-two id
-        relabel = torch.randperm(n, generator=gen, device=device)
-        r, cc = relabel[r], relabel[cc]
     if symmetric:
         r, cc = torch.cat([r, cc]), torch.cat([cc, r])
     return Graph.from_coo(r, cc, None, n, n)
@@ -139,32 +127,16 @@ def rmat_graph(scale: int, num_edges: int, device, seed: int = 0, probs=(0.57, 0
 def rmat_row_block(scale: int, num_edges: int, num_nodes: int, row_lo: int, n_rows: int, n_cols: int, device,
                    seed: int = 0, probs=(0.57, 0.19, 0.19, 0.05), chunk: int = 1 << 26) -> Graph:
     """destination rows [row_lo, row_lo + n_rows) of the SAME R-MAT multigraph rmat_graph(scale, num_edges,
-    num_nodes=..., seed=...) would build -- every rank of a row-sharded run replays the identical edge
-    stream (same generator seed) and keeps only the entries of its own rows, so no rank ever holds the
-    whole edge list (BASELINE.json config 5: 1 B edges over 8 ranks)."""
-    a, b, c, d = probs
+    num_nodes=..., seed=...) builds -- every rank of a row-sharded run replays the identical edge stream (it
+    is a function of the edge id) chunk by chunk and keeps only the entries of its own rows, so no rank ever
+    holds the whole edge list (BASELINE.json config 5: 1 B edges over 8 ranks)."""
+    from . import ops
     n = int(num_nodes)
-    gen = torch.Generator(device=device).manual_seed(seed)
     rows, cols = [], []
-    done = 0
-    pending = []
-    while done < num_edges:
-        m = min(chunk, num_edges - done)
-        r = torch.zeros(m, dtype=torch.int64, device=device)
-        cc = torch.zeros(m, dtype=torch.int64, device=device)
-        for _ in range(scale):
-            u = torch.rand(m, generator=gen, device=device)
-            right = ((u >= a) & (u < a + b)) | (u >= a + b + c)
-            down = u >= a + b
-            r = (r << 1) | down.to(torch.int64)
-            cc = (cc << 1) | right.to(torch.int64)
-        pending.append(((r % n).to(torch.int32), (cc % n).to(torch.int32)))      # 8 bytes per edge while waiting
-        done += m
-    relabel = torch.randperm(n, generator=gen, device=device)       # drawn after the edges, as in rmat_graph
-    for r, cc in pending:
-        r, cc = relabel[r.long()], relabel[cc.long()]
+    for e0 in range(0, num_edges, chunk):
+        r, c = ops.rmat_edges(scale, n, e0, min(chunk, num_edges - e0), seed, device, probs)
         keep = (r >= row_lo) & (r < row_lo + n_rows)
         rows.append(r[keep] - row_lo)
-        cols.append(cc[keep])
-    del pending
+        cols.append(c[keep])
+        del r, c, keep
     return Graph.from_coo(torch.cat(rows), torch.cat(cols), None, n_rows, n_cols)

@@ -36,7 +36,8 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.plnlp_abi_version() == 6
+    header = open(os.path.join(ROOT, "include", "plnlp_hip.h")).read()
+    assert lib.plnlp_abi_version() == int(re.search(r"#define PLNLP_ABI_VERSION (\d+)", header).group(1)) == 7
     assert lib.plnlp_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5):
         assert lib.plnlp_error_string(code).startswith(b"plnlp:")
@@ -48,6 +49,9 @@ def test_argument_validation_without_launch(lib):
     assert lib.plnlp_gemm_f32(None, 1, 0, 1, None, 4, 4, 4, None, 1, None, 0, None) == -1
     assert lib.plnlp_adam_step_f32(None, None, None, None, -1, 0.1, 0.9, 0.999, 1e-8, 0.0, 0, 1, None, 0.0, 1.0, None) == -2
     assert lib.plnlp_dropout_f32(None, None, 4, 4, 1.5, 0, None) == -2
+    assert lib.plnlp_rmat_edges(0, 16, 0, 4, 1, 1, 2, 3, 1, None, None, None) == -2          # scale < 1
+    assert lib.plnlp_rmat_edges(4, 16, 0, 4, 1, 3, 2, 3, 1, None, None, None) == -2          # thresholds not ordered
+    assert lib.plnlp_rmat_edges(4, 16, 0, 4, 1, 1, 2, 3, 1, None, None, None) == -1          # NULL outputs
     assert lib.plnlp_loss_workspace_floats(65536) == 257
     assert lib.plnlp_sqnorm_partials(0) == 0 and lib.plnlp_sqnorm_partials(1) == 1
 

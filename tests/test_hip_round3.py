@@ -1,0 +1,253 @@
+"""GPU parity, third batch (round 3): BASELINE.json config 5 -- the R-MAT edge stream and the row-sharded
+forward-only SAGE encoder -- against the CPU oracle, plus the full-size properties of the largest R-MAT one
+GPU holds.  Same rules as tests/test_hip_parity.py: through the C ABI, fp32 tolerance 1e-5 relative, integer
+outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from gpu_util import close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import plnlp_amd
+    from plnlp_amd import _lib
+    _lib.load()                      # no library -> the GPU suite must fail, not skip
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return plnlp_amd
+
+
+def _csr_of(rows: np.ndarray, cols: np.ndarray, n_rows: int, n_cols: int):
+    """(rowptr, col) of the multigraph with entries ordered by (row, col), duplicates kept -- what
+    Graph.from_coo builds"""
+    order = np.lexsort((cols, rows))
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n_rows), out=rowptr[1:])
+    return rowptr, cols[order].astype(np.int32)
+
+
+# --------------------------------------------------------------- config 5: the edge stream ----
+@pytest.mark.parametrize("scale,n_nodes,relabel", [(16, 1 << 16, True), (16, 50_000, True), (10, 1000, False),
+                                                    (26, 50_000_000, True)])
+def test_rmat_edge_stream_is_bit_exact_against_the_oracle(P, scale, n_nodes, relabel):
+    """plnlp_rmat_edges == oracle.rmat_edges_ref on the same (scale, seed, edge ids): every index, including a
+    window deep inside the stream (edge ids beyond 2^32 / 64 exercise the high word of the counter) and
+    config 5's own geometry (scale 26, ids mod 50 M)"""
+    seed = 0x1234_5678_9ABC_DEF0
+    for edge_lo, m in ((0, 200_000), (999_999_000, 4096), ((1 << 33) + 7, 1000)):
+        r, c = P.ops.rmat_edges(scale, n_nodes, edge_lo, m, seed, "cuda", relabel=relabel)
+        rr, cr = O.rmat_edges_ref(scale, n_nodes, edge_lo, m, seed, relabel=relabel)
+        assert r.dtype == torch.int32 and int(r.min()) >= 0 and int(r.max()) < n_nodes
+        assert np.array_equal(r.cpu().numpy().astype(np.int64), rr)
+        assert np.array_equal(c.cpu().numpy().astype(np.int64), cr)
+
+
+def test_rmat_edge_stream_has_the_rmat_marginals(P):
+    """the stream IS R-MAT (.57, .19, .19, .05): each raw row bit is 1 with probability c + d = 0.24, each raw
+    column bit with b + d = 0.24, the two are correlated through quadrant d, and the hub takes (a + b)^scale of
+    the edges; relabelling is a bijection (the degree multiset is unchanged)"""
+    scale, m = 12, 1 << 20
+    r, c = P.ops.rmat_edges(scale, 1 << scale, 0, m, 5, "cuda", relabel=False)
+    r, c = r.long(), c.long()
+    for b in range(scale):
+        pr = float(((r >> b) & 1).float().mean())
+        pc = float(((c >> b) & 1).float().mean())
+        both = float((((r >> b) & 1) & ((c >> b) & 1)).float().mean())
+        assert abs(pr - 0.24) < 4e-3 and abs(pc - 0.24) < 4e-3 and abs(both - 0.05) < 3e-3, (b, pr, pc, both)
+    hub = float((r == 0).float().mean())
+    assert abs(hub - 0.76 ** scale) < 0.1 * 0.76 ** scale
+    r2, _ = P.ops.rmat_edges(scale, 1 << scale, 0, m, 5, "cuda", relabel=True)
+    d_raw = torch.bincount(r, minlength=1 << scale).sort().values
+    d_rel = torch.bincount(r2.long(), minlength=1 << scale).sort().values
+    assert torch.equal(d_raw, d_rel)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_rmat_row_blocks_equal_the_whole_graph_and_the_oracle(P, world):
+    """synthetic.rmat_row_block over W row blocks == synthetic.rmat_graph == the CSR of the oracle's edge
+    stream, at scale 2^16 (bit-exact rowptr and column lists): what each rank of a row-sharded run builds for
+    itself without ever holding the whole edge list.  Chunked generation (chunk < num_edges) included."""
+    from plnlp_amd import shard, synthetic
+    scale, n, nnz, seed = 16, 60_000, 700_000, 11
+    rr, cr = O.rmat_edges_ref(scale, n, 0, nnz, seed)
+    rowptr_ref, col_ref = _csr_of(rr, cr, n, n)
+    full = synthetic.rmat_graph(scale, nnz, "cuda", seed=seed, num_nodes=n, chunk=1 << 18)
+    assert np.array_equal(full.rowptr.cpu().numpy(), rowptr_ref)
+    assert np.array_equal(full.col.cpu().numpy(), col_ref)
+    got_ptr, got_col, base = [np.zeros(1, dtype=np.int64)], [], 0
+    for rank in range(world):
+        part = shard.RowPartition(n, world, rank)
+        blk = synthetic.rmat_row_block(scale, nnz, n, part.lo, part.rows, part.padded, "cuda", seed=seed,
+                                       chunk=300_000)
+        assert blk.n_rows == part.rows and blk.n_cols == part.padded
+        # the block == the same rows cut out of the whole graph (Graph.row_block)
+        cut = full.row_block(part.lo, part.rows, part.padded)
+        assert torch.equal(blk.rowptr, cut.rowptr) and torch.equal(blk.col, cut.col)
+        rp = blk.rowptr.cpu().numpy()
+        got_ptr.append(rp[1:] + base)
+        got_col.append(blk.col.cpu().numpy())
+        base += int(rp[-1])
+    got_ptr = np.concatenate(got_ptr)[: n + 1]
+    assert base == nnz and np.array_equal(got_ptr, rowptr_ref)
+    assert np.array_equal(np.concatenate(got_col), col_ref)
+
+
+# --------------------------------------------- config 5: the row-sharded forward vs the oracle ----
+def _oracle_rows_of_two_layer_sage(rowptr, col, x, layers, rows):
+    """float64 oracle of a 2-layer SAGE encoder (plnlp/layer.py:18-36: relu between the layers, none after the
+    last; PyG SAGEConv: lin_l(mean of the neighbours) + lin_r(root)) at the sampled output `rows` only: layer 1
+    is evaluated at those rows and their neighbours, on the oracle's own conv modules and SpMM"""
+    def sub_csr(rs):
+        beg, end = rowptr[rs], rowptr[rs + 1]
+        cnt = end - beg
+        rp = np.zeros(len(rs) + 1, dtype=np.int64)
+        np.cumsum(cnt, out=rp[1:])
+        idx = np.concatenate([np.arange(b, e) for b, e in zip(beg, end)]) if rp[-1] else np.zeros(0, dtype=np.int64)
+        return rp, col[idx].astype(np.int64)
+
+    n = x.shape[0]
+    rp2, c2 = sub_csr(rows)
+    need1 = np.unique(np.concatenate([rows, c2]))                 # rows of layer 1 that layer 2 reads
+    rp1, c1 = sub_csr(need1)
+    convs = []
+    for wl, b, wr in layers:
+        conv = O.SAGEConvRef(wl.shape[1], wl.shape[0]).double()
+        conv.lin_l.weight.data.copy_(wl.double().cpu())
+        conv.lin_l.bias.data.copy_(b.double().cpu())
+        conv.lin_r.weight.data.copy_(wr.double().cpu())
+        convs.append(conv)
+    x64 = x.double()
+    with torch.no_grad():
+        csr1 = O.CSR(torch.from_numpy(rp1), torch.from_numpy(c1), None, n)
+        h1 = torch.relu(convs[0].lin_l(O.spmm(csr1, x64, "mean", use_values=False)) + convs[0].lin_r(x64[need1]))
+        h1_full = torch.zeros(n, h1.shape[1], dtype=torch.float64)
+        h1_full[need1] = h1
+        csr2 = O.CSR(torch.from_numpy(rp2), torch.from_numpy(c2), None, n)
+        return convs[1].lin_l(O.spmm(csr2, h1_full, "mean", use_values=False)) + convs[1].lin_r(h1_full[rows])
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_rmat_row_sharded_forward_through_rccl_matches_the_oracle(P, math):
+    """bench.py --workload rmat's encoder (shard.RowShardedSAGEForward: rank-local R-MAT row block, replicated
+    X, all-gather between the two SAGE layers into X's own storage) at N = 2^18 / 4 M edges / F = 512 through a
+    1-rank RCCL group -- the collective really runs -- against the float64 oracle at sampled output rows
+    (a long row that takes the split passes and empty rows included), 1e-5 relative; both GEMM forms."""
+    import torch.distributed as dist
+    from test_sharded_encoder import _free_port
+    from plnlp_amd import shard, synthetic
+    scale, n, nnz, F, seed = 18, 1 << 18, 1 << 22, 512, 11
+    old = P.ops.GEMM_MATH["mode"]
+    P.ops.GEMM_MATH["mode"] = math
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        part = shard.RowPartition(n, 1, 0)
+        blk = synthetic.rmat_row_block(scale, nnz, n, part.lo, part.rows, part.padded, "cuda", seed=seed)
+        gen = torch.Generator(device="cuda").manual_seed(12)
+        x = torch.randn(part.padded, F, device="cuda", generator=gen)
+        x_cpu = x.cpu()
+        ws = [torch.randn(F, F, device="cuda", generator=gen) * 0.03 for _ in range(4)]
+        bs = [torch.randn(F, device="cuda", generator=gen) * 0.1 for _ in range(2)]
+        layers = [(ws[0], bs[0], ws[1]), (ws[2], bs[1], ws[3])]
+        enc = shard.RowShardedSAGEForward(blk, part, layers, group=dist.group.WORLD)
+        P.ops.tune_aggregation(blk, [F], group=dist.group.WORLD)
+        y = enc.forward(x).clone()
+        torch.cuda.synchronize()
+        # oracle on the SAME edge stream (its own restatement of it), at sampled rows
+        rr, cr = O.rmat_edges_ref(scale, n, 0, nnz, seed)
+        rowptr, col = _csr_of(rr, cr, n, n)
+        assert np.array_equal(blk.rowptr.cpu().numpy(), rowptr)
+        deg = np.diff(rowptr)
+        rs = np.random.RandomState(3)
+        # 48 random rows, the longest row below 2000 entries (it takes the chunk / finalize passes: the split
+        # threshold is 128 here; THE hub's own 2-hop neighbourhood would be most of the graph -- the hub is covered
+        # by the property test below) and two empty rows
+        big = int(np.argmax(np.where(deg <= 2000, deg, -1)))
+        assert deg[big] > 256
+        rows = np.unique(np.concatenate([rs.randint(0, n, 48), [big], np.nonzero(deg == 0)[0][:2]]))
+        ref = _oracle_rows_of_two_layer_sage(rowptr, col, x_cpu, layers, rows)
+        close(y[torch.from_numpy(rows).cuda()], ref, rtol=1e-5)
+        # determinism of the whole pass (x was overwritten by layer 1's output: restore it first)
+        x.copy_(x_cpu)
+        assert torch.equal(enc.forward(x), y)
+    finally:
+        P.ops.GEMM_MATH["mode"] = old
+        dist.destroy_process_group()
+
+
+# ------------------------------------- config 5 at the largest size one GPU holds: properties ----
+def test_full_size_rmat_properties(P):
+    """BASELINE.json config 5 at scale 0.25 -- the largest R-MAT one GPU holds: 12.5 M nodes / 250 M edges,
+    F = 512 (25.6 GB per feature matrix) -- through size-independent properties: constants are fixed points of
+    the mean (hence of a SAGE layer: y = c (Wl 1 + Wr 1) + b on every non-empty row), the column checksum of the
+    sum aggregation equals the out-degree-weighted checksum of the input, the transposed pass is the adjoint,
+    two runs agree bit for bit, and the edge stream itself checks out against the oracle on sampled windows."""
+    from plnlp_amd import _lib, shard, synthetic
+    n, nnz, F, seed = 12_500_000, 250_000_000, 512, 11
+    scale = (n - 1).bit_length()
+    part = shard.RowPartition(n, 1, 0)
+    blk = synthetic.rmat_row_block(scale, nnz, n, 0, part.rows, part.padded, "cuda", seed=seed)
+    assert blk.nnz == nnz and blk.n_rows == part.rows
+    # the stream behind it, on three windows
+    for lo in (0, 123_456_789, nnz - 5000):
+        r, c = P.ops.rmat_edges(scale, n, lo, 5000, seed, "cuda")
+        rr, cr = O.rmat_edges_ref(scale, n, lo, 5000, seed)
+        assert np.array_equal(r.cpu().numpy(), rr) and np.array_equal(c.cpu().numpy(), cr)
+    deg = blk.degree()
+    assert int(deg.sum()) == nnz and int(deg.max()) > 100_000          # a hub row: the chunk / finalize passes run
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    # 1. mean of a constant row vector
+    c = torch.randn(F, device="cuda", generator=gen)
+    xc = c.expand(part.padded, F).contiguous()
+    out = P.ops.csr_aggregate(blk, xc, "mean", False)
+    nz = (deg > 0)
+    # (a k-term fp32 sum of equal values is exact only up to k * 2^-24 relative in the worst case; the long rows
+    # are summed in 1024-entry chunks)
+    err = (out - c).abs().amax(dim=1)
+    assert float(err[nz].max()) <= 2e-5 * float(c.abs().max()), float(err[nz].max())
+    assert float(out.abs().amax(dim=1)[~nz].max()) == 0.0
+    del err
+    # ... and of one SAGE layer on it: y = c (Wl 1 + Wr 1) + b on non-empty rows (checked in float64)
+    wl = torch.randn(F, F, device="cuda", generator=gen) * 0.03
+    wr = torch.randn(F, F, device="cuda", generator=gen) * 0.03
+    b = torch.randn(F, device="cuda", generator=gen)
+    y = P.ops.gemm([(out, wl), (xc[: part.rows], wr)], False, True, epilogue=_lib.make_epilogue(bias=b))
+    want = (wl.double() @ c.double()) + (wr.double() @ c.double()) + b.double()
+    want0 = (wr.double() @ c.double()) + b.double()
+    tol = 1e-5 * float(want.abs().max())
+    assert float((y[nz].double() - want).abs().max()) <= tol
+    assert float((y[~nz].double() - want0).abs().max()) <= tol
+    del xc, out, y
+    # 2. checksum of checksums
+    x = torch.empty(part.padded, F, device="cuda")
+    for lo in range(0, part.padded, 1 << 20):
+        x[lo:lo + (1 << 20)].normal_(generator=gen)
+    ysum = P.ops.csr_aggregate(blk, x, "sum", False)
+    outdeg = torch.bincount(blk.col.long(), minlength=part.padded).double()
+    lhs = torch.zeros(F, dtype=torch.float64, device="cuda")
+    rhs = torch.zeros(F, dtype=torch.float64, device="cuda")
+    mag = torch.zeros(F, dtype=torch.float64, device="cuda")
+    step = 1 << 21
+    for lo in range(0, part.padded, step):                  # float64 in slices: 51 GB at once would not be polite
+        xs = x[lo:lo + step].double()
+        rhs += (outdeg[lo:lo + step, None] * xs).sum(0)
+        mag += (outdeg[lo:lo + step, None] * xs.abs()).sum(0)
+        lhs += ysum[lo:lo + step].double().sum(0)
+    assert bool(((lhs - rhs).abs() <= 3e-7 * mag).all()), float(((lhs - rhs).abs() / mag).max())
+    # 3. determinism at full size
+    assert torch.equal(ysum, P.ops.csr_aggregate(blk, x, "sum", False))
+    # 4. adjoint: <A x, z> == <x, A^T z>
+    z = torch.empty(part.rows, F, device="cuda")
+    for lo in range(0, part.rows, 1 << 20):
+        z[lo:lo + (1 << 20)].normal_(generator=gen)
+    zt = P.ops.csr_aggregate(blk.t(), z, "sum", False)
+    lhs = rhs = 0.0
+    for lo in range(0, part.padded, step):
+        lhs += float((ysum[lo:lo + step].double() * z[lo:lo + step].double()).sum())
+        rhs += float((x[lo:lo + step].double() * zt[lo:lo + step].double()).sum())
+    assert abs(lhs - rhs) <= 1e-8 * max(abs(lhs), abs(rhs)) + 1e-2, (lhs, rhs)

@@ -383,3 +383,32 @@ def test_spmm_max_first_maximum_wins_and_gradient_goes_to_it():
     out.sum().backward()
     np.testing.assert_allclose(x.grad.numpy(), want_grad.detach().numpy(), rtol=1e-12)
     assert int(csr.rowptr[8] - csr.rowptr[7]) == 0 and float(out[7].abs().max()) == 0.0
+
+
+# ------------------------------------------------ R-MAT edge stream (BASELINE config 5) ----
+def test_rmat_reference_stream_properties():
+    """the oracle's restatement of the R-MAT stream (the GPU kernel is held bit-exact to it in
+    tests/test_hip_round3.py): a window equals the same edges of a longer run (a function of the edge id),
+    the relabelling is a bijection of [0, 2^scale), the quadrant marginals are (.57, .19, .19, .05), thresholds
+    are the integer images of the cumulative probabilities, and ids are folded mod N"""
+    from oracle.reference_path import _rmat_relabel
+    assert O.rmat_thresholds() == (round(0.57 * 2 ** 32), round(0.76 * 2 ** 32), round(0.95 * 2 ** 32))
+    r, c = O.rmat_edges_ref(14, 10_000, 0, 300_000, 9)
+    r2, c2 = O.rmat_edges_ref(14, 10_000, 123_456, 777, 9)
+    assert np.array_equal(r2, r[123_456:123_456 + 777]) and np.array_equal(c2, c[123_456:123_456 + 777])
+    assert r.min() >= 0 and r.max() < 10_000 and c.max() < 10_000
+    for scale, seed in ((14, 9), (15, 1), (7, 0), (26, 11)):
+        if scale <= 16:
+            x = np.arange(1 << scale, dtype=np.uint64)
+            assert np.unique(_rmat_relabel(x.copy(), scale, seed)).size == 1 << scale
+        else:                                               # too large to enumerate: no collisions in a sample
+            x = np.random.RandomState(0).randint(0, 1 << scale, 200_000).astype(np.uint64)
+            x = np.unique(x)
+            assert np.unique(_rmat_relabel(x.copy(), scale, seed)).size == x.size
+    raw_r, raw_c = O.rmat_edges_ref(12, 1 << 12, 0, 1 << 19, 5, relabel=False)
+    for b in range(12):
+        rb, cb = (raw_r >> b) & 1, (raw_c >> b) & 1
+        assert abs(rb.mean() - 0.24) < 5e-3 and abs(cb.mean() - 0.24) < 5e-3 and abs((rb & cb).mean() - 0.05) < 4e-3
+    # a different seed is a different stream
+    r3, _ = O.rmat_edges_ref(14, 10_000, 0, 1000, 10)
+    assert not np.array_equal(r3, r[:1000])
