@@ -4,16 +4,23 @@
   python bench.py --gpus N --steps K --warmup W        (N > 1 without WORLD_SIZE: starts its own N ranks)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the training hot path (plnlp/model.py:148-167) over one
-batch of synthetic input: full-graph SAGE encoder forward+backward, fused
-gather+DOT scoring of B positives and B*k negatives, WeightedHingeAUC loss,
-gradient SUM all-reduce (N>1), per-group clipping and Adam -- nothing skipped.
-Inputs are resident in HBM before the timed region.  Weak scaling: every rank
-scores its own B positives (+B*k negatives) per step against a full replica.
+A step = one pass of the training hot path (plnlp/model.py:148-167) over one batch of synthetic input:
+SAGE encoder forward+backward, fused gather+DOT scoring of B positives and B*k negatives, WeightedHingeAUC
+loss, per-group clipping and Adam (N > 1: plus the exchange `config.dp_exchange` names).  Loss, every
+gradient and the update are those of the reference's step -- but the work is NOT the reference's launch list:
+with `config.sparse_forward` the 1-layer encoder is evaluated only at the rows the batch's edges read
+(`config.touched_fraction` of the nodes; the reference computes all N rows, model.py:150-151, and reads only
+those, model.py:155-156) and its backward runs on those rows; outputs are bit-identical to the full-matrix
+step (tests/test_hip_round2.py) and the full-matrix step is timed beside it (`ms_per_step_full_forward`), as
+is the step on the exact-f32 MFMA form (`ms_per_step_f32_mfma`).  Inputs are resident in HBM before the timed
+region.  Weak scaling: every rank scores its own B positives (+B*k negatives) per step.
 
-Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline`
-is measured live for the dominant kernel (CSR neighbour aggregation) with device
-events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the
+Rank 0 prints ONE JSON line; see the task contract for the fields.  Beyond the contract:
+`train_epoch` = edges/s through BaseModel.train for one epoch of the workload (sampler and permutation times
+separate), `eval_scoring` = edges/s of BaseModel.test.  `roofline` is measured live with device events on the
+launch stream for the aggregation kernel on the graph that does not fit the caches (its `subject` says so);
+`roofline_workload_agg`, `roofline_mfma` and `roofline_agg_adam` time the launches the step really makes
+(touched rows, gathered operands, the Adam epilogue).  `cpu_baseline` times the CPU oracle (a port of the
 reference's PyG path, which cannot run here) on the host cores, rank 0, N=1.
 """
 import argparse
@@ -55,6 +62,8 @@ def parse():
     ap.add_argument("--no-stress", action="store_true", help="skip the >>256 MiB HBM roofline measurement")
     ap.add_argument("--cpu-steps", type=int, default=6,
                     help="timed steps of the CPU oracle (collab: ~1.8 s each on 16 CPUs -> ~13 s with the warm-up step)")
+    ap.add_argument("--epoch-steps", type=int, default=400,
+                    help="cap of the train_epoch measurement in batches (collab's random-walk epoch is ~350 steps: whole)")
     ap.add_argument("--no-parity", action="store_true", help="skip the Hits@50 GPU-vs-oracle training parity run")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the DP path on 1 GPU)")
@@ -317,6 +326,18 @@ def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
         except Exception:
             from_profile = None
     alg = by_min if cached else by
+    skewed = not cached and not shape.startswith("uniform")
+    if skewed:
+        # hub rows are re-read from the caches: the gather model overstates what crosses the HBM pins (it gave
+        # fractions above 1 on R-MAT), so no roofline fraction is claimed from it
+        return {"bound": "hbm", "kernel": "csr_agg_vec_kernel (%s, F=%d)" % ("weighted sum" if weighted else "mean", feat),
+                "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                "traffic_from_profile": from_profile, "algorithmic_bytes": by, "bytes_model": "gather",
+                "compulsory_bytes": by_min, "effective_GBps": by / t / 1e9, "compulsory_GBps": by_min / t / 1e9,
+                "kernel_ms": t * 1e3, "source_MiB": src_mib,
+                "note": "source exceeds the 256 MiB Infinity Cache but the graph is SKEWED: hub rows are re-read from the "
+                        "caches, so gather-model bytes / time is an effective rate, not an HBM fraction (frac = null); the "
+                        "no-reuse fraction of this kernel is taken on the uniform graph (default workload's `roofline`)"}
     return {"bound": "cache" if cached else "hbm",
             "kernel": "csr_agg_vec_kernel (%s, F=%d)" % ("weighted sum" if weighted else "mean", feat),
             "launches": "one aggregation = csr_agg_vec_kernel (rows <= 256 entries) + csr_agg_chunk_kernel + "
@@ -374,6 +395,103 @@ def measure_gemm_roofline(P, n_rows, k_in, hidden, device, sage=True):
     mine, other = (x3_form, f32_form) if mode0 == "bf16x3" else (f32_form, x3_form)
     return dict({"bound": "mfma", "math": mode0, "traffic": None, "flops": flop}, **mine,
                 **{"other_form": dict({"math": "f32" if mode0 == "bf16x3" else "bf16x3"}, **other)})
+
+
+def measure_step_launches(P, model, data, pos_b, neg_b, cfg, device):
+    """The three dominant launches of the collab step AS THE STEP MAKES THEM (1-layer SAGE on the embedding
+    table, row-sparse forward and backward), each timed live with device events on the launch stream, on the
+    index structures of a real batch:
+      forward aggregation   csr_aggregate(adj, table, mean, row_index = touched rows)              [T, F]
+      forward GEMM          [agg | table[rows]] @ [Wl | Wr]^T + bias/relu/dropout, root rows gathered (a_index)
+      transposed agg + Adam csr_aggregate(adj^T D^-1, gagg_c, src_map) + indexed addend, Adam step on the table in
+                            the epilogue (PLNLP_EPI_ADAM) -- the step's longest launch
+    Byte models: `gather` = what the kernel requests (every neighbour row once per entry),
+    `compulsory` = what must cross the HBM pins at least once."""
+    from plnlp_amd import _lib
+    ops = P.ops
+    adj = data.adj_t
+    n, F = model.emb.weight.shape
+    h = cfg["hidden"]
+    batch = model.prepare_edges(pos_b, neg_b)
+    inc = batch.join().incidence
+    T, Tp = inc.count, inc.n_rows
+    rows, node_map = inc.rows, inc.node_map
+    x = model.emb.weight.detach()
+    conv = model.encoder.convs[0]
+    deg = adj.degree()
+    nnz_T = int(deg[rows[:T].long()].sum().item())
+    touched_nnz = node_map[adj.row_index()] >= 0
+    distinct_src = int(torch.unique(adj.col[touched_nnz]).numel())
+    out = {}
+    # ---- forward aggregation over the touched rows
+    agg = torch.empty(Tp, F, device=device)
+    t = time_kernel(lambda: ops.csr_aggregate(adj, x, "mean", False, row_index=rows, out_map=node_map, out=agg))
+    by = nnz_T * (4 * F + 4) + Tp * (4 * F + 4 + 16)
+    by_min = nnz_T * 4 + Tp * (4 + 16) + distinct_src * 4 * F + Tp * 4 * F
+    src_mib = n * F * 4 / 2 ** 20
+    out["roofline_workload_agg"] = {
+        "bound": "cache" if src_mib <= 256 else "hbm", "subject": "the step's own forward aggregation launch",
+        "kernel": "csr_agg_vec_kernel (mean, F=%d, row_index: %d touched rows of %d) + chunk + finalize passes" % (F, T, n),
+        "achieved": by_min / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by_min / t / 8.0e12, "traffic": None,
+        "algorithmic_bytes": by_min, "bytes_model": "compulsory", "gather_model_bytes": by, "effective_GBps": by / t / 1e9,
+        "kernel_ms": t * 1e3, "source_MiB": src_mib, "rows": T, "entries": nnz_T, "distinct_source_rows": distinct_src,
+        "note": "source matrix (%.0f MiB) fits the 256 MiB Infinity Cache: cache-bound; frac = compulsory bytes over the "
+                "HBM peak, effective_GBps = gather-model rate (not a roofline fraction)" % src_mib}
+    # ---- forward GEMM on the touched rows, root operand gathered in the loader
+    epi = _lib.make_epilogue(bias=conv.lin_l.bias, relu=True, dropout_p=cfg["dropout"], dropout_seed=1,
+                             dropout_rows=rows)
+    y = torch.empty(Tp, h, device=device)
+    flop = 2.0 * Tp * h * 2 * F
+    mode0 = ops.GEMM_MATH["mode"]
+    times = {}
+    try:
+        for mode in ("f32", "bf16x3"):
+            ops.GEMM_MATH["mode"] = mode
+            times[mode] = time_kernel(lambda: ops.gemm([(agg, conv.lin_l.weight), (x, conv.lin_r.weight)], False, True,
+                                                       out=y, epilogue=epi, a_index=[None, rows]))
+    finally:
+        ops.GEMM_MATH["mode"] = mode0
+    kname = "M=%d (touched rows), N=%d, K=%d+%d, root rows gathered (a_index), bias+relu+dropout epilogue" % (Tp, h, F, F)
+    f32_form = {"math": "f32", "kernel": "g16::gemm_f32_kernel (%s)" % kname, "achieved": flop / times["f32"] / 1e12,
+                "peak": 157.3, "unit": "TFLOP/s", "frac": flop / times["f32"] / 157.3e12, "kernel_ms": times["f32"] * 1e3}
+    tx = times["bf16x3"]
+    x3_form = {"math": "bf16x3", "kernel": "x16::gemm_f32_kernel (%s)" % kname, "achieved": 6 * flop / tx / 1e12,
+               "peak": 2500.0, "unit": "TFLOP/s", "frac": 6 * flop / tx / 2.5e15, "kernel_ms": tx * 1e3,
+               "f32_equivalent_TFLOPs": flop / tx / 1e12,
+               "note": "fp32 in / fp32 out; operands split into three bf16 terms, six bf16 MFMAs per block (executed flops = "
+                       "6 x algorithmic) against the dense bf16 peak"}
+    mine, other = (x3_form, f32_form) if mode0 == "bf16x3" else (f32_form, x3_form)
+    out["roofline_mfma"] = dict({"bound": "mfma", "subject": "the step's own forward GEMM launch", "traffic": None,
+                                 "flops": flop}, **mine, other_form=other)
+    # ---- transposed aggregation with the indexed addend and the table's Adam step in the epilogue
+    gt = adj.t_mean()
+    gagg_c = torch.randn(Tp, F, device=device) * 1e-3
+    gx_c = torch.randn(Tp, F, device=device) * 1e-3
+    table, m, v = x.clone(), torch.zeros_like(x), torch.zeros_like(x)
+    step_no = [0]
+
+    def agg_adam():
+        step_no[0] += 1
+        e = _lib.make_epilogue(addend=gx_c, addend_index=node_map, adam=(m, v, step_no[0], 1e-3, 0.9, 0.999, 1e-8))
+        ops.csr_aggregate(gt, gagg_c, "sum", True, src_map=node_map, out=table, epilogue=e)
+    t = time_kernel(agg_adam)
+    mapped = int(touched_nnz.sum().item())       # entries whose source row carries a gradient (graph symmetric)
+    by_min = gt.nnz * 8 + (n + 1) * 8 + 2 * n * 4 + 2 * Tp * 4 * F + 6 * n * 4 * F
+    by = gt.nnz * 8 + (n + 1) * 8 + n * 4 + gt.nnz * 4 + mapped * 4 * F + T * 4 * F + 6 * n * 4 * F
+    out["roofline_agg_adam"] = {
+        "bound": "hbm", "subject": "the step's own backward launch: transposed aggregation + Adam on the table (the "
+                                   "step's longest kernel)",
+        "kernel": "csr_agg_vec_kernel<weighted> (F=%d, src_map, ADDEND|ADAM epilogue) + chunk + finalize passes" % F,
+        "achieved": by_min / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by_min / t / 8.0e12, "traffic": None,
+        "algorithmic_bytes": by_min, "bytes_model": "compulsory: index + value lists, node map twice, the compact gradient "
+                                                    "and addend once, 3 reads + 3 writes of the [N, F] table / moments",
+        "gather_model_bytes": by, "effective_GBps": by / t / 1e9, "kernel_ms": t * 1e3,
+        "rows_with_gradient": T, "mapped_entries": mapped,
+        "note": "param + two moments (3 x %.0f MiB, read and written once each) cannot stay in the 256 MiB Infinity Cache: "
+                "that stream is HBM traffic; the %d gathered gradient rows (%.0f MiB) are cache-resident" %
+                (src_mib, T, Tp * F * 4 / 2 ** 20)}
+    out["touched_fraction"] = T / float(n)
+    return out
 
 
 def cpu_baseline(cfg, g, pos, neg, w, steps):
@@ -555,9 +673,11 @@ def main():
         pairs, weights = P.ops.random_walk_pairs(g["adj_t"], starts.repeat(reps), 10, 777)
         sel = torch.randperm(pairs.size(0), generator=gen, device=device)[:need]
         pos_all, w_all = pairs[sel], weights[sel]
+        epoch_pairs, epoch_weights = pairs, weights          # one epoch of the recipe = every random-walk pair
     else:
         sel = torch.randint(0, g["edges"].size(0), (need,), generator=gen, device=device)
         pos_all, w_all = g["edges"][sel], None
+        epoch_pairs, epoch_weights = g["edges"], None         # one epoch = every training edge (model.py:147)
     # negatives: the recipe's own sampler (README.md:24,35: 'global' for ddi / collab, :40 'local' for
     # citation2), run the way BaseModel.train runs it -- once per "epoch" (here: all the steps of the run),
     # the structured one on the device the edge list lives on.  Timed, reported, outside the timed steps
@@ -599,7 +719,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed_steps(m, mode, ranks, global_batch, my_rank, collective=True):
+    def timed_steps(m, mode, ranks, global_batch, my_rank, collective=True, K=K, W=W):
         """W warm-up + K timed steps of `m` at the given GLOBAL batch over `ranks` ranks (every rank holds the
         same resident edge tensors); returns (seconds of the K steps, max over ranks; last loss)"""
         plans = {}
@@ -650,6 +770,11 @@ def main():
 
     n_ranks = world if pg is not None else 1
     host_enqueue_s = []
+    if pg is not None and dp_mode != "shard":
+        # all ranks agree on the aggregation kernel's form on the full graph NOW, collectively, so that the
+        # rank-0-only measurements further down (roofline, control model) find the choice made: the op itself never
+        # communicates (ops.tune_aggregation / ops._agg_tune)
+        P.ops.tune_aggregation(g["adj_t"], [cfg["hidden"], cfg.get("emb", cfg["hidden"])], group=pg)
     dt, final_loss = timed_steps(model, dp_mode, n_ranks, B * world, rank)
     host_ms_per_step = host_enqueue_s[0] / K * 1e3
     edges_per_step = B * (1 + k) * world
@@ -672,6 +797,79 @@ def main():
             del solo
         torch.distributed.barrier()
 
+    sparse_fwd = bool(P.ops.SPARSE_FORWARD["enabled"] and cfg["gnn_layers"] >= 1)
+    if world == 1:
+        # ---- the same step under the two switches that change WHAT is launched (not what is computed) ----------
+        Kv, Wv = max(5, min(K, 10)), 2
+        old_math = P.ops.GEMM_MATH["mode"]
+        other_math = "f32" if old_math == "bf16x3" else "bf16x3"
+        P.ops.GEMM_MATH["mode"] = other_math
+        try:
+            dtv, _ = timed_steps(model, dp_mode, 1, B, 0, K=Kv, W=Wv)
+        finally:
+            P.ops.GEMM_MATH["mode"] = old_math
+        extra["ms_per_step_%s" % ("f32_mfma" if other_math == "f32" else "bf16x3")] = dtv / Kv * 1e3
+        if sparse_fwd:
+            P.ops.SPARSE_FORWARD["enabled"] = False
+            try:
+                dtv, _ = timed_steps(model, dp_mode, 1, B, 0, K=Kv, W=Wv)
+            finally:
+                P.ops.SPARSE_FORWARD["enabled"] = True
+            extra["ms_per_step_full_forward"] = dtv / Kv * 1e3
+        # ---- edges/s through BaseModel.train for ONE EPOCH of the workload -----------------------
+        # (model.py:128-173: per-epoch negative sampling + the DataLoader permutation + every step + the loss
+        # read-back); the sampler's and the permutation's shares reported beside it.  citation2's epoch is 464
+        # steps of ~29 ms: capped at --epoch-steps batches of edges.
+        cap = args.epoch_steps * B
+        ep_edges = epoch_pairs if epoch_pairs.size(0) <= cap else epoch_pairs[:cap]
+        if sampler == "local":          # the local sampler draws on the CPU generator from CPU edge lists (negative_sample.py:31-43)
+            ep_edges = ep_edges.cpu()
+        tr = {"edge": ep_edges}
+        if epoch_weights is not None:
+            tr["weight"] = epoch_weights[:ep_edges.size(0)]
+        split_ep = {"train": tr}
+        model.train(data, split_ep, B, sampler, k)               # warm-up epoch (allocator, first-touch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ep_loss = model.train(data, split_ep, B, sampler, k)
+        torch.cuda.synchronize()
+        t_ep = time.perf_counter() - t0
+        st = model.last_epoch
+        extra["train_epoch"] = {
+            "value": st["edges_scored"] / (t_ep - st["sampler_s"]), "unit": "edges/s", "steps": st["steps"],
+            "positives": st["positives"], "epoch_s": t_ep, "sampler_s": st["sampler_s"],
+            "permutation_s": st.get("permutation_s"), "ms_per_step": (t_ep - st["sampler_s"]) / st["steps"] * 1e3,
+            "value_incl_sampler": st["edges_scored"] / t_ep, "loss": ep_loss,
+            "full_epoch": bool(ep_edges.size(0) == epoch_pairs.size(0)),
+            "note": "BaseModel.train (model.py:128-173) for one epoch: value = Sum_steps B_step (1 + k) / (wall time - "
+                    "negative-sampler time); the wall time includes the DataLoader-equivalent CPU permutation "
+                    "(permutation_s, bit-exact to the reference's: torch.randperm on the host) and the epoch's loss read-back"}
+        # ---- eval scoring edges/s of test() (model.py:175-226) ----------------------------------------------------
+        gen_e = torch.Generator(device=device).manual_seed(99)
+        n_pos, n_neg = (60084, 100000) if cfg["shape"] == "collab" else (133489, 100000) if cfg["shape"] == "ddi" else (86596, 86596 * 50)
+        def some_edges(cnt):
+            return g["edges"][torch.randint(0, g["edges"].size(0), (cnt,), generator=gen_e, device=device)]
+        def some_negs(cnt):
+            return torch.randint(0, n, (cnt, 2), generator=gen_e, device=device)
+        split_ev = {"train": tr, "valid": {"edge": some_edges(n_pos), "edge_neg": some_negs(n_neg)},
+                    "test": {"edge": some_edges(n_pos), "edge_neg": some_negs(n_neg)}}
+        ev = P.utils.Evaluator("ogbl-collab" if cfg["shape"] == "collab" else "ogbl-ddi")
+        model.test(data, split_ev, B, ev, "hits")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps_ev = 3
+        for _ in range(reps_ev):
+            res_ev = model.test(data, split_ev, B, ev, "hits")
+        torch.cuda.synchronize()
+        t_ev = (time.perf_counter() - t0) / reps_ev
+        model.encoder.train()
+        model.predictor.train()
+        extra["eval_scoring"] = {
+            "value": 2 * (n_pos + n_neg) / t_ev, "unit": "edges/s", "edges": 2 * (n_pos + n_neg), "ms": t_ev * 1e3,
+            "note": "BaseModel.test (model.py:184-226): eval-mode encoder over all %d nodes + mean row, valid and test "
+                    "positives (%d each) and negatives (%d each) scored in batches of %d, Hits@20/50/100 ranked on the "
+                    "device; value = scored edges / wall time of test()" % (n, n_pos, n_neg, B)}
+
     result = {
         "metric": "pos+neg edges scored/sec", "value": edges_per_step * K / dt, "unit": "edges/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
@@ -688,47 +886,60 @@ def main():
                    "parallelism": ("dp%d (edge batch sliced over ranks; encoder rows, embedding table and its Adam state "
                                    "sharded over ranks)" if dp_mode == "shard" else
                                    "dp%d (edge-batch, replicated encoder)") % world,
-                   "dp_exchange": dp_mode, "scale": args.scale, "batch_mult": args.batch_mult},
+                   "dp_exchange": dp_mode, "scale": args.scale, "batch_mult": args.batch_mult,
+                   "sparse_forward": sparse_fwd,
+                   "sparse_forward_note": "the last conv is evaluated only at the rows the batch's edges read (and its "
+                                          "backward runs on those rows); bit-identical loss / gradients / update to the "
+                                          "full-matrix step, which is timed as ms_per_step_full_forward"},
         "final_loss": final_loss, "negative_sampling_s": sampler_s,
         "negative_sampler": "%s (plnlp_amd.negative_sample, %d negatives in one call)" % (sampler, need * k),
         "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 1,
     }
     result.update(extra)
+    if pg is not None:
+        result["replicas_in_sync"] = model.check_replicas()
     if rank == 0:
         nb = 2 * B
         pos_cpu, neg_cpu = pos_all[:nb].cpu(), neg_all[:nb].cpu()
         w_cpu = None if w_all is None else w_all[:nb].cpu()
-        if not args.no_roofline:
-            # the workload's own aggregation launch; `bound` says whether HBM or the cache hierarchy limits it
-            result["roofline"] = measure_roofline(P, g["adj_t"], cfg["hidden"], device,
-                                                  weighted=cfg["encoder"] == "GCN", shape=cfg["shape"])
-        if world == 1 and not args.no_roofline:
-            result["roofline_mfma"] = measure_gemm_roofline(
-                P, n, cfg.get("emb", cfg["hidden"]) + feats, cfg["hidden"], device, sage=cfg["encoder"] == "SAGE")
+        step_shaped = (world == 1 and cfg["encoder"] == "SAGE" and cfg["gnn_layers"] == 1 and sparse_fwd
+                       and not args.no_roofline)
+        if step_shaped:
+            # the launches the step really makes (touched rows, gathered operands, the Adam epilogue)
+            launches = measure_step_launches(P, model, data, pos_all[:B], neg_all[:B], cfg, device)
+            result["config"]["touched_fraction"] = launches.pop("touched_fraction")
+            result.update(launches)
+        elif not args.no_roofline:
+            # the workload's own aggregation launch over all rows; `bound` says whether HBM or the caches limit it
+            result["roofline_workload_agg"] = measure_roofline(P, g["adj_t"], cfg["hidden"], device,
+                                                               weighted=cfg["encoder"] == "GCN", shape=cfg["shape"])
+            if world == 1:
+                result["roofline_mfma"] = measure_gemm_roofline(
+                    P, n, cfg.get("emb", cfg["hidden"]) + feats, cfg["hidden"], device, sage=cfg["encoder"] == "SAGE")
         if world == 1 and not args.no_roofline and not args.no_stress:
-            # the workload's source matrix may fit the 256 MiB Infinity Cache; the HBM roofline proper is
-            # taken on a citation2-sized graph without skew or locality at h=512 (6 GB source matrix)
+            # `roofline`: the aggregation kernel against the HBM roofline proper (north_star: >= 60 % at h = 512), on a
+            # citation2-sized graph without skew or locality at h = 512 (5.7 GB source matrix: no reuse to flatter the
+            # byte model).  It is NOT a launch of the benchmarked step -- `subject` says so; the step's own launches are
+            # roofline_workload_agg / roofline_mfma / roofline_agg_adam.
             del model, pos_all, neg_all
             torch.cuda.empty_cache()
             big = synthetic.uniform_graph(2_927_963, 30_387_995, device, seed=3)
             r = measure_roofline(P, big, 512, device, shape="uniform_big")
             r["graph"] = "uniform random, N=2927963, nnz=%d (citation2-sized), F=512" % big.nnz
-            if result["roofline"]["bound"] == "cache":
-                # the workload's source matrix is cache-resident: the HBM roofline of this kernel (north_star:
-                # >= 60 % at h = 512) is the measurement on the graph that does not fit; the workload's own
-                # launch keeps its place as `roofline_workload_agg` with bound = "cache"
-                result["roofline_workload_agg"] = result["roofline"]
-                result["roofline"] = r
-            else:
-                result["roofline_hbm_stress"] = r
+            r["subject"] = ("the aggregation kernel on a graph whose source matrix (5.7 GB) is far beyond the caches: the "
+                            "HBM roofline of the kernel -- NOT a launch of the benchmarked %s step (h=%d), whose own "
+                            "launches are roofline_workload_agg / roofline_mfma / roofline_agg_adam"
+                            % (cfg["shape"], cfg["hidden"]))
+            result["roofline"] = r
             del big
             torch.cuda.empty_cache()
+        elif "roofline_workload_agg" in result:
+            result["roofline"] = dict(result["roofline_workload_agg"], subject="the workload's own aggregation launch")
         if world == 1 and not args.no_parity:
             result["hits50_parity"] = hits_parity(P, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, g, pos_cpu, neg_cpu, w_cpu, args.cpu_steps)
     if pg is not None:
-        result["replicas_in_sync"] = model.check_replicas()
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:        # last thing on stdout: the one JSON line (RCCL's banner sits in the C stdio buffer)

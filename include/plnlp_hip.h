@@ -407,6 +407,19 @@ int plnlp_adam_multi_f32(const plnlp_adam_tensor* tensors /* HOST array */, int 
  * keep torch.optim as the optimiser */
 int plnlp_clip_scale_f32(float* grad, int64_t n, const float* sqnorm, float max_norm, void* stream);
 
+/* ---- HOST side: the DataLoader batch permutation (plnlp/model.py:147), produced incrementally ------------
+ * torch.randperm(n, generator=torch.Generator().manual_seed(seed)) on the CPU -- what DataLoader(range(E), B,
+ * shuffle=True) permutes with -- is a forward Fisher-Yates shuffle driven by MT19937: after iteration i the entries
+ * perm[0..i] are final.  These two functions reproduce it bit for bit in HOST memory (perm: int64 [n], mt_state:
+ * uint32 [625], both caller-owned; no GPU work, no stream) and in slices: _init writes the identity and seeds the
+ * generator, _advance(from, to) runs iterations [from, to) in order -- after it perm[0 .. to) is final (all of it when
+ * to == n).  Calls must cover [0, n) in increasing, contiguous slices.  A trainer shuffles a few batches ahead of the
+ * GPU on a host thread instead of running the whole shuffle before the first step.  n < 2^32 / 20 (ATen's own branch
+ * for this algorithm); larger n: PLNLP_E_UNSUPPORTED. */
+int plnlp_host_randperm_init(uint64_t seed, int64_t n, int64_t* perm /* HOST */, uint32_t* mt_state /* HOST [625] */);
+int plnlp_host_randperm_advance(int64_t n, int64_t* perm /* HOST */, uint32_t* mt_state /* HOST [625] */,
+                                int64_t from, int64_t to);
+
 /* ---- small element-wise helpers -------------------------------------------- */
 /* y = gate>0 ? g*scale : 0  (relu+dropout backward as a stand-alone pass) */
 int plnlp_gate_f32(const float* g, const float* gate, float scale, float* y, int64_t n, void* stream);

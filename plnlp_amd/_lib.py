@@ -73,6 +73,8 @@ SIGNATURES = {
                                     C.c_void_p]),
     "plnlp_rmat_edges": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plnlp_host_randperm_init": (C.c_int, [C.c_uint64, c_i64, C.c_void_p, C.c_void_p]),
+    "plnlp_host_randperm_advance": (C.c_int, [c_i64, C.c_void_p, C.c_void_p, c_i64, c_i64]),
     "plnlp_incidence_temp_bytes": (c_i64, [c_i64]),
     "plnlp_incidence_build": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

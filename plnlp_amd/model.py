@@ -27,13 +27,16 @@ from . import ops
 from .layer import (GCN, SAGE, WSAGE, BaseGNN, BilinearPredictor, DotPredictor, GCNConv, MLPBilPredictor,
                     MLPCatPredictor, MLPDotPredictor, MLPPredictor, SAGEConv, Transformer)
 from .optim import FusedAdam, fused_adam_state, group_sqnorm
-from .utils import batch_permutation, evaluate_hits, evaluate_mrr, get_pos_neg_edges
+from .utils import StreamedPermutation, batch_permutation, evaluate_hits, evaluate_mrr, get_pos_neg_edges
 
 import os
 
 # single process, SAGE on the raw embedding table: the table's Adam step rides in the epilogue of the kernel that
 # finishes its gradient (BaseModel._embedding_grad_sink); PLNLP_FUSE_EMBEDDING_ADAM=0 keeps gradient and update apart
 FUSE_EMBEDDING_ADAM = {"enabled": os.environ.get("PLNLP_FUSE_EMBEDDING_ADAM", "1") != "0"}
+# the epoch's batch permutation shuffled a few batches ahead of the GPU by a host thread (utils.StreamedPermutation);
+# PLNLP_STREAM_PERMUTATION=0: the whole torch.randperm before the first step, as the reference's DataLoader does
+STREAM_PERMUTATION = {"enabled": os.environ.get("PLNLP_STREAM_PERMUTATION", "1") != "0"}
 
 
 class BaseModel(object):
@@ -664,6 +667,8 @@ class BaseModel(object):
 
         # the structured ("global") samplers run on the device the edge list lives on: on the host they
         # cost ten times the epoch's GPU time at collab scale (seeded from the CPU generator either way)
+        import time
+        t_epoch = time.perf_counter()
         edge_index = data.edge_index
         if neg_sampler_name != 'local' and edge_index is not None and self.device.type == "cuda":
             edge_index = edge_index.to(self.device)
@@ -674,14 +679,37 @@ class BaseModel(object):
         edge_weight_margin = None
         if 'weight' in split_edge['train']:
             edge_weight_margin = split_edge['train']['weight'].to(self.device)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)       # once per epoch: separates the sampler's time from the steps'
+        t_sampled = time.perf_counter()
 
         global_batch = batch_size * world if (world > 1 and self.dp_scaling == "weak") else batch_size
-        batches = batch_permutation(pos_train_edge.size(0), global_batch, True)
-        order = torch.cat(batches).to(self.device) if batches else None
+        # the DataLoader permutation (model.py:147), bit-exact; on the device path it is STREAMED: a host thread
+        # shuffles a few batches ahead of the GPU instead of the whole epoch before the first step
+        n_train = pos_train_edge.size(0)
+        streamed = None
+        if self.device.type == "cuda" and 0 < n_train < StreamedPermutation.LIMIT and STREAM_PERMUTATION["enabled"]:
+            streamed = StreamedPermutation(n_train, global_batch, self.device)
+            sizes = streamed.sizes
+            perm_stream = (ops.side_stream(self.device) if ops.PROLOGUE_OVERLAP["enabled"]
+                           else torch.cuda.current_stream(self.device))
+
+            def perm_of(bi):
+                return streamed.batch(bi, perm_stream)
+        else:
+            batches = batch_permutation(n_train, global_batch, True)
+            order = torch.cat(batches).to(self.device) if batches else None
+            sizes = [b.numel() for b in batches]
+            offsets = [0]
+            for sz in sizes:
+                offsets.append(offsets[-1] + sz)
+
+            def perm_of(bi):
+                return order[offsets[bi]:offsets[bi + 1]]
+        t_permuted = time.perf_counter()          # (host time in FRONT of the first step)
 
         loss_acc = torch.zeros((), dtype=torch.float64, device=self.device)   # Python-float accumulation in the reference
         total_examples = 0
-        start = 0
         # the per-batch gathers of the epoch tensors run on the side stream, like the rest of a batch's
         # pre-processing (ops.EdgeBatch): they depend on nothing the training steps produce
         side = main = None
@@ -720,10 +748,8 @@ class BaseModel(object):
                 got = take(perm)
             return got + (self.shard_plan(got[0], got[1], num_neg),)
 
-        for bi, b in enumerate(batches):
-            n_b = b.numel()
-            perm_all = order[start:start + n_b]
-            start += n_b
+        for bi, n_b in enumerate(sizes):
+            perm_all = perm_of(bi)
             if mode == "shard":
                 # one batch of look-ahead: the request plan of the NEXT batch is started before this step
                 # is enqueued, so its device work and its count read-back hide behind this step
@@ -731,8 +757,8 @@ class BaseModel(object):
                     pending = shard_batch(perm_all, True)
                 pos_b, neg_b, weight_margin, plan_b = pending
                 pending = None
-                if bi + 1 < len(batches):
-                    pending = shard_batch(order[start:start + batches[bi + 1].numel()], False)
+                if bi + 1 < len(sizes):
+                    pending = shard_batch(perm_of(bi + 1), False)
                 # (the step touches the batch tensors only after plan.join(), which orders the main stream
                 # behind everything the side stream did for this batch, the gather included)
                 loss = self.train_step_sharded(data, pos_b, neg_b, num_neg, weight_margin, plan=plan_b)
@@ -761,8 +787,8 @@ class BaseModel(object):
                 pending = gather_and_prepare(perm_all)
             pos_b, neg_b, weight_margin, prepared = pending
             pending = None
-            if bi + 1 < len(batches):
-                pending = gather_and_prepare(order[start:start + batches[bi + 1].numel()])
+            if bi + 1 < len(sizes):
+                pending = gather_and_prepare(perm_of(bi + 1))
             loss = self.train_step(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None,
                                    global_count=n_b, prepared=prepared)
             loss_acc += loss.double() * n_b
@@ -775,7 +801,17 @@ class BaseModel(object):
             if mode in ("scores", "shard") and not self.check_replicas():
                 raise RuntimeError("data-parallel replicas diverged (dp_exchange='scores' relies on every rank "
                                    "computing the same deterministic update)")
-        return loss_acc.item() / max(total_examples, 1)
+        epoch_loss = loss_acc.item() / max(total_examples, 1)          # (the epoch's one read-back: the device is idle after it)
+        t_end = time.perf_counter()
+        # what SURVEY.md 8(d) defines the metric on: Sum_steps B_step * (1 + k) over the wall time of train(), the
+        # negative sampler's time reported separately (model.py:132-136 draws them once per epoch, before the loop)
+        if streamed is not None:
+            streamed.join()
+        self.last_epoch = {"steps": len(sizes), "positives": total_examples,
+                           "edges_scored": total_examples * (1 + num_neg),
+                           "sampler_s": t_sampled - t_epoch, "permutation_s": t_permuted - t_sampled,
+                           "steps_s": t_end - t_permuted, "epoch_s": t_end - t_epoch}
+        return epoch_loss
 
     # ------------------------------------------------------------------- eval ---
     @torch.no_grad()

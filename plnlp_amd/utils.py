@@ -50,6 +50,113 @@ def batch_permutation(n: int, batch_size: int, shuffle: bool) -> List[torch.Tens
     return list(order.split(batch_size))
 
 
+_perm_host = {"buf": None}
+
+
+class StreamedPermutation:
+    """The same index batches as batch_permutation(n, batch_size, True) -- i.e. as the reference's
+    `DataLoader(range(n), batch_size, shuffle=True)` (model.py:147), bit for bit -- delivered WHILE the shuffle is
+    still running.
+
+    torch.randperm on the CPU generator is a forward Fisher-Yates shuffle: entry i is final after iteration i.  The
+    reference shuffles the whole epoch before its first step; at the collab recipe's 23 M random-walk pairs that is
+    0.8 s of host time in front of a 0.6 s GPU epoch.  Here a host thread runs the shuffle in slices of a few batches
+    through the library's host entry points (plnlp_host_randperm_*: same MT19937 stream, same swaps, a third of the
+    time) into pinned memory and copies every finished slice to the device on its own stream; `batch(i, stream)`
+    blocks only until slice i exists and makes `stream` wait for its copy.  The default CPU generator is consumed
+    exactly as the loader consumes it (base seed, sampler seed), so everything drawn after it stays in step."""
+
+    LIMIT = 0xFFFFFFFF // 20          # ATen's own range for this algorithm (randperm_cpu)
+
+    def __init__(self, n: int, batch_size: int, device, chunk_batches: int = 4):
+        import threading
+        from . import _lib as L
+        self._L, self._lib = L, L.load()
+        self.n, self.batch_size = int(n), int(batch_size)
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        assert self.device.type == "cuda" and 0 < self.n < self.LIMIT
+        torch.empty((), dtype=torch.int64).random_()                                   # the loader's base-seed draw
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())               # the sampler's seed
+        self.sizes = [min(self.batch_size, self.n - lo) for lo in range(0, self.n, self.batch_size)]
+        buf = _perm_host["buf"]
+        if buf is None or buf.numel() < self.n:
+            buf = _perm_host["buf"] = torch.empty(max(self.n, 1 << 20), dtype=torch.int64, pin_memory=True)
+        self._host = buf[: self.n]
+        self._mt = torch.empty(625, dtype=torch.int32)
+        self._copy = _copy_stream(self.device)
+        self._copy.synchronize()              # a previous epoch's copies out of the shared pinned buffer are done
+        L.check(self._lib.plnlp_host_randperm_init(seed & 0xFFFFFFFFFFFFFFFF, self.n, self._host.data_ptr(),
+                                                   self._mt.data_ptr()), "plnlp_host_randperm_init")
+        self.order = torch.empty(self.n, dtype=torch.int64, device=self.device)
+        self._chunk = max(1, int(chunk_batches)) * self.batch_size
+        self._cv = threading.Condition()
+        self._chunks = []                     # (end index, event of its copy), in order
+        self._error = None
+        self._waited = 0                      # chunks whose event the consumer already waited for, per stream id
+        self._seen = {}
+        self._thread = threading.Thread(target=self._run, name="plnlp-permutation", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        try:
+            torch.cuda.set_device(self.device)
+            pos = 0
+            while pos < self.n:
+                # the first slice is one batch (the first step can start at once), the rest a few batches each
+                to = min(self.n, pos + (self.batch_size if pos == 0 else self._chunk))
+                self._L.check(self._lib.plnlp_host_randperm_advance(self.n, self._host.data_ptr(), self._mt.data_ptr(),
+                                                                    pos, to), "plnlp_host_randperm_advance")
+                with torch.cuda.stream(self._copy):
+                    self.order[pos:to].copy_(self._host[pos:to], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy)
+                with self._cv:
+                    self._chunks.append((to, ev))
+                    self._cv.notify_all()
+                pos = to
+        except BaseException as exc:          # surfaced by the consumer
+            with self._cv:
+                self._error = exc
+                self._cv.notify_all()
+
+    def batch(self, i: int, stream=None) -> torch.Tensor:
+        """index batch i (a view of the device-resident order); `stream` (default: the current one) is made to wait
+        for the copy that delivered it"""
+        lo = i * self.batch_size
+        hi = lo + self.sizes[i]
+        with self._cv:
+            while self._error is None and (not self._chunks or self._chunks[-1][0] < hi):
+                self._cv.wait()
+            if self._error is not None:
+                raise self._error
+            upto = len(self._chunks)
+            need = next(j for j, (end, _) in enumerate(self._chunks) if end >= hi)
+            ev = self._chunks[need][1]
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        key = stream.cuda_stream
+        if self._seen.get(key, -1) < need:       # copies complete in order: the event of the covering slice suffices
+            stream.wait_event(ev)
+            self._seen[key] = need
+        return self.order[lo:hi]
+
+    def join(self):
+        self._thread.join()
+        if self._error is not None:
+            raise self._error
+
+
+_copy_streams = {}
+
+
+def _copy_stream(device):
+    key = torch.device(device).index or 0
+    if key not in _copy_streams:
+        _copy_streams[key] = torch.cuda.Stream(device=device)
+    return _copy_streams[key]
+
+
 class Evaluator:
     """ogb.linkproppred.Evaluator (1.3.2) semantics for the two metrics PLNLP
     uses.  `eval({'y_pred_pos', 'y_pred_neg'})` -> {'hits@K': float} or

@@ -334,3 +334,50 @@ class _CsrEncoder(torch.nn.Module):
 
     def forward(self, x, adj):
         return self.ref(x, O.CSR(adj.rowptr, adj.col.to(torch.int64), None, adj.n_cols))
+
+
+# ---------------------------------------------- the streamed DataLoader permutation (host entry points) ----
+def test_host_randperm_entry_points_reproduce_torch_randperm_bit_for_bit():
+    """plnlp_host_randperm_init / _advance (HOST functions of the C-ABI library: no GPU involved) == torch.randperm on
+    a seeded CPU generator -- what DataLoader(range(n), B, shuffle=True) permutes with (model.py:147, fixture G6) --
+    for several (seed, n), whole and in slices; after advance(.., to) the prefix [0, to) is already final."""
+    from plnlp_amd import _lib as L
+    lib = L.load()
+    for seed, n, cuts in ((123, 10, [4, 7]), (0, 1, []), (5, 2, [1]), (2 ** 40 + 77, 100_003, [1, 4096, 65_536]),
+                          (0x7FFF_FFFF_FFFF_FFFF, 300_000, [65_536, 131_072, 299_999])):
+        want = torch.randperm(n, generator=torch.Generator().manual_seed(seed))
+        perm = torch.empty(n, dtype=torch.int64)
+        mt = torch.empty(625, dtype=torch.int32)
+        L.check(lib.plnlp_host_randperm_init(seed, n, perm.data_ptr(), mt.data_ptr()), "init")
+        assert torch.equal(perm, torch.arange(n))
+        pos = 0
+        for to in cuts + [n]:
+            L.check(lib.plnlp_host_randperm_advance(n, perm.data_ptr(), mt.data_ptr(), pos, to), "advance")
+            assert torch.equal(perm[:to], want[:to]), (seed, n, to)          # the prefix is final
+            pos = to
+        assert torch.equal(perm, want)
+    # argument validation (nothing is touched)
+    mt = torch.empty(625, dtype=torch.int32)
+    assert lib.plnlp_host_randperm_init(1, -1, None, mt.data_ptr()) == -2
+    assert lib.plnlp_host_randperm_init(1, 0xFFFFFFFF // 20, None, mt.data_ptr()) == -4
+    assert lib.plnlp_host_randperm_advance(10, None, mt.data_ptr(), 5, 3) == -2
+    assert lib.plnlp_host_randperm_advance(10, None, mt.data_ptr(), 0, 10) == -1
+
+
+def test_host_randperm_matches_the_dataloader_fixture(golden):
+    """through the reference's own fixture (G6: batches DataLoader(range(n), B, shuffle=True) produced under
+    torch.manual_seed): the two default-generator draws of utils.batch_permutation, then the native shuffle"""
+    from plnlp_amd import _lib as L
+    lib = L.load()
+    g6 = golden("g6_dataloader")
+    for seed, n, B in [(123, 10, 4), (5, 1000, 64), (77, 65, 65), (8, 3, 10)]:
+        torch.manual_seed(seed)
+        torch.empty((), dtype=torch.int64).random_()
+        s2 = int(torch.empty((), dtype=torch.int64).random_().item())
+        perm = torch.empty(n, dtype=torch.int64)
+        mt = torch.empty(625, dtype=torch.int32)
+        L.check(lib.plnlp_host_randperm_init(s2, n, perm.data_ptr(), mt.data_ptr()), "init")
+        L.check(lib.plnlp_host_randperm_advance(n, perm.data_ptr(), mt.data_ptr(), 0, n), "advance")
+        np.testing.assert_array_equal(perm.numpy(), g6[f"s{seed}_n{n}_B{B}_perm"])
+        after = torch.randint(0, 1 << 30, (4,))
+        np.testing.assert_array_equal(after.numpy(), g6[f"s{seed}_n{n}_B{B}_after"])     # same RNG consumption
