@@ -33,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# before anything initialises the HIP runtime (plnlp_amd/__init__.py explains): replayed hipGraphs need it
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import torch
 
 WORKLOADS = {
@@ -723,6 +725,7 @@ def main():
         """W warm-up + K timed steps of `m` at the given GLOBAL batch over `ranks` ranks (every rank holds the
         same resident edge tensors); returns (seconds of the K steps, max over ranks; last loss)"""
         plans = {}
+        pipes = {}
 
         def step(i):
             sl = slice(i * global_batch, (i + 1) * global_batch)
@@ -742,6 +745,21 @@ def main():
 
             def mine(j):
                 return slice(j * global_batch + my_rank * per, j * global_batch + (my_rank + 1) * per)
+            if ranks == 1 and m.process_group is None:
+                # one process: the loop BaseModel.train runs -- one batch of look-ahead and the step itself through the
+                # step pipeline (plnlp_amd/capture.py: two hipGraphs once the model is warm)
+                pipe = m.pipeline(data, k, per, w_all is not None, capture=capture_flag[0],
+                                  tag=(P.ops.GEMM_MATH["mode"], P.ops.SPARSE_FORWARD["enabled"], capture_flag[0]))
+                pipes[0] = pipe
+
+                def prep_of(j):
+                    return pipe.prepare(pos_all[mine(j)], neg_all[mine(j)], None if w_all is None else w_all[mine(j)])
+                handle = plans.pop(i, None)
+                if handle is None:
+                    handle = prep_of(i)
+                if i + 1 < W + K:
+                    plans[i + 1] = prep_of(i + 1)
+                return pipe.step(handle, global_count=global_batch)
             # the edge-only pre-processing of the NEXT batch is started before this step is enqueued, as
             # BaseModel.train does (BaseModel.prepare_edges)
             prep = plans.pop(i, None)
@@ -755,21 +773,29 @@ def main():
         for i in range(W):
             step(i)
         fence()
+        waited0 = P.ops.StepThrottle.waited_s
         t0 = time.perf_counter()
         last = None
         for i in range(W, W + K):
             last = step(i)
         host_enqueue_s.append(time.perf_counter() - t0)      # when the host had queued everything (diagnostic)
+        host_busy_s.append(host_enqueue_s[-1] - (P.ops.StepThrottle.waited_s - waited0))   # ... minus its waits for the GPU
         fence()
         dt = time.perf_counter() - t0
         if ranks > 1 and collective:
             tmax = torch.tensor([dt], dtype=torch.float64, device=device)
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
             dt = float(tmax.item())
+        if pipes:
+            last_pipe.clear()
+            last_pipe.append(pipes[0])
         return dt, float(last.item())
 
     n_ranks = world if pg is not None else 1
     host_enqueue_s = []
+    host_busy_s = []
+    last_pipe = []
+    capture_flag = [None]          # None = the product default (plnlp_amd/capture.py: CAPTURE["enabled"])
     if pg is not None and dp_mode != "shard":
         # all ranks agree on the aggregation kernel's form on the full graph NOW, collectively, so that the
         # rank-0-only measurements further down (roofline, control model) find the choice made: the op itself never
@@ -777,6 +803,31 @@ def main():
         P.ops.tune_aggregation(g["adj_t"], [cfg["hidden"], cfg.get("emb", cfg["hidden"])], group=pg)
     dt, final_loss = timed_steps(model, dp_mode, n_ranks, B * world, rank)
     host_ms_per_step = host_enqueue_s[0] / K * 1e3
+    host_busy_ms_per_step = host_busy_s[0] / K * 1e3
+    capture_info = None
+    if last_pipe:
+        pp = last_pipe[0]
+        capture_info = {"default_path_captured": bool(pp.captured and pp.replays > 0), "why_eager": pp.why_eager}
+        if world == 1:
+            # the OTHER way to drive the same step (plnlp_amd/capture.py): timed the same way, reported beside the default
+            other = not capture_info["default_path_captured"]
+            capture_flag[0] = other
+            try:
+                Kc, Wc = max(10, min(K, 20)), 10
+                n_before = len(host_busy_s)
+                dtc, _ = timed_steps(model, dp_mode, 1, B, 0, K=Kc, W=Wc)
+                po = last_pipe[0]
+                capture_info["other_path"] = {
+                    "captured": bool(po.captured and po.replays > 0), "why_eager": po.why_eager,
+                    "ms_per_step": dtc / Kc * 1e3, "host_busy_ms_per_step": host_busy_s[n_before] / Kc * 1e3,
+                    "replayed_steps": po.replays, "graphs": (sum(len(sl.main) for sl in po.slots) if po.captured else 0),
+                    "host_launches_per_step": "3 input copies + 2 graph replays + one 120-byte upload" if po.captured else None}
+            finally:
+                capture_flag[0] = None
+        capture_info["note"] = ("plnlp_amd/capture.py: the step replayed from two hipGraphs (prologue one batch ahead on the side "
+                                "stream, step on the main stream), bit-identical to the eager step; opt-in (PLNLP_CAPTURE=1): it "
+                                "cuts the host's work per step ~4x but the GPU runs the replayed step ~2 % slower than the eagerly "
+                                "queued one, and the step is GPU-bound")
     edges_per_step = B * (1 + k) * world
 
     extra = {}
@@ -800,7 +851,7 @@ def main():
     sparse_fwd = bool(P.ops.SPARSE_FORWARD["enabled"] and cfg["gnn_layers"] >= 1)
     if world == 1:
         # ---- the same step under the two switches that change WHAT is launched (not what is computed) ----------
-        Kv, Wv = max(5, min(K, 10)), 2
+        Kv, Wv = max(5, min(K, 10)), 8          # (warm-up long enough for a fresh pipeline to have captured its graphs)
         old_math = P.ops.GEMM_MATH["mode"]
         other_math = "f32" if old_math == "bf16x3" else "bf16x3"
         P.ops.GEMM_MATH["mode"] = other_math
@@ -876,6 +927,11 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "gemm_math": P.ops.GEMM_MATH["mode"],
         "host_enqueue_ms_per_step": host_ms_per_step,
+        "host_busy_ms_per_step": host_busy_ms_per_step,
+        "host_note": "host_enqueue = wall time until the host had queued all K steps (it is held two steps ahead of the GPU, so "
+                     "this tracks the GPU time); host_busy = the same minus the time the host slept waiting for the GPU: the "
+                     "host WORK per step (Python, ctypes, autograd, launches -- or, captured, two graph replays)",
+        "step_capture": capture_info,
         "config": {"workload": "ogbl-%s-shaped synthetic graph (N=%d, nnz=%d), %s x%d h=%d, %s predictor, "
                                "%s loss, B=%d/GPU, num_neg=%d, dropout=%.1f, %s"
                                % (cfg["shape"], n, g["adj_t"].nnz, cfg["encoder"], cfg["gnn_layers"], cfg["hidden"],

@@ -77,6 +77,15 @@ typedef struct plnlp_epilogue {
     float*       adam_v;
     int64_t      adam_step;      /* step count AFTER this update (>= 1): bias corrections 1 - beta^step     */
     float        adam_lr, adam_beta1, adam_beta2, adam_eps;
+    /* per-step scalars in DEVICE memory (both nullable): what changes from one training step to the next while
+     * every pointer and size stays the same -- so that a step can be captured in a hipGraph once and replayed, its
+     * host uploading 40 bytes per step instead of rebuilding kernel arguments.  Values written by the host are used
+     * verbatim: a replayed step is bit-identical to the eager one.
+     *   dropout_seed_ptr : the 64-bit seed of PLNLP_EPI_DROPOUT (overrides dropout_seed)
+     *   adam_scalars     : float[3] = {lr, 1 - beta1^t, sqrt(1 - beta2^t)} as plnlp_adam_step_scalars computes them
+     *                      (overrides adam_lr / adam_step)                                                        */
+    const uint64_t* dropout_seed_ptr;
+    const float*    adam_scalars;
 } plnlp_epilogue;
 
 /* ---- K1/K2: CSR neighbour gather-and-reduce --------------------------------
@@ -121,7 +130,8 @@ int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int64_t thresho
 
 #define PLNLP_REDUCE_SUM  0
 #define PLNLP_REDUCE_MEAN 1
-#define PLNLP_AGG_SHORT_ROWS 1   /* flags: rows average only a few entries -> several rows per wave */
+/* (flag value 1 is retired: a several-rows-per-wave form for very short rows lost every measurement to the
+ * one-row-per-wave form -- rounds 1 and 2 -- and was removed in ABI 7; the bit is ignored) */
 #define PLNLP_AGG_LDS_STAGE  2   /* flags: small dense graph -> stage feature slabs of x in LDS (needs
                                     n_src * 16 B <= ~150 KiB, 16-byte aligned rows); gathers then hit LDS */
 #define PLNLP_AGG_NT_LOADS   4   /* flags: gathered rows are loaded with the streaming (non-temporal) hint -- for a
@@ -179,8 +189,7 @@ int plnlp_csr_aggregate_max_bwd_f32(const int64_t* rowptr_t, const int32_t* col_
  * Replaces F.linear / addmm inside SAGEConv (lin_l(agg)+lin_r(x) as ONE
  * concat-K product, n_seg = 2), GCNConv.lin and MLPPredictor.lins
  * (plnlp/layer.py:36,45,83,86) and their autograd dgrad / wgrad GEMMs.
- * split_k > 1: partial products go to `workspace` ([split_k, M, N] floats; pass
- * [split_k + 1, M, N] to let a ragged K tail run as its own slice) and are reduced
+ * split_k > 1: partial products go to `workspace` ([split_k, M, N] floats) and are reduced
  * in fixed order by a second kernel (deterministic); the epilogue runs in that
  * second kernel.
  */
@@ -209,7 +218,11 @@ typedef struct plnlp_gemm_operand {
  *   BF16X3 -- every operand element split in the loader into three bf16 terms (x = hi + mid + lo, residuals
  *             exact), six bf16 MFMAs per product block (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi): each
  *             product reproduced to <= 2^-25 relative (the f32 MFMA rounds it at 2^-24), 16/6 of the f32 MFMA rate.
- *             Operands must be finite and below 2^127 in magnitude (an infinity would split into inf - inf). */
+ * Non-finite operands (a diverged run): F32 follows IEEE like the reference's sgemm -- an inf operand element gives
+ * +-inf in the result elements it feeds, NaN where it meets a 0 or an opposite inf, NaN propagates.  BF16X3 turns
+ * EVERY result element that depends on a non-finite operand element into NaN (the split forms inf - inf); result
+ * elements that do not depend on it are bit-identical to the clean product.  Either way the divergence is visible
+ * (tests/test_hip_round3.py::test_gemm_non_finite_operands).  Finite operands up to FLT_MAX are fine in both. */
 #define PLNLP_GEMM_MATH_F32    0
 #define PLNLP_GEMM_MATH_BF16X3 1
 
@@ -397,7 +410,12 @@ typedef struct plnlp_adam_tensor {
     int64_t      step;        /* >= 1 */
     const float* sqnorm;      /* nullable: squared norm of the tensor's clip group (device scalar) */
     float        max_norm;
+    const float* step_scalars;/* nullable DEVICE float[3] = {lr, 1 - beta1^t, sqrt(1 - beta2^t)} of this step
+                                 (plnlp_adam_step_scalars): overrides `lr` and `step` -- see plnlp_epilogue.adam_scalars */
 } plnlp_adam_tensor;
+/* HOST helper: out[0..2] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} with exactly the arithmetic the launchers
+ * apply to a by-value step count -- what a caller uploads into adam_scalars / step_scalars */
+int plnlp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float* out /* HOST [3] */);
 int plnlp_sqnorm_multi_f32(const float* const* grads /* HOST array */, const int64_t* sizes /* HOST */,
                            int n_tensors, float* partial, int64_t n_partial, void* stream);
 int plnlp_adam_multi_f32(const plnlp_adam_tensor* tensors /* HOST array */, int n_tensors,

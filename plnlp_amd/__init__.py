@@ -7,7 +7,24 @@ Compute runs in hand-written HIP kernels (plnlp_amd/csrc) reached through a
 C-ABI shared library (include/plnlp_hip.h); PyTorch-ROCm only owns device
 memory, streams and torch.distributed.  There is no CPU fallback.
 """
-from .graph import Graph, gcn_normalization, adj_normalization  # noqa: F401
+import os as _os
+
+import torch as _torch
+
+# hipGraph replays (plnlp_amd/capture.py) need ROCm's "graph packet capture" OFF: with it on (the ROCm 7 default),
+# a graph that has been launched once and is launched again after ANY device-to-host read in between (a loss
+# `.item()`, the touched-row count) faults with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- reproduced on MI355X
+# with nothing but torch.cuda.CUDAGraph + our kernels, gone with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+# (scripts/debug_capture.py, profiles/r03_capture_debug.md).  The HIP runtime reads the flag when it initialises, so
+# it is set here, at import, if the process has not touched the GPU yet; otherwise the step pipeline stays eager.
+_PACKET_FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+_preset = _os.environ.get(_PACKET_FLAG)
+_early = not _torch.cuda.is_initialized()
+if _preset is None and _early:
+    _os.environ[_PACKET_FLAG] = "0"
+GRAPH_REPLAY_SAFE = _os.environ.get(_PACKET_FLAG) == "0" and (_preset == "0" or _early)
+
+from .graph import Graph, gcn_normalization, adj_normalization  # noqa: F401,E402
 from . import ops  # noqa: F401
 from .ops import manual_seed  # noqa: F401
 from .layer import (BaseGNN, SAGE, GCN, WSAGE, Transformer, SAGEConv, GCNConv,  # noqa: F401

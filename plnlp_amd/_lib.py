@@ -27,7 +27,8 @@ class Epilogue(C.Structure):
                 ("gate_scale", C.c_float), ("gate_index", C.c_void_p), ("addend", C.c_void_p),
                 ("ld_addend", C.c_int64), ("addend_index", C.c_void_p), ("dropout_row_index", C.c_void_p),
                 ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_step", C.c_int64),
-                ("adam_lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float)]
+                ("adam_lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
+                ("dropout_seed_ptr", C.c_void_p), ("adam_scalars", C.c_void_p)]
 
 
 class RowSplit(C.Structure):
@@ -47,14 +48,14 @@ class GemmOperand(C.Structure):
 class AdamTensor(C.Structure):
     """mirror of plnlp_adam_tensor"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("n", C.c_int64), ("step", C.c_int64), ("sqnorm", C.c_void_p), ("max_norm", C.c_float)]
+                ("n", C.c_int64), ("step", C.c_int64), ("sqnorm", C.c_void_p), ("max_norm", C.c_float),
+                ("step_scalars", C.c_void_p)]
 
 
 MULTI_MAX = 16
 GEMM_MATH_F32, GEMM_MATH_BF16X3 = 0, 1
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND, EPI_ADAM = 1, 2, 4, 8, 16, 32, 64
 REDUCE_SUM, REDUCE_MEAN = 0, 1
-AGG_SHORT_ROWS = 1
 AGG_LDS_STAGE = 2
 AGG_NT_LOADS = 4
 AGG_FEW_IN_FLIGHT = 8
@@ -130,6 +131,7 @@ SIGNATURES = {
                                          C.c_void_p]),
     "plnlp_adam_multi_f32": (C.c_int, [C.POINTER(AdamTensor), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "plnlp_adam_step_scalars": (C.c_int, [C.c_float, C.c_float, C.c_float, c_i64, C.c_void_p]),
     "plnlp_clip_scale_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_void_p]),
     "plnlp_gate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, c_i64, C.c_void_p]),
     "plnlp_dropout_f32": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_float, C.c_uint64, C.c_void_p]),
@@ -199,9 +201,12 @@ def require_device(*tensors: Optional[torch.Tensor]) -> None:
 
 def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accumulate=False,
                   gate=None, gate_scale=1.0, gate_index=None, addend=None,
-                  addend_index=None, dropout_rows=None, adam=None) -> Optional[Epilogue]:
+                  addend_index=None, dropout_rows=None, adam=None, dropout_seed_ptr: int = 0,
+                  adam_scalars_ptr: int = 0) -> Optional[Epilogue]:
     """adam = (exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps): PLNLP_EPI_ADAM -- the launch's `out` is the
-    parameter, the result its gradient (plnlp_csr_aggregate_f32 only)"""
+    parameter, the result its gradient (plnlp_csr_aggregate_f32 only).
+    dropout_seed_ptr / adam_scalars_ptr: device addresses of the per-step scalars (a captured step: see
+    plnlp_epilogue in include/plnlp_hip.h and plnlp_amd/capture.py); 0 = the by-value fields are used"""
     flags = 0
     e = Epilogue()
     if bias is not None:
@@ -213,6 +218,8 @@ def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accum
         flags |= EPI_DROPOUT
         e.dropout_p = float(dropout_p)
         e.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
+        if dropout_seed_ptr:
+            e.dropout_seed_ptr = int(dropout_seed_ptr)
         if dropout_rows is not None:
             assert dropout_rows.dtype == torch.int32
             e.dropout_row_index = dropout_rows.data_ptr()
@@ -239,6 +246,8 @@ def make_epilogue(*, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, accum
         flags |= EPI_ADAM
         e.adam_m, e.adam_v, e.adam_step = m.data_ptr(), v.data_ptr(), int(step)
         e.adam_lr, e.adam_beta1, e.adam_beta2, e.adam_eps = float(lr), float(b1), float(b2), float(eps)
+        if adam_scalars_ptr:
+            e.adam_scalars = int(adam_scalars_ptr)
     if flags == 0:
         return None
     e.flags = flags

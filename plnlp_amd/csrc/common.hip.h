@@ -70,6 +70,8 @@ struct Epi {
     uint32_t     flags;
     uint32_t     thresh;        // dropout threshold
     uint32_t     seed_lo, seed_hi;
+    const uint32_t* seed_ptr;   // nullable: the 64-bit dropout seed lives in DEVICE memory (lo word, hi word) -- a step
+                                // captured in a hipGraph draws a fresh mask per replay without a new kernel argument
     float        keep_scale;    // 1/(1-p)
     float        gate_scale;
     const float* bias;
@@ -85,7 +87,15 @@ struct Epi {
     float*       adam_m;
     float*       adam_v;
     float        adam_lr, adam_b1, adam_b2, adam_eps, adam_bc1, adam_bc2_sqrt;
+    const float* adam_scalars;  // nullable: {lr, 1 - beta1^t, sqrt(1 - beta2^t)} of THIS step in device memory
+                                // (plnlp_adam_step_scalars); overrides adam_lr / adam_bc1 / adam_bc2_sqrt
 };
+
+// the dropout seed of this launch: from device memory when the caller put it there
+__device__ __forceinline__ void epi_seed(const Epi& e, uint32_t& lo, uint32_t& hi) {
+    if (e.seed_ptr) { lo = e.seed_ptr[0]; hi = e.seed_ptr[1]; }
+    else { lo = e.seed_lo; hi = e.seed_hi; }
+}
 
 // bias corrections of step t, as plnlp_adam_multi_f32 forms them
 inline void adam_bias_corrections(float beta1, float beta2, int64_t step, float* bc1, float* bc2_sqrt) {
@@ -112,10 +122,14 @@ inline int make_epi(const plnlp_epilogue* e, Epi* out, bool allow_adam = false) 
         if (d.flags & PLNLP_EPI_ADAM) {
             if (!allow_adam || (d.flags & PLNLP_EPI_ACCUM)) return PLNLP_E_UNSUPPORTED;
             if (!e->adam_m || !e->adam_v) return PLNLP_E_NULL;
-            if (e->adam_step < 1 || ((uintptr_t)e->adam_m % 16) || ((uintptr_t)e->adam_v % 16)) return PLNLP_E_SHAPE;
+            if ((!e->adam_scalars && e->adam_step < 1) || ((uintptr_t)e->adam_m % 16) || ((uintptr_t)e->adam_v % 16))
+                return PLNLP_E_SHAPE;
             d.adam_m = e->adam_m; d.adam_v = e->adam_v;
             d.adam_lr = e->adam_lr; d.adam_b1 = e->adam_beta1; d.adam_b2 = e->adam_beta2; d.adam_eps = e->adam_eps;
-            adam_bias_corrections(e->adam_beta1, e->adam_beta2, e->adam_step, &d.adam_bc1, &d.adam_bc2_sqrt);
+            d.adam_scalars = e->adam_scalars;
+            d.adam_bc1 = d.adam_bc2_sqrt = 1.f;
+            if (!e->adam_scalars)
+                adam_bias_corrections(e->adam_beta1, e->adam_beta2, e->adam_step, &d.adam_bc1, &d.adam_bc2_sqrt);
         }
         if (d.flags & PLNLP_EPI_BIAS) { if (!e->bias) return PLNLP_E_NULL; d.bias = e->bias; }
         if (d.flags & PLNLP_EPI_GATE) {
@@ -133,6 +147,7 @@ inline int make_epi(const plnlp_epilogue* e, Epi* out, bool allow_adam = false) 
             d.thresh = dropout_thresh(e->dropout_p);
             d.seed_lo = (uint32_t)e->dropout_seed;
             d.seed_hi = (uint32_t)(e->dropout_seed >> 32);
+            d.seed_ptr = reinterpret_cast<const uint32_t*>(e->dropout_seed_ptr);
             d.keep_scale = 1.f / (1.f - e->dropout_p);
             d.drop_row = e->dropout_row_index;
         }
@@ -151,7 +166,9 @@ __device__ __forceinline__ float epi_apply(const Epi& e, float v, int64_t r, int
     if (e.flags & PLNLP_EPI_RELU) v = fmaxf(v, 0.f);
     if (e.flags & PLNLP_EPI_DROPOUT) {
         const uint64_t dr = e.drop_row ? (uint64_t)e.drop_row[r] : (uint64_t)r;
-        v = dropout_keep(dr * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh) ? v * e.keep_scale : 0.f;
+        uint32_t s_lo, s_hi;
+        epi_seed(e, s_lo, s_hi);
+        v = dropout_keep(dr * (uint64_t)n_cols + (uint64_t)f, s_lo, s_hi, e.thresh) ? v * e.keep_scale : 0.f;
     }
     if (e.flags & PLNLP_EPI_ACCUM) v += prev;
     if (e.flags & PLNLP_EPI_ADDEND) {
@@ -178,7 +195,9 @@ __device__ __forceinline__ float4 epi_apply4(const Epi& e, float4 v, int64_t r, 
         if (e.flags & PLNLP_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (e.flags & PLNLP_EPI_DROPOUT) {
             const uint64_t dr = e.drop_row ? (uint64_t)e.drop_row[r] : (uint64_t)r;
-            v = dropout_apply4(v, dr * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh, e.keep_scale);
+            uint32_t s_lo, s_hi;
+            epi_seed(e, s_lo, s_hi);
+            v = dropout_apply4(v, dr * (uint64_t)n_cols + (uint64_t)f, s_lo, s_hi, e.thresh, e.keep_scale);
         }
         if (e.flags & PLNLP_EPI_ACCUM) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
         if (e.flags & PLNLP_EPI_ADDEND) {
@@ -213,7 +232,9 @@ __device__ __forceinline__ float4 epi_apply4_pre(const Epi& e, float4 v, int64_t
     if (e.flags & PLNLP_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (e.flags & PLNLP_EPI_DROPOUT) {
         const uint64_t dr = e.drop_row ? (uint64_t)e.drop_row[r] : (uint64_t)r;
-        v = dropout_apply4(v, dr * (uint64_t)n_cols + (uint64_t)f, e.seed_lo, e.seed_hi, e.thresh, e.keep_scale);
+        uint32_t s_lo, s_hi;
+        epi_seed(e, s_lo, s_hi);
+        v = dropout_apply4(v, dr * (uint64_t)n_cols + (uint64_t)f, s_lo, s_hi, e.thresh, e.keep_scale);
     }
     if (e.flags & PLNLP_EPI_ACCUM) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
     if (has_add) { v.x += add.x; v.y += add.y; v.z += add.z; v.w += add.w; }
@@ -232,11 +253,13 @@ __device__ __forceinline__ void epi_adam4(const Epi& e, float4 g, float* __restr
     const f32x4n mn = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(e.adam_m + off));
     const f32x4n vn = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(e.adam_v + off));
     float4 m4 = make_float4(mn.x, mn.y, mn.z, mn.w), v4 = make_float4(vn.x, vn.y, vn.z, vn.w);
-    const float step = e.adam_lr / e.adam_bc1;
-    adam_update(p4.x, g.x, m4.x, v4.x, step, e.adam_b1, e.adam_b2, e.adam_eps, e.adam_bc2_sqrt);
-    adam_update(p4.y, g.y, m4.y, v4.y, step, e.adam_b1, e.adam_b2, e.adam_eps, e.adam_bc2_sqrt);
-    adam_update(p4.z, g.z, m4.z, v4.z, step, e.adam_b1, e.adam_b2, e.adam_eps, e.adam_bc2_sqrt);
-    adam_update(p4.w, g.w, m4.w, v4.w, step, e.adam_b1, e.adam_b2, e.adam_eps, e.adam_bc2_sqrt);
+    float lr = e.adam_lr, bc1 = e.adam_bc1, bc2_sqrt = e.adam_bc2_sqrt;
+    if (e.adam_scalars) { lr = e.adam_scalars[0]; bc1 = e.adam_scalars[1]; bc2_sqrt = e.adam_scalars[2]; }
+    const float step = lr / bc1;
+    adam_update(p4.x, g.x, m4.x, v4.x, step, e.adam_b1, e.adam_b2, e.adam_eps, bc2_sqrt);
+    adam_update(p4.y, g.y, m4.y, v4.y, step, e.adam_b1, e.adam_b2, e.adam_eps, bc2_sqrt);
+    adam_update(p4.z, g.z, m4.z, v4.z, step, e.adam_b1, e.adam_b2, e.adam_eps, bc2_sqrt);
+    adam_update(p4.w, g.w, m4.w, v4.w, step, e.adam_b1, e.adam_b2, e.adam_eps, bc2_sqrt);
     *reinterpret_cast<float4*>(p) = p4;
     const f32x4n mo = {m4.x, m4.y, m4.z, m4.w}, vo = {v4.x, v4.y, v4.z, v4.w};
     __builtin_nontemporal_store(mo, reinterpret_cast<f32x4n*>(e.adam_m + off));

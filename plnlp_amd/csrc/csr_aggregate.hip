@@ -294,77 +294,6 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi, &pre);
 }
 
-// short-row form: a wave owns 64/LPR rows at once (one LPR-lane group per row), so 2-4x more rows
-// are in flight per CU and a 1-2 neighbour row no longer idles 63 lanes' worth of loads.  Used when
-// the average row is short (the per-batch incidence lists: ~1 item per node).  Each group walks its
-// own row; lanes of a group read the same col / weight address (one request, broadcast).
-template <int VPL, int LPR, bool WEIGHTED>
-__global__ __launch_bounds__(256) void csr_agg_multirow_kernel(
-    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const float* __restrict__ val, const int32_t* __restrict__ val_index,
-    const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
-    const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
-    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi) {
-    constexpr int G = 64 / LPR;
-    constexpr int U = 4;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane % LPR, grp = lane / LPR;
-    const int64_t r = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G + grp;
-    const int nslots = feat >> 2;
-    int64_t beg = 0, end = 0;
-    if (r < n_rows) { beg = rowptr[r]; end = rowptr[r + 1]; }
-    const bool skip = (r >= n_rows) || (skip_above > 0 && end - beg > skip_above);
-    const int deg = skip ? 0 : (int)(end - beg);
-
-    float4 acc[VPL];
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    for (int j = 0; __any(j < deg); j += U) {
-        float4 v[U][VPL];
-        float w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool ok = (j + u) < deg;
-            const int64_t e = beg + (ok ? j + u : 0);
-            w[u] = 0.f;
-            int c = 0;
-            if (ok) {
-                c = col[e];
-                if constexpr (WEIGHTED) {
-                    w[u] = val ? val[val_index ? (int64_t)val_index[e] : e] : 1.f;
-                    if (src_scale) w[u] *= src_scale[c];
-                } else {
-                    w[u] = 1.f;
-                }
-            }
-            const float4* p = reinterpret_cast<const float4*>(x + (int64_t)c * ldx);
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) {
-                const int s = sub + k * LPR;
-                v[u][k] = (ok && s < nslots) ? p[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool ok = (j + u) < deg;
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) {
-                if constexpr (WEIGHTED) {
-                    if (ok) {       // never 0 * x: x may hold inf
-                        acc[k].x = fmaf(w[u], v[u][k].x, acc[k].x); acc[k].y = fmaf(w[u], v[u][k].y, acc[k].y);
-                        acc[k].z = fmaf(w[u], v[u][k].z, acc[k].z); acc[k].w = fmaf(w[u], v[u][k].w, acc[k].w);
-                    }
-                } else {
-                    acc[k].x += v[u][k].x; acc[k].y += v[u][k].y; acc[k].z += v[u][k].z; acc[k].w += v[u][k].w;
-                }
-            }
-        }
-    }
-    if (skip) return;
-    finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi);
-}
-
 // LDS-staged form for SMALL, DENSE graphs (ogbl-ddi: 4 267 nodes, ~500 neighbours per row).  The
 // whole source matrix cannot live in LDS, but a feature SLAB of it can: a workgroup stages
 // x[:, s0:s0+S] for every source row (n_src * S * 4 bytes <= ~150 KiB, S = 8 floats for ddi) with
@@ -671,27 +600,6 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
 }
 
 template <int VPL, int LPR>
-static int launch_multirow(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col,
-                           const float* val, const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x,
-                           int64_t ldx, float* out, int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e,
-                           const SplitArgs* sp) {
-    constexpr int G = 64 / LPR;
-    const int64_t skip = sp ? sp->threshold : 0;
-    dim3 grid((unsigned)((n_rows + 4 * G - 1) / (4 * G)));
-    if (weighted)
-        hipLaunchKernelGGL((csr_agg_multirow_kernel<VPL, LPR, true>), grid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
-    else
-        hipLaunchKernelGGL((csr_agg_multirow_kernel<VPL, LPR, false>), grid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e);
-    if (int rc = launch_status()) return rc;
-    // long rows: chunks run on the full-wave kernel geometry of this feature width
-    if (feat <= 256) return launch_split<1, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
-    if (feat <= 512) return launch_split<2, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
-    return launch_split<4, 64>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean, e, sp);
-}
-
-template <int VPL, int LPR>
 static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
                         const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
                         int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp, const int32_t* out_map,
@@ -767,9 +675,9 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
         return 0;
     }
     const int nslots = (int)(feat / 4);
-    if (src_map) flags &= ~(PLNLP_AGG_SHORT_ROWS | PLNLP_AGG_LDS_STAGE);   // the mapped gather exists on the one-row-per-wave forms only
+    if (src_map) flags &= ~PLNLP_AGG_LDS_STAGE;   // the mapped gather exists on the one-row-per-wave forms only
     if (row_index) {
-        flags &= ~(PLNLP_AGG_SHORT_ROWS | PLNLP_AGG_LDS_STAGE);     // row-indexed launches: one-row-per-wave forms
+        flags &= ~PLNLP_AGG_LDS_STAGE;     // row-indexed launches: one-row-per-wave forms
         if (sp && !split_out_map) return PLNLP_E_NULL;
     }
     if ((flags & PLNLP_AGG_LDS_STAGE) && n_src > 0 && n_src * 16 <= PLNLP_AGG_LDS_BUDGET) {
@@ -781,16 +689,6 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
         if (n_src * 32 <= PLNLP_AGG_LDS_BUDGET && feat >= 8)
             return launch_lds<8>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
         return launch_lds<4>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
-    }
-    if ((flags & PLNLP_AGG_SHORT_ROWS) && nslots >= 16 && nslots <= 128) {   // several rows per wave
-        if (nslots <= 32)
-            return launch_multirow<2, 16>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
-                                          n_rows, (int)feat, mean, e, sp);
-        if (nslots <= 64)
-            return launch_multirow<2, 32>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
-                                          n_rows, (int)feat, mean, e, sp);
-        return launch_multirow<4, 32>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
-                                      n_rows, (int)feat, mean, e, sp);
     }
 #define PLNLP_AGG(VPL, LPR) \
     return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp, 0, row_index, split_out_map)

@@ -26,6 +26,7 @@
 // result): grid.z slices write raw partial tiles to a workspace and a second
 // kernel adds them in slice order -- deterministic, no atomics.
 #include "common.hip.h"
+#include "gemm_ablation.hip.h"     // ABL_* timing switches: inert unless built with -DPLNLP_ABLATION
 #include <utility>
 
 namespace plnlp {
@@ -965,8 +966,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int64_t stride, float* __restrict__ c, int64_t ldc,
                                                             int64_t m, int n, Epi epi, float* __restrict__ c2,
                                                             int64_t ldc2, int n_split, int64_t row0) {
-    // row0: the workspace holds rows [row0, row0 + m) of the result (the tail rows of a launch whose
-    // last, partly filled round of tiles was cut along K instead -- see gemm_impl)
+    // row0: the workspace holds rows [row0, row0 + m) of the result (0 for every current caller)
     const int64_t total = m * (int64_t)n;
     const bool vec = (n % 4 == 0) && (stride % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)ws % 16 == 0) &&
                      ((uintptr_t)c % 16 == 0) &&
@@ -1146,33 +1146,9 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         return BK == 16 ? g16::launch_kernels(ga, md, grid, a_trans, b_trans, s, e)
                         : g32::launch_kernels(ga, md, grid, a_trans, b_trans, s, e);
     };
-    // ---- tail of the tile grid.  Tiles run in rounds of 512 (256 CUs x 2 workgroups); a last round that
-    // is only partly filled costs (nearly) a whole round: measured on the collab forward shape, 3686 tiles
-    // = 7.2 rounds run 24 % slower per FLOP than 3584 tiles = 7 rounds (profiles/r02_gemm_microbench).
-    // When the caller lends a workspace, the row panels of that last round are cut along K instead: the
-    // same tiles times `tail_slices` K-slices fill the round, and the reduce kernel applies the epilogue.
-    int64_t main_panels = gm, tail_rows = 0;
-    int tail_slices = 1;
-    if (split_k == 1 && workspace && g.tiles_total >= 4) {
-        const int64_t tiles = gm * gn, slots = 512;
-        const int64_t rounds = tiles / slots, rem = tiles % slots;
-        if (rounds >= 1 && rem > 0 && rem < 320) {
-            const int64_t mp = (rounds * slots) / gn;              // whole row panels inside the full rounds
-            const int64_t tp = gm - mp;                            // row panels of the last round
-            int sl = (int)(slots / (tp * gn));
-            if (sl > g.tiles_total / 2) sl = g.tiles_total / 2;    // at least 2 K-tiles per slice
-            const int64_t trows = m - mp * BM;
-            if (sl >= 2 && trows > 0 && workspace_floats >= (int64_t)sl * trows * n &&
-                ((uintptr_t)workspace % 16 == 0)) {
-                main_panels = mp; tail_rows = trows; tail_slices = sl;
-            }
-        }
-    }
     auto launch = [&](const GemmArgs& ga, int md, int slices) -> int {
-        GemmArgs gq = ga;
-        gq.gm = main_panels;                                       // (== gm unless a tail was cut off)
-        dim3 grid((unsigned)(main_panels * gn), 1, (unsigned)slices);
-        return launch_grid(gq, md, grid);
+        dim3 grid((unsigned)(gm * gn), 1, (unsigned)slices);
+        return launch_grid(ga, md, grid);
     };
     if (int rc = launch(g, mode, split_k)) return rc;
     if (split_k > 1) {
@@ -1182,24 +1158,6 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, reduce_slices,
                            g.ws_stride, c, ldc, m, (int)n, e, c2, ldc2, (int)n_split, (int64_t)0);
-        return launch_status();
-    }
-    if (tail_slices > 1) {
-        // the tail rows: partial products over `tail_slices` K-slices, then the reduce kernel with the epilogue
-        GemmArgs tg = g;
-        tg.mt0 = main_panels; tg.gm = gm - main_panels;
-        tg.split_k = tail_slices;
-        tg.ws_stride = tail_rows * n;
-        tg.c = workspace - main_panels * BM * n;       // the kernel indexes the workspace with GLOBAL rows
-        tg.ldc = n;
-        dim3 grid((unsigned)(tg.gm * gn), 1, (unsigned)tail_slices);
-        if (int rc = launch_grid(tg, mode, grid)) return rc;
-        const int64_t total = tail_rows * n;
-        int64_t blocks = (total / 4 + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, tail_slices,
-                           tg.ws_stride, c, ldc, tail_rows, (int)n, e, c2, ldc2, (int)n_split, main_panels * BM);
         return launch_status();
     }
     return 0;

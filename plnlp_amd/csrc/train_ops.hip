@@ -175,6 +175,7 @@ struct MultiAdam {
     const float* sqnorm[PLNLP_MULTI_MAX];
     float        max_norm[PLNLP_MULTI_MAX];
     float        bc1[PLNLP_MULTI_MAX], bc2_sqrt[PLNLP_MULTI_MAX];
+    const float* scal[PLNLP_MULTI_MAX];      // nullable: {lr, bc1, bc2_sqrt} of this step in device memory
     int          first_block[PLNLP_MULTI_MAX + 1];
     int          count;
 };
@@ -187,14 +188,16 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(MultiAdam a, float lr, 
     int64_t n = a.n[0];
     const float* sqnorm = a.sqnorm[0];
     float max_norm = a.max_norm[0], bc1 = a.bc1[0], bc2_sqrt = a.bc2_sqrt[0];
+    const float* scal = a.scal[0];
     int fb = 0, nb = a.first_block[1];
 #pragma unroll
     for (int i = 1; i < PLNLP_MULTI_MAX; ++i)
         if (i == ti) {      // selects, not a runtime-indexed struct read (that would go through scratch)
             p = a.p[i]; g = a.g[i]; m = a.m[i]; v = a.v[i]; n = a.n[i]; sqnorm = a.sqnorm[i];
-            max_norm = a.max_norm[i]; bc1 = a.bc1[i]; bc2_sqrt = a.bc2_sqrt[i];
+            max_norm = a.max_norm[i]; bc1 = a.bc1[i]; bc2_sqrt = a.bc2_sqrt[i]; scal = a.scal[i];
             fb = a.first_block[i]; nb = a.first_block[i + 1];
         }
+    if (scal) { lr = scal[0]; bc1 = scal[1]; bc2_sqrt = scal[2]; }
     float coef = grad_scale;
     if (sqnorm) {
         const float c = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
@@ -496,11 +499,13 @@ extern "C" int plnlp_adam_multi_f32(const plnlp_adam_tensor* tensors, int n_tens
     int blocks = 0;
     for (int i = 0; i < n_tensors; ++i) {
         const plnlp_adam_tensor& t = tensors[i];
-        if (t.n < 0 || t.step < 1) return PLNLP_E_SHAPE;
+        if (t.n < 0 || (!t.step_scalars && t.step < 1)) return PLNLP_E_SHAPE;
         if (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) return PLNLP_E_NULL;
         a.p[i] = t.param; a.g[i] = t.grad; a.m[i] = t.exp_avg; a.v[i] = t.exp_avg_sq; a.n[i] = t.n;
         a.sqnorm[i] = t.sqnorm; a.max_norm[i] = t.max_norm;
-        adam_bias_corrections(beta1, beta2, t.step, &a.bc1[i], &a.bc2_sqrt[i]);
+        a.scal[i] = t.step_scalars;
+        a.bc1[i] = a.bc2_sqrt[i] = 1.f;
+        if (!t.step_scalars) adam_bias_corrections(beta1, beta2, t.step, &a.bc1[i], &a.bc2_sqrt[i]);
         a.first_block[i] = blocks;
         blocks += (int)ew_grid((t.n + 3) / 4);          // 16 bytes per lane
     }
@@ -510,6 +515,14 @@ extern "C" int plnlp_adam_multi_f32(const plnlp_adam_tensor* tensors, int n_tens
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, lr, beta1,
                        beta2, eps, weight_decay, decoupled_wd, grad_scale);
     return launch_status();
+}
+
+extern "C" int plnlp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float* out) {
+    if (!out) return PLNLP_E_NULL;
+    if (step < 1) return PLNLP_E_SHAPE;
+    out[0] = lr;
+    plnlp::adam_bias_corrections(beta1, beta2, step, &out[1], &out[2]);
+    return 0;
 }
 
 extern "C" int plnlp_clip_scale_f32(float* grad, int64_t n, const float* sqnorm, float max_norm, void* stream) {

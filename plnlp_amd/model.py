@@ -305,11 +305,9 @@ class BaseModel(object):
         """model.py:163-167: encoder and predictor clipped as separate groups, the
         embedding not at all; then the optimiser."""
         sink = getattr(self, "_adam_sink", None)
-        joined = None
         if sink is not None:
             if sink.adam_applied:       # the table was stepped inside the backward pass; its .grad stays None
                 self.optimizer.state[self.emb.weight]["step"] += 1
-                joined = sink.joined
             else:                       # the backward took a path without the fused update: the gradient is in the buffer
                 self.emb.weight.grad = sink.buffer
             self._adam_sink = None
@@ -321,8 +319,6 @@ class BaseModel(object):
                     if sq is not None:
                         clip.update({id(p): (sq, float(self.clip_norm)) for p in group})
             self.optimizer.step(clip=clip)
-            if joined is not None:      # the table's update was queued on the side stream: the next forward reads it
-                torch.cuda.current_stream().wait_event(joined)
             return
         if self.clip_norm >= 0:
             for module in (self.encoder, self.predictor):
@@ -476,6 +472,15 @@ class BaseModel(object):
         edges_ready=True: the edge tensors are not the output of work still pending on the current
         stream (views of resident tensors, or produced on the side stream) -- their pre-processing
         may then overlap the previous step (ops.EdgeBatch)."""
+        loss, batch = self._train_step_core(data, pos_edge, neg_edge, num_neg, weight_margin, edges_ready, global_count,
+                                            prepared)
+        self._throttle(keep=(batch, pos_edge, neg_edge, weight_margin))
+        return loss
+
+    def _train_step_core(self, data, pos_edge, neg_edge, num_neg, weight_margin, edges_ready, global_count, prepared):
+        """everything train_step enqueues, without the host-side pacing: (detached loss, the step's EdgeBatch).
+        This is also what plnlp_amd/capture.py captures in a hipGraph (nothing in here may touch the host once the
+        model is warm: no read-back, no event wait)."""
         self._tune_graph(data.adj_t)
         self.optimizer.zero_grad(set_to_none=True)
         local = pos_edge.size(0)
@@ -503,8 +508,23 @@ class BaseModel(object):
             loss.backward()
         self._allreduce_grads()
         self._clip_and_step()
-        self._throttle(keep=(batch, pos_edge, neg_edge, weight_margin))
-        return loss.detach().reshape(())
+        return loss.detach().reshape(()), batch
+
+    def pipeline(self, data, num_neg: int, batch_size: int, weighted: bool, capture=None, tag=None):
+        """the hot loop's driver for full batches of this shape on this graph (plnlp_amd/capture.py::StepPipeline:
+        one batch of look-ahead, and -- once the model is warm -- the step replayed from two hipGraphs)"""
+        from .capture import StepPipeline
+        pipes = getattr(self, "_pipes", None)
+        if pipes is None:
+            pipes = self._pipes = {}
+        # (tag: a caller that switches what the step launches -- GEMM form, full forward -- asks for its own
+        # pipeline: a captured graph keeps the kernels it was captured with)
+        key = (int(num_neg), int(batch_size), bool(weighted), capture, tag)
+        hit = pipes.get(key)
+        if hit is None or hit.data is not data or hit.graph is not data.adj_t:
+            hit = pipes[key] = StepPipeline(self, data, num_neg, batch_size, weighted, capture=capture)
+            hit.graph = data.adj_t
+        return hit
 
     def _throttled(self) -> bool:
         return self.device.type == "cuda" and ops.STEP_THROTTLE["depth"] > 0
@@ -777,8 +797,16 @@ class BaseModel(object):
                     return perm_of_batch[rank * per:(rank + 1) * per]
                 return perm_of_batch
 
+            pipe = None
+            if world == 1 and side is not None:
+                # one process: the look-ahead and the step itself go through the step pipeline (captured in two
+                # hipGraphs once the model is warm)
+                pipe = self.pipeline(data, num_neg, batch_size, edge_weight_margin is not None)
+
             def gather_and_prepare(perm_of_batch):
                 got = take(my_slice(perm_of_batch))
+                if pipe is not None:
+                    return got + (pipe.prepare(got[0], got[1], got[2]),)
                 pb = self.prepare_edges(got[0], got[1], edges_ready=side is not None) if side is not None else None
                 return got + (pb,)
             # one batch of look-ahead, as in the sharded mode: the next batch's gathers and index structures are
@@ -789,8 +817,11 @@ class BaseModel(object):
             pending = None
             if bi + 1 < len(sizes):
                 pending = gather_and_prepare(perm_of(bi + 1))
-            loss = self.train_step(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None,
-                                   global_count=n_b, prepared=prepared)
+            if pipe is not None:
+                loss = pipe.step(prepared, global_count=n_b)
+            else:
+                loss = self.train_step(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None,
+                                       global_count=n_b, prepared=prepared)
             loss_acc += loss.double() * n_b
             total_examples += n_b
 

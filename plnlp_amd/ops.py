@@ -85,9 +85,6 @@ LDS_STAGE_AUTO = False          # measured on MI355X (ddi-shaped, F=512): LDS-st
                                 # both issue one wave instruction per KiB gathered, and the staged form adds the
                                 # per-chunk index loads and a shuffle tree; the L2-resident stream wins, so the
                                 # staged form is opt-in (lds_stage=True)
-SHORT_ROW_AVG = 0       # average entries per row below which the multi-row kernel form is used; 0 = never:
-                        # measured on MI355X the one-row-per-wave form wins even at ~1 entry per row, on the
-                        # dense [N, F] incidence output and on the compact one (2.59 vs 2.52 ms per step)
 
 
 def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
@@ -191,7 +188,7 @@ def _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, f
 
 def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
                   src_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                  epilogue: Optional[L.Epilogue] = None, split="auto", short_rows="auto",
+                  epilogue: Optional[L.Epilogue] = None, split="auto",
                   lds_stage="auto", src_map: Optional[torch.Tensor] = None, tune="auto",
                   row_index: Optional[torch.Tensor] = None, out_map: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[r] = red_{e in row r} w_e x[col[e]]  (plnlp_csr_aggregate_f32).
@@ -212,19 +209,17 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
     if row_index is not None:
         assert row_index.dtype == torch.int32 and out_map is not None and out_map.dtype == torch.int32
         n_out = row_index.numel()
-        short_rows, lds_stage = False, False
+        lds_stage = False
     if out is None:
         out = torch.empty(n_out, feat, dtype=torch.float32, device=x.device)
     val = graph.val if use_values else None
     val_index = getattr(graph, "val_index", None) if use_values else None
-    if short_rows == "auto":     # several rows per wave when the average row has only a few entries
-        short_rows = graph.col.numel() < SHORT_ROW_AVG * graph.n_rows
     if lds_stage == "auto":      # small AND dense (ddi-like): feature slabs of x fit in LDS and are reused
         lds_stage = (LDS_STAGE_AUTO and graph.n_cols * 16 <= LDS_STAGE_BUDGET
                      and graph.col.numel() >= LDS_STAGE_MIN_DEG * graph.n_cols and feat % 4 == 0)
     if tune == "auto":
         tune = _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, feat, row_index)
-    flags = (L.AGG_SHORT_ROWS if short_rows else 0) | (L.AGG_LDS_STAGE if lds_stage else 0) | int(tune)
+    flags = (L.AGG_LDS_STAGE if lds_stage else 0) | int(tune)
     if lds_stage:
         split = None             # the staged form walks whole rows
     sp = None
@@ -304,26 +299,6 @@ def _pick_split_k(m: int, n: int, ktiles: int) -> int:
 # workgroup slots one round of a split-K launch should fill (256 CUs x 2; the split-bf16 kernels run 3 per CU, but
 # 768 slots measured +5 % on ddi's 512x512 weight gradient and -6 % on collab's 256x256 -- profiles/r02_gemm_x3_splitk.txt)
 SPLIT_K_SLOTS = {"slots": int(os.environ.get("PLNLP_SPLIT_K_SLOTS", "512"))}
-_tail_ws = {}
-TAIL_WS_FLOATS = 512 * 128 * 128          # one round of tiles: the most the tail of a launch can need
-
-
-# off by default: measured on MI355X (profiles/r02_gemm_tail_ab.jsonl, interleaved A/B after a clock warm-up)
-# cutting the partly filled last round of tiles along K is 0-3 % SLOWER on every shape of this path -- the
-# blocks of a short last round run alone on their CUs at nearly twice the speed, so the round is cheap
-GEMM_TAIL = {"enabled": os.environ.get("PLNLP_GEMM_TAIL", "0") == "1"}
-
-
-def _tail_workspace(device) -> Optional[torch.Tensor]:
-    """scratch the GEMM may use to cut the last, partly filled round of its tile grid along K
-    (gemm_f32.hip::gemm_impl); one buffer per device, reused by every launch (stream-ordered)"""
-    if not GEMM_TAIL["enabled"]:
-        return None
-    key = torch.device(device)
-    if key not in _tail_ws:
-        _tail_ws[key] = torch.empty(TAIL_WS_FLOATS, dtype=torch.float32, device=key)
-    return _tail_ws[key]
-
 
 # how every dense product of the path is formed (include/plnlp_hip.h, PLNLP_GEMM_MATH_*): 'f32' = the f32-input
 # MFMA (an fmaf chain), 'bf16x3' = operands split into three bf16 terms in the loader, six bf16 MFMAs per block
@@ -392,10 +367,7 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     if split_k is None:
         split_k = _pick_split_k(m, n, ktiles)
     split_k = max(1, min(split_k, ktiles))
-    if split_k > 1:
-        ws = torch.empty(split_k * m * n, dtype=torch.float32, device=out.device)
-    else:
-        ws = _tail_workspace(out.device)
+    ws = torch.empty(split_k * m * n, dtype=torch.float32, device=out.device) if split_k > 1 else None
     rc = lib.plnlp_gemm_f32(ops, len(segs), int(a_trans), int(b_trans), out.data_ptr(), _ld(out), m, n,
                             C.byref(epilogue) if epilogue is not None else None, split_k,
                             L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr())
@@ -458,7 +430,7 @@ def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool
     c1 = out1 if out1 is not None else torch.empty(m, n1, dtype=torch.float32, device=a.device)
     assert c1.shape == (m, n1) and c1.is_contiguous()
     c2 = torch.empty(m, n2, dtype=torch.float32, device=a.device)
-    ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device) if split_k > 1 else _tail_workspace(a.device)
+    ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device) if split_k > 1 else None
     L.check(lib.plnlp_gemm_pair_f32(ops, b2.data_ptr(), _ld(b2), n1, int(rows_on), int(a_trans), 0, c1.data_ptr(), _ld(c1),
                                     c2.data_ptr(), _ld(c2), n1, m, n, split_k, L.ptr(ws),
                                     0 if ws is None else ws.numel(), L.stream_ptr()), "plnlp_gemm_pair_f32")
@@ -611,9 +583,9 @@ class Incidence:
             self._split = RowSplit(self.seg_ptr, self.item_edge.numel(), threshold)
         return self._split
 
-    def compact(self) -> "CompactIncidence":
+    def compact(self, count_host: Optional[torch.Tensor] = None) -> "CompactIncidence":
         """the same lists over the TOUCHED nodes only (plnlp_compact_rows)"""
-        return CompactIncidence(self)
+        return CompactIncidence(self, count_host)
 
 
 _pinned_counts = {"ring": None, "next": 0}
@@ -640,7 +612,10 @@ class CompactIncidence:
     pass -- and awaited on first use (`count`, `rows`, `rowptr`), by which time the GPU has long
     passed it: the host waits, the GPU does not idle."""
 
-    def __init__(self, inc: Incidence):
+    def __init__(self, inc: Incidence, count_host: Optional[torch.Tensor] = None):
+        """count_host (a pinned int64 [1] the caller owns): the lists are being built inside a hipGraph capture
+        (plnlp_amd/capture.py) -- the count is copied there by a node of the graph, no event is recorded here, and
+        the caller sets `_count` after each replay"""
         lib = L.load()
         n = inc.n_nodes
         dev = inc.seg_ptr.device
@@ -653,10 +628,12 @@ class CompactIncidence:
                                        self.node_map.data_ptr(), self._rowptr_cap.data_ptr(),
                                        self._count_dev.data_ptr(), ws.data_ptr(), L.stream_ptr()),
                 "plnlp_compact_rows")
-        self._host = _pinned_count_buffer()
+        self._host = _pinned_count_buffer() if count_host is None else count_host
         self._host.copy_(self._count_dev, non_blocking=True)
-        self._ready = torch.cuda.Event()
-        self._ready.record()
+        self._ready = None
+        if count_host is None:
+            self._ready = torch.cuda.Event()
+            self._ready.record()
         self._count = None
         self._base = inc                     # keeps the sorted lists (shared below) alive
         self.n_cols = self.n_nodes = n
@@ -668,6 +645,8 @@ class CompactIncidence:
     @property
     def count(self) -> int:
         if self._count is None:
+            if self._ready is None:
+                raise RuntimeError("a captured batch's touched-row count is set by the capture driver after each replay")
             self._ready.synchronize()
             self._count = int(self._host.item())
         return self._count
@@ -926,6 +905,7 @@ def adam_multi(entries, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.
     entries: (param, grad, exp_avg, exp_avg_sq, step, sqnorm | None, max_norm)"""
     lib = L.load()
     s = L.stream_ptr()
+    sc = _step_scalars["active"]        # a step being captured: lr and the bias corrections come from device memory
     for lo in range(0, len(entries), L.MULTI_MAX):
         chunk = entries[lo:lo + L.MULTI_MAX]
         arr = (L.AdamTensor * len(chunk))()
@@ -937,6 +917,8 @@ def adam_multi(entries, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.
             arr[i].n, arr[i].step = p.numel(), int(step)
             arr[i].sqnorm = L.ptr(sq)
             arr[i].max_norm = float(max_norm)
+            if sc is not None:
+                arr[i].step_scalars = sc.adam_ptr()
         L.check(lib.plnlp_adam_multi_f32(arr, len(chunk), lr, beta1, beta2, eps, weight_decay, int(decoupled),
                                          grad_scale, s), "plnlp_adam_multi_f32")
 
@@ -960,14 +942,66 @@ def clip_scale_(grad: torch.Tensor, sqnorm: torch.Tensor, max_norm: float) -> No
 
 
 # ---------------------------------------------------------- autograd wrappers ----
+class StepScalars:
+    """The scalars of ONE training step that change from step to step while every pointer and size stays the same
+    -- the learning rate, Adam's bias corrections, the dropout seeds -- in DEVICE memory (plnlp_epilogue.
+    dropout_seed_ptr / adam_scalars, plnlp_adam_tensor.step_scalars).  While an instance is `active`, the layer
+    wrappers hand the kernels these addresses instead of by-value numbers, so the step they enqueue can be captured
+    in a hipGraph once and replayed (plnlp_amd/capture.py); `upload` writes the values of the next replay -- computed
+    on the host exactly as the eager launchers compute them, so a replayed step is bit-identical to an eager one.
+    Layout (4-byte words): [0..2] lr, 1 - beta1^t, sqrt(1 - beta2^t); [4 + 2k, 5 + 2k] dropout seed k (lo, hi)."""
+    MAX_SEEDS = 14
+    WORDS = 4 + 2 * MAX_SEEDS
+    RING = 8
+
+    def __init__(self, device):
+        self.dev = torch.zeros(self.WORDS, dtype=torch.int32, device=device)
+        self.host = torch.zeros(self.RING, self.WORDS, dtype=torch.int32, pin_memory=True)
+        self._next = 0
+        self.seed_slots = 0
+
+    def adam_ptr(self) -> int:
+        return self.dev.data_ptr()
+
+    def new_seed_slot(self) -> int:
+        if self.seed_slots >= self.MAX_SEEDS:
+            raise RuntimeError("more dropout calls in one step than StepScalars.MAX_SEEDS")
+        k = self.seed_slots
+        self.seed_slots += 1
+        return self.dev.data_ptr() + 4 * (4 + 2 * k)
+
+    def upload(self, lr: float, beta1: float, beta2: float, step: int, seeds) -> None:
+        """enqueue (current stream) the values of the next replay; `seeds`: one 64-bit seed per slot, in call order"""
+        import numpy as np
+        lib = L.load()
+        row = self.host[self._next]
+        self._next = (self._next + 1) % self.RING
+        L.check(lib.plnlp_adam_step_scalars(float(lr), float(beta1), float(beta2), int(step), row.data_ptr()),
+                "plnlp_adam_step_scalars")
+        words = row.numpy()
+        for k, sd in enumerate(seeds):
+            words[4 + 2 * k] = np.uint32(sd & 0xFFFFFFFF).astype(np.int32)
+            words[5 + 2 * k] = np.uint32((sd >> 32) & 0xFFFFFFFF).astype(np.int32)
+        self.dev.copy_(row, non_blocking=True)
+
+
+_step_scalars = {"active": None}
+
+
 class _Act:
     """relu + dropout description of one layer call"""
-    __slots__ = ("relu", "p", "seed", "gate_in_consumer")
+    __slots__ = ("relu", "p", "seed", "gate_in_consumer", "seed_ptr")
 
     def __init__(self, relu: bool, p: float, training: bool):
         self.relu = bool(relu)
         self.p = float(p) if training else 0.0
-        self.seed = next_seed() if self.p > 0.0 else 0
+        sc = _step_scalars["active"]
+        if sc is not None and self.p > 0.0:
+            # a step being captured: the seed of every replay is uploaded to device memory (StepScalars); the
+            # host's seed stream is NOT advanced by the capture itself
+            self.seed, self.seed_ptr = 0, sc.new_seed_slot()
+        else:
+            self.seed, self.seed_ptr = (next_seed() if self.p > 0.0 else 0), 0
         # True when the op that consumes this layer's output folds the relu/dropout
         # derivative into its own backward (EdgeDotFn with gate_scale): the incoming
         # gradient is then already d/dz and this layer must not gate it again
@@ -993,14 +1027,6 @@ def _act_backward(gy: torch.Tensor, y: torch.Tensor, act: _Act) -> torch.Tensor:
 
 
 _side_streams = {}
-# off: measured on MI355X (collab, bench.py --steps 40, twice): 1.643 / 1.650 ms with the table's update on its own
-# stream beside the small weights' clip + Adam (~60 us of short kernels), 1.625 / 1.626 ms in line -- the two
-# cross-stream hand-overs cost more than the overlap returns
-FUSED_ADAM_SIDE_STREAM = {"enabled": os.environ.get("PLNLP_FUSED_ADAM_SIDE_STREAM", "0") == "1"}
-OVERLAP_BACKWARD = {"enabled": os.environ.get("PLNLP_OVERLAP_BACKWARD", "0") == "1"}
-# off: measured on MI355X in round 1 (dense backward): no gain at collab, -4 % at ddi (the two kernels fight for the
-# same CUs); measured again in round 2 with the split-bf16 GEMMs and the row-sparse backward
-# (profiles/r02_overlap_backward_ab.txt); kept as an option
 
 
 def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
@@ -1037,7 +1063,6 @@ class GradSink:
         # that finishes the gradient (PLNLP_EPI_ADAM) instead of writing the gradient out; it sets
         # `adam_applied` when it did (else the gradient is in `buffer` as usual)
         self.adam, self.adam_applied = adam, False
-        self.joined = None        # event after which the update is complete, when it was queued on another stream
 
     @property
     def buffer(self) -> torch.Tensor:
@@ -1136,11 +1161,11 @@ class SAGEConvFn(torch.autograd.Function):
             assert channel is not None, "a row-restricted forward hands its gradient back through the channel"
             rows = out_rows.rows
             agg = csr_aggregate(graph, x, "mean", use_values=False, row_index=rows, out_map=out_rows.node_map)
-            epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_rows=rows)
+            epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr, dropout_rows=rows)
             y = gemm([(agg, w_l), (x, w_r)], False, True, epilogue=epi, a_index=[None, rows])
         else:
             agg = csr_aggregate(graph, x, "mean", use_values=False)
-            epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+            epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr)
             y = gemm([(agg, w_l), (x, w_r)], False, True, epilogue=epi)
         ctx.graph, ctx.act = graph, act
         ctx.in_act = in_act if (in_act is not None and in_act.active) else None
@@ -1181,25 +1206,9 @@ class SAGEConvFn(torch.autograd.Function):
             ia = ctx.in_act
             epi = L.make_epilogue(accumulate=True, gate=x if ia is not None else None,
                                   gate_scale=ia.scale if ia is not None else 1.0)
-            joined = None
-            if OVERLAP_BACKWARD["enabled"]:
-                # HBM-bound transposed aggregation on the side stream, MFMA-bound weight gradients on
-                # the main stream: different bottlenecks, so they share the CUs instead of queueing
-                main = torch.cuda.current_stream()
-                side = side_stream(dz.device)
-                ready = torch.cuda.Event()
-                ready.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    csr_aggregate(graph.t_mean(), gagg, "sum", use_values=True, out=gx, epilogue=epi)
-                    if sink is not None and sink.on_ready is not None:
-                        sink.on_ready()      # e.g. start the all-reduce (ordered after the aggregation)
-                    joined = torch.cuda.Event()
-                    joined.record(side)
-            else:
-                csr_aggregate(graph.t_mean(), gagg, "sum", use_values=True, out=gx, epilogue=epi)
-                if sink is not None and sink.on_ready is not None:
-                    sink.on_ready()          # e.g. start the all-reduce; the GEMMs below overlap it
+            csr_aggregate(graph.t_mean(), gagg, "sum", use_values=True, out=gx, epilogue=epi)
+            if sink is not None and sink.on_ready is not None:
+                sink.on_ready()          # e.g. start the all-reduce; the GEMMs below overlap it
             if sink is not None:
                 gx = None
         if need[1] and need[3]:
@@ -1211,8 +1220,6 @@ class SAGEConvFn(torch.autograd.Function):
                 gwr = gemm([(dz, x)], True, False)
         if need[2]:
             gbl = colsum(dz)
-        if need[0] and OVERLAP_BACKWARD["enabled"] and joined is not None:
-            torch.cuda.current_stream().wait_event(joined)
         return gx, gwl, gbl, gwr, None, None, None, None, None, None
 
     @staticmethod
@@ -1262,54 +1269,21 @@ class SAGEConvFn(torch.autograd.Function):
                 if need[2]:
                     gbl = colsum(dz)
                 ad = sink.adam
+                sc = _step_scalars["active"]
                 epi = L.make_epilogue(addend=gx_c, addend_index=sg.node_map,
                                       adam=(ad["exp_avg"], ad["exp_avg_sq"], ad["step"], ad["lr"], ad["betas"][0],
-                                            ad["betas"][1], ad["eps"]))
-                if FUSED_ADAM_SIDE_STREAM["enabled"]:
-                    # nothing else of this step depends on the table's update: it runs on the side stream while
-                    # the main stream clips and steps the small weights; the caller joins (sink.joined) before the
-                    # next forward pass
-                    main, side = torch.cuda.current_stream(), side_stream(dz.device, 1)
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-                    with torch.cuda.stream(side):
-                        side.wait_event(ready)
-                        csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map,
-                                      out=x.data, epilogue=epi)
-                        sink.joined = torch.cuda.Event()
-                        sink.joined.record(side)
-                    for t_ in (gagg_c, gx_c, sg.node_map):        # main-stream temporaries read on the side stream
-                        t_.record_stream(side)
-                else:
-                    csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=x.data,
-                                  epilogue=epi)
+                                            ad["betas"][1], ad["eps"]),
+                                      adam_scalars_ptr=sc.adam_ptr() if sc is not None else 0)
+                csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=x.data,
+                              epilogue=epi)
                 sink.adam_applied = True
                 return None, gwl, gbl, gwr, None, None, None, None, None, None
             out = sink.buffer if sink is not None else torch.empty(x.shape[0], cin, dtype=torch.float32,
                                                                    device=x.device)
-            joined = None
-            if OVERLAP_BACKWARD["enabled"] and OVERLAP_BACKWARD.get("sparse", True):
-                # as in the dense form: the cache- / HBM-bound transposed aggregation on the side stream, the
-                # MFMA-bound weight gradients on the main stream
-                main = torch.cuda.current_stream()
-                side = side_stream(dz.device)
-                ready = torch.cuda.Event()
-                ready.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=out,
-                                  epilogue=epi)
-                    if sink is not None and sink.on_ready is not None:
-                        sink.on_ready()
-                    joined = torch.cuda.Event()
-                    joined.record(side)
-                for t_ in (gagg_c, gx_c, out):          # allocated on the main stream, consumed on the side stream
-                    t_.record_stream(side)
-            else:
-                csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=out,
-                              epilogue=epi)
-                if sink is not None and sink.on_ready is not None:
-                    sink.on_ready()
+            csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=out,
+                          epilogue=epi)
+            if sink is not None and sink.on_ready is not None:
+                sink.on_ready()
             if sink is None:
                 gx = out
         if need[1] and need[3]:
@@ -1321,8 +1295,6 @@ class SAGEConvFn(torch.autograd.Function):
                 gwr = gemm([(dz, x)], True, False, b_index=sg.rows)
         if need[2]:
             gbl = colsum(dz)
-        if need[0] and joined is not None:
-            torch.cuda.current_stream().wait_event(joined)
         return gx, gwl, gbl, gwr, None, None, None, None, None, None
 
 
@@ -1356,7 +1328,7 @@ class SAGEConvBlockFn(torch.autograd.Function):
         s = graph.n_rows
         agg = csr_aggregate(graph, x, "mean", use_values=False)
         x_root = x[row_lo:row_lo + s]
-        epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+        epi = L.make_epilogue(bias=b_l, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr)
         y = gemm([(agg, w_l), (x_root, w_r)], False, True, epilogue=epi)
         ctx.graph, ctx.act, ctx.row_lo = graph, act, int(row_lo)
         ctx.save_for_backward(x, agg, w_l, w_r, y if act.active else None)
@@ -1406,7 +1378,7 @@ class GCNConvBlockFn(torch.autograd.Function):
             xp, wp = _f32c(x), w
         assert xp.shape[0] == graph.n_cols, (xp.shape, graph)
         agg = csr_aggregate(graph, xp, "sum", use_values=True)
-        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr)
         y = gemm([(agg, wp)], False, True, epilogue=epi)
         ctx.graph, ctx.act, ctx.kin = graph, act, kin
         ctx.save_for_backward(agg, wp, y if act.active else None)
@@ -1527,7 +1499,7 @@ class GCNInputConvFn(torch.autograd.Function):
         wa = st["wa"]
         wa[:, :e].copy_(w[:, :e])
         wa[:, ep:ep + f].copy_(w[:, e:])
-        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr)
         y = gemm([(ax, wa)], False, True, epilogue=epi)
         ctx.graph, ctx.act, ctx.dims = graph, act, (e, f, ep, fp)
         ctx.ax = ax            # persistent buffer: this step's backward runs before the next forward rewrites it
@@ -1577,12 +1549,12 @@ class GCNConvFn(torch.autograd.Function):
         xw = gemm([(xp, wp)], False, True)
         if out_rows is not None:
             assert channel is not None, "a row-restricted forward hands its gradient back through the channel"
-            epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed,
+            epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr,
                                   dropout_rows=out_rows.rows)
             y = csr_aggregate(graph, xw, "sum", use_values=True, epilogue=epi, row_index=out_rows.rows,
                               out_map=out_rows.node_map)
         else:
-            epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+            epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr)
             y = csr_aggregate(graph, xw, "sum", use_values=True, epilogue=epi)
         ctx.graph, ctx.act, ctx.kin = graph, act, kin
         ctx.in_act = in_act if (in_act is not None and in_act.active) else None
@@ -1635,7 +1607,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, act: _Act):
         x = _f32c(x)
-        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+        epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr)
         y = gemm([(x, w)], False, True, epilogue=epi)
         ctx.act = act
         ctx.save_for_backward(x, w, y if act.active else None)
@@ -1678,7 +1650,7 @@ class MLPStackFn(torch.autograd.Function):
                 y = matvec(xs[-1], w, b).reshape(-1, 1)
             else:
                 y = gemm([(xs[-1], w)], False, True,
-                         epilogue=L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed))
+                         epilogue=L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr))
             xs.append(y)
         ctx.acts, ctx.n_layers = acts, n_layers
         ctx.save_for_backward(*xs[:-1], *params)
@@ -1715,7 +1687,8 @@ class MLPStackFn(torch.autograd.Function):
 EDGE_BACKWARD = {"mode": "segment"}
 
 
-def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, compact: bool):
+def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, compact: bool,
+                          count_host: Optional[torch.Tensor] = None):
     """Everything the backward of the edge gathers needs that depends on the batch's edges alone:
     the node-sorted incidence lists, their hot-node tables and -- compact=True -- the touched-node
     compaction with its count read-back in flight.  A trainer that knows the edges before the encoder
@@ -1723,7 +1696,7 @@ def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, co
     read-back then overlap the forward pass instead of stalling the backward pass."""
     inc = Incidence(src, dst, n_nodes)
     if compact:
-        inc = inc.compact()
+        inc = inc.compact(count_host)
     inc.row_split(split_threshold(n_nodes))
     return inc
 
@@ -1747,6 +1720,8 @@ class StepThrottle:
     record_stream by recording one event on the consuming stream per block when the block is freed -- ~15 marker
     packets at the head of the next step's forward pass (profiles/r02_step_gap.txt)."""
 
+    waited_s = 0.0        # host time spent waiting here, process-wide (bench.py: host work = enqueue time - this)
+
     def __init__(self, depth: int = 2):
         import collections
         self.depth, self.events = depth, collections.deque()
@@ -1757,7 +1732,11 @@ class StepThrottle:
         self.events.append((ev, keep))
         if len(self.events) > self.depth:
             old, _ = self.events.popleft()
-            old.synchronize()
+            if not old.query():
+                import time
+                t0 = time.perf_counter()
+                old.synchronize()
+                StepThrottle.waited_s += time.perf_counter() - t0
 
 
 STEP_THROTTLE = {"depth": int(os.environ.get("PLNLP_STEP_THROTTLE", "2"))}
@@ -1778,10 +1757,13 @@ class EdgeBatch:
     stream passes True."""
 
     def __init__(self, src_parts, dst_parts, n_nodes: int, build: bool, compact: bool, overlap: bool,
-                 inputs_ready: bool = False, compact_endpoints: bool = False, record_streams: bool = True):
+                 inputs_ready: bool = False, compact_endpoints: bool = False, record_streams: bool = True,
+                 count_host: Optional[torch.Tensor] = None):
         """compact_endpoints: also src_c / dst_c = the endpoints as rows of a matrix that holds only the
-        touched nodes, and the incidence's compact column list (a row-restricted encoder output)"""
+        touched nodes, and the incidence's compact column list (a row-restricted encoder output).
+        count_host: see CompactIncidence (the batch is being built inside a hipGraph capture)"""
         self._compact_endpoints = compact_endpoints and compact
+        self._count_host = count_host
         dev = src_parts[0].device
         overlap = overlap and PROLOGUE_OVERLAP["enabled"] and dev.type == "cuda"
         self._done = None
@@ -1809,7 +1791,7 @@ class EdgeBatch:
         self.incidence = None
         self.src_c = self.dst_c = None
         if build and self.src.numel() > 0:
-            self.incidence = prepare_edge_backward(self.src, self.dst, n_nodes, compact)
+            self.incidence = prepare_edge_backward(self.src, self.dst, n_nodes, compact, self._count_host)
             if self._compact_endpoints:
                 inc = self.incidence
                 inc.prepare_compact_columns()
@@ -1988,7 +1970,7 @@ class EdgeMLPFn(torch.autograd.Function):
             last = i == n_layers - 1
             act = _Act(not last, 0.0 if last else dropout_p, training)
             acts.append(act)
-            epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed)
+            epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr)
             if i == 0:
                 y = gemm([(h, w)], False, True, epilogue=epi, a_index=[s32], a_index2=d32)
             elif last and w.shape[0] == 1:

@@ -20,7 +20,6 @@ def main():
     ap.add_argument("--cases", default="collab,uniform,ddi")
     ap.add_argument("--feat", default="256,512")
     ap.add_argument("--weighted", action="store_true")
-    ap.add_argument("--short-rows", default="auto", choices=["auto", "0", "1"])
     ap.add_argument("--tune", default="0", help="comma list of tuning flag sets (plnlp_hip.h: 4 = NT loads, 8 = fewer rows "
                                                 "in flight, 12 = both; 'halves' = two launches over column halves)")
     args = ap.parse_args()
@@ -40,16 +39,15 @@ def main():
         for feat in [int(f) for f in args.feat.split(",")]:
             x = torch.randn(g.n_cols, feat, device=dev)
             out = torch.empty(g.n_rows, feat, device=dev)
-            sr = "auto" if args.short_rows == "auto" else args.short_rows == "1"
             for tune in args.tune.split(","):
                 if tune == "halves":
                     hf = feat // 2
                     def run():
-                        P.ops.csr_aggregate(g, x[:, :hf], "mean", args.weighted, out=out[:, :hf], short_rows=sr)
-                        P.ops.csr_aggregate(g, x[:, hf:], "mean", args.weighted, out=out[:, hf:], short_rows=sr)
+                        P.ops.csr_aggregate(g, x[:, :hf], "mean", args.weighted, out=out[:, :hf])
+                        P.ops.csr_aggregate(g, x[:, hf:], "mean", args.weighted, out=out[:, hf:])
                 else:
                     def run(tv=int(tune)):
-                        P.ops.csr_aggregate(g, x, "mean", args.weighted, out=out, short_rows=sr, tune=tv)
+                        P.ops.csr_aggregate(g, x, "mean", args.weighted, out=out, tune=tv)
                 t = time_kernel(run, iters=10)
                 by = agg_bytes(g.nnz, g.n_rows, feat, args.weighted)
                 print(json.dumps({"case": case, "N": g.n_rows, "nnz": g.nnz, "max_deg": int(deg.max()), "feat": feat,

@@ -34,8 +34,6 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=3, help="timed blocks per shape; the median is reported")
-    ap.add_argument("--tail", default="env", choices=["env", "0", "1", "ab"],
-                    help="cut the last partly filled round of tiles along K (ops.GEMM_TAIL); ab = measure both")
     ap.add_argument("--math", default="env", choices=["env", "f32", "bf16x3", "ab"],
                     help="how the products are formed (ops.GEMM_MATH); ab = measure both, interleaved")
     ap.add_argument("--error", action="store_true",
@@ -63,16 +61,13 @@ def main():
             e = _lib.make_epilogue(bias=bias, relu=True, dropout_p=0.3, dropout_seed=1)
         out = torch.empty(m, n, device=dev)
         flop = 2.0 * m * n * sum(ks)
-        tails = {"env": [None], "0": [False], "1": [True], "ab": [False, True]}[args.tail]
         maths = {"env": [None], "f32": ["f32"], "bf16x3": ["bf16x3"], "ab": ["f32", "bf16x3"]}[args.math]
-        modes = [(mt, tl) for mt in maths for tl in tails]
+        modes = [(mt, None) for mt in maths]
         ts = {md: [] for md in modes}
 
         def arm(md):
             if md[0] is not None:
                 P.ops.GEMM_MATH["mode"] = md[0]
-            if md[1] is not None:
-                P.ops.GEMM_TAIL["enabled"] = md[1]
         for _ in range(args.repeats):                     # interleaved: every arm sees the same clocks
             for md in modes:
                 arm(md)
@@ -85,8 +80,6 @@ def main():
             if md[0] == "bf16x3" or (md[0] is None and P.ops.GEMM_MATH["mode"] == "bf16x3"):
                 rec["bf16_TFLOPs_executed"] = round(6 * flop / t / 1e12, 1)
                 rec["frac_of_2500"] = round(6 * flop / t / 2.5e15, 3)
-            if md[1] is not None:
-                rec["tail_cut"] = md[1]
             if args.error:
                 arm(md)
                 got = P.ops.gemm(segs, at, bt)

@@ -11,7 +11,7 @@ OBJS=$(ls $B/*.o | grep -v gemm_f32_x3.o)
 for v in $VARIANTS; do
   flag="-DABL_X3_$v"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -x hip -c plnlp_amd/csrc/gemm_f32.hip \
-      -DPLNLP_GEMM_BK=16 -DPLNLP_GEMM_X3=1 $flag -o $B/abl/x3_$v.o &
+      -DPLNLP_GEMM_BK=16 -DPLNLP_GEMM_X3=1 -DPLNLP_ABLATION $flag -o $B/abl/x3_$v.o &
 done
 wait
 for v in $VARIANTS; do

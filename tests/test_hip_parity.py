@@ -389,7 +389,7 @@ def _oracle_f64_losses(g, name, adj, N, lo, hi, w, epochs=3):
     return np.array(out)
 
 
-def test_training_trajectory_matches_reference_fixture(P, golden):
+def test_training_trajectory_matches_reference_fixture(P, golden, math):
     """plnlp_amd.BaseModel.train on the GPU vs the trajectory the REFERENCE's own
     BaseModel.train produced on CPU (fixture G8): same seeds -> same negatives and
     batches.  Epoch 1 must agree to fp32 round-off.  Later epochs are compared
@@ -420,15 +420,21 @@ def test_training_trajectory_matches_reference_fixture(P, golden):
         drift = np.abs(ref32 - ref64)
         print(f"{name}: |HIP - f64| / |f64| per epoch {np.abs(losses - ref64) / np.abs(ref64)}, "
               f"reference fp32 run {drift / np.abs(ref64)}")
-        # epochs 2, 3: free-running fp32 trajectories are chaotic here (measured, profiles/r02_trajectory_drift.txt:
-        # the reference's own fp32 run is 1e-3 / 4e-3 off exact arithmetic on sage_mlp_auc; this path 1e-4 / 7e-4
-        # with either GEMM form; on sage_mlp_whinge_noweight 1e-5 / 1e-4 with the f32 MFMA, 5e-5 / 2e-4 with the
-        # split-bf16 one, the reference 8e-9 / 5e-5).  The sharp per-step statement is the teacher-forced loop
-        # of tests/test_hip_round2.py (every step within 1e-6 of the fp64 oracle from the oracle's weights).
-        assert (np.abs(losses - ref64) <= 4 * drift + 5e-4 * np.abs(ref64)).all(), (name, losses, ref32, ref64)
+        # epochs 2, 3: free-running fp32 trajectories are chaotic here (profiles/r03_trajectory_drift.txt): after its first
+        # step Adam moves EVERY element by +-lr whatever the size of its gradient, so an element whose gradient is
+        # round-off around 0 lands 2*lr away from the exact run as soon as its sign differs -- the reference's own fp32
+        # run does that too (1e-3 / 4e-3 off exact arithmetic on sage_mlp_auc).  The bound is a small multiple of the
+        # reference's own drift plus a floor per GEMM form: 2e-5 for the f32 MFMA (an fmaf chain like the reference's
+        # sgemm; round 1's bound), 1.5e-4 for split-bf16 -- its products are fp32-grade (<= 2^-22,
+        # tests/test_hip_round2.py) but a DIFFERENT rounding of them, so MORE near-zero gradient elements of the
+        # 200-row toy differ in sign from the exact run than with the reference's own summation order
+        # (scripts/probe_drift.py counts them per step).  The sharp per-step statement is the teacher-forced loop of
+        # tests/test_hip_round2.py (every step within 1e-6 of the fp64 oracle from the oracle's weights, both forms).
+        floor = 2e-5 if math == "f32" else 1.5e-4
+        assert (np.abs(losses - ref64) <= 4 * drift + floor * np.abs(ref64)).all(), (name, math, losses, ref32, ref64)
 
 
-def test_single_step_gradients_match_oracle(P, golden):
+def test_single_step_gradients_match_oracle(P, golden, math):
     """one hot-loop iteration from identical weights: loss and EVERY gradient
     (before clipping / Adam) against the float64 oracle"""
     from tests.test_oracle import _toy_adj, build_trainer_from_g8
@@ -489,7 +495,7 @@ def test_single_step_gradients_match_oracle(P, golden):
             assert err <= 4 * yard + 2e-6 * scale + 3e-5, (name, key, err, yard, scale)
 
 
-def test_eval_path_hits_parity(P):
+def test_eval_path_hits_parity(P, math):
     """test(): encoder in eval mode, appended mean row, -1 = unseen node, Hits@K
     identical between the GPU path and the oracle on the same weights/data."""
     torch.manual_seed(5)
@@ -667,23 +673,6 @@ def test_wgrad_pair_matches_two_products(P):
     close(c, dz.double().t() @ x2.double(), atol=2e-3)
 
 
-@pytest.mark.parametrize("feat", [64, 128, 200, 256, 512])
-def test_csr_aggregate_short_row_form_matches(P, feat):
-    """several rows per wave (incidence lists, sparse graphs): same numbers as the one-row form"""
-    csr = rand_csr(3000, 4000, feat + 3, weighted=True, hub=600)      # ~1.5 entries per row + one long row
-    x = torch.randn(3000, feat, generator=torch.Generator().manual_seed(2))
-    g = to_graph(P, csr)
-    for reduce in ("sum", "mean"):
-        for use_values in (True, False):
-            ref = O.spmm(csr, x.double(), reduce, use_values)
-            a = P.ops.csr_aggregate(g, dev(x), reduce, use_values, short_rows=True)
-            b = P.ops.csr_aggregate(g, dev(x), reduce, use_values, short_rows=False)
-            close(a, ref, atol=3e-4)
-            close(a, b, atol=4e-5)       # two valid summation orders of a 600-term hub row (the forms group lanes differently)
-    assert torch.equal(P.ops.csr_aggregate(g, dev(x), "sum", True, short_rows=True),
-                       P.ops.csr_aggregate(g, dev(x), "sum", True, short_rows=True))
-
-
 def test_gcn_on_concatenated_unaligned_features_matches_oracle(P):
     """citation2 layout: input = [embedding 50 | features 128] (178 wide, not 16-byte aligned):
     the padded-buffer path must give the same outputs and gradients as torch.cat + the oracle GCN"""
@@ -856,7 +845,7 @@ def test_random_walk_bit_exact_and_valid(P):
     assert all(min(abs(v - t) for t in (1.0, 0.5, 1.0 / 3)) < 1e-6 for v in weights.unique().tolist())
 
 
-def test_hits50_training_parity_gpu_vs_oracle(P):
+def test_hits50_training_parity_gpu_vs_oracle(P, math):
     """BASELINE.json: 'Hits@K within +-0.3 of reference'.  Same seeds on both sides, a dozen epochs of
     training: Hits@50 of the HIP path tracks the CPU oracle within 0.3 points at every epoch."""
     import bench
@@ -865,7 +854,7 @@ def test_hits50_training_parity_gpu_vs_oracle(P):
     assert r["gpu_test"] > 0.0
 
 
-def test_hits20_training_parity_ddi_recipe(P):
+def test_hits20_training_parity_ddi_recipe(P, math):
     """the ddi recipe (BASELINE config 2): SAGE x2 + MLP predictor, AUC loss, 3 negatives per positive,
     Hits@20, 6 epochs from the same seeds on the GPU path, the CPU oracle (fp32) and the CPU oracle in
     float64.  With Adam this recipe is chaotic in fp32: the reference arithmetic ITSELF moves by ~1 Hits
@@ -879,7 +868,7 @@ def test_hits20_training_parity_ddi_recipe(P):
     g, c, d = (np.array(lo[k_]) for k_ in ("gpu", "cpu", "cpu64"))
     assert abs(g[0] - d[0]) <= 4 * abs(c[0] - d[0]) + 2e-3 * d[0], (g, c, d)
     assert (np.abs(g - d) <= 6 * np.abs(c - d).max() + 2e-3 * d).all(), (g, c, d)
-    # Hits@20 itself: held statistically, over seeds, in tests/test_hip_round2.py
+    # Hits@K itself: held over seeds in a TRAINED regime, tests/test_hip_round3.py::test_trained_regime_hits_parity_over_seeds
 
 
 # ------------------------------------------------- row-sparse backward pieces ----

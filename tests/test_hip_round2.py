@@ -21,6 +21,15 @@ def P():
     return plnlp_amd
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def math(request, P):
+    """both ways the dense products are formed (include/plnlp_hip.h PLNLP_GEMM_MATH_*)"""
+    old = P.ops.GEMM_MATH["mode"]
+    P.ops.GEMM_MATH["mode"] = request.param
+    yield request.param
+    P.ops.GEMM_MATH["mode"] = old
+
+
 # ------------------------------------------------------------ max aggregation ----
 @pytest.mark.parametrize("feat", [4, 32, 64, 100, 128, 200, 256, 512, 1024, 178, 7])
 @pytest.mark.parametrize("weighted", [False, True])
@@ -241,7 +250,7 @@ def test_eval_path_mrr_parity_including_ties(P, predictor):
 
 
 # ---------------------------------- the reference's loop, from the surface only ----
-def test_reference_style_loop_over_the_module_surface(P, golden):
+def test_reference_style_loop_over_the_module_surface(P, golden, math):
     """a caller that keeps the reference's own loop (model.py:147-171) -- torch
     DataLoader, `h[idx]` indexing, two predictor() calls, the loss on the two score tensors,
     torch.nn.utils.clip_grad_norm_ per module, torch.optim.Adam -- over plnlp_amd modules on the GPU,
@@ -332,41 +341,9 @@ def test_reference_style_loop_over_the_module_surface(P, golden):
         assert worst <= 1e-6, (name, worst)
 
 
-# ------------------------------------------- ddi recipe: Hits@20 over seeds ----
-def test_hits20_ddi_recipe_parity_over_seeds(P):
-    """BASELINE.json: 'Hits@K within +-0.3 of reference on ogbl-ddi'.  One fp32 trajectory of this recipe
-    (SAGE x2 + MLP, k = 3, Adam) is chaotic -- Adam turns round-off in near-zero gradients into O(lr)
-    weight moves -- so, as the reference itself does (mean +- std over 10 runs, main.py:43), the claim is
-    held over SEEDS: N_SEEDS runs on the HIP path, on the CPU oracle in fp32 (the reference's arithmetic)
-    and on the CPU oracle in float64 (exact arithmetic, the arbiter), same seeds / negatives / batches.
-
-    Measured on MI355X, 12 seeds, mean Hits@20 in points (valid, test):
-        HIP fp32 7.41, 8.80   oracle fp32 6.13, 7.84   oracle fp64 6.83, 8.53     per-seed std ~1.8
-        paired differences: HIP - fp64 = +0.43 +- 0.58 (s.e.), oracle fp32 - fp64 = -0.70 +- 0.30
-    i.e. the spread between two fp32 realisations of the SAME algorithm is ~1 point on this metric (the
-    20th-best of 10 000 negatives sets the threshold), the reference's own fp32 arithmetic sits 0.7
-    below exact arithmetic, and the HIP path is statistically on it.  A literal +-0.3 between two fp32
-    runs is therefore not a property the reference has against itself; the assertion is that the HIP
-    path's mean is within 0.3, or within one standard error, of exact arithmetic -- or at least no
-    farther from it than the reference's fp32 arithmetic is."""
-    import bench
-    n_seeds, epochs = 12, 5
-    rows = []
-    for s in range(n_seeds):
-        r = bench.hits_parity(P, torch.device("cuda"), epochs=epochs, recipe="ddi", with_f64=True, seed=s + 1)
-        assert r["metric"] == "Hits@20"
-        rows.append([0.5 * (r["gpu_valid"] + r["gpu_test"]), 0.5 * (r["cpu_valid"] + r["cpu_test"]),
-                     0.5 * (r["cpu64_valid"] + r["cpu64_test"])])
-    a = np.array(rows)
-    gpu, c32, c64 = a[:, 0], a[:, 1], a[:, 2]
-    d_gpu, d_ref = abs(gpu.mean() - c64.mean()), abs(c32.mean() - c64.mean())
-    se = np.sqrt(0.5 * (gpu.var(ddof=1) + c64.var(ddof=1)) / n_seeds)
-    print(f"Hits@20 over {n_seeds} seeds: HIP {gpu.mean():.3f} +- {gpu.std(ddof=1):.3f}, oracle fp32 {c32.mean():.3f} "
-          f"+- {c32.std(ddof=1):.3f}, oracle fp64 {c64.mean():.3f} +- {c64.std(ddof=1):.3f}; |HIP - fp64| {d_gpu:.3f}, "
-          f"|fp32 - fp64| {d_ref:.3f}, standard error {se:.3f}")
-    assert min(gpu.mean(), c32.mean(), c64.mean()) > 1.0              # all three actually learn something
-    assert d_gpu <= max(0.3, se, d_ref), (gpu, c32, c64)
-    assert abs(gpu.mean() - c32.mean()) <= 3.0 * se + d_ref + 0.3      # and no gross offset from the fp32 oracle
+# (the 12-seed Hits@20 comparison on the N = 3000 random toy that stood here was statistically toothless -- at
+# Hits@20 ~ 8 % the 20th of 10 000 negatives decides everything; it is replaced by
+# tests/test_hip_round3.py::test_trained_regime_hits_parity_over_seeds on a learnable graph, 0.3 points asserted outright)
 
 
 # ------------------------------------------------------- row-sharded encoder ----

@@ -2,6 +2,8 @@
 forward-only SAGE encoder -- against the CPU oracle, plus the full-size properties of the largest R-MAT one
 GPU holds.  Same rules as tests/test_hip_parity.py: through the C ABI, fp32 tolerance 1e-5 relative, integer
 outputs bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -310,3 +312,151 @@ def test_training_epochs_identical_with_and_without_the_streamed_permutation(P):
             M.STREAM_PERMUTATION["enabled"] = True
     assert out[True][0] == out[False][0]
     assert torch.equal(out[True][1], out[False][1])
+
+
+# ------------------------------------------------ Hits@K parity in a TRAINED regime ----
+def test_trained_regime_hits_parity_over_seeds(P, golden):
+    """BASELINE.json: "Hits@K within +-0.3 of reference".  On the learnable problem of tests/trained_parity.py
+    (stochastic block model with 10 % unrankable positives: a converged model sits at the data's ceiling of 90 % at
+    every K -- the regime of the reference's own table, README.md:7-10) both recipes are trained for 10 seeds on
+    the HIP path with BOTH GEMM forms, from the initial weights / negatives / permutations the float32 and float64
+    oracles used (their per-seed results: fixture g10, made by tests/golden/make_trained_parity.py).  Wherever the
+    float64 oracle's mean is above 50 % the HIP mean must be within 0.3 points of it -- asserted outright, for valid
+    and test, no standard-error escape."""
+    import trained_parity as T
+    g10 = golden("g10_trained_parity")
+    assert g10["problem"].tolist() == [T.PROBLEM["num_nodes"], T.PROBLEM["community"], T.PROBLEM["seed"]]
+    np.testing.assert_allclose(g10["hyper"], [T.H, T.B, T.PROBLEM["p_in"], T.PROBLEM["cross_per_node"],
+                                              T.PROBLEM["unlearnable"]])
+    seeds = g10["seeds"].tolist()
+    assert len(seeds) >= 10
+    ks = ["Hits@%d" % k for k in g10["ks"].tolist()]
+    live = os.environ.get("PLNLP_TRAINED_PARITY_LIVE") == "1"
+    g = T.problem()
+    report, checked = [], 0
+    for recipe in ("collab", "ddi"):
+        epochs = int(g10[f"{recipe}_epochs"])
+        np.testing.assert_allclose(g10[f"{recipe}_hyper"], [T.RECIPES[recipe]["lr"], T.RECIPES[recipe]["clip"], epochs])
+        tab = {"oracle_f64": g10[f"{recipe}_f64"], "oracle_f32": g10[f"{recipe}_f32"]}      # [seeds, K, (valid, test)]
+        if live:        # re-run the oracle here instead of trusting the fixture
+            for dt in ("f64", "f32"):
+                tab["oracle_" + dt] = np.array([[T.run_oracle((recipe, s, dt, epochs))[k] for k in ks] for s in seeds])
+        for math in ("bf16x3", "f32"):
+            tab["hip_" + math] = np.array([[T.run_hip(P, recipe, s, math, epochs, g)[k] for k in ks] for s in seeds])
+        report.append(f"== {recipe} recipe, {epochs} epochs, {len(seeds)} seeds")
+        report.append(T.summarize({a: {k: v[:, i] for i, k in enumerate(ks)} for a, v in tab.items()}))
+        ref = tab["oracle_f64"].mean(0)                                                      # [K, 2]
+        for math in ("bf16x3", "f32"):
+            got = tab["hip_" + math].mean(0)
+            for i, k in enumerate(ks):
+                if ref[i].min() <= 50.0:
+                    continue                      # not a trained regime at this K
+                checked += 1
+                assert np.abs(got[i] - ref[i]).max() <= 0.3, (recipe, math, k, got[i], ref[i], "\n".join(report))
+    print("\n".join(report))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "trained_parity_table.txt"), "w").write("\n".join(report) + "\n")
+    assert checked >= 4, "the problem must put at least one K per recipe and arithmetic in the trained regime"
+
+
+# ------------------------------------------------------- non-finite GEMM operands ----
+@pytest.mark.parametrize("at,bt", [(False, True), (False, False), (True, False)])
+def test_gemm_non_finite_operands(P, at, bt):
+    """include/plnlp_hip.h, PLNLP_GEMM_MATH_*: what an inf / NaN operand element does in each form.  F32: IEEE, like
+    the reference's sgemm (checked against torch's CPU fp32 matmul: same inf / NaN pattern, same signs).  BF16X3:
+    every result row fed by a non-finite element is NaN; all other rows are bit-identical to the clean product."""
+    gen = torch.Generator().manual_seed(3)
+    m, n, k = 300, 128, 64
+    a = torch.randn(m, k, generator=gen)
+    b = torch.randn(n, k, generator=gen)
+    b[:, 7] = b[:, 7].abs() + 0.1            # inf in column 7 of A meets strictly positive factors ...
+    b[3, 7] = 0.0                            # ... and one exact zero (inf * 0 = NaN)
+    bad = a.clone()
+    bad[5, 7] = float("inf")
+    bad[9, 3] = float("-inf")
+    bad[20, 1] = float("nan")
+    bad_rows = torch.tensor([5, 9, 20])
+    ref = bad @ b.t()                        # CPU fp32 reference semantics
+    A, Ab, B = a.cuda(), bad.cuda(), b.cuda()
+    if at:
+        A, Ab = A.t().contiguous(), Ab.t().contiguous()
+    Bop = B if bt else B.t().contiguous()
+    old = P.ops.GEMM_MATH["mode"]
+    try:
+        out = {}
+        for math in ("f32", "bf16x3"):
+            P.ops.GEMM_MATH["mode"] = math
+            clean = P.ops.gemm([(A, Bop)], at, bt)
+            got = P.ops.gemm([(Ab, Bop)], at, bt)
+            rest = torch.ones(m, dtype=torch.bool)
+            rest[bad_rows] = False
+            assert torch.equal(got[rest.cuda()], clean[rest.cuda()]), math          # untouched rows: same bits
+            assert bool(torch.isfinite(clean).all())
+            out[math] = got[bad_rows.cuda()].cpu()
+        want = ref[bad_rows]
+        f32 = out["f32"]
+        assert torch.equal(torch.isnan(f32), torch.isnan(want))
+        assert torch.equal(torch.isinf(f32), torch.isinf(want)) and torch.equal(f32[torch.isinf(f32)], want[torch.isinf(want)])
+        assert bool(torch.isnan(want[0, 3])) and bool(torch.isinf(want[0, 0]))     # the case really has both
+        assert bool(torch.isnan(out["bf16x3"]).all())
+    finally:
+        P.ops.GEMM_MATH["mode"] = old
+
+
+# -------------------------------------------------- the step replayed from hipGraphs ----
+@pytest.mark.parametrize("recipe", ["collab", "ddi", "citation2"])
+def test_captured_steps_are_bit_identical_to_eager_steps(P, recipe):
+    """plnlp_amd/capture.py: BaseModel.train with the step replayed from two hipGraphs (default) == the eager loop
+    (PLNLP_CAPTURE=0) to the last bit -- epoch losses AND every parameter -- over 3 epochs with dropout ON (the
+    replayed graph must draw a fresh mask per step from the seed uploaded for it), Adam's bias corrections moving,
+    a learning-rate change between epochs (adjust_lr), a partial last batch (which runs eagerly in between), and
+    touched-row counts that change from batch to batch (bucketed launches).
+    collab: SAGE x1 + DOT + WeightedHingeAUC, row-sparse forward / backward, the table's Adam in the aggregation
+    epilogue; ddi: SAGE x2 + MLP, dense backward; citation2: GCN x2 on [embedding | features] + MLP."""
+    from plnlp_amd import capture, synthetic
+    n = 3000
+    g = synthetic.make_graph("collab", seed=4, device="cpu", num_nodes=n, num_edges=20500, weighted=True)
+    data = g["data"]
+    feats = 0
+    if recipe == "citation2":
+        data.adj_t = P.gcn_normalization(g["adj_t"].to("cuda"))
+        data.x = torch.randn(n, 18, generator=torch.Generator().manual_seed(8)).cuda()
+        feats = 18
+    else:
+        data.adj_t = g["adj_t"].to("cuda")
+    split = {"train": {"edge": g["edges"]}}
+    if recipe == "collab":
+        split["train"]["weight"] = g["weight"] / 5.0
+    cfg = {"collab": ("SAGE", 1, "DOT", "WeightedHingeAUC", 1, 64, 64),
+           "ddi": ("SAGE", 2, "MLP", "AUC", 3, 64, 64),
+           "citation2": ("GCN", 2, "MLP", "AUC", 2, 40, 64)}[recipe]
+    enc, layers, pred, loss, k, emb, h = cfg
+    out = {}
+    for captured in (True, False):
+        old = dict(capture.CAPTURE)
+        capture.CAPTURE.update(enabled=captured, bucket=256)           # small buckets: several graphs get captured
+        try:
+            torch.manual_seed(9)
+            P.manual_seed(9)
+            m = P.BaseModel(lr=0.01, dropout=0.3, grad_clip_norm=1.0, gnn_num_layers=layers, mlp_num_layers=2,
+                            emb_hidden_channels=emb, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n,
+                            num_node_feats=feats, gnn_encoder_name=enc, predictor_name=pred, loss_func=loss,
+                            optimizer_name="Adam", device="cuda", use_node_feats=feats > 0, train_node_emb=True)
+            m.param_init()
+            losses = []
+            for epoch in range(3):
+                losses.append(m.train(data, split, 2048, "local", k))          # 20500 edges: 10 full batches + 1 of 20
+                P.adjust_lr(m.optimizer, (epoch + 1) / 10.0, 0.01)
+            pipe = next(iter(m._pipes.values()))
+            if captured:
+                assert pipe.captured and pipe.replays >= 20, (pipe.why_eager, pipe.replays)
+                assert sum(len(s.main) for s in pipe.slots) >= 2
+            else:
+                assert pipe.replays == 0
+            out[captured] = (losses, [p.detach().clone() for p in m.para_list])
+        finally:
+            capture.CAPTURE.update(old)
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    for a, b in zip(out[True][1], out[False][1]):
+        assert torch.equal(a, b)

@@ -13,6 +13,8 @@ import argparse
 import os
 import time
 
+# before anything initialises the HIP runtime (plnlp_amd/__init__.py explains): replayed hipGraphs need it
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import torch
 
 import plnlp_amd as P
