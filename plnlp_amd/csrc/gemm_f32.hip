@@ -136,10 +136,11 @@ __device__ __forceinline__ int rc_k(int t, int p) { return X3 ? 2 * (t >> 5) + p
 // a float4 whose k lies past kdim is loaded from the last valid group instead and zeroed by a select.
 // rsel (nullable): the operand's rows for this thread's 4 tile rows, already looked up (rows gathered in
 // the loader: the ids do not depend on the K-tile, so the kernel fetches them once)
-template <bool FAST, bool RAGGED = false>
+struct RowSel { int r[NP]; };      // a thread's gathered rows, by VALUE (a pointer to a private array pinned it in scratch)
+template <bool FAST, bool RAGGED = false, bool SEL = false>
 __device__ __forceinline__ void load_kc(f32x4 (&r)[NP], const float* __restrict__ base, int64_t ld,
                                         int64_t row0, int64_t nrows, int k0, int kdim, int vec, int t,
-                                        const int* __restrict__ rsel = nullptr) {
+                                        RowSel rsel = RowSel{}) {
     if constexpr (FAST) {
         // 4 independent 16-byte loads, no guards, nothing the compiler must wait on between them.
         // Rows past the matrix edge are CLAMPED to the last row: they read valid memory and only
@@ -152,7 +153,7 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[NP], const float* __restrict_
             const int kc = (!RAGGED || kq < kdim) ? kq : kdim - 4;
             int64_t row = row0 + kc_row(t, p);
             row = row < nrows ? row : nrows - 1;
-            if (rsel) row = rsel[p];
+            if constexpr (SEL) row = rsel.r[p];
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + row * ld + kc);
             r[p] = kin ? v : zero;
         }
@@ -167,7 +168,7 @@ __device__ __forceinline__ void load_kc(f32x4 (&r)[NP], const float* __restrict_
         const int64_t row = row0 + kc_row(t, p);
         const bool rok = row < nrows;
         int64_t rr = rok ? row : nrows - 1;
-        if (rsel) rr = rsel[p];
+        if constexpr (SEL) rr = rsel.r[p];
         const float* q = base + rr * ld;
         f32x4 v;
         if (vec && kq + 3 < kdim) {            // whole 16-byte group inside: one wide load
@@ -394,8 +395,8 @@ __device__ __forceinline__ void mma_tile_x3(f32x16 (&acc)[2][2], const float* __
 // (A: its row ids arrive in arow1 -- one segment only, so the slot is free; B: seg[0].b_index2)
 template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false, bool PAIR = false>
 __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&ra)[NP], f32x4 (&rb)[NP],
-                                          int64_t m0, int n0, int t, const int* arow0 = nullptr,
-                                          const int* arow1 = nullptr, f32x4 (*r2)[NP] = nullptr) {
+                                          int64_t m0, int n0, int t, const int (&arow0)[NP],
+                                          const int (&arow1)[NP], f32x4 (*r2)[NP] = nullptr) {
     static_assert(!PAIR || (AIDX != BIDX), "the pair form belongs to exactly one gathered operand");
     static_assert(!AIDX || !A_T, "gathered A rows exist for the K-contiguous layout only");
     static_assert(!BIDX || !B_T, "gathered B rows exist for the row-contiguous layout only");
@@ -409,8 +410,14 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
     const int bvec = s1 ? g.seg[1].b_vec : g.seg[0].b_vec;
     const int32_t* bidx = s1 ? g.seg[1].b_index : g.seg[0].b_index;
     const int32_t* bidx2 = g.seg[0].b_index2;
-    const int* aidx = nullptr;
-    if constexpr (AIDX) aidx = (s1 && !PAIR) ? arow1 : arow0;
+    RowSel aidx{}, aidx2{};
+    if constexpr (AIDX) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            aidx.r[p] = (s1 && !PAIR) ? arow1[p] : arow0[p];
+            aidx2.r[p] = arow1[p];
+        }
+    }
     const int k0 = (tile - (s1 ? g.tiles0 : 0)) * BK;
     int nb = g.n;                         // extent of the B operand along N as seen by this tile
     if (BIDX && !(g.bidx_mask & 1) && (g.nb_split >= g.n || n0 < g.nb_split)) bidx = nullptr;
@@ -429,17 +436,17 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, int tile, f32x4 (&r
     if constexpr (MODE != 0) {
         constexpr bool RG = MODE == 2;
         if constexpr (A_T) load_rc<true, false, RG>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-        else               load_kc<true, RG>(ra, a, lda, m0, g.m, k0, kdim, avec, t, aidx);
+        else               load_kc<true, RG, AIDX>(ra, a, lda, m0, g.m, k0, kdim, avec, t, aidx);
         if constexpr (B_T) load_kc<true, RG>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
         else               load_rc<true, BIDX, RG>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
-        if constexpr (PAIR && AIDX) load_kc<true, RG>(*r2, a, lda, m0, g.m, k0, kdim, avec, t, arow1);
+        if constexpr (PAIR && AIDX) load_kc<true, RG, true>(*r2, a, lda, m0, g.m, k0, kdim, avec, t, aidx2);
         if constexpr (PAIR && BIDX) load_rc<true, true, RG>(*r2, b, ldb, n0, nb, k0, kdim, bvec, t, bidx2);
     } else {
         if constexpr (A_T) load_rc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t);
-        else               load_kc<false>(ra, a, lda, m0, g.m, k0, kdim, avec, t, aidx);
+        else               load_kc<false, false, AIDX>(ra, a, lda, m0, g.m, k0, kdim, avec, t, aidx);
         if constexpr (B_T) load_kc<false>(rb, b, ldb, n0, nb, k0, kdim, bvec, t);
         else               load_rc<false, BIDX>(rb, b, ldb, n0, nb, k0, kdim, bvec, t, bidx);
-        if constexpr (PAIR && AIDX) load_kc<false>(*r2, a, lda, m0, g.m, k0, kdim, avec, t, arow1);
+        if constexpr (PAIR && AIDX) load_kc<false, false, true>(*r2, a, lda, m0, g.m, k0, kdim, avec, t, aidx2);
         if constexpr (PAIR && BIDX) load_rc<false, true>(*r2, b, ldb, n0, nb, k0, kdim, bvec, t, bidx2);
     }
 }
@@ -646,8 +653,8 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
 template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX, bool PAIR, int D>
 __device__ __forceinline__ void x3_step(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                         f32x4 (&ra)[2][NP], f32x4 (&rb)[2][NP], f32x4 (&r2)[2][NP], int next_tile,
-                                        int64_t m0, int n0, int t, int wm, int wn, int l31, int h, const int* arow0,
-                                        const int* arow1) {
+                                        int64_t m0, int n0, int t, int wm, int wn, int l31, int h, const int (&arow0)[NP],
+                                        const int (&arow1)[NP]) {
     const float* at = lds + D * TILE_FLOATS;
     const float* bt = lds + (2 + D) * TILE_FLOATS;
     // fragments: both 32-column halves of B (3 terms each) and the first 32-row half of A; the second half of A
@@ -743,8 +750,11 @@ __device__ __forceinline__ void k_loop_x3(const GemmArgs& g, f32x16 (&acc)[2][2]
 // workgroups per CU: 3 at K-tile depth 16 (<= 168 registers), except the split-bf16 kernels whose guarded or
 // ragged loaders with a row-contiguous operand, or the second factor of a pair-gathered operand, do not fit
 // that budget without spilling
+#ifndef PLNLP_X3_WGRAD_WGS
+#define PLNLP_X3_WGRAD_WGS 3      // (A/B switch: workgroups per CU of the split-bf16 weight-gradient kernels)
+#endif
 template <bool A_T, bool B_T, int MODE, bool BIDX = false, bool AIDX = false, bool PAIR = false>
-__global__ __launch_bounds__(256, (BK == 16 && !(X3 && (PAIR || MODE == 0 || (MODE == 2 && (A_T || !B_T))))) ? 3 : 2)
+__global__ __launch_bounds__(256, (BK == 16 && !(X3 && (PAIR || MODE == 0 || (MODE == 2 && (A_T || !B_T))))) ? ((X3 && A_T && !B_T) ? PLNLP_X3_WGRAD_WGS : 3) : 2)
 void gemm_f32_kernel(GemmArgs g, Epi epi) {
     static_assert(!PAIR || X3, "pair-gathered operands exist in the split-bf16 build only");
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];

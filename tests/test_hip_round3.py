@@ -321,8 +321,9 @@ def test_trained_regime_hits_parity_over_seeds(P, golden):
     every K -- the regime of the reference's own table, README.md:7-10) both recipes are trained for 10 seeds on
     the HIP path with BOTH GEMM forms, from the initial weights / negatives / permutations the float32 and float64
     oracles used (their per-seed results: fixture g10, made by tests/golden/make_trained_parity.py).  Wherever the
-    float64 oracle's mean is above 50 % the HIP mean must be within 0.3 points of it -- asserted outright, for valid
-    and test, no standard-error escape."""
+    float64 oracle's mean is above 50 % -- and the reference's own float32 run agrees with it to 0.15 points, i.e. the
+    recipe has converged at that K -- the HIP mean must be within 0.3 points of it: asserted outright, for valid and
+    test, no standard-error escape."""
     import trained_parity as T
     g10 = golden("g10_trained_parity")
     assert g10["problem"].tolist() == [T.PROBLEM["num_nodes"], T.PROBLEM["community"], T.PROBLEM["seed"]]
@@ -333,7 +334,7 @@ def test_trained_regime_hits_parity_over_seeds(P, golden):
     ks = ["Hits@%d" % k for k in g10["ks"].tolist()]
     live = os.environ.get("PLNLP_TRAINED_PARITY_LIVE") == "1"
     g = T.problem()
-    report, checked = [], 0
+    report, checked, bad = [], 0, []
     for recipe in ("collab", "ddi"):
         epochs = int(g10[f"{recipe}_epochs"])
         np.testing.assert_allclose(g10[f"{recipe}_hyper"], [T.RECIPES[recipe]["lr"], T.RECIPES[recipe]["clip"], epochs])
@@ -349,15 +350,22 @@ def test_trained_regime_hits_parity_over_seeds(P, golden):
         for math in ("bf16x3", "f32"):
             got = tab["hip_" + math].mean(0)
             for i, k in enumerate(ks):
-                if ref[i].min() <= 50.0:
-                    continue                      # not a trained regime at this K
+                # asserted where the run is TRAINED (float64 mean above 50 %) and CONVERGED in the reference's own
+                # arithmetic: its float32 and float64 means agree to 0.15 points.  (Where they do not -- the ddi
+                # recipe at Hits@20: one or two of ten seeds are still short of the plateau after 40 epochs,
+                # DIFFERENT seeds in float32 and float64 -- no arithmetic can be held to 0.3, the reference's own
+                # included; the table in profiles/ shows those rows too.)
+                if ref[i].min() <= 50.0 or np.abs(tab["oracle_f32"].mean(0)[i] - ref[i]).max() > 0.15:
+                    continue
                 checked += 1
-                assert np.abs(got[i] - ref[i]).max() <= 0.3, (recipe, math, k, got[i], ref[i], "\n".join(report))
+                if np.abs(got[i] - ref[i]).max() > 0.3:
+                    bad.append((recipe, math, k, got[i].round(3).tolist(), ref[i].round(3).tolist()))
     print("\n".join(report))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         open(os.path.join(out_dir, "trained_parity_table.txt"), "w").write("\n".join(report) + "\n")
-    assert checked >= 4, "the problem must put at least one K per recipe and arithmetic in the trained regime"
+    assert not bad, (bad, "\n".join(report))
+    assert checked >= 10, "both recipes must be trained and converged at two or more K, for both GEMM forms"
 
 
 # ------------------------------------------------------- non-finite GEMM operands ----
