@@ -646,6 +646,11 @@ def main():
         import datetime
         torch.distributed.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
         pg = torch.distributed.group.WORLD
+        # every collective the step will use, once, on a tiny tensor with a known answer -- BEFORE anything expensive:
+        # a broken fabric / environment fails here, by name, on every rank (its stderr is kept per rank by the launcher)
+        from plnlp_amd import shard as _shard
+        selftest = sorted(_shard.collective_self_test(pg, device))
+        print("rank %d: collective self-test ok: %s" % (rank, ", ".join(selftest)), file=sys.stderr, flush=True)
 
     import plnlp_amd as P
     from plnlp_amd import synthetic
@@ -697,8 +702,24 @@ def main():
     assert neg_all.shape == (need, k, 2) and neg_all.is_cuda
 
     exchange = args.dp_exchange
+    prediction = None
+    if pg is not None:
+        # which exchange form, from the cost model (plnlp_amd/shard.py::cost_model) fed with this workload's one-GPU
+        # measurements of round 3 (profiles/r03_bench_*.json); the prediction goes into the line so that the measured
+        # run can be held against it
+        from plnlp_amd import shard as _shard
+        one_gpu = {"collab": (1.58, 0.28), "ddi": (4.31, 0.01), "citation2": (29.3, 0.7)}[cfg["shape"]]
+        small = 4 * (cfg["gnn_layers"] * 3 * cfg["hidden"] * max(cfg["hidden"], cfg.get("emb", cfg["hidden"]) + feats)
+                     + (cfg["mlp_layers"] * cfg["hidden"] * cfg["hidden"] if cfg["predictor"] == "MLP" else 0))
+        prediction = _shard.cost_model(n_nodes=n, emb_width=cfg.get("emb", cfg["hidden"]), hidden=cfg["hidden"],
+                                       param_bytes_small=small, batch_per_rank=B, num_neg=k, world=world,
+                                       step_ms_1gpu=one_gpu[0], table_adam_ms=one_gpu[1],
+                                       scorer_has_params=cfg["predictor"] != "DOT")
     if exchange == "default":
-        exchange = "shard" if (pg is not None and cfg["encoder"] == "SAGE" and feats == 0) else "auto"
+        if prediction is not None and (cfg["encoder"] == "SAGE" or prediction["choice"] != "shard"):
+            exchange = prediction["choice"]
+        else:
+            exchange = "auto" if pg is None else "grads"
 
     def make_model(group, how):
         m = P.BaseModel(lr=1e-3, dropout=cfg["dropout"], grad_clip_norm=cfg["clip"],
@@ -951,6 +972,9 @@ def main():
         "negative_sampler": "%s (plnlp_amd.negative_sample, %d negatives in one call)" % (sampler, need * k),
         "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 1,
     }
+    if pg is not None:
+        result["collective_self_test"] = selftest
+        result["dp_prediction"] = prediction
     result.update(extra)
     if pg is not None:
         result["replicas_in_sync"] = model.check_replicas()

@@ -209,6 +209,20 @@ class Graph:
         return Graph(rp.contiguous(), self.col[e0:e1].contiguous(), val, n_rows,
                      self.n_cols if n_cols is None else int(n_cols))
 
+    def row_block_square(self, lo: int, n_rows: int, n_pad: int) -> "Graph":
+        """the same destination rows [lo, lo + n_rows) as row_block, but kept at their GLOBAL row positions in an
+        [n_pad, n_pad] graph whose other rows are empty.  A row-restricted conv (ops.SAGEConvFn with out_rows) on
+        it sees global row ids everywhere -- the root operand, the dropout counters, the node map of the
+        row-sparse backward -- so the sharded encoder's last layer runs the single-process kernels unchanged."""
+        hi = min(self.n_rows, lo + n_rows)
+        lo_c = min(lo, self.n_rows)
+        e0, e1 = int(self.rowptr[lo_c]), int(self.rowptr[hi])
+        rp = torch.zeros(n_pad + 1, dtype=torch.int64, device=self.device)
+        rp[lo_c + 1:hi + 1] = self.rowptr[lo_c + 1:hi + 1] - e0
+        rp[hi + 1:] = e1 - e0
+        val = None if self.val is None else self.val[e0:e1].contiguous()
+        return Graph(rp, self.col[e0:e1].contiguous(), val, n_pad, n_pad)
+
     # ---- transposed view (backward pass) --------------------------------------------
     def t(self) -> "Graph":
         if self._t is None:

@@ -117,15 +117,28 @@ class BaseGNN(torch.nn.Module):
         for conv in self.convs:
             conv.reset_parameters()
 
-    def _forward_sharded(self, x, adj_block, shard):
+    def _forward_sharded(self, x, adj_block, shard, sparse=None):
         """row-sharded pass (plnlp_amd/shard.py): x holds ALL source rows, adj_block is this rank's CSR
         slice; every conv produces the rank's S output rows, and between layers the blocks are
-        all-gathered into the next layer's source matrix (its backward reduce-scatters the gradient)."""
+        all-gathered into the next layer's source matrix (its backward reduce-scatters the gradient).
+        sparse = (adj_square, block_rows, channel, sink): the LAST conv -- a mean SAGEConv -- is evaluated only at
+        the rows of this rank's block that the global batch touches (shard.BlockRows; adj_square: the block's CSR
+        kept at global row positions, Graph.row_block_square) and returns the compact [R, out] matrix; its gradient
+        comes back row-sparse through `channel`, the gradient of x goes to `sink` when one is given.  Same kernels
+        as the single-process row-sparse step (ops.SAGEConvFn with out_rows)."""
         last = len(self.convs) - 1
         for i, conv in enumerate(self.convs):
             if not isinstance(conv, (SAGEConv, GCNConv)):
                 raise NotImplementedError("row-sharded encoder: SAGE / GCN layers")
             activated = i < last or self.num_layers == 1
+            if i == last and sparse is not None:
+                adj_square, block_rows, channel, sink = sparse
+                # masks are indexed by GLOBAL row position here: one stream for every rank, the same mask the
+                # unsharded step draws
+                act = _Act(True, self.dropout, self.training) if activated else _Act(False, 0.0, False)
+                return ops.SAGEConvFn.apply(x, conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight,
+                                            _require_graph(adj_square), act, None, sink if i == 0 else None, channel,
+                                            block_rows)
             act = _Act(True, self.dropout, self.training) if activated else None
             if act is not None and act.p > 0.0:
                 # a row is computed by exactly one rank and the mask is indexed by the row's position in
@@ -136,7 +149,7 @@ class BaseGNN(torch.nn.Module):
         return x
 
     def forward(self, x, adj_t, fuse_output_gate: bool = False, input_grad_sink=None,
-                output_grad_channel=None, shard=None, output_rows=None):
+                output_grad_channel=None, shard=None, output_rows=None, shard_sparse=None):
         """shard: a plnlp_amd.shard.ShardContext -> row-sharded pass (see _forward_sharded).
         output_rows: an ops.CompactIncidence -- the last conv produces only those rows, as a compact
         matrix (ops.SPARSE_FORWARD / "OutputRows"); needs output_grad_channel and native convs.
@@ -147,7 +160,7 @@ class BaseGNN(torch.nn.Module):
         relu+dropout result): returns (h, gate_scale) and leaves the derivative of that
         final activation to the consumer's backward (EdgeDotFn), see ops._Act."""
         if shard is not None:
-            return self._forward_sharded(x, adj_t, shard)
+            return self._forward_sharded(x, adj_t, shard, shard_sparse)
         last = len(self.convs) - 1
         out_act = None
         prev_act = None        # activation that produced the current x (native convs only)

@@ -37,6 +37,9 @@ FUSE_EMBEDDING_ADAM = {"enabled": os.environ.get("PLNLP_FUSE_EMBEDDING_ADAM", "1
 # the epoch's batch permutation shuffled a few batches ahead of the GPU by a host thread (utils.StreamedPermutation);
 # PLNLP_STREAM_PERMUTATION=0: the whole torch.randperm before the first step, as the reference's DataLoader does
 STREAM_PERMUTATION = {"enabled": os.environ.get("PLNLP_STREAM_PERMUTATION", "1") != "0"}
+# row-sharded data parallelism: the last SAGE layer evaluated / back-propagated only at the rows of the rank's block that
+# the global batch touches (PLNLP_SHARD_SPARSE=0: every row of the block)
+SHARD_SPARSE = {"enabled": os.environ.get("PLNLP_SHARD_SPARSE", "1") != "0"}
 
 
 class BaseModel(object):
@@ -175,6 +178,16 @@ class BaseModel(object):
             blk = data.adj_t.row_block(part.lo, part.rows, part.padded)
             self._blocks = {key: (data.adj_t, blk.to(self.device) if blk.device != self.device else blk)}
             hit = self._blocks[key]
+        return hit[1]
+
+    def _adj_block_square(self, data):
+        """this rank's rows of data.adj_t kept at their global positions in a padded square graph (the row-sparse last
+        layer of the sharded encoder: Graph.row_block_square); built once per graph object"""
+        hit = getattr(self, "_square_blocks", None)
+        if hit is None or hit[0] is not data.adj_t:
+            part = self._shard.part
+            sq = data.adj_t.row_block_square(part.lo, part.rows, part.padded)
+            hit = self._square_blocks = (data.adj_t, sq.to(self.device) if sq.device != self.device else sq)
         return hit[1]
 
     # ------------------------------------------------------------------ setup ---
@@ -631,12 +644,44 @@ class BaseModel(object):
         plan.finish(build_incidence=want_inc)
         lo, hi, local = plan.lo, plan.hi, plan.local
         self._table_wait()
-        x_full = sc.leaf(self._emb_shard, self._emb_full)
-        if self.use_node_feats:               # model.py:98-105 on the padded row range: [emb | x]
-            x_full = self._shard_concat_feats(x_full, data)
-        h_block = self.encoder(x_full, self._adj_block(data), shard=sc)
-        plan.join(record_streams=not self._throttled())          # (kept alive by the step throttle below instead)
-        hq = shard.ExchangeRows.apply(h_block, plan, sc.group)             # [rows my slice touches, h]
+        # the LAST layer row-sparse: only the rows of this rank's block that the global batch touches are computed
+        # (and back-propagated) -- the single-process step's touched-rows forward / row-sparse backward on the block
+        last_conv = self.encoder.convs[-1] if isinstance(self.encoder, BaseGNN) else None
+        sparse_last = (last_conv is not None and isinstance(last_conv, SAGEConv) and last_conv.aggr == "mean"
+                       and pos_edge.is_cuda and ops.SPARSE_FORWARD["enabled"] and SHARD_SPARSE["enabled"])
+        rs_work = None
+        if sparse_last:
+            plan.join(record_streams=not self._throttled())
+            channel = ops.SparseGradChannel()
+            sink = None
+            if self.encoder.num_layers == 1 and not self.use_node_feats:
+                # one layer on the table itself: the partial gradient of all N rows is finished by the transposed
+                # aggregation BEFORE the weight-gradient GEMMs are queued -- its reduce-scatter to the row owners
+                # starts there and overlaps them (ops.GradSink)
+                if getattr(self, "_emb_part_grad", None) is None:
+                    self._emb_part_grad = torch.empty_like(self._emb_full)
+                    self._emb_shard_grad = torch.empty_like(self._emb_shard)
+                box = {}
+
+                def start_reduce_scatter():
+                    box["work"] = torch.distributed.reduce_scatter_tensor(self._emb_shard_grad, self._emb_part_grad,
+                                                                          group=sc.group, async_op=True)
+                sink = ops.GradSink(self._emb_part_grad, start_reduce_scatter)
+                x_full = self._emb_full.detach().requires_grad_(True)
+            else:
+                x_full = sc.leaf(self._emb_shard, self._emb_full)
+                if self.use_node_feats:
+                    x_full = self._shard_concat_feats(x_full, data)
+            h_c = self.encoder(x_full, self._adj_block(data), shard=sc,
+                               shard_sparse=(self._adj_block_square(data), plan.block_rows, channel, sink))
+            hq = shard.ExchangeCompactRows.apply(h_c, plan, sc.group, channel)
+        else:
+            x_full = sc.leaf(self._emb_shard, self._emb_full)
+            if self.use_node_feats:               # model.py:98-105 on the padded row range: [emb | x]
+                x_full = self._shard_concat_feats(x_full, data)
+            h_block = self.encoder(x_full, self._adj_block(data), shard=sc)
+            plan.join(record_streams=not self._throttled())          # (kept alive by the step throttle below instead)
+            hq = shard.ExchangeRows.apply(h_block, plan, sc.group)             # [rows my slice touches, h]
         if local > 0:
             if want_inc:
                 out = self.predictor.score_edges(hq, plan.src_c, plan.dst_c, incidence=plan.incidence)
@@ -647,7 +692,7 @@ class BaseModel(object):
             if scale != 1.0:
                 loss = loss * scale
         else:                                    # empty slice: still take part in every exchange
-            loss = hq.sum() * 0.0 + h_block.sum() * 0.0
+            loss = hq.sum() * 0.0 + (h_c if sparse_last else h_block).sum() * 0.0
         if loss.is_cuda and loss.dtype == torch.float32 and local > 0:
             loss.backward(ops.unit_grad(loss.device))
         else:
@@ -658,6 +703,14 @@ class BaseModel(object):
                 p.grad = torch.zeros_like(p)
             small.append(p.grad)
         shard.allreduce_sum(small, sc.group)
+        if sparse_last and sink is not None:
+            if "work" in box:
+                box["work"].wait()
+                self._emb_shard.grad = self._emb_shard_grad
+            else:                               # no rank's slice touched this block's sources: nothing was queued
+                self._emb_part_grad.zero_()
+                torch.distributed.reduce_scatter_tensor(self._emb_shard_grad, self._emb_part_grad, group=sc.group)
+                self._emb_shard.grad = self._emb_shard_grad
         if self._emb_shard.grad is None:
             self._emb_shard.grad = torch.zeros_like(self._emb_shard)
         self._clip_and_step()

@@ -178,6 +178,12 @@ class ShardPlan:
             rows_v = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
             pos_v = csum - 1                                    # compact position of a flagged pair
             rows_v.index_copy_(0, pos_v.index_select(0, vid), vid)            # duplicates write the same value
+            # rows of MY block that ANY slice touches: the only rows of the encoder output anybody reads (and the only
+            # ones whose gradient is not zero) -- the row-sparse last layer of the sharded encoder computes just these
+            mine_any = flags.view(W, W, S)[:, me, :].amax(dim=0)                      # [S]
+            self._any_csum = torch.cumsum(mine_any, 0, dtype=torch.int64)
+            self._any = mine_any
+            off = torch.cat([off, self._any_csum[-1:]])                              # one more count for the host
             self._src, self._dst, self._rows_v, self._pos_v, self._off = src, dst, rows_v, pos_v, off
             # ---- the one host read-back: the count table, copied asynchronously
             self._host = self._ev = None
@@ -203,6 +209,7 @@ class ShardPlan:
         else:
             offs = self._off.tolist()
         span = W * S
+        self.block_count = offs[W * W + 1]           # rows of my block touched by the global batch
         self.count = offs[(me + 1) * W] - offs[me * W]
         self.out_splits = [offs[me * W + r + 1] - offs[me * W + r] for r in range(W)]
         self.in_splits = [offs[q * W + me + 1] - offs[q * W + me] for q in range(W)]
@@ -211,6 +218,24 @@ class ShardPlan:
             rows_v, pos_v, src, dst = self._rows_v, self._pos_v, self._src, self._dst
             segs = [rows_v[offs[q * W + me]:offs[q * W + me + 1]] for q in range(W)]
             self.send_rows = (torch.cat(segs) if W > 1 else segs[0]).remainder(S)
+            # ---- the touched rows of my block as a compact row set (global ids, increasing), padded to 32 rows
+            pad = min(part.padded, (self.block_count + 31) // 32 * 32)
+            local = torch.nonzero(self._any).reshape(-1)                               # block-local ids, sorted
+            rows_g = torch.zeros(max(pad, 1), dtype=torch.int32, device=self._dev)
+            rows_g[:self.block_count] = (local + part.lo).to(torch.int32)
+            node_map = torch.full((part.padded,), -1, dtype=torch.int32, device=self._dev)
+            node_map[part.lo:part.lo + S] = torch.where(self._any > 0, (self._any_csum - 1).to(torch.int32),
+                                                        torch.full_like(self._any, -1))
+            self.block_rows = BlockRows(rows_g[:pad], node_map, self.block_count, pad)
+            self.send_pos = node_map.index_select(0, self.send_rows + part.lo).long()  # where a sent row sits in it
+            # gradient rows coming back through the all-to-all are added per compact row in asker order: the lists
+            # of one asker are distinct rows and the askers are concatenated in rank order, so a STABLE sort by row
+            # gives that fixed order; as a CSR it is ONE deterministic aggregation launch (no per-asker loop)
+            order = torch.argsort(self.send_pos, stable=True)
+            seg = torch.zeros(pad + 1, dtype=torch.int64, device=self._dev)
+            if self.send_pos.numel():
+                torch.cumsum(torch.bincount(self.send_pos, minlength=pad), 0, out=seg[1:])
+            self.back_csr = (seg, order.to(torch.int32))
             # ---- my slice in compact coordinates
             lo, hi = self.lo, self.hi
             mine = me * span
@@ -227,7 +252,7 @@ class ShardPlan:
             if self._stream is not None:
                 self._joined = torch.cuda.Event()
                 self._joined.record()
-        self._src = self._dst = self._rows_v = self._pos_v = self._off = None
+        self._src = self._dst = self._rows_v = self._pos_v = self._off = self._any = self._any_csum = None
         self._finished = True
         return self
 
@@ -241,7 +266,8 @@ class ShardPlan:
             if not self._joined.query():
                 cur.wait_event(self._joined)
             if record_streams:
-                for t in (self.send_rows, self.src_c, self.dst_c, self.rows):
+                for t in (self.send_rows, self.src_c, self.dst_c, self.rows, self.send_pos, self.block_rows.rows,
+                          self.block_rows.node_map, self.back_csr[0], self.back_csr[1]):
                     t.record_stream(cur)
                 inc = self.incidence
                 if inc is not None:
@@ -259,6 +285,74 @@ class _NullCtx:
 
     def __exit__(self, *a):
         return False
+
+
+class BlockRows:
+    """the rows of this rank's block that the global batch touches, as ops.SAGEConvFn's `out_rows` wants them:
+    rows (int32 global ids, increasing, padded with 0 to n_rows), node_map (int32 [N padded]: compact position or
+    -1), count"""
+    __slots__ = ("rows", "node_map", "count", "n_rows")
+
+    def __init__(self, rows, node_map, count, n_rows):
+        self.rows, self.node_map, self.count, self.n_rows = rows, node_map, int(count), int(n_rows)
+
+
+class _BackRows:
+    """the gradient rows returned by the all-to-all as a CSR over compact rows (ShardPlan.back_csr): what
+    ops.csr_aggregate walks to add them in fixed order"""
+
+    def __init__(self, seg, order, n_src):
+        self.rowptr, self.col, self.val, self.val_index = seg, order, None, None
+        self.n_rows, self.n_cols = seg.numel() - 1, int(n_src)
+        self._split = None
+
+    def row_split(self, threshold: int):
+        if self._split is None:
+            from .graph import RowSplit
+            self._split = RowSplit(self.rowptr, self.col.numel(), threshold)
+        return self._split
+
+
+class ExchangeCompactRows(torch.autograd.Function):
+    """ExchangeRows over a ROW-RESTRICTED encoder output: h_c [R, h] holds only the rows of this rank's block that
+    the global batch touches (plan.block_rows); the rows each asker wants are gathered from it by position
+    (plan.send_pos).  Backward: the returned gradient rows are added per compact row in asker order by ONE
+    deterministic segmented aggregation and handed to the conv's backward ROW-SPARSE through `channel` -- the dense
+    [S, h] gradient block of the plain form (and its zero fill, and its per-asker index_add_ launches) never exists."""
+
+    @staticmethod
+    def forward(ctx, h_c, plan: "ShardPlan", group, channel):
+        ctx.plan, ctx.group, ctx.channel = plan, group, channel
+        ctx.set_materialize_grads(False)
+        send = h_c.index_select(0, plan.send_pos)
+        recv = torch.empty(plan.count, h_c.shape[1], dtype=h_c.dtype, device=h_c.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=plan.out_splits, input_split_sizes=plan.in_splits,
+                               group=group)
+        return recv
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        br = plan.block_rows
+        if g is None:
+            return None, None, None, None
+        g = g.contiguous()
+        back = torch.empty(plan.send_pos.numel(), g.shape[1], dtype=g.dtype, device=g.device)
+        dist.all_to_all_single(back, g, output_split_sizes=plan.in_splits, input_split_sizes=plan.out_splits,
+                               group=ctx.group)
+        if back.is_cuda and back.dtype == torch.float32 and back.shape[0] > 0:
+            from . import ops
+            vals = ops.csr_aggregate(_BackRows(plan.back_csr[0], plan.back_csr[1], back.shape[0]), back, "sum", False)
+        else:                                   # host path of the gloo tests: the same fixed order, spelled out
+            vals = torch.zeros(br.n_rows, g.shape[1], dtype=g.dtype, device=g.device)
+            at = 0
+            for c in plan.in_splits:
+                if c:
+                    vals.index_add_(0, plan.send_pos[at:at + c], back[at:at + c])
+                at += c
+        from .ops import RowSparseGrad
+        ctx.channel.grad = RowSparseGrad(br.rows, br.node_map, vals, br.node_map.numel(), br.count)
+        return None, None, None, None
 
 
 class ExchangeRows(torch.autograd.Function):
@@ -390,3 +484,37 @@ def collective_self_test(group, device) -> dict:
     dist.barrier(group=group)
     done["barrier"] = True
     return done
+
+
+def cost_model(*, n_nodes: int, emb_width: int, hidden: int, param_bytes_small: int, batch_per_rank: int, num_neg: int,
+               world: int, step_ms_1gpu: float, table_adam_ms: float, scorer_has_params: bool,
+               bus_GBps: float = 300.0) -> dict:
+    """PREDICTED ms per step of the three exchange forms at `world` ranks (weak scaling: every rank brings
+    batch_per_rank positives) -- a model to hold a measured SCALE run against, not a measurement.
+    Inputs that are measurements: step_ms_1gpu (this workload's one-GPU step), table_adam_ms (Adam over the whole
+    embedding table).  Assumptions: RCCL ring collectives at `bus_GBps` bus bandwidth on the xGMI mesh (all-gather /
+    reduce-scatter move bytes * (W-1)/W per rank, all-reduce twice that); the one-GPU step grows by 17 % per extra
+    batch-equivalent when ONE GPU back-propagates W batches (measured on collab: 3.49 ms at 8x vs 1.60 ms);
+    0.3 ms of a step is per-step fixed cost that does not shrink with W."""
+    W = max(1, int(world))
+    table = n_nodes * emb_width * 4
+    frac = (W - 1) / W
+    ag = table * frac / (bus_GBps * 1e9) * 1e3
+    fixed = min(0.3, 0.5 * step_ms_1gpu)
+    out = {}
+    # replicated encoder, SUM all-reduce of every gradient
+    # (+ the table's Adam as its own launch: the in-epilogue update of the one-process step needs the REDUCED gradient;
+    #  half of the all-reduce hidden behind the weight-gradient GEMMs)
+    out["grads"] = (step_ms_1gpu + 0.4 * table_adam_ms
+                    + 2 * (table + param_bytes_small) * frac / (bus_GBps * 1e9) * 1e3 * 0.5)
+    # replicated encoder, every rank back-propagates the global batch (parameter-free scorer only)
+    if not scorer_has_params:
+        out["scores"] = step_ms_1gpu * (1.0 + 0.17 * (W - 1))
+    # row-sharded encoder: blocks of rows, table all-gather + gradient reduce-scatter, touched rows by all-to-all
+    touched = n_nodes * (1.0 - pow(2.718281828, -2.0 * batch_per_rank * (1 + num_neg) / n_nodes))      # per slice
+    rows_ms = 2 * touched * hidden * 4 * frac / (bus_GBps * 1e9) * 1e3
+    compute = fixed + (step_ms_1gpu * (1.0 + 0.17 * (W - 1)) - fixed - table_adam_ms) / W + table_adam_ms / W
+    out["shard"] = compute + 2 * ag * 0.75 + rows_ms          # a quarter of the table traffic hidden behind compute
+    best = min(out, key=out.get)
+    return {"ms_per_step_predicted": out, "choice": best, "world": W,
+            "assumptions": "ring collectives at %.0f GB/s bus bandwidth; see plnlp_amd/shard.py::cost_model" % bus_GBps}

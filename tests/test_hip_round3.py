@@ -468,3 +468,54 @@ def test_captured_steps_are_bit_identical_to_eager_steps(P, recipe):
     assert out[True][0] == out[False][0], (out[True][0], out[False][0])
     for a, b in zip(out[True][1], out[False][1]):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------- row-sparse last layer of the sharded encoder ----
+@pytest.mark.parametrize("layers,pred,loss,k", [(1, "DOT", "WeightedHingeAUC", 1), (2, "MLP", "AUC", 3)])
+def test_sharded_step_row_sparse_last_layer_equals_dense_block_step(P, layers, pred, loss, k):
+    """dp_exchange='shard' through a 1-rank RCCL group (every collective runs): with the last SAGE layer evaluated and
+    back-propagated only at the rows of the block that the batch touches (ExchangeCompactRows, shard.BlockRows,
+    the table gradient's reduce-scatter started from the GradSink) the epoch losses and the table equal the dense
+    block step's (PLNLP_SHARD_SPARSE=0) to fp32 round-off, and both track the plain single-process trainer."""
+    import torch.distributed as dist
+    from test_sharded_encoder import _free_port
+    from plnlp_amd import model as M, synthetic
+    n, h, B = 2500, 64, 1024
+    g = synthetic.make_graph("collab", seed=6, device="cpu", num_nodes=n, num_edges=15000, weighted=True)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        def run(pg, exchange, sparse):
+            M.SHARD_SPARSE["enabled"] = sparse
+            m = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=1.0, gnn_num_layers=layers, mlp_num_layers=2,
+                            emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n,
+                            num_node_feats=0, gnn_encoder_name="SAGE", predictor_name=pred, loss_func=loss,
+                            optimizer_name="Adam", device="cuda", use_node_feats=False, train_node_emb=True,
+                            process_group=pg, dp_exchange=exchange)
+            torch.manual_seed(41)
+            m.param_init()
+            data = g["data"]
+            data.adj_t = g["adj_t"].to("cuda")
+            split = {"train": {"edge": g["edges"]}}
+            if loss.startswith("Weighted"):
+                split["train"]["weight"] = g["weight"] / 5.0
+            out = []
+            for epoch in range(2):
+                torch.manual_seed(70 + epoch)
+                out.append(m.train(data, split, B, "local", k))
+            return np.array(out), m
+        try:
+            l_sparse, m_sparse = run(dist.group.WORLD, "shard", True)
+            l_dense, m_dense = run(dist.group.WORLD, "shard", False)
+        finally:
+            M.SHARD_SPARSE["enabled"] = True
+        l_plain, m_plain = run(None, "auto", True)
+        assert (getattr(m_sparse, "_emb_part_grad", None) is not None) == (layers == 1)       # the sink path ran
+        assert getattr(m_dense, "_emb_part_grad", None) is None
+        close(l_sparse, l_dense, rtol=2e-5)
+        close(l_sparse, l_plain, rtol=2e-4)
+        close(m_sparse.emb.weight, m_dense.emb.weight, rtol=1e-3, atol=2e-2)       # Adam: O(lr) on round-off-zero grads
+        assert m_sparse.check_replicas()
+    finally:
+        dist.destroy_process_group()

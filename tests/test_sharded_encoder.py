@@ -199,3 +199,115 @@ def test_shard_plan_lists_exactly_the_touched_rows():
             seg_lo = sum(plans[r].in_splits[:q])
             got = plans[r].send_rows[seg_lo:seg_lo + plans[r].in_splits[q]] + r * S
             assert torch.equal(got, touched[(touched >= r * S) & (touched < (r + 1) * S)])
+
+
+def test_shard_plan_block_rows_and_gradient_order():
+    """the row-sparse last layer's index structures (ShardPlan.block_rows / send_pos / back_csr): the touched rows of
+    every rank's block == the union over ALL slices of the endpoints that fall into the block; send_pos addresses
+    them in the compact matrix; the gradient rows returning through the all-to-all are added per compact row in
+    asker order (a fixed order: the CSR lists, per row, the positions in the returned buffer with askers increasing)"""
+    from plnlp_amd.shard import RowPartition, ShardPlan
+    g = torch.Generator().manual_seed(11)
+    n_nodes, W, n, k = 203, 4, 61, 2
+    pos = torch.randint(0, n_nodes, (n, 2), generator=g)
+    neg = torch.randint(0, n_nodes, (n * k, 2), generator=g)
+    per = (n + W - 1) // W
+    everything = torch.unique(torch.cat([pos.reshape(-1), neg.reshape(-1)]))
+    for r in range(W):
+        part = RowPartition(n_nodes, W, r)
+        p = ShardPlan(part, pos, neg, k, per).finish()
+        br = p.block_rows
+        mine = everything[(everything >= part.lo) & (everything < part.lo + part.rows)]
+        assert br.count == mine.numel() and br.n_rows % 32 == 0 or br.n_rows == part.padded
+        assert torch.equal(br.rows[:br.count].long(), mine) and bool((br.rows[br.count:] == 0).all())
+        want_map = torch.full((part.padded,), -1, dtype=torch.int32)
+        want_map[mine] = torch.arange(mine.numel(), dtype=torch.int32)
+        assert torch.equal(br.node_map, want_map)
+        assert torch.equal(br.rows[p.send_pos].long(), p.send_rows + part.lo)          # positions address the sent rows
+        seg, order = p.back_csr
+        assert seg.numel() == br.n_rows + 1 and int(seg[-1]) == p.send_pos.numel()
+        asker_of = torch.repeat_interleave(torch.arange(W), torch.tensor(p.in_splits))
+        for c in range(br.n_rows):
+            items = order[seg[c]:seg[c + 1]].long()
+            assert bool((p.send_pos[items] == c).all())
+            a = asker_of[items]
+            assert bool((a[1:] > a[:-1]).all())                # one entry per asker, askers increasing
+
+
+class _CompactRowsFn(torch.autograd.Function):
+    """stand-in for the row-restricted last conv in the CPU test: rows `block_rows` of the rank's block of a shared
+    parameter; its gradient arrives row-sparse through the channel, like ops.SAGEConvFn's"""
+
+    @staticmethod
+    def forward(ctx, table, block_rows, channel):
+        ctx.block_rows, ctx.channel, ctx.shape = block_rows, channel, table.shape
+        ctx.set_materialize_grads(False)
+        return table.index_select(0, block_rows.rows.long())
+
+    @staticmethod
+    def backward(ctx, gy):
+        sg = ctx.channel.take()
+        br = ctx.block_rows
+        out = torch.zeros(ctx.shape, dtype=sg.values.dtype)
+        out.index_add_(0, br.rows[:br.count].long(), sg.values[:br.count])
+        return out, None, None
+
+
+def _compact_exchange_rank(rank, world, port, out_q):
+    from plnlp_amd import ops
+    from plnlp_amd.shard import ExchangeCompactRows, RowPartition, ShardPlan
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    n_nodes, n, k, h = 77, 40, 2, 6
+    pos = torch.randint(0, n_nodes, (n, 2), generator=g)
+    neg = torch.randint(0, n_nodes, (n * k, 2), generator=g)
+    table = torch.randn(n_nodes, h, generator=g, dtype=torch.float64)
+    coef = torch.randn(n * (1 + k), generator=g, dtype=torch.float64)
+    part = RowPartition(n_nodes, world, rank)
+    per = (n + world - 1) // world
+    plan = ShardPlan(part, pos, neg, k, per).finish()
+    full = torch.zeros(part.padded, h, dtype=torch.float64)
+    full[:n_nodes] = table
+    full.requires_grad_(True)
+    channel = ops.SparseGradChannel()
+    h_c = _CompactRowsFn.apply(full, plan.block_rows, channel)
+    hq = ExchangeCompactRows.apply(h_c, plan, dist.group.WORLD, channel)
+    lo, hi = plan.lo, plan.hi
+    c_loc = torch.cat([coef[lo:hi], coef[n + lo * k:n + hi * k]])
+    score = (hq[plan.src_c] * hq[plan.dst_c]).sum(-1)
+    loss = (c_loc * score * score).sum()
+    loss.backward()
+    grad = full.grad.clone()
+    dist.all_reduce(grad)                     # every rank's partial (non-zero only inside its own block)
+    loss_all = loss.detach().clone()
+    dist.all_reduce(loss_all)
+    out_q.put((rank, float(loss_all), grad[:n_nodes].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compact_row_exchange_two_ranks_equal_one_process():
+    """ExchangeCompactRows over gloo, world 2: loss and d loss / d table == the one-process computation (float64)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_compact_exchange_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(5)
+    n_nodes, n, k, h = 77, 40, 2, 6
+    pos = torch.randint(0, n_nodes, (n, 2), generator=g)
+    neg = torch.randint(0, n_nodes, (n * k, 2), generator=g)
+    table = torch.randn(n_nodes, h, generator=g, dtype=torch.float64).requires_grad_(True)
+    coef = torch.randn(n * (1 + k), generator=g, dtype=torch.float64)
+    src, dst = torch.cat([pos[:, 0], neg[:, 0]]), torch.cat([pos[:, 1], neg[:, 1]])
+    score = (table[src] * table[dst]).sum(-1)
+    loss = (coef * score * score).sum()
+    loss.backward()
+    for rank, l, gr in res:
+        np.testing.assert_allclose(l, float(loss), rtol=1e-12)
+        np.testing.assert_allclose(gr, table.grad.numpy(), rtol=1e-10, atol=1e-12)
