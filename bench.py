@@ -493,6 +493,20 @@ def measure_step_launches(P, model, data, pos_b, neg_b, cfg, device):
                 "that stream is HBM traffic; the %d gathered gradient rows (%.0f MiB) are cache-resident" %
                 (src_mib, T, Tp * F * 4 / 2 ** 20)}
     out["touched_fraction"] = T / float(n)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            for key, obj in (("step_collab_fwd_agg", "roofline_workload_agg"), ("step_collab_agg_adam", "roofline_agg_adam")):
+                if tj.get(key) is not None and cfg["shape"] == "collab":
+                    out[obj]["traffic_from_profile"] = {
+                        "bytes": tj[key], "file": "profiles/traffic.json",
+                        "ratio_to_algorithmic": tj[key] / out[obj]["algorithmic_bytes"],
+                        "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/bench_step_launches.py (the same "
+                               "launch on a real batch; counted on the fabric side of L2, so Infinity-Cache hits are "
+                               "included; an earlier run, NOT measured in this one)"}
+        except Exception:
+            pass
     return out
 
 
@@ -673,7 +687,7 @@ def main():
     if feats:
         data.x = torch.randn(n, feats, device=device, generator=torch.Generator(device=device).manual_seed(5))
     gen = torch.Generator(device=device).manual_seed(777)
-    need = (K + W) * B * world
+    need = max(K + W, 40) * B * world          # (the side measurements -- other arithmetic, captured loop -- take up to 36 steps)
     if cfg["shape"] == "collab":      # random-walk augmented pairs, main.py:241-253
         starts = g["edges"].reshape(-1)
         reps = (need // (starts.numel() * 9)) + 1
@@ -834,7 +848,7 @@ def main():
             other = not capture_info["default_path_captured"]
             capture_flag[0] = other
             try:
-                Kc, Wc = max(10, min(K, 20)), 10
+                Kc, Wc = max(10, min(K, 20)), 16          # (every bucket's graph captured before the timed steps)
                 n_before = len(host_busy_s)
                 dtc, _ = timed_steps(model, dp_mode, 1, B, 0, K=Kc, W=Wc)
                 po = last_pipe[0]
