@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PLNLP_ABI_VERSION 7
+#define PLNLP_ABI_VERSION 8
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -116,6 +116,15 @@ typedef struct plnlp_row_split {
     const int32_t* chunk_long;       /* [n_chunks] slot in long_rows owning the chunk, -1 = idle */
     float*         workspace;        /* [n_chunks, feat], 16-byte aligned                 */
     int64_t        workspace_floats;
+    /* optional (all three or none; plnlp_csr_aggregate_f32 only) -- EXPLICIT chunks, processed in table order:
+     * chunk c covers entries [seg_beg[c], seg_beg[c] + seg_len[c]) of col / val and adds into workspace slot
+     * seg_slot[c] (-1 = idle); the slots of long row l are chunk_beg[l] .. chunk_beg[l] + chunk_cnt[l] - 1 as
+     * before, so the partial sums of a row are still added in slot order.  Lets the caller cut hub rows by SOURCE
+     * RANGE and order the chunks range-major (plnlp_amd/graph.py::SourceOrderedSplit): waves that run together
+     * then gather from the same few thousand source rows.  chunk_long is not read in this form. */
+    const int64_t* seg_beg;
+    const int32_t* seg_len;
+    const int32_t* seg_slot;
 } plnlp_row_split;
 
 /* Build the tables above on the device (no host sync): capacities are upper bounds
@@ -141,6 +150,12 @@ int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int64_t thresho
 #define PLNLP_AGG_SLABS_128 16    /* flags: one wave per (row, 128-column slab) instead of one per row: more    */
 #define PLNLP_AGG_SLABS_256 32    /* (256-column slab) independent gather chains in flight -- for a source matrix
                                      far beyond the caches (HBM-bound); not combined with a dropout epilogue  */
+#define PLNLP_AGG_SLABS_XCD 64    /* flags: eight feat/8-column slabs, slab = workgroup id mod 8 -> pinned to the XCD
+                                     the workgroup lands on (F = 256 / 512 / 1024): each XCD's L2 sees an eighth of
+                                     every source row -- for a source matrix the Infinity Cache holds but one L2
+                                     does not; not combined with a dropout epilogue                            */
+#define PLNLP_AGG_HUB_XCD 128     /* flags: the same pinned slabs for the LONG rows' chunk pass only (the main pass
+                                     keeps one full-width wave per row)                                        */
 int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                             const float* val,        /* nullable: [nnz], or indexed through val_index */
                             const int32_t* val_index,/* nullable: [nnz]; weight of entry e = val[val_index[e]] */

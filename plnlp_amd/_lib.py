@@ -35,7 +35,8 @@ class RowSplit(C.Structure):
     """mirror of plnlp_row_split"""
     _fields_ = [("threshold", C.c_int64), ("n_long", C.c_int64), ("long_rows", C.c_void_p),
                 ("chunk_beg", C.c_void_p), ("chunk_cnt", C.c_void_p), ("n_chunks", C.c_int64),
-                ("chunk_long", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
+                ("chunk_long", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
+                ("seg_beg", C.c_void_p), ("seg_len", C.c_void_p), ("seg_slot", C.c_void_p)]
 
 
 class GemmOperand(C.Structure):
@@ -61,6 +62,8 @@ AGG_NT_LOADS = 4
 AGG_FEW_IN_FLIGHT = 8
 AGG_SLABS_128 = 16
 AGG_SLABS_256 = 32
+AGG_SLABS_XCD = 64
+AGG_HUB_XCD = 128
 LOSS_KINDS = {"auc": 0, "hinge_auc": 1, "weighted_auc": 2, "adaptive_auc": 3,
               "weighted_hinge_auc": 4, "adaptive_hinge_auc": 5, "log_rank": 6}
 
@@ -159,7 +162,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.plnlp_abi_version() != 7:
+    if lib.plnlp_abi_version() != 8:
         raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

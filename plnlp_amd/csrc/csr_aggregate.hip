@@ -92,7 +92,13 @@ __device__ __forceinline__ void agg_chunk(float4 (&acc)[VPL], const float* __res
     }
 }
 
-// accumulate edges [beg, end) of one row into acc (wave-cooperative)
+// accumulate edges [beg, end) of one row into acc (wave-cooperative).
+// The entries go in batches of 64 (one index per lane).  A batch is a chain of dependent round trips: index ->
+// (source map ->) gathered rows; a long row or chunk repeats it per batch.  The NEXT batch's indices (and weight
+// positions) are therefore requested before this batch's rows -- they arrive while the rows are in flight -- and the
+// weights that hang off the indices (val[val_index[e]], src_scale[col]) are requested at the head of the batch, ahead
+// of the rows, so that the wave waits for them with the rows still outstanding: one round trip per batch instead of
+// two to four (measured on the collab hub pass, profiles/r03_agg_hub_pass.md).
 template <int VPL, int LPR, bool WEIGHTED, int CHX = 0, bool NT = false>
 __device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64_t end,
                                           const int32_t* __restrict__ col, const float* __restrict__ val,
@@ -101,17 +107,41 @@ __device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64
                                           int64_t ldx, int lane, int sub, int grp, int nslots) {
     constexpr int NG = 64 / LPR;
     constexpr int CH = CHX > 0 ? CHX : ((VPL >= 4) ? 4 : 8);     // neighbour rows in flight per wave
+    if (beg >= end) return;
+    int n = (int)((end - beg) < 64 ? (end - beg) : 64);
+    int cvec = 0, vidx = 0;
+    float wraw = 1.f;
+    if (lane < n) {
+        cvec = col[beg + lane];
+        if constexpr (WEIGHTED) {
+            if (val && val_index) vidx = val_index[beg + lane];
+            else if (val) wraw = val[beg + lane];
+        }
+    }
     for (int64_t e0 = beg; e0 < end; e0 += 64) {
-        int n = (int)((end - e0) < 64 ? (end - e0) : 64);
-        int cvec = 0;
+        // ---- the next batch's indices: requested now, consumed at the bottom
+        const int64_t e1 = e0 + 64;
+        int n_next = 0, c_next = 0, vidx_next = 0;
+        float wraw_next = 1.f;
+        if (e1 < end) {
+            n_next = (int)((end - e1) < 64 ? (end - e1) : 64);
+            if (lane < n_next) {
+                c_next = col[e1 + lane];
+                if constexpr (WEIGHTED) {
+                    if (val && val_index) vidx_next = val_index[e1 + lane];
+                    else if (val) wraw_next = val[e1 + lane];
+                }
+            }
+        }
+        // ---- this batch's weights (they hang off indices that have arrived)
         float wvec = 0.f;
-        if (lane < n) {
-            cvec = col[e0 + lane];
-            if constexpr (WEIGHTED) {
-                wvec = val ? val[val_index ? (int64_t)val_index[e0 + lane] : e0 + lane] : 1.f;
+        if constexpr (WEIGHTED) {
+            if (lane < n) {
+                wvec = (val && val_index) ? val[vidx] : wraw;
                 if (src_scale) wvec *= src_scale[cvec];
             }
         }
+        bool any = true;
         if (src_map) {   // wave-uniform
             // x holds only the mapped source rows: translate the 64 indices and squeeze the entries
             // without a row to the back with one lane permutation (order of the rest kept, so the
@@ -128,39 +158,42 @@ __device__ __forceinline__ void agg_range(float4 (&acc)[VPL], int64_t beg, int64
             cvec = cvec < 0 ? 0 : cvec;      // lanes past nv: a loadable row (ragged lane groups still issue the load)
             if constexpr (WEIGHTED) wvec = __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(wvec)));
             n = nv;
-            if (n == 0) continue;
+            any = n > 0;
         }
-        const int ngroups = (n + NG - 1) / NG;  // wave instructions needed
-        for (int j = 0; j < ngroups; j += CH) {
-            const int m = (ngroups - j) < CH ? (ngroups - j) : CH;
-            if constexpr (NG == 1) {
-                agg_chunk<VPL, LPR, CH, WEIGHTED, NT>(acc, x, ldx, cvec, wvec, j, m, sub, grp, nslots);
-            } else {
-                // a lane group whose neighbour index runs past n must contribute nothing
-                // (not even 0*x: x may hold inf): complete groups first, the ragged one under a select.
-                const int full = (n / NG);
-                if (j + m <= full) {
-                    agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j * NG, m, sub, grp, nslots);
+        if (any) {
+            const int ngroups = (n + NG - 1) / NG;  // wave instructions needed
+            for (int j = 0; j < ngroups; j += CH) {
+                const int m = (ngroups - j) < CH ? (ngroups - j) : CH;
+                if constexpr (NG == 1) {
+                    agg_chunk<VPL, LPR, CH, WEIGHTED, NT>(acc, x, ldx, cvec, wvec, j, m, sub, grp, nslots);
                 } else {
-                    const int mfull = full - j > 0 ? full - j : 0;
-                    if (mfull > 0)
-                        agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j * NG, mfull, sub, grp, nslots);
-                    const int jl = (j + mfull) * NG;  // first neighbour of the ragged group
-                    if (jl < n) {
-                        float4 part[VPL];
+                    // a lane group whose neighbour index runs past n must contribute nothing
+                    // (not even 0*x: x may hold inf): complete groups first, the ragged one under a select.
+                    const int full = (n / NG);
+                    if (j + m <= full) {
+                        agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j * NG, m, sub, grp, nslots);
+                    } else {
+                        const int mfull = full - j > 0 ? full - j : 0;
+                        if (mfull > 0)
+                            agg_chunk<VPL, LPR, CH, WEIGHTED>(acc, x, ldx, cvec, wvec, j * NG, mfull, sub, grp, nslots);
+                        const int jl = (j + mfull) * NG;  // first neighbour of the ragged group
+                        if (jl < n) {
+                            float4 part[VPL];
 #pragma unroll
-                        for (int k = 0; k < VPL; ++k) part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        agg_chunk<VPL, LPR, 1, WEIGHTED>(part, x, ldx, cvec, wvec, jl, 1, sub, grp, nslots);
-                        const bool ok = (jl + grp) < n;
+                            for (int k = 0; k < VPL; ++k) part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            agg_chunk<VPL, LPR, 1, WEIGHTED>(part, x, ldx, cvec, wvec, jl, 1, sub, grp, nslots);
+                            const bool ok = (jl + grp) < n;
 #pragma unroll
-                        for (int k = 0; k < VPL; ++k) {
-                            acc[k].x += ok ? part[k].x : 0.f; acc[k].y += ok ? part[k].y : 0.f;
-                            acc[k].z += ok ? part[k].z : 0.f; acc[k].w += ok ? part[k].w : 0.f;
+                            for (int k = 0; k < VPL; ++k) {
+                                acc[k].x += ok ? part[k].x : 0.f; acc[k].y += ok ? part[k].y : 0.f;
+                                acc[k].z += ok ? part[k].z : 0.f; acc[k].w += ok ? part[k].w : 0.f;
+                            }
                         }
                     }
                 }
             }
         }
+        n = n_next; cvec = c_next; vidx = vidx_next; wraw = wraw_next;
     }
 }
 
@@ -255,10 +288,20 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
     int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, int64_t row_base, int slab_feat,
-    const int32_t* __restrict__ row_index) {
+    const int32_t* __restrict__ row_index, int xcd_slabs) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t r = row_base + (int64_t)blockIdx.x * 4 + wave;
+    int64_t bx = blockIdx.x;
+    int slab = blockIdx.y;
+    if (xcd_slabs > 0) {
+        // slabs PINNED to the XCDs: consecutive workgroups go round-robin to the 8 XCDs, so with the slab as the fastest
+        // index XCD k only ever gathers columns [k * slab_feat, (k + 1) * slab_feat) of the source rows -- its 4 MiB L2
+        // then serves an eighth of the matrix (8x the source rows stay resident), and a source row piece crosses the
+        // fabric once per launch at best instead of once per XCD that meets it
+        slab = (int)(bx % xcd_slabs);
+        bx /= xcd_slabs;
+    }
+    const int64_t r = row_base + bx * 4 + wave;
     if (r >= n_rows) return;
     const int64_t rg = row_index ? (int64_t)row_index[r] : r;      // CSR row behind result row r
     const int sub = lane % LPR, grp = lane / LPR;
@@ -269,7 +312,7 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
         // a ~20-neighbour row is fetched in one or two batches instead of three, and there are
         // feat/slab_feat times as many independent chains in flight (the index lists are re-read per
         // slab: 4 bytes per 512).  No dropout epilogue here (its counter is the full-width column).
-        const int c0 = blockIdx.y * slab_feat;
+        const int c0 = slab * slab_feat;
         x += c0;
         out += c0;
         if (epi.bias) epi.bias += c0;
@@ -415,6 +458,11 @@ struct SplitArgs {
     int64_t n_chunks;
     const int32_t* chunk_long;
     float* ws;
+    // explicit chunks (plnlp_row_split.seg_*): chunk c = entries [seg_beg[c], seg_beg[c] + seg_len[c]), partial sum to
+    // workspace slot seg_slot[c]; processed in table order (the caller's order: by source range)
+    const int64_t* seg_beg;
+    const int32_t* seg_len;
+    const int32_t* seg_slot;
 };
 
 template <int VPL, int LPR, bool WEIGHTED>
@@ -422,26 +470,38 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
-    const float* __restrict__ x, int64_t ldx, int feat, SplitArgs sp, int slab_feat) {
+    const float* __restrict__ x, int64_t ldx, int feat, SplitArgs sp, int slab_feat, int xcd_slabs,
+    int64_t chunk_base) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+    int64_t bx = blockIdx.x;
+    int slab = blockIdx.y;
+    if (xcd_slabs > 0) { slab = (int)(bx % xcd_slabs); bx /= xcd_slabs; }   // see csr_agg_vec_kernel
+    const int64_t c = chunk_base + bx * 4 + wave;
     if (c >= sp.n_chunks) return;
     const int feat_full = feat;
     int c0 = 0;
     if (slab_feat > 0) {          // feature slab of this block (see csr_agg_vec_kernel): columns [c0, c0 + slab_feat)
-        c0 = blockIdx.y * slab_feat;
+        c0 = slab * slab_feat;
         x += c0;
         feat = (feat - c0) < slab_feat ? (feat - c0) : slab_feat;
     }
-    const int l = sp.chunk_long[c];
-    if (l < 0) return;                 // idle chunk slot
-    const int64_t r = sp.long_rows[l];
-    if (r < 0) return;
-    const int64_t j = c - sp.chunk_beg[l];
-    const int64_t rb = rowptr[r], re = rowptr[r + 1];
-    const int64_t beg = rb + j * sp.threshold;
-    const int64_t end = (beg + sp.threshold) < re ? (beg + sp.threshold) : re;
+    int64_t beg, end, slot = c;
+    if (sp.seg_beg) {
+        beg = sp.seg_beg[c];
+        end = beg + sp.seg_len[c];
+        slot = sp.seg_slot[c];
+        if (slot < 0) return;
+    } else {
+        const int l = sp.chunk_long[c];
+        if (l < 0) return;                 // idle chunk slot
+        const int64_t r = sp.long_rows[l];
+        if (r < 0) return;
+        const int64_t j = c - sp.chunk_beg[l];
+        const int64_t rb = rowptr[r], re = rowptr[r + 1];
+        beg = rb + j * sp.threshold;
+        end = (beg + sp.threshold) < re ? (beg + sp.threshold) : re;
+    }
     const int sub = lane % LPR, grp = lane / LPR;
     const int nslots = feat >> 2;
     float4 acc[VPL];
@@ -450,7 +510,7 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
-    float* w = sp.ws + c * (int64_t)feat_full + c0;
+    float* w = sp.ws + slot * (int64_t)feat_full + c0;
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
         int s = sub + k * LPR;
@@ -567,34 +627,47 @@ template <int VPL, int LPR>
 static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
                         const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
                         int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp,
-                        const int32_t* out_map = nullptr, int slab_feat = 0);
+                        const int32_t* out_map = nullptr, int slab_feat = 0, int xcd_slabs = 0);
 
 template <int VPL, int LPR, int CHX = 0, bool NT = false>
 static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* rowptr, const int32_t* col,
                       const float* val, const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x,
                       int64_t ldx, float* out,
                       int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e, const SplitArgs* sp,
-                      int slab_feat = 0, const int32_t* row_index = nullptr, const int32_t* out_map = nullptr) {
+                      int slab_feat = 0, const int32_t* row_index = nullptr, const int32_t* out_map = nullptr,
+                      int xcd_slabs = 0, bool hub_xcd = false) {
     const int64_t skip = sp ? sp->threshold : 0;
     // a launch may not exceed 2^32 threads: beyond 2^22 blocks (16 Mi rows) the rows go in slices
     const int n_slabs = slab_feat > 0 ? (feat + slab_feat - 1) / slab_feat : 1;
     const int64_t MAX_BLOCKS = ((int64_t)1 << 22) / n_slabs;
     const int64_t blocks = grid.x;
     for (int64_t b0 = 0; b0 < blocks; b0 += MAX_BLOCKS) {
-        const dim3 g((unsigned)((blocks - b0) < MAX_BLOCKS ? (blocks - b0) : MAX_BLOCKS), (unsigned)n_slabs);
+        const int64_t nb = (blocks - b0) < MAX_BLOCKS ? (blocks - b0) : MAX_BLOCKS;
+        const dim3 g = xcd_slabs > 0 ? dim3((unsigned)(nb * xcd_slabs)) : dim3((unsigned)nb, (unsigned)n_slabs);
         if (weighted)
             hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true, CHX, NT>), g, dim3(256), 0, s, rowptr, col, val,
                                val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4,
-                               slab_feat, row_index);
+                               slab_feat, row_index, xcd_slabs);
         else
             hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false, CHX, NT>), g, dim3(256), 0, s, rowptr, col, val,
                                val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4,
-                               slab_feat, row_index);
+                               slab_feat, row_index, xcd_slabs);
         if (int rc = launch_status()) return rc;
+    }
+    if (hub_xcd && slab_feat == 0 && (feat == 256 || feat == 512 || feat == 1024)) {
+        // full-width main pass, but the long rows' chunks in eight slabs pinned to the XCDs (PLNLP_AGG_HUB_XCD)
+        if (feat == 256)
+            return launch_split<1, 8>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat,
+                                      mean, e, sp, out_map, 32, 8);
+        if (feat == 512)
+            return launch_split<1, 16>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat,
+                                       mean, e, sp, out_map, 64, 8);
+        return launch_split<1, 32>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat,
+                                   mean, e, sp, out_map, 128, 8);
     }
     if (slab_feat > 0)        // the long rows' chunks run per slab too (same geometry); the finalize pass is full width
         return launch_split<VPL, LPR>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean,
-                                      e, sp, out_map, slab_feat);
+                                      e, sp, out_map, slab_feat, xcd_slabs);
     return launch_split<VPL, LPR>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, feat, mean,
                                   e, sp, out_map);
 }
@@ -603,17 +676,23 @@ template <int VPL, int LPR>
 static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, const int32_t* col, const float* val,
                         const int32_t* val_index, const float* src_scale, const int32_t* src_map, const float* x, int64_t ldx, float* out,
                         int64_t ldo, int feat, int mean, const Epi& e, const SplitArgs* sp, const int32_t* out_map,
-                        int slab_feat) {
+                        int slab_feat, int xcd_slabs) {
     if (!sp || sp->n_long == 0 || sp->n_chunks == 0) return 0;
     const int n_slabs = slab_feat > 0 ? (feat + slab_feat - 1) / slab_feat : 1;
-    dim3 cgrid((unsigned)((sp->n_chunks + 3) / 4), (unsigned)n_slabs);
-    if (weighted)
-        hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, true>), cgrid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, src_map, x, ldx, feat, *sp, slab_feat);
-    else
-        hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, false>), cgrid, dim3(256), 0, s, rowptr, col, val,
-                           val_index, src_scale, src_map, x, ldx, feat, *sp, slab_feat);
-    if (int rc = launch_status()) return rc;
+    // (a launch may not exceed 2^32 threads: the chunks go in slices of 2^22 workgroups over all slabs)
+    const int64_t cblocks = (sp->n_chunks + 3) / 4;
+    const int64_t MAX_BLOCKS = ((int64_t)1 << 22) / (xcd_slabs > 0 ? xcd_slabs : n_slabs);
+    for (int64_t b0 = 0; b0 < cblocks; b0 += MAX_BLOCKS) {
+        const int64_t nb = (cblocks - b0) < MAX_BLOCKS ? (cblocks - b0) : MAX_BLOCKS;
+        const dim3 cgrid = xcd_slabs > 0 ? dim3((unsigned)(nb * xcd_slabs)) : dim3((unsigned)nb, (unsigned)n_slabs);
+        if (weighted)
+            hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, true>), cgrid, dim3(256), 0, s, rowptr, col, val,
+                               val_index, src_scale, src_map, x, ldx, feat, *sp, slab_feat, xcd_slabs, b0 * 4);
+        else
+            hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, false>), cgrid, dim3(256), 0, s, rowptr, col, val,
+                               val_index, src_scale, src_map, x, ldx, feat, *sp, slab_feat, xcd_slabs, b0 * 4);
+        if (int rc = launch_status()) return rc;
+    }
     hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)sp->n_long), dim3(256), 0, s, rowptr,
                        feat, mean, *sp, out, ldo, e, out_map);
     return launch_status();
@@ -656,6 +735,10 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
         sa.chunk_beg = split->chunk_beg; sa.chunk_cnt = split->chunk_cnt; sa.n_chunks = split->n_chunks;
         sa.chunk_long = split->chunk_long;
         sa.ws = split->workspace;
+        if (split->seg_beg) {
+            if (!split->seg_len || !split->seg_slot) return PLNLP_E_NULL;
+            sa.seg_beg = split->seg_beg; sa.seg_len = split->seg_len; sa.seg_slot = split->seg_slot;
+        }
         sp = &sa;
     }
     // the Adam epilogue updates every result row exactly once: the vector path over ALL rows (no row subset)
@@ -690,10 +773,21 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
             return launch_lds<8>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
         return launch_lds<4>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
     }
+    const bool hub_xcd = (flags & PLNLP_AGG_HUB_XCD) != 0;
 #define PLNLP_AGG(VPL, LPR) \
-    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp, 0, row_index, split_out_map)
+    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp, 0, row_index, split_out_map, 0, hub_xcd)
 #define PLNLP_AGGX(VPL, LPR, CHX, NT) \
     return launch_vec<VPL, LPR, CHX, NT>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp, 0, row_index, split_out_map)
+    // eight feature slabs pinned to the eight XCDs (see csr_agg_vec_kernel): F = 256 / 512 / 1024
+    if ((flags & PLNLP_AGG_SLABS_XCD) && !(e.flags & PLNLP_EPI_DROPOUT) && grid.x <= (1u << 22) / 8) {
+#define PLNLP_AGG_XCD(LPR) \
+    return launch_vec<1, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, \
+                              n_rows, (int)feat, mean, e, sp, (int)feat / 8, row_index, split_out_map, 8)
+        if (feat == 256) PLNLP_AGG_XCD(8);
+        if (feat == 512) PLNLP_AGG_XCD(16);
+        if (feat == 1024) PLNLP_AGG_XCD(32);
+#undef PLNLP_AGG_XCD
+    }
     // feature slabs: 128 or 256 columns per wave (see csr_agg_vec_kernel); rows and slabs fill the grid
     if ((flags & (PLNLP_AGG_SLABS_128 | PLNLP_AGG_SLABS_256)) && nslots > 32 && !(e.flags & PLNLP_EPI_DROPOUT)) {
         if ((flags & PLNLP_AGG_SLABS_128))

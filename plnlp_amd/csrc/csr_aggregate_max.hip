@@ -346,6 +346,7 @@ extern "C" int plnlp_csr_aggregate_max_f32(const int64_t* rowptr, const int32_t*
     if (split && split->n_long > 0 && split->n_chunks > 0) {
         if (!vec_ok) return PLNLP_E_UNSUPPORTED;
         if (split->threshold < 64) return PLNLP_E_SHAPE;
+        if (split->seg_beg) return PLNLP_E_UNSUPPORTED;      // explicit chunks: the sum kernel only
         if (!split->long_rows || !split->chunk_beg || !split->chunk_cnt || !split->chunk_long || !split->workspace ||
             !arg_workspace) return PLNLP_E_NULL;
         if (split->workspace_floats < split->n_chunks * feat) return PLNLP_E_WORKSPACE;

@@ -63,6 +63,72 @@ class RowSplit:
         return self.n_long > 0 and self.n_chunks > 0
 
 
+class SourceOrderedSplit:
+    """Long-row tables with EXPLICIT chunks cut by source range (plnlp_row_split.seg_*), for a STATIC graph whose
+    source matrix sits in the Infinity Cache but not in one XCD's L2 (the collab-shaped graph: 241 MB at F = 256).
+
+    Position chunks (RowSplit) of a hub row each gather 128 source rows spread over the whole id range, and the
+    chunks that run at the same time belong to a handful of hubs: nothing is shared, every gathered row is a fabric
+    request (measured: L2 hit rate 21 % in that pass against 38 % in the main pass, profiles/r03_agg_pmc_step_launches.json).
+    Here a hub row is cut where its (sorted) source ids cross multiples of `part_rows`, pieces longer than `max_len` are
+    cut again, and the chunks are processed RANGE-major: the waves in flight all gather from the same few thousand source
+    rows, which the hubs share (a source row is an entry of ~3 hub rows on that graph).  Together with slabs pinned to the
+    XCDs (PLNLP_AGG_SLABS_XCD) a source row piece crosses the fabric about once.  The partial sums of a row are still
+    added in slot (= position) order by the finalize pass: deterministic, but a different summation tree than RowSplit's
+    -- a graph uses one form for ALL its launches at a width (the tuned form, ops._agg_tune: AGG_HUB_RANGES)."""
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, threshold: int, part_rows: int = 8192,
+                 max_len: int = 128):
+        dev = rowptr.device
+        self.threshold, self.part_rows, self.max_len = int(threshold), int(part_rows), int(max_len)
+        deg = rowptr[1:] - rowptr[:-1]
+        long_rows = torch.nonzero(deg > threshold).flatten()
+        self.n_long = int(long_rows.numel())
+        self.long_rows = long_rows.contiguous()
+        self.n_chunks = 0
+        if self.n_long == 0:
+            return
+        ldeg = deg[long_rows]
+        lbeg = rowptr[long_rows]
+        # every entry of a long row: its position, its row's slot, its source range
+        slot_of = torch.repeat_interleave(torch.arange(self.n_long, device=dev), ldeg)
+        first = torch.cumsum(ldeg, 0) - ldeg
+        pos = lbeg[slot_of] + (torch.arange(slot_of.numel(), device=dev) - first[slot_of])
+        part = col[pos].to(torch.int64) // self.part_rows
+        n_parts = int(part.max()) + 1
+        key = slot_of * n_parts + part
+        # runs of equal (row, range): sorted columns give one run per pair; unsorted ones simply give more runs
+        start = torch.ones_like(key, dtype=torch.bool)
+        start[1:] = key[1:] != key[:-1]
+        run_first = torch.nonzero(start).flatten()
+        run_len = torch.diff(run_first, append=torch.tensor([key.numel()], device=dev))
+        # cut runs longer than max_len
+        pieces = (run_len + self.max_len - 1) // self.max_len
+        run_of = torch.repeat_interleave(torch.arange(run_first.numel(), device=dev), pieces)
+        pfirst = torch.cumsum(pieces, 0) - pieces
+        j = torch.arange(run_of.numel(), device=dev) - pfirst[run_of]
+        seg_off = run_first[run_of] + j * self.max_len                       # offset into `pos`
+        seg_len = torch.minimum(run_len[run_of] - j * self.max_len, torch.tensor(self.max_len, device=dev))
+        seg_beg = pos[seg_off]
+        seg_row = slot_of[seg_off]
+        seg_part = part[seg_off]
+        n = int(seg_beg.numel())
+        # slots: position order within the row (= the order built above); processing order: range-major
+        order = torch.argsort(seg_part, stable=True)
+        self.n_chunks = n
+        self.seg_beg = seg_beg[order].contiguous()
+        self.seg_len = seg_len[order].to(torch.int32).contiguous()
+        self.seg_slot = order.to(torch.int32).contiguous()
+        cnt = torch.bincount(seg_row, minlength=self.n_long)
+        self.chunk_cnt = cnt.to(torch.int32).contiguous()
+        self.chunk_beg = (torch.cumsum(cnt, 0) - cnt).contiguous()
+        self.chunk_long = seg_row.to(torch.int32).contiguous()              # (not read by the explicit form)
+
+    @property
+    def active(self) -> bool:
+        return self.n_long > 0 and self.n_chunks > 0
+
+
 class Graph:
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor],
                  n_rows: int, n_cols: int):
@@ -76,12 +142,23 @@ class Graph:
         self._t: Optional["Graph"] = None
         self._inv_deg: Optional[torch.Tensor] = None
         self._split: Optional[RowSplit] = None
+        self._range_split: Optional[SourceOrderedSplit] = None
         self._agg_tune = {}      # measured choice of aggregation kernel form per feature width (ops._agg_tune);
                                  # shared with the transposed views: the backward passes cannot be timed themselves
 
-    def row_split(self, threshold: int = 256) -> RowSplit:
-        """long-row tables of this (static) graph, built once"""
+    def row_split(self, threshold: int = 256, ranges=None):
+        """long-row tables of this (static) graph, built once: position chunks (RowSplit), or -- ranges = (part_rows,
+        max_len) -- chunks cut by source range and processed range-major (SourceOrderedSplit)"""
+        if ranges is not None:
+            key = (threshold,) + tuple(ranges)
+            if getattr(self._range_split, "_key", None) != key:
+                self._range_split = SourceOrderedSplit(self.rowptr, self.col, threshold, *ranges)
+                self._range_split._key = key
+            return self._range_split
         if self._split is None or self._split.threshold != threshold:
+            self._split = RowSplit(self.rowptr, self.nnz, threshold, exact=True)
+        return self._split
+        if self._split is None or self._split.threshold != threshold or hasattr(self._split, "_key"):
             self._split = RowSplit(self.rowptr, self.nnz, threshold, exact=True)
         return self._split
 

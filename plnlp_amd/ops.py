@@ -92,8 +92,28 @@ def _vector_path(x: torch.Tensor, out: torch.Tensor, feat: int) -> bool:
             and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0)
 
 
+# host-side bit of a tuned form (never passed to the library): the long rows' chunks are cut by SOURCE RANGE and
+# processed range-major (graph.SourceOrderedSplit) instead of by position.  With the chunk pass in XCD-pinned slabs
+# (AGG_HUB_XCD) the waves in flight on an XCD gather the same 128-byte pieces of the same source rows.  Measured on
+# MI355X, collab graph, F = 256 (profiles/r03_agg_hub_pass.md): chunk pass 117 -> 80 us, whole aggregation 0.288 -> 0.246 ms
+AGG_HUB_RANGES = 1 << 16
+# a range is at least part_rows source rows (65 536 measured best on the collab graph, 16 K ... 128 K within 4 %), and a
+# graph is cut into at most max_ranges of them: a hub of degree d leaves d / ranges entries per chunk, and chunks of a
+# handful of entries are all latency (12.5 M-node R-MAT at 65 536 rows per range: 10 M chunks of 7 entries)
+HUB_RANGES = {"part_rows": 65536, "max_len": 256, "max_ranges": 8}
+
+
+def hub_ranges(n_source_rows: int):
+    """(part_rows, max_len) of graph.SourceOrderedSplit for a source matrix of this many rows"""
+    per = -(-int(n_source_rows) // HUB_RANGES["max_ranges"])
+    return max(HUB_RANGES["part_rows"], per), HUB_RANGES["max_len"]
 AGG_AUTOTUNE = {"enabled": os.environ.get("PLNLP_AGG_AUTOTUNE", "1") != "0", "min_feat": 256,
-                "candidates": (0, L.AGG_SLABS_128, L.AGG_SLABS_256)}
+                "candidates": (0, L.AGG_SLABS_128, L.AGG_SLABS_256, L.AGG_HUB_XCD | AGG_HUB_RANGES)}
+
+
+def mapped_form(tune: int) -> int:
+    """the form a launch with a source map runs when the graph's tuned form is `tune`"""
+    return int(tune) & ~(L.AGG_HUB_XCD | AGG_HUB_RANGES)
 
 
 def _multi_rank() -> bool:
@@ -219,17 +239,30 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
                      and graph.col.numel() >= LDS_STAGE_MIN_DEG * graph.n_cols and feat % 4 == 0)
     if tune == "auto":
         tune = _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, feat, row_index)
-    flags = (L.AGG_LDS_STAGE if lds_stage else 0) | int(tune)
+    if src_map is not None:
+        # the mapped gather keeps the position chunks at full width: over half of a hub's entries have no mapped row on
+        # the step's transposed pass, and eight slab waves per chunk each repeat the index translation for what is left
+        # (measured: the collab step's transposed launch 0.449 -> 0.474 ms with the pinned form)
+        tune = mapped_form(tune)
+    flags = (L.AGG_LDS_STAGE if lds_stage else 0) | (int(tune) & 0xFFFF)
     if lds_stage:
         split = None             # the staged form walks whole rows
     sp = None
     if split == "auto":
-        split = graph.row_split(split_threshold(graph.n_cols)) if _vector_path(x, out, feat) else None
+        split = None
+        if _vector_path(x, out, feat):
+            if (int(tune) & AGG_HUB_RANGES) and isinstance(graph, Graph):
+                split = graph.row_split(split_threshold(graph.n_cols), hub_ranges(graph.n_cols))
+            else:
+                split = graph.row_split(split_threshold(graph.n_cols))
     if split is not None and split.active and _vector_path(x, out, feat):
         ws = torch.empty(split.n_chunks * feat, dtype=torch.float32, device=x.device)
         sp = L.RowSplit(split.threshold, split.n_long, split.long_rows.data_ptr(), split.chunk_beg.data_ptr(),
                         split.chunk_cnt.data_ptr(), split.n_chunks, split.chunk_long.data_ptr(), ws.data_ptr(),
                         ws.numel())
+        if hasattr(split, "seg_beg"):       # chunks by source range (graph.SourceOrderedSplit)
+            sp.seg_beg, sp.seg_len, sp.seg_slot = (split.seg_beg.data_ptr(), split.seg_len.data_ptr(),
+                                                   split.seg_slot.data_ptr())
     rc = lib.plnlp_csr_aggregate_f32(
         graph.rowptr.data_ptr(), graph.col.data_ptr() or graph.rowptr.data_ptr(), L.ptr(val), L.ptr(val_index),
         L.ptr(src_scale), L.ptr(src_map), L.ptr(row_index), L.ptr(out_map),

@@ -1127,7 +1127,10 @@ def test_full_size_collab_shape_properties(P):
     z = torch.randn(n, feat, device="cuda", generator=gen)
     zt = P.ops.csr_aggregate(adj.t(), z, "sum", False)
     lhs, rhs = float((y.double() * z.double()).sum()), float((x.double() * zt.double()).sum())
-    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs)) + 1e-3, (lhs, rhs)
+    # (both sides carry the fp32 rounding of 60 M row-sum terms, a random walk whose size depends on the summation
+    #  tree of the form the tuner picked: bound it by 1e-10 of the sum of magnitudes -- one dropped or doubled entry
+    #  would move the difference by ~1, five orders above this)
+    assert abs(lhs - rhs) <= 1e-10 * float((y.double().abs() * z.double().abs()).sum()), (lhs, rhs)
     # 4. determinism at full size, hub rows included (max degree 44 243)
     assert int(deg.max()) > 40000
     assert torch.equal(y, P.ops.csr_aggregate(adj, x, "sum", False))
@@ -1137,9 +1140,11 @@ def test_full_size_collab_shape_properties(P):
     nmap = torch.full((n,), -1, dtype=torch.int32, device="cuda")
     nmap[rows] = torch.arange(rows.numel(), dtype=torch.int32, device="cuda")
     zz = torch.where(keep[:, None], z, torch.zeros((), device="cuda"))
-    dense = P.ops.csr_aggregate(adj.t_mean(), zz, "sum", True)
     comp = P.ops.csr_aggregate(adj.t_mean(), z[rows].contiguous(), "sum", True, src_map=nmap)
+    # (bit for bit on the same kernel form: a mapped launch runs ops.mapped_form of the graph's tuned form)
+    dense = P.ops.csr_aggregate(adj.t_mean(), zz, "sum", True, tune=P.ops.mapped_form(adj._agg_tune.get(feat, 0)))
     assert torch.equal(dense, comp)
+    close(P.ops.csr_aggregate(adj.t_mean(), zz, "sum", True), comp, rtol=2e-6)
 
 
 def test_sparse_channel_tolerates_a_second_consumer(P):

@@ -352,8 +352,8 @@ def test_trained_regime_hits_parity_over_seeds(P, golden):
             for i, k in enumerate(ks):
                 # asserted where the run is TRAINED (float64 mean above 50 %) and CONVERGED in the reference's own
                 # arithmetic: its float32 and float64 means agree to 0.15 points.  (Where they do not -- the ddi
-                # recipe at Hits@20: one or two of ten seeds are still short of the plateau after 40 epochs,
-                # DIFFERENT seeds in float32 and float64 -- no arithmetic can be held to 0.3, the reference's own
+                # recipe at Hits@20: one of ten seeds is still short of the plateau after 60 epochs,
+                # a DIFFERENT seed in each arithmetic -- no arithmetic can be held to 0.3, the reference's own
                 # included; the table in profiles/ shows those rows too.)
                 if ref[i].min() <= 50.0 or np.abs(tab["oracle_f32"].mean(0)[i] - ref[i]).max() > 0.15:
                     continue
@@ -513,9 +513,71 @@ def test_sharded_step_row_sparse_last_layer_equals_dense_block_step(P, layers, p
         l_plain, m_plain = run(None, "auto", True)
         assert (getattr(m_sparse, "_emb_part_grad", None) is not None) == (layers == 1)       # the sink path ran
         assert getattr(m_dense, "_emb_part_grad", None) is None
-        close(l_sparse, l_dense, rtol=2e-5)
-        close(l_sparse, l_plain, rtol=2e-4)
+        # (the MLP scorer's biases have an exactly-zero gradient under a pairwise loss: in fp32 every arithmetic moves
+        #  them by +-lr with the sign of its own rounding noise -- profiles/r03_trajectory_drift.txt -- so two correct
+        #  realisations of the MLP recipe drift apart at the 1e-3 level within two epochs; the DOT recipe has no such
+        #  parameter and is held to round-off)
+        close(l_sparse, l_dense, rtol=2e-5 if pred == "DOT" else 2e-3)
+        close(l_sparse, l_plain, rtol=2e-4 if pred == "DOT" else 2e-3)
         close(m_sparse.emb.weight, m_dense.emb.weight, rtol=1e-3, atol=2e-2)       # Adam: O(lr) on round-off-zero grads
         assert m_sparse.check_replicas()
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------ aggregation: XCD-pinned slabs, hub chunks by source range ----
+@pytest.mark.parametrize("feat", [256, 512, 1024])
+@pytest.mark.parametrize("form", ["xcd", "hub_xcd", "hub_xcd_ranges"])
+def test_csr_aggregate_xcd_pinned_and_source_range_forms_match_oracle(P, feat, form):
+    """the forms round 3 added to the tuner's candidates (PLNLP_AGG_SLABS_XCD, PLNLP_AGG_HUB_XCD, explicit chunks of
+    the long rows cut by source range: graph.SourceOrderedSplit) against the oracle: plain, weighted, with the
+    epilogues of the training path, restricted to a row subset (row_index), through a source map, and bit-identical
+    from run to run"""
+    from gpu_util import dev, rand_csr, to_graph
+    from plnlp_amd import _lib
+    n = 700
+    csr = rand_csr(n, 9000, feat + len(form), weighted=True, hub=2500)
+    g = to_graph(P, csr)
+    old = dict(P.ops.HUB_RANGES)
+    P.ops.HUB_RANGES.update(part_rows=128, max_len=64)          # several ranges and cut pieces on this small graph
+    tune = {"xcd": _lib.AGG_SLABS_XCD, "hub_xcd": _lib.AGG_HUB_XCD,
+            "hub_xcd_ranges": _lib.AGG_HUB_XCD | P.ops.AGG_HUB_RANGES}[form]
+    try:
+        gen = torch.Generator().manual_seed(8)
+        x = torch.randn(n, feat, generator=gen)
+        for reduce, use_values in (("mean", False), ("sum", True)):
+            ref = O.spmm(csr, x.double(), reduce, use_values)
+            out = P.ops.csr_aggregate(g, dev(x), reduce, use_values, tune=tune)
+            close(out, ref, msg=f"{reduce} feat={feat} {form}")
+            again = P.ops.csr_aggregate(g, dev(x), reduce, use_values, tune=tune)
+            assert torch.equal(out, again)
+        if form == "hub_xcd_ranges":
+            sp = g.row_split(P.ops.split_threshold(g.n_cols), P.ops.hub_ranges(g.n_cols))
+            assert sp.n_long >= 1 and sp.n_chunks > 2500 // 64
+        # epilogues: bias + relu + accumulate; indexed addend + gate
+        bias = torch.randn(feat, generator=gen)
+        base = torch.randn(n, feat, generator=gen)
+        out = dev(base.clone())
+        P.ops.csr_aggregate(g, dev(x), "sum", True, out=out, tune=tune,
+                            epilogue=_lib.make_epilogue(bias=dev(bias), relu=True, accumulate=True))
+        close(out, base.double() + torch.relu(O.spmm(csr, x.double(), "sum", True) + bias.double()))
+        # a row subset: only the rows in row_index are produced, the long row among them or not
+        for rows in (torch.tensor([3, 0, 699, 5, 17]), torch.tensor([1, 2, 4])):
+            ri = rows.to(torch.int32)
+            omap = torch.full((n,), -1, dtype=torch.int32)
+            omap[rows] = torch.arange(rows.numel(), dtype=torch.int32)
+            sub = P.ops.csr_aggregate(g, dev(x), "mean", False, tune=tune, row_index=dev(ri), out_map=dev(omap))
+            close(sub, O.spmm(csr, x.double(), "mean", False)[rows])
+            full = P.ops.csr_aggregate(g, dev(x), "mean", False, tune=tune)
+            assert torch.equal(sub, full[dev(rows)])             # the same arithmetic per produced row
+        # a source map (x holds only the mapped rows)
+        keep = torch.rand(n, generator=gen) < 0.5
+        rows = torch.nonzero(keep).reshape(-1)
+        nmap = torch.full((n,), -1, dtype=torch.int32)
+        nmap[rows] = torch.arange(rows.numel(), dtype=torch.int32)
+        xz = x.clone()
+        xz[~keep] = 0.0
+        comp = P.ops.csr_aggregate(g, dev(x[rows].contiguous()), "sum", True, src_map=dev(nmap), tune=tune)
+        close(comp, O.spmm(csr, xz.double(), "sum", True), rtol=2e-6)
+    finally:
+        P.ops.HUB_RANGES.update(old)

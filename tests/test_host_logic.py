@@ -381,3 +381,59 @@ def test_host_randperm_matches_the_dataloader_fixture(golden):
         np.testing.assert_array_equal(perm.numpy(), g6[f"s{seed}_n{n}_B{B}_perm"])
         after = torch.randint(0, 1 << 30, (4,))
         np.testing.assert_array_equal(after.numpy(), g6[f"s{seed}_n{n}_B{B}_after"])     # same RNG consumption
+
+
+def test_source_ordered_split_tables_cover_every_long_row_entry_once():
+    """graph.SourceOrderedSplit (explicit chunks of plnlp_row_split): every entry of a long row in exactly one
+    chunk, no entry of a short row in any; a chunk stays inside one source range and under max_len; its workspace
+    slot lies in its row's slot range, every slot is used once; processing order is range-major; slot order within a
+    row is position order (the finalize pass adds the partial sums in slot order)"""
+    import torch
+    from plnlp_amd.graph import SourceOrderedSplit
+    torch.manual_seed(0)
+    n, thr, part, max_len = 300, 64, 32, 4
+    rows, cols = [], []
+    for r in range(n):
+        d = 200 if r % 50 == 0 else (64 if r == 7 else 5)          # row 7 sits exactly AT the threshold: short
+        c = torch.randperm(n)[:d].sort().values
+        rows += [r] * d
+        cols += c.tolist()
+    rows = torch.tensor(rows)
+    col = torch.tensor(cols, dtype=torch.int32)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    sp = SourceOrderedSplit(rowptr, col, thr, part_rows=part, max_len=max_len)
+    assert sp.n_long == 6 and sp.active
+    cover = torch.zeros(col.numel(), dtype=torch.int32)
+    first_of_slot = {}
+    for c in range(sp.n_chunks):
+        b, l, slot = int(sp.seg_beg[c]), int(sp.seg_len[c]), int(sp.seg_slot[c])
+        assert 0 < l <= max_len
+        cover[b:b + l] += 1
+        ranges = col[b:b + l] // part
+        assert bool((ranges == ranges[0]).all())
+        row = int(torch.searchsorted(rowptr, torch.tensor(b), right=True)) - 1
+        li = int((sp.long_rows == row).nonzero())
+        assert int(sp.chunk_beg[li]) <= slot < int(sp.chunk_beg[li]) + int(sp.chunk_cnt[li])
+        first_of_slot[slot] = b
+    deg = rowptr[1:] - rowptr[:-1]
+    for r in range(n):
+        assert bool((cover[rowptr[r]:rowptr[r + 1]] == (1 if deg[r] > thr else 0)).all())
+    assert sorted(first_of_slot) == list(range(sp.n_chunks))
+    starts = [first_of_slot[s] for s in range(sp.n_chunks)]
+    assert starts == sorted(starts)                                  # slot order == position order
+    order = [int(col[int(b)] // part) for b in sp.seg_beg]
+    assert order == sorted(order)                                    # range-major processing order
+    # unsorted columns inside a row: still a cover (more, shorter chunks)
+    perm_col = col.clone()
+    seg = slice(int(rowptr[50]), int(rowptr[51]))
+    perm_col[seg] = col[seg][torch.randperm(200)]
+    sp2 = SourceOrderedSplit(rowptr, perm_col, thr, part_rows=part, max_len=max_len)
+    cover = torch.zeros(col.numel(), dtype=torch.int32)
+    for c in range(sp2.n_chunks):
+        b, l = int(sp2.seg_beg[c]), int(sp2.seg_len[c])
+        cover[b:b + l] += 1
+    assert bool((cover[seg] == 1).all()) and sp2.n_chunks > sp.n_chunks
+    # no long row at all
+    sp3 = SourceOrderedSplit(rowptr, col, 1000)
+    assert not sp3.active
