@@ -39,13 +39,6 @@ from . import ops
 # eager loop stays the default for throughput; the captured loop is for hosts that cannot keep up (a CPU quota shared
 # by many ranks, a slower host): it makes the step time independent of host speed.
 CAPTURE = {"enabled": os.environ.get("PLNLP_CAPTURE", "0") == "1", "bucket": 512, "warm_steps": 3}
-_DEBUG = os.environ.get("PLNLP_CAPTURE_DEBUG") == "1"
-
-
-def _dbg(what):
-    if _DEBUG:
-        torch.cuda.synchronize()
-        print("[capture]", what, flush=True)
 
 
 class _Slot:
@@ -127,17 +120,13 @@ class StepPipeline:
         with torch.cuda.stream(side):
             if slot.main_done is not None:          # the step that last read this buffer set must be through
                 side.wait_event(slot.main_done)
-            _dbg("prepare: waited")
             slot.pos.copy_(pos)
             slot.neg.copy_(neg.reshape(slot.neg.shape))
             if self.weighted:
                 slot.w.copy_(w)
-            _dbg("prepare: inputs copied")
             if slot.pro_graph is None:
                 self._capture_prologue(slot)
-                _dbg("prepare: prologue captured")
             slot.pro_graph.replay()
-            _dbg("prepare: prologue replayed")
             slot.pro_done = torch.cuda.Event(blocking=True)
             slot.pro_done.record(side)
         return ("captured", slot)
@@ -193,9 +182,7 @@ class StepPipeline:
         t_adam = steps.pop() + 1
         self.scalars.upload(group["lr"], group["betas"][0], group["betas"][1], t_adam,
                             [ops.next_seed() for _ in range(n_seeds)])
-        _dbg("step: scalars uploaded")
         graph.replay()
-        _dbg("step: replayed")
         for p in group["params"]:
             st = m.optimizer.state.get(p)
             if st:
