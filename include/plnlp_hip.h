@@ -156,6 +156,9 @@ int plnlp_row_split_build(const int64_t* rowptr, int64_t n_rows, int64_t thresho
                                      does not; not combined with a dropout epilogue                            */
 #define PLNLP_AGG_HUB_XCD 128     /* flags: the same pinned slabs for the LONG rows' chunk pass only (the main pass
                                      keeps one full-width wave per row)                                        */
+#define PLNLP_AGG_FUSED_PASSES 256 /* flags: the long rows' chunk pass runs inside the main pass's launch (its workgroups
+                                     first), F > 128 full-width forms: same sums, same bits, two launches instead of
+                                     three -- the chunks' latency chains hide behind the short rows' traffic  */
 int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                             const float* val,        /* nullable: [nnz], or indexed through val_index */
                             const int32_t* val_index,/* nullable: [nnz]; weight of entry e = val[val_index[e]] */
@@ -391,6 +394,18 @@ int plnlp_pairwise_loss_f32(int kind, const float* pos, const float* neg, const 
                             int64_t batch, int64_t num_neg, float grad_scale,
                             float* loss, float* gpos, float* gneg,
                             float* workspace, int64_t workspace_floats, void* stream);
+/* The same in ONE launch: the last workgroup to finish adds the partial sums (same order, same bits as the
+ * two-launch form) -- a dependent launch of a one-block kernel costs 5-9 us on this part.
+ *   block_counter: one DEVICE word, 0 at launch, left 0 (one persistent word per caller and stream); null = the
+ *                  two-launch form above;
+ *   loss_acc     : nullable DEVICE double: *loss_acc += (double)loss * acc_weight -- the epoch's running sum
+ *                  `total_loss += loss.item() * num_examples` (plnlp/model.py:169) without its three element-wise
+ *                  launches and without the read-back. */
+int plnlp_pairwise_loss_tail_f32(int kind, const float* pos, const float* neg, const float* weight,
+                                 int64_t batch, int64_t num_neg, float grad_scale,
+                                 float* loss, float* gpos, float* gneg,
+                                 float* workspace, int64_t workspace_floats,
+                                 unsigned int* block_counter, double* loss_acc, double acc_weight, void* stream);
 
 /* ---- optimiser step (plnlp/model.py:163-167) -------------------------------
  * sum of squares of a gradient tensor into partial[n_partial] (fixed order), so
@@ -433,6 +448,11 @@ typedef struct plnlp_adam_tensor {
 int plnlp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float* out /* HOST [3] */);
 int plnlp_sqnorm_multi_f32(const float* const* grads /* HOST array */, const int64_t* sizes /* HOST */,
                            int n_tensors, float* partial, int64_t n_partial, void* stream);
+/* ... with the sum of the partials in the same launch (last-workgroup pattern, see plnlp_pairwise_loss_tail_f32):
+ * out[0] = sum of this call's partials; block_counter null = plnlp_sqnorm_multi_f32 */
+int plnlp_sqnorm_multi_sum_f32(const float* const* grads /* HOST array */, const int64_t* sizes /* HOST */,
+                               int n_tensors, float* partial, int64_t n_partial, float* out /* DEVICE [1] */,
+                               unsigned int* block_counter, void* stream);
 int plnlp_adam_multi_f32(const plnlp_adam_tensor* tensors /* HOST array */, int n_tensors,
                          float lr, float beta1, float beta2, float eps, float weight_decay,
                          int decoupled_wd, float grad_scale, void* stream);

@@ -64,6 +64,7 @@ AGG_SLABS_128 = 16
 AGG_SLABS_256 = 32
 AGG_SLABS_XCD = 64
 AGG_HUB_XCD = 128
+AGG_FUSED_PASSES = 256
 LOSS_KINDS = {"auc": 0, "hinge_auc": 1, "weighted_auc": 2, "adaptive_auc": 3,
               "weighted_hinge_auc": 4, "adaptive_hinge_auc": 5, "log_rank": 6}
 
@@ -124,6 +125,9 @@ SIGNATURES = {
     "plnlp_loss_workspace_floats": (c_i64, [c_i64]),
     "plnlp_pairwise_loss_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_float,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_pairwise_loss_tail_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_float,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p,
+                                               C.c_void_p, C.c_double, C.c_void_p]),
     "plnlp_sqnorm_partials": (c_i64, [c_i64]),
     "plnlp_sqnorm_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p]),
     "plnlp_sum_partials_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_int, C.c_void_p]),
@@ -132,6 +136,8 @@ SIGNATURES = {
                                       C.c_float, C.c_float, C.c_void_p]),
     "plnlp_sqnorm_multi_f32": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(c_i64), C.c_int, C.c_void_p, c_i64,
                                          C.c_void_p]),
+    "plnlp_sqnorm_multi_sum_f32": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(c_i64), C.c_int, C.c_void_p, c_i64,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "plnlp_adam_multi_f32": (C.c_int, [C.POINTER(AdamTensor), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "plnlp_adam_step_scalars": (C.c_int, [C.c_float, C.c_float, C.c_float, c_i64, C.c_void_p]),

@@ -51,7 +51,7 @@ class _Slot:
         self.count_host = torch.zeros(1, dtype=torch.int64, pin_memory=True)
         self.batch: Optional[ops.EdgeBatch] = None
         self.pro_graph = None
-        self.main = {}               # bucket -> (graph, loss tensor, seed slots)
+        self.main = {}               # (bucket, accumulator) -> (graph, loss tensor, seed slots, feeds the accumulator)
         self.pro_done = None         # event: the prologue replay that filled this slot has finished
         self.main_done = None        # event: the step that read this slot has finished
 
@@ -69,6 +69,7 @@ class StepPipeline:
         self.captured = self.why_eager is None
         self.steps = 0
         self.replays = 0
+        self.last_fed = False        # did the step just enqueued feed ops.LOSS_ACC (the epoch's running loss sum)?
         self._prepared = 0
         if self.captured:
             dev = model.device
@@ -152,8 +153,11 @@ class StepPipeline:
         self.steps += 1
         if handle[0] == "eager":
             _, pos, neg, w, batch = handle
-            return m.train_step(self.data, pos, neg, self.k, w, edges_ready=True, global_count=global_count,
+            fed0 = ops.LOSS_ACC["fed"]
+            loss = m.train_step(self.data, pos, neg, self.k, w, edges_ready=True, global_count=global_count,
                                 prepared=batch)
+            self.last_fed = ops.LOSS_ACC["fed"] != fed0
+            return loss
         slot = handle[1]
         main = torch.cuda.current_stream(m.device)
         inc = slot.batch.incidence
@@ -170,10 +174,13 @@ class StepPipeline:
             inc._count = bucket
         if not slot.pro_done.query():
             main.wait_event(slot.pro_done)
-        entry = slot.main.get(bucket)
+        # (a captured loss kernel carries the accumulator it was captured with: one graph per accumulator and weight)
+        acc = ops.LOSS_ACC["buf"]
+        key = (bucket, None if acc is None else (acc.data_ptr(), float(ops.LOSS_ACC["weight"])))
+        entry = slot.main.get(key)
         if entry is None:
-            entry = slot.main[bucket] = self._capture_step(slot, global_count)
-        graph, loss, n_seeds = entry
+            entry = slot.main[key] = self._capture_step(slot, global_count)
+        graph, loss, n_seeds, self.last_fed = entry
         # ---- the scalars of THIS step, computed as the eager launchers compute them
         group = m.optimizer.param_groups[0]
         steps = {m.optimizer.state[p]["step"] for p in group["params"] if m.optimizer.state.get(p)}
@@ -199,6 +206,7 @@ class StepPipeline:
         saved = {p: opt.state[p]["step"] for p in opt.param_groups[0]["params"] if opt.state.get(p)}
         sc = self.scalars
         first_slot = sc.seed_slots = 0
+        fed0 = ops.LOSS_ACC["fed"]
         ops._step_scalars["active"] = sc
         g = torch.cuda.CUDAGraph()
         try:
@@ -211,4 +219,4 @@ class StepPipeline:
             for p, s in saved.items():             # the capture enqueued nothing: the counters must not move
                 opt.state[p]["step"] = s
             m._adam_sink = None
-        return g, loss, sc.seed_slots - first_slot
+        return g, loss, sc.seed_slots - first_slot, ops.LOSS_ACC["fed"] != fed0

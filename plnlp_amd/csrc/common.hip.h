@@ -266,6 +266,27 @@ __device__ __forceinline__ void epi_adam4(const Epi& e, float4 g, float* __restr
     __builtin_nontemporal_store(vo, reinterpret_cast<f32x4n*>(e.adam_v + off));
 }
 
+// True in exactly ONE workgroup of the launch -- the last to arrive -- once every workgroup's earlier global writes are
+// visible to it: the "last block finishes the reduction" pattern that saves the follow-up launch of a one-block
+// kernel (every dependent launch costs 5-9 us on this part whatever it does).  *counter must be 0 at launch; the
+// winner puts it back to 0, so a caller keeps ONE persistent zeroed word per use site and stream.
+// (release: each thread's writes -> __syncthreads -> thread 0's device-scope fence, which on a multi-XCD part writes
+// this XCD's L2 back; acquire: the winner's fence invalidates what its own L2 / L1 hold of other XCDs' lines.)
+__device__ __forceinline__ bool last_workgroup(unsigned int* counter, unsigned int n_groups) {
+    __shared__ int last_flag;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int ticket = atomicAdd(counter, 1u);
+        last_flag = ticket == n_groups - 1u;
+        if (last_flag) *counter = 0u;
+    }
+    __syncthreads();
+    const bool last = last_flag != 0;
+    if (last) __threadfence();
+    return last;
+}
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -281,8 +281,10 @@ __device__ __forceinline__ void finish_row(float4 (&acc)[VPL], int64_t r, int64_
 }
 
 // main pass: one wave per row; rows longer than skip_above (> 0) are left to the split passes
+// (bx, slab: the workgroup's position -- blockIdx.x / .y in the stand-alone launch, an offset block id in the fused one)
 template <int VPL, int LPR, bool WEIGHTED, int CHX = 0, bool NT = false>
-__global__ __launch_bounds__(256) void csr_agg_vec_kernel(
+__device__ __forceinline__ void vec_body(
+    int64_t bx, int slab,
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
@@ -291,8 +293,6 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     const int32_t* __restrict__ row_index, int xcd_slabs) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int64_t bx = blockIdx.x;
-    int slab = blockIdx.y;
     if (xcd_slabs > 0) {
         // slabs PINNED to the XCDs: consecutive workgroups go round-robin to the 8 XCDs, so with the slab as the fastest
         // index XCD k only ever gathers columns [k * slab_feat, (k + 1) * slab_feat) of the source rows -- its 4 MiB L2
@@ -335,6 +335,19 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
     finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi, &pre);
+}
+
+template <int VPL, int LPR, bool WEIGHTED, int CHX = 0, bool NT = false>
+__global__ __launch_bounds__(256) void csr_agg_vec_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, const int32_t* __restrict__ val_index,
+    const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, int64_t row_base, int slab_feat,
+    const int32_t* __restrict__ row_index, int xcd_slabs) {
+    vec_body<VPL, LPR, WEIGHTED, CHX, NT>((int64_t)blockIdx.x, (int)blockIdx.y, rowptr, col, val, val_index, src_scale, src_map,
+                                          x, ldx, out, ldo, n_rows, feat, mean, skip_above, epi, row_base, slab_feat,
+                                          row_index, xcd_slabs);
 }
 
 // LDS-staged form for SMALL, DENSE graphs (ogbl-ddi: 4 267 nodes, ~500 neighbours per row).  The
@@ -466,7 +479,8 @@ struct SplitArgs {
 };
 
 template <int VPL, int LPR, bool WEIGHTED>
-__global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
+__device__ __forceinline__ void chunk_body(
+    int64_t bx, int slab,
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const int32_t* __restrict__ val_index,
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
@@ -474,9 +488,7 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
     int64_t chunk_base) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int64_t bx = blockIdx.x;
-    int slab = blockIdx.y;
-    if (xcd_slabs > 0) { slab = (int)(bx % xcd_slabs); bx /= xcd_slabs; }   // see csr_agg_vec_kernel
+    if (xcd_slabs > 0) { slab = (int)(bx % xcd_slabs); bx /= xcd_slabs; }   // see vec_body
     const int64_t c = chunk_base + bx * 4 + wave;
     if (c >= sp.n_chunks) return;
     const int feat_full = feat;
@@ -516,6 +528,41 @@ __global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
         int s = sub + k * LPR;
         if (s < nslots) *reinterpret_cast<float4*>(w + s * 4) = acc[k];
     }
+}
+
+template <int VPL, int LPR, bool WEIGHTED>
+__global__ __launch_bounds__(256) void csr_agg_chunk_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, const int32_t* __restrict__ val_index,
+    const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
+    const float* __restrict__ x, int64_t ldx, int feat, SplitArgs sp, int slab_feat, int xcd_slabs,
+    int64_t chunk_base) {
+    chunk_body<VPL, LPR, WEIGHTED>((int64_t)blockIdx.x, (int)blockIdx.y, rowptr, col, val, val_index, src_scale, src_map, x,
+                                   ldx, feat, sp, slab_feat, xcd_slabs, chunk_base);
+}
+
+// main pass and chunk pass in ONE launch (PLNLP_AGG_FUSED_PASSES): the first chunk_blocks workgroups take the long
+// rows' chunks, the rest one short row per wave.  The two passes write disjoint memory (result rows / workspace) and
+// are bound by different things -- the short rows by the bytes they pull through the fabric, the chunks by their chain
+// of dependent round trips -- so run back to back each leaves the other's resource idle; co-resident, the chunk
+// waves' latency hides behind the row waves' traffic.  Chunks first: they are the long poles.  The finalize pass (one
+// workgroup per long row) stays a launch of its own: it needs every partial sum.
+template <int VPL, int LPR, int CVPL, int CLPR, bool WEIGHTED>
+__global__ __launch_bounds__(256) void csr_agg_fused_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, const int32_t* __restrict__ val_index,
+    const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+    int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, const int32_t* __restrict__ row_index,
+    SplitArgs sp, int chunk_slab_feat, int chunk_xcd_slabs, int64_t chunk_blocks) {
+    const int64_t bx = blockIdx.x;
+    if (bx < chunk_blocks) {       // block-uniform
+        chunk_body<CVPL, CLPR, WEIGHTED>(bx, 0, rowptr, col, val, val_index, src_scale, src_map, x, ldx, feat, sp,
+                                         chunk_slab_feat, chunk_xcd_slabs, 0);
+        return;
+    }
+    vec_body<VPL, LPR, WEIGHTED>(bx - chunk_blocks, 0, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
+                                 n_rows, feat, mean, skip_above, epi, 0, 0, row_index, 0);
 }
 
 // split pass 2: one BLOCK per long row.  Its 4 waves take the row's chunk sums round-robin (wave w:
@@ -635,8 +682,30 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
                       int64_t ldx, float* out,
                       int64_t ldo, int64_t n_rows, int feat, int mean, const Epi& e, const SplitArgs* sp,
                       int slab_feat = 0, const int32_t* row_index = nullptr, const int32_t* out_map = nullptr,
-                      int xcd_slabs = 0, bool hub_xcd = false) {
+                      int xcd_slabs = 0, bool hub_xcd = false, bool fused = false) {
     const int64_t skip = sp ? sp->threshold : 0;
+    if constexpr (LPR == 64 && CHX == 0 && !NT) {
+        // PLNLP_AGG_FUSED_PASSES: the chunk pass rides in the main pass's launch (csr_agg_fused_kernel)
+        const bool pin = hub_xcd && (feat == 256 || feat == 512 || feat == 1024);
+        if (fused && sp && sp->n_long > 0 && sp->n_chunks > 0 && slab_feat == 0) {
+            const int64_t cblocks = ((sp->n_chunks + 3) / 4) * (pin ? 8 : 1);
+            if (cblocks + (int64_t)grid.x <= ((int64_t)1 << 22)) {
+                const dim3 g((unsigned)(cblocks + (int64_t)grid.x));
+#define PLNLP_FUSED(CV, CL, W, CSLAB, CXCD) \
+    hipLaunchKernelGGL((csr_agg_fused_kernel<VPL, LPR, CV, CL, W>), g, dim3(256), 0, s, rowptr, col, val, val_index, \
+                       src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, row_index, *sp, CSLAB, CXCD, cblocks)
+                if (!pin) { if (weighted) PLNLP_FUSED(VPL, LPR, true, 0, 0); else PLNLP_FUSED(VPL, LPR, false, 0, 0); }
+                else if (feat == 256) { if (weighted) PLNLP_FUSED(1, 8, true, 32, 8); else PLNLP_FUSED(1, 8, false, 32, 8); }
+                else if (feat == 512) { if (weighted) PLNLP_FUSED(1, 16, true, 64, 8); else PLNLP_FUSED(1, 16, false, 64, 8); }
+                else { if (weighted) PLNLP_FUSED(1, 32, true, 128, 8); else PLNLP_FUSED(1, 32, false, 128, 8); }
+#undef PLNLP_FUSED
+                if (int rc = launch_status()) return rc;
+                hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)sp->n_long), dim3(256), 0, s, rowptr,
+                                   feat, mean, *sp, out, ldo, e, out_map);
+                return launch_status();
+            }
+        }
+    }
     // a launch may not exceed 2^32 threads: beyond 2^22 blocks (16 Mi rows) the rows go in slices
     const int n_slabs = slab_feat > 0 ? (feat + slab_feat - 1) / slab_feat : 1;
     const int64_t MAX_BLOCKS = ((int64_t)1 << 22) / n_slabs;
@@ -773,9 +842,9 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
             return launch_lds<8>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
         return launch_lds<4>(weighted, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, (int)feat, mean, e);
     }
-    const bool hub_xcd = (flags & PLNLP_AGG_HUB_XCD) != 0;
+    const bool hub_xcd = (flags & PLNLP_AGG_HUB_XCD) != 0, fused = (flags & PLNLP_AGG_FUSED_PASSES) != 0;
 #define PLNLP_AGG(VPL, LPR) \
-    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp, 0, row_index, split_out_map, 0, hub_xcd)
+    return launch_vec<VPL, LPR>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp, 0, row_index, split_out_map, 0, hub_xcd, fused)
 #define PLNLP_AGGX(VPL, LPR, CHX, NT) \
     return launch_vec<VPL, LPR, CHX, NT>(weighted, grid, s, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, sp, 0, row_index, split_out_map)
     // eight feature slabs pinned to the eight XCDs (see csr_agg_vec_kernel): F = 256 / 512 / 1024

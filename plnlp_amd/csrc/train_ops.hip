@@ -40,7 +40,10 @@ __global__ __launch_bounds__(256) void pairwise_loss_kernel(int kind, const floa
                                                             const float* __restrict__ weight, int64_t batch,
                                                             int num_neg, float term_scale, float grad_scale,
                                                             float* __restrict__ gpos, float* __restrict__ gneg,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial,
+                                                            unsigned int* __restrict__ counter,
+                                                            float* __restrict__ loss, double* __restrict__ loss_acc,
+                                                            double acc_weight) {
     __shared__ float sm[4];
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float lsum = 0.f;
@@ -60,6 +63,17 @@ __global__ __launch_bounds__(256) void pairwise_loss_kernel(int kind, const floa
     }
     const float tot = block_sum_256(lsum, sm);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot * term_scale;
+    if (!counter) return;                   // two-launch form: sum_partials_kernel follows
+    // the last workgroup adds the partials exactly as sum_partials_kernel does (same order, same bits) ...
+    if (!last_workgroup(counter, gridDim.x)) return;
+    float v = 0.f;
+    for (int64_t i = threadIdx.x; i < (int64_t)gridDim.x; i += 256) v += partial[i];
+    const float total = block_sum_256(v, sm);
+    if (threadIdx.x == 0) {
+        loss[0] = total;
+        // ... and feeds the epoch's running sum (model.py:169: total_loss += loss.item() * num_examples, in double)
+        if (loss_acc) loss_acc[0] += (double)total * acc_weight;
+    }
 }
 
 // one block: out = (accumulate ? out : 0) + sum_i partial[i], fixed order
@@ -139,7 +153,9 @@ struct MultiSq {
     int          first_block[PLNLP_MULTI_MAX + 1];   // block range of tensor i = its range of partials
     int          count;
 };
-__global__ __launch_bounds__(256) void sqnorm_multi_kernel(MultiSq a, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void sqnorm_multi_kernel(MultiSq a, float* __restrict__ partial,
+                                                           unsigned int* __restrict__ counter,
+                                                           float* __restrict__ out) {
     __shared__ float sm[4];
     int ti = 0;
 #pragma unroll
@@ -164,6 +180,12 @@ __global__ __launch_bounds__(256) void sqnorm_multi_kernel(MultiSq a, float* __r
     }
     const float tot = block_sum_256(v, sm);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+    if (!counter) return;
+    if (!last_workgroup(counter, gridDim.x)) return;        // (as in pairwise_loss_kernel: sum_partials_kernel's sum)
+    float w = 0.f;
+    for (int64_t i = threadIdx.x; i < (int64_t)gridDim.x; i += 256) w += partial[i];
+    const float total = block_sum_256(w, sm);
+    if (threadIdx.x == 0) out[0] = total;
 }
 
 struct MultiAdam {
@@ -404,12 +426,14 @@ static inline unsigned ew_grid(int64_t n) {
 
 extern "C" int64_t plnlp_loss_workspace_floats(int64_t batch) { return (batch + 255) / 256 + 1; }
 
-extern "C" int plnlp_pairwise_loss_f32(int kind, const float* pos, const float* neg, const float* weight,
-                                       int64_t batch, int64_t num_neg, float grad_scale, float* loss,
-                                       float* gpos, float* gneg, float* workspace, int64_t workspace_floats,
-                                       void* stream) {
+extern "C" int plnlp_pairwise_loss_tail_f32(int kind, const float* pos, const float* neg, const float* weight,
+                                            int64_t batch, int64_t num_neg, float grad_scale, float* loss,
+                                            float* gpos, float* gneg, float* workspace, int64_t workspace_floats,
+                                            unsigned int* block_counter, double* loss_acc, double acc_weight,
+                                            void* stream) {
     using namespace plnlp;
     if (!pos || !neg || !loss || !gpos || !gneg || !workspace) return PLNLP_E_NULL;
+    if (loss_acc && !block_counter) return PLNLP_E_NULL;
     if (batch <= 0 || num_neg <= 0 || num_neg > 1 << 20) return PLNLP_E_SHAPE;
     if (kind < PLNLP_LOSS_AUC || kind > PLNLP_LOSS_LOG_RANK) return PLNLP_E_UNSUPPORTED;
     const bool needs_w = kind == PLNLP_LOSS_WEIGHTED_AUC || kind == PLNLP_LOSS_ADAPTIVE_AUC ||
@@ -421,10 +445,18 @@ extern "C" int plnlp_pairwise_loss_f32(int kind, const float* pos, const float* 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(pairwise_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, s, kind, pos, neg,
                        needs_w ? weight : nullptr, batch, (int)num_neg, term_scale, grad_scale, gpos, gneg,
-                       workspace);
+                       workspace, block_counter, loss, loss_acc, acc_weight);
     if (int rc = launch_status()) return rc;
+    if (block_counter) return 0;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, workspace, blocks, loss, 0);
     return launch_status();
+}
+
+extern "C" int plnlp_pairwise_loss_f32(int kind, const float* pos, const float* neg, const float* weight, int64_t batch,
+                                       int64_t num_neg, float grad_scale, float* loss, float* gpos, float* gneg,
+                                       float* workspace, int64_t workspace_floats, void* stream) {
+    return plnlp_pairwise_loss_tail_f32(kind, pos, neg, weight, batch, num_neg, grad_scale, loss, gpos, gneg, workspace,
+                                        workspace_floats, nullptr, nullptr, 0.0, stream);
 }
 
 extern "C" int64_t plnlp_sqnorm_partials(int64_t n) { return n <= 0 ? 0 : (n + plnlp::SQ_CHUNK - 1) / plnlp::SQ_CHUNK; }
@@ -464,9 +496,11 @@ extern "C" int plnlp_adam_step_f32(float* param, const float* grad, float* exp_a
     return launch_status();
 }
 
-extern "C" int plnlp_sqnorm_multi_f32(const float* const* grads, const int64_t* sizes, int n_tensors, float* partial,
-                                      int64_t n_partial, void* stream) {
+extern "C" int plnlp_sqnorm_multi_sum_f32(const float* const* grads, const int64_t* sizes, int n_tensors,
+                                          float* partial, int64_t n_partial, float* out,
+                                          unsigned int* block_counter, void* stream) {
     using namespace plnlp;
+    if (block_counter && !out) return PLNLP_E_NULL;
     if (n_tensors < 0 || n_tensors > PLNLP_MULTI_MAX) return PLNLP_E_SHAPE;
     if (n_tensors == 0) return 0;
     if (!grads || !sizes || !partial) return PLNLP_E_NULL;
@@ -484,8 +518,14 @@ extern "C" int plnlp_sqnorm_multi_f32(const float* const* grads, const int64_t* 
     a.count = n_tensors;
     if (n_partial < blocks) return PLNLP_E_WORKSPACE;
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL(sqnorm_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, partial);
+    hipLaunchKernelGGL(sqnorm_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, partial,
+                       block_counter, out);
     return launch_status();
+}
+
+extern "C" int plnlp_sqnorm_multi_f32(const float* const* grads, const int64_t* sizes, int n_tensors, float* partial,
+                                      int64_t n_partial, void* stream) {
+    return plnlp_sqnorm_multi_sum_f32(grads, sizes, n_tensors, partial, n_partial, nullptr, nullptr, stream);
 }
 
 extern "C" int plnlp_adam_multi_f32(const plnlp_adam_tensor* tensors, int n_tensors, float lr, float beta1,

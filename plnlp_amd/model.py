@@ -37,6 +37,9 @@ FUSE_EMBEDDING_ADAM = {"enabled": os.environ.get("PLNLP_FUSE_EMBEDDING_ADAM", "1
 # the epoch's batch permutation shuffled a few batches ahead of the GPU by a host thread (utils.StreamedPermutation);
 # PLNLP_STREAM_PERMUTATION=0: the whole torch.randperm before the first step, as the reference's DataLoader does
 STREAM_PERMUTATION = {"enabled": os.environ.get("PLNLP_STREAM_PERMUTATION", "1") != "0"}
+# the epoch's running sum of loss * examples (model.py:169) fed by the loss kernel's own tail (ops.LOSS_ACC) in a
+# one-process run; PLNLP_FUSE_LOSS_ACC=0: three element-wise launches per step, as the reference's line does it
+FUSE_LOSS_ACC = {"enabled": os.environ.get("PLNLP_FUSE_LOSS_ACC", "1") != "0"}
 # row-sharded data parallelism: the last SAGE layer evaluated / back-propagated only at the rows of the rank's block that
 # the global batch touches (PLNLP_SHARD_SPARSE=0: every row of the block)
 SHARD_SPARSE = {"enabled": os.environ.get("PLNLP_SHARD_SPARSE", "1") != "0"}
@@ -781,7 +784,14 @@ class BaseModel(object):
                 return order[offsets[bi]:offsets[bi + 1]]
         t_permuted = time.perf_counter()          # (host time in FRONT of the first step)
 
-        loss_acc = torch.zeros((), dtype=torch.float64, device=self.device)   # Python-float accumulation in the reference
+        # Python-float accumulation in the reference (model.py:169); here a resident double that, in one process, the
+        # loss kernel itself feeds (ops.LOSS_ACC: no cast / multiply / add launches per step).  Persistent: a captured
+        # step keeps pointing at it
+        acc_buf = getattr(self, "_loss_acc_buf", None)
+        if acc_buf is None or acc_buf.device != self.device:
+            acc_buf = self._loss_acc_buf = torch.zeros(1, dtype=torch.float64, device=self.device)
+        acc_buf.zero_()
+        loss_acc = acc_buf.reshape(())
         total_examples = 0
         # the per-batch gathers of the epoch tensors run on the side stream, like the rest of a batch's
         # pre-processing (ops.EdgeBatch): they depend on nothing the training steps produce
@@ -870,12 +880,22 @@ class BaseModel(object):
             pending = None
             if bi + 1 < len(sizes):
                 pending = gather_and_prepare(perm_of(bi + 1))
-            if pipe is not None:
-                loss = pipe.step(prepared, global_count=n_b)
-            else:
-                loss = self.train_step(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None,
-                                       global_count=n_b, prepared=prepared)
-            loss_acc += loss.double() * n_b
+            feed = FUSE_LOSS_ACC["enabled"] and world == 1 and self.device.type == "cuda"
+            fed0 = ops.LOSS_ACC["fed"]
+            if feed:
+                ops.LOSS_ACC.update(buf=acc_buf, weight=float(n_b))
+            try:
+                if pipe is not None:
+                    loss = pipe.step(prepared, global_count=n_b)
+                    fed = pipe.last_fed
+                else:
+                    loss = self.train_step(data, pos_b, neg_b, num_neg, weight_margin, edges_ready=side is not None,
+                                           global_count=n_b, prepared=prepared)
+                    fed = ops.LOSS_ACC["fed"] != fed0
+            finally:
+                ops.LOSS_ACC.update(buf=None, weight=0.0)
+            if not (feed and fed):           # a loss outside the fused kernel, or several ranks: the reference's way
+                loss_acc += loss.double() * n_b
             total_examples += n_b
 
         if mode == "shard":

@@ -103,6 +103,11 @@ AGG_HUB_RANGES = 1 << 16
 HUB_RANGES = {"part_rows": 65536, "max_len": 256, "max_ranges": 8}
 
 
+# the long rows' chunk pass inside the main pass's launch (PLNLP_AGG_FUSED_PASSES): the same sums in the same order --
+# not a tuned form, a launch shape; PLNLP_AGG_FUSED=0 restores the three-launch sequence for A/B runs
+AGG_FUSED = {"enabled": os.environ.get("PLNLP_AGG_FUSED", "1") != "0"}
+
+
 def hub_ranges(n_source_rows: int):
     """(part_rows, max_len) of graph.SourceOrderedSplit for a source matrix of this many rows"""
     per = -(-int(n_source_rows) // HUB_RANGES["max_ranges"])
@@ -245,6 +250,8 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
         # (measured: the collab step's transposed launch 0.449 -> 0.474 ms with the pinned form)
         tune = mapped_form(tune)
     flags = (L.AGG_LDS_STAGE if lds_stage else 0) | (int(tune) & 0xFFFF)
+    if AGG_FUSED["enabled"]:
+        flags |= L.AGG_FUSED_PASSES
     if lds_stage:
         split = None             # the staged form walks whole rows
     sp = None
@@ -882,6 +889,31 @@ def edge_scatter_bwd(h: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, g: t
     return out
 
 
+# one persistent zeroed word per use site (plnlp_pairwise_loss_tail_f32, plnlp_sqnorm_multi_sum_f32: the last
+# workgroup finishes the reduction and puts the word back to 0) -- allocated once per device, also what a captured
+# hipGraph keeps pointing at
+_tail_words = {}
+TAIL_LOSS, TAIL_SQNORM = 0, 1
+
+
+def tail_counter(device, slot: int) -> int:
+    """device pointer of the `slot`-th persistent zero word on this device (64 bytes apart)"""
+    key = torch.device(device)
+    if key.index is None and key.type == "cuda":
+        key = torch.device("cuda", torch.cuda.current_device())
+    buf = _tail_words.get(key)
+    if buf is None:
+        buf = _tail_words[key] = torch.zeros(16 * 8, dtype=torch.int32, device=key)
+    return buf.data_ptr() + 64 * slot
+
+
+# the running sum an epoch keeps of loss * examples (plnlp/model.py:169), fed by the loss kernel itself while set:
+# {"buf": float64 [1] device tensor, "weight": examples of the step being enqueued,
+#  "fed": how many loss launches have taken it so far -- a caller compares before / after to learn whether the step it
+#  enqueued went through the fused loss at all: a stock-torch loss does not, and is then added the reference's way)
+LOSS_ACC = {"buf": None, "weight": 0.0, "fed": 0}
+
+
 def pairwise_loss(kind: str, pos: torch.Tensor, neg: torch.Tensor, num_neg: int,
                   weight: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
                   grad_out: Optional[torch.Tensor] = None):
@@ -903,9 +935,15 @@ def pairwise_loss(kind: str, pos: torch.Tensor, neg: torch.Tensor, num_neg: int,
     gpos, gneg = grad_out[:b], grad_out[b:]
     nws = lib.plnlp_loss_workspace_floats(b)
     ws = torch.empty(nws, dtype=torch.float32, device=pos.device)
-    L.check(lib.plnlp_pairwise_loss_f32(L.LOSS_KINDS[kind], pos.data_ptr(), neg.data_ptr(), L.ptr(weight), b,
-                                        num_neg, grad_scale, loss.data_ptr(), gpos.data_ptr(), gneg.data_ptr(),
-                                        ws.data_ptr(), nws, L.stream_ptr()), "plnlp_pairwise_loss_f32")
+    acc = LOSS_ACC["buf"]
+    if acc is not None:
+        assert acc.dtype == torch.float64 and acc.device == pos.device
+        LOSS_ACC["fed"] += 1
+    L.check(lib.plnlp_pairwise_loss_tail_f32(L.LOSS_KINDS[kind], pos.data_ptr(), neg.data_ptr(), L.ptr(weight), b,
+                                             num_neg, grad_scale, loss.data_ptr(), gpos.data_ptr(), gneg.data_ptr(),
+                                             ws.data_ptr(), nws, tail_counter(pos.device, TAIL_LOSS), L.ptr(acc),
+                                             float(LOSS_ACC["weight"]), L.stream_ptr()),
+            "plnlp_pairwise_loss_tail_f32")
     return loss, gpos, gneg
 
 
@@ -920,6 +958,12 @@ def sqnorm_into(tensors: Sequence[torch.Tensor], out: torch.Tensor) -> torch.Ten
     for t in tensors:
         L.require_device(t)
         assert t.is_contiguous() and t.dtype == torch.float32
+    if 0 < len(tensors) <= L.MULTI_MAX and total > 0:       # the usual case: one launch, the sum included
+        ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        sizes = (C.c_int64 * len(tensors))(*[t.numel() for t in tensors])
+        L.check(lib.plnlp_sqnorm_multi_sum_f32(ptrs, sizes, len(tensors), part.data_ptr(), total, out.data_ptr(),
+                                               tail_counter(out.device, TAIL_SQNORM), s), "plnlp_sqnorm_multi_sum_f32")
+        return out
     for lo in range(0, len(tensors), L.MULTI_MAX):          # one launch per <= 16 tensors
         chunk = tensors[lo:lo + L.MULTI_MAX]
         ptrs = (C.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])

@@ -573,10 +573,13 @@ def test_row_split_hub_rows_match_oracle_and_unsplit(P, feat):
     for reduce in ("sum", "mean"):
         for use_values in (True, False):
             ref = O.spmm(csr, x.double(), reduce, use_values)
-            a = P.ops.csr_aggregate(gr, dev(x), reduce, use_values)                 # static split
-            b = P.ops.csr_aggregate(gr, dev(x), reduce, use_values, split=None)     # no split
-            d = P.ops.csr_aggregate(gr, dev(x), reduce, use_values,
+            # (tune=0: the tuner may pick, per graph and width, a form with its own summation tree for the long
+            #  rows -- slabs, chunks by source range --; bit-equality is a statement about ONE form)
+            a = P.ops.csr_aggregate(gr, dev(x), reduce, use_values, tune=0)                 # static split
+            b = P.ops.csr_aggregate(gr, dev(x), reduce, use_values, split=None, tune=0)     # no split
+            d = P.ops.csr_aggregate(gr, dev(x), reduce, use_values, tune=0,
                                     split=RowSplit(gr.rowptr, gr.nnz, th))       # upper-bound sized tables
+            close(P.ops.csr_aggregate(gr, dev(x), reduce, use_values), ref, atol=2e-4)      # whatever the tuner picks
             close(a, ref, atol=2e-4)
             close(b, ref, atol=3e-3)      # unsplit: one sequential fp32 chain over 3000 terms
             assert torch.equal(a, d)
