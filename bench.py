@@ -342,16 +342,14 @@ def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
                         "no-reuse fraction of this kernel is taken on the uniform graph (default workload's `roofline`)"}
     return {"bound": "cache" if cached else "hbm",
             "kernel": "csr_agg_vec_kernel (%s, F=%d)" % ("weighted sum" if weighted else "mean", feat),
-            "launches": "one aggregation = csr_agg_vec_kernel (rows <= 256 entries) + csr_agg_chunk_kernel + "
-                        "csr_agg_finalize_kernel (hub rows); kernel_ms and achieved cover all three",
+            "launches": "one aggregation = csr_agg_fused_kernel (one wave per short row + the long rows' chunks, in one "
+                        "launch) + csr_agg_finalize_kernel (the long rows' partial sums); kernel_ms and achieved cover both",
             "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 8.0e12,
             "traffic": None, "traffic_from_profile": from_profile,
             "algorithmic_bytes": alg, "bytes_model": "compulsory" if cached else "gather",
             "gather_model_bytes": by, "compulsory_bytes": by_min, "effective_GBps": by / t / 1e9,
             "kernel_ms": t * 1e3, "source_MiB": src_mib,
-            "kernel_form": {0: "one wave per row", 16: "one wave per (row, 128-column slab)",
-                            32: "one wave per (row, 256-column slab)"}.get(
-                                getattr(graph, "_agg_tune", {}).get(feat, 0), "?") + " (measured choice, ops._agg_tune)",
+            "kernel_form": P.ops.describe_form(getattr(graph, "_agg_tune", {}).get(feat, 0)),
             "note": ("source fits the 256 MiB Infinity Cache: cache-bound, frac is compulsory bytes over the HBM "
                      "peak; effective_GBps is the gather-model rate (not a roofline fraction)") if cached else
                     ("source exceeds the 256 MiB Infinity Cache: HBM-bound, gather-model bytes" +
@@ -433,7 +431,9 @@ def measure_step_launches(P, model, data, pos_b, neg_b, cfg, device):
     src_mib = n * F * 4 / 2 ** 20
     out["roofline_workload_agg"] = {
         "bound": "cache" if src_mib <= 256 else "hbm", "subject": "the step's own forward aggregation launch",
-        "kernel": "csr_agg_vec_kernel (mean, F=%d, row_index: %d touched rows of %d) + chunk + finalize passes" % (F, T, n),
+        "kernel": "csr_agg_fused_kernel (mean, F=%d, row_index: %d touched rows of %d; short rows + hub chunks) + "
+                  "csr_agg_finalize_kernel" % (F, T, n),
+        "kernel_form": P.ops.describe_form(adj._agg_tune.get(F, 0)),
         "achieved": by_min / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by_min / t / 8.0e12, "traffic": None,
         "algorithmic_bytes": by_min, "bytes_model": "compulsory", "gather_model_bytes": by, "effective_GBps": by / t / 1e9,
         "kernel_ms": t * 1e3, "source_MiB": src_mib, "rows": T, "entries": nnz_T, "distinct_source_rows": distinct_src,
@@ -483,7 +483,8 @@ def measure_step_launches(P, model, data, pos_b, neg_b, cfg, device):
     out["roofline_agg_adam"] = {
         "bound": "hbm", "subject": "the step's own backward launch: transposed aggregation + Adam on the table (the "
                                    "step's longest kernel)",
-        "kernel": "csr_agg_vec_kernel<weighted> (F=%d, src_map, ADDEND|ADAM epilogue) + chunk + finalize passes" % F,
+        "kernel": "csr_agg_fused_kernel<weighted> (F=%d, src_map, ADDEND|ADAM epilogue; short rows + hub chunks) + "
+                  "csr_agg_finalize_kernel" % F,
         "achieved": by_min / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by_min / t / 8.0e12, "traffic": None,
         "algorithmic_bytes": by_min, "bytes_model": "compulsory: index + value lists, node map twice, the compact gradient "
                                                     "and addend once, 3 reads + 3 writes of the [N, F] table / moments",

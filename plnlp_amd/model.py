@@ -376,8 +376,10 @@ class BaseModel(object):
         """once per (static) graph object: let the ranks of this model's group agree on the form of the
         aggregation kernel at the widths this encoder aggregates (ops.tune_aggregation -- rank 0's measurement
         is broadcast).  Every training-step entry point calls this first, i.e. at a point all ranks of the group
-        pass together; the aggregation op itself never communicates.  One process: the op measures lazily."""
-        if self.process_group is None or not isinstance(self.encoder, BaseGNN) or graph.device.type != "cuda":
+        pass together; the aggregation op itself never communicates.  One process: the same call without a group --
+        the op's own lazy measurement only fires on a PLAIN launch, and a training step with the row-restricted
+        forward and the mapped backward never makes one (it ran the default form until an evaluation pass tuned it)."""
+        if not isinstance(self.encoder, BaseGNN) or graph.device.type != "cuda":
             return
         seen = getattr(self, "_tuned_graphs", None)
         if seen is None:

@@ -116,6 +116,20 @@ AGG_AUTOTUNE = {"enabled": os.environ.get("PLNLP_AGG_AUTOTUNE", "1") != "0", "mi
                 "candidates": (0, L.AGG_SLABS_128, L.AGG_SLABS_256, L.AGG_HUB_XCD | AGG_HUB_RANGES)}
 
 
+def describe_form(tune: int) -> str:
+    """a tuned aggregation form in words (bench lines, profiles)"""
+    t = int(tune)
+    rows = {0: "one wave per row", L.AGG_SLABS_128: "one wave per (row, 128-column slab)",
+            L.AGG_SLABS_256: "one wave per (row, 256-column slab)",
+            L.AGG_SLABS_XCD: "one wave per (row, F/8-column slab pinned to an XCD)"}.get(
+                t & (L.AGG_SLABS_128 | L.AGG_SLABS_256 | L.AGG_SLABS_XCD), "?")
+    hubs = "long rows: position chunks"
+    if t & L.AGG_HUB_XCD:
+        hubs = ("long rows: chunks by source range, eight XCD-pinned column slabs" if t & AGG_HUB_RANGES
+                else "long rows: position chunks in eight XCD-pinned column slabs")
+    return "%s; %s (measured choice, ops._agg_tune)" % (rows, hubs)
+
+
 def mapped_form(tune: int) -> int:
     """the form a launch with a source map runs when the graph's tuned form is `tune`"""
     return int(tune) & ~(L.AGG_HUB_XCD | AGG_HUB_RANGES)
@@ -127,20 +141,30 @@ def _multi_rank() -> bool:
 
 
 def _time_agg_forms(graph, x, out, reduce, use_values, src_scale, epilogue) -> int:
-    """three timed launches per candidate form on this rank; a slab form must win clearly (3 %)"""
-    best, best_t = 0, None
-    for cand in AGG_AUTOTUNE["candidates"]:
-        times = []
-        for it in range(3):
+    """which candidate form is fastest on this graph, by measurement on this rank: every form is launched once untimed
+    (its tables get built, the clocks come up), then five timed rounds go over the forms in turn -- a cold or drifting
+    clock then biases no form -- and each form keeps its best time; a form other than the default must win by 3 %"""
+    cands = list(AGG_AUTOTUNE["candidates"])
+
+    def run(cand):
+        csr_aggregate(graph, x, reduce, use_values, src_scale=src_scale, out=out, epilogue=epilogue, tune=cand)
+    for cand in cands:
+        run(cand)
+    for cand in cands:
+        run(cand)
+    best_t = {c: float("inf") for c in cands}
+    for _ in range(5):
+        for cand in cands:
             s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s_ev.record()
-            csr_aggregate(graph, x, reduce, use_values, src_scale=src_scale, out=out, epilogue=epilogue, tune=cand)
+            run(cand)
             e_ev.record()
             e_ev.synchronize()
-            times.append(s_ev.elapsed_time(e_ev))
-        t = min(times[1:])
-        if best_t is None or t < 0.97 * best_t:
-            best, best_t = cand, t
+            best_t[cand] = min(best_t[cand], s_ev.elapsed_time(e_ev))
+    best = cands[0]
+    for cand in cands[1:]:
+        if best_t[cand] < 0.97 * best_t[best]:
+            best = cand
     return best
 
 

@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --stats -f csv -d $R/prof -o collab -- python3 bench.py
 f=$(find $R/prof -name "*kernel_stats.csv" | head -1); cp $f $R/bench_collab_rocprofv3_kernel_stats.csv
 f=$(find $R/prof -name "*kernel_trace.csv" | head -1)
 python scripts/kernel_calls.py $f "csr_agg_vec_kernel<1, 32, false" 20 > $R/roofline_kernel_calls.txt
-python scripts/kernel_calls.py $f "csr_agg_vec_kernel<1, 64, true" 20 >> $R/roofline_kernel_calls.txt
+python scripts/kernel_calls.py $f "csr_agg_fused_kernel<1, 64, 1, 64, true" 20 >> $R/roofline_kernel_calls.txt
 rm -rf $R/prof
 # 2. the step alone under the kernel trace: per-step breakdown and launch sequence
 rocprofv3 --kernel-trace --stats -f csv -d $R/prof -o step -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-stress --no-roofline > /dev/null 2>&1
@@ -39,4 +39,5 @@ done
 python bench.py --workload citation2 --force-dist --dp-exchange grads --steps 10 --warmup 5 --no-cpu-baseline --no-parity --no-stress --no-roofline > $R/bench_citation2_grads_1rank.json 2>/dev/null
 python scripts/bench_gemm.py --math ab --error > $R/gemm_microbench.jsonl 2>/dev/null
 python scripts/bench_agg.py --cases collab,uniform_big,ddi --feat 256,512 --tune 0,16,32 > $R/agg_microbench.jsonl 2>/dev/null
+python scripts/bench_agg.py --cases collab --feat 256 --tune 128 --hub-order 65536:256 >> $R/agg_microbench.jsonl 2>/dev/null
 ls -la $R
