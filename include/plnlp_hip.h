@@ -235,7 +235,9 @@ typedef struct plnlp_gemm_operand {
  *   F32    -- v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain over k (157 TFLOP/s peak)
  *   BF16X3 -- every operand element split in the loader into three bf16 terms (x = hi + mid + lo, residuals
  *             exact), six bf16 MFMAs per product block (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi): each
- *             product reproduced to <= 2^-25 relative (the f32 MFMA rounds it at 2^-24), 16/6 of the f32 MFMA rate.
+ *             product reproduced to 2^-22 relative in the worst case (bf16 unit round-off 2^-8: dropped cross terms
+ *             and operand residuals of 2^-24 each), measured at or below the f32 MFMA's error against fp64 (which
+ *             rounds every product at 2^-24); 16/6 of the f32 MFMA rate.
  * Non-finite operands (a diverged run): F32 follows IEEE like the reference's sgemm -- an inf operand element gives
  * +-inf in the result elements it feeds, NaN where it meets a 0 or an opposite inf, NaN propagates.  BF16X3 turns
  * EVERY result element that depends on a non-finite operand element into NaN (the split forms inf - inf); result

@@ -50,9 +50,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate) with every f32 operand element split, on its way into
 // LDS, into three bf16 terms  x = hi + mid + lo  (round-to-nearest each, the residuals exact in f32, so the
 // three carry 24+ significant bits) and the product formed from the six terms that matter:
-//     a b ~= hi hi + (hi mid + mid hi) + (mid mid + hi lo + lo hi),     dropped: mid lo, lo mid, lo lo <= 2^-26 |a b|
-// i.e. each product is reproduced to 2^-25..2^-26 relative -- tighter than the one f32 rounding (2^-24) the
-// f32 MFMA applies to it -- and accumulated in f32 like before.  Six bf16 MFMAs of K = 16 replace eight f32
+//     a b ~= hi hi + (hi mid + mid hi) + (mid mid + hi lo + lo hi),     dropped: mid lo, lo mid, lo lo
+// bf16 rounds to 8 significant bits (unit round-off 2^-8): |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|, and what the three
+// terms leave of x is <= 2^-24 |x|.  WORST case per product: the two dropped cross terms 2 x 2^-24, the two operand
+// residuals 2 x 2^-24, lo lo 2^-32 -- about 2^-22 |a b|, four times the one rounding (2^-24) the f32 MFMA applies to
+// the product; for operands that do not sit at the rounding boundaries the terms are a factor 4-16 smaller and of
+// random sign, and the error MEASURED against fp64 is at or below the f32 MFMA's on every shape of the path
+// (profiles/r02_gemm_bf16x3_error.jsonl; the test bound is 2^-22 and 1.5 x the f32 MFMA's own error).
+// The sum is accumulated in f32 like before.  Six bf16 MFMAs of K = 16 replace eight f32
 // MFMAs of K = 2 per 32x32x16 block: 6 x 32 = 192 cycles instead of 512.  Which form a launch uses is the
 // caller's choice (plnlp_gemm_operand.math); tests/test_hip_round2.py measures both against fp64.
 #ifndef PLNLP_GEMM_X3
