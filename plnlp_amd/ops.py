@@ -112,8 +112,11 @@ def hub_ranges(n_source_rows: int):
     """(part_rows, max_len) of graph.SourceOrderedSplit for a source matrix of this many rows"""
     per = -(-int(n_source_rows) // HUB_RANGES["max_ranges"])
     return max(HUB_RANGES["part_rows"], per), HUB_RANGES["max_len"]
+# PLNLP_AGG_FORM=<int>: no measurement, this form on every static graph (counter-collection runs, whose serialised
+# kernels would otherwise time differently from the run they are meant to explain)
 AGG_AUTOTUNE = {"enabled": os.environ.get("PLNLP_AGG_AUTOTUNE", "1") != "0", "min_feat": 256,
-                "candidates": (0, L.AGG_SLABS_128, L.AGG_SLABS_256, L.AGG_HUB_XCD | AGG_HUB_RANGES)}
+                "candidates": (0, L.AGG_SLABS_128, L.AGG_SLABS_256, L.AGG_HUB_XCD | AGG_HUB_RANGES),
+                "force": int(os.environ["PLNLP_AGG_FORM"]) if os.environ.get("PLNLP_AGG_FORM") else None}
 
 
 def describe_form(tune: int) -> str:
@@ -144,6 +147,8 @@ def _time_agg_forms(graph, x, out, reduce, use_values, src_scale, epilogue) -> i
     """which candidate form is fastest on this graph, by measurement on this rank: every form is launched once untimed
     (its tables get built, the clocks come up), then five timed rounds go over the forms in turn -- a cold or drifting
     clock then biases no form -- and each form keeps its best time; a form other than the default must win by 3 %"""
+    if AGG_AUTOTUNE["force"] is not None:
+        return int(AGG_AUTOTUNE["force"])
     cands = list(AGG_AUTOTUNE["candidates"])
 
     def run(cand):

@@ -19,7 +19,7 @@ for pass in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   d=$R/pmc_a/$(echo $pass | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $pass -f csv -d $d -o a -- python3 scripts/bench_agg.py --cases uniform_big --feat 512 --tune 16 > /dev/null 2>&1
   d=$R/pmc_s/$(echo $pass | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $pass -f csv -d $d -o s -- python3 scripts/bench_step_launches.py > /dev/null 2>&1
+  PLNLP_AGG_FORM=65664 rocprofv3 --kernel-trace --pmc $pass -f csv -d $d -o s -- python3 scripts/bench_step_launches.py > /dev/null 2>&1   # (the form the tuner picks on this graph, pinned: counter runs serialise the kernels it would time)
 done
 python3 scripts/pmc_collect.py csr_agg $R/agg_pmc_uniform_big.json "$R/pmc_a/**/*counter_collection.csv" > /dev/null
 python3 scripts/pmc_collect.py csr_agg $R/agg_pmc_step_launches.json "$R/pmc_s/**/*counter_collection.csv" > /dev/null
