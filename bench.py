@@ -342,8 +342,11 @@ def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
                         "no-reuse fraction of this kernel is taken on the uniform graph (default workload's `roofline`)"}
     return {"bound": "cache" if cached else "hbm",
             "kernel": "csr_agg_vec_kernel (%s, F=%d)" % ("weighted sum" if weighted else "mean", feat),
-            "launches": "one aggregation = csr_agg_fused_kernel (one wave per short row + the long rows' chunks, in one "
-                        "launch) + csr_agg_finalize_kernel (the long rows' partial sums); kernel_ms and achieved cover both",
+            "launches": ("one aggregation = csr_agg_fused_kernel (one wave per short row + the long rows' chunks, in one "
+                         "launch) + csr_agg_finalize_kernel (the long rows' partial sums); kernel_ms and achieved cover both")
+                        if graph.row_split(P.ops.split_threshold(graph.n_cols)).active else
+                        "one aggregation = one launch of csr_agg_vec_kernel (no row of this graph is longer than the split "
+                        "threshold)",
             "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 8.0e12,
             "traffic": None, "traffic_from_profile": from_profile,
             "algorithmic_bytes": alg, "bytes_model": "compulsory" if cached else "gather",
