@@ -344,6 +344,18 @@ int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int64_t n_edge
 int64_t plnlp_compact_rows_workspace(int64_t n_rows);
 int plnlp_compact_rows(const int64_t* rowptr, int64_t n_rows, int32_t* rows, int32_t* node_map,
                        int64_t* rowptr_c, int64_t* count, int32_t* block_ws, void* stream);
+/* The endpoint lists of a batch, one launch each (the side stream ran them as 2 cat + 3 gather + 3 cast launches of
+ * stock ops per step):
+ *   plnlp_edge_endpoints   : src / dst [n_pos + n_neg] = column 0 / 1 of [pos ; neg], both row-major [*, 2] int64 --
+ *                            the `pos_edge[:, 0]`, `neg_edge[..., 0]` ... of plnlp/model.py:152-156 as two lists;
+ *   plnlp_compact_endpoints: src_c / dst_c = node_map[src / dst] (int64), other_c = node_map[item_other] (int32) --
+ *                            the same endpoints as rows of a matrix that holds only the touched nodes
+ *                            (plnlp_compact_rows' node_map; every endpoint of the batch is a touched node). */
+int plnlp_edge_endpoints(const int64_t* pos, int64_t n_pos, const int64_t* neg, int64_t n_neg,
+                         int64_t* src, int64_t* dst, void* stream);
+int plnlp_compact_endpoints(const int32_t* node_map, const int64_t* src, const int64_t* dst, int64_t n_edges,
+                            const int32_t* item_other, int64_t n_items, int64_t* src_c, int64_t* dst_c,
+                            int32_t* other_c, void* stream);
 /* uniform random walks for the random-walk pair augmentation (main.py:241-253; replaces
  * torch_cluster.random_walk): walks[w, 0] = start[w], walks[w, l+1] = a uniformly chosen neighbour of
  * walks[w, l] (the node itself if it has none).  Randomness: counter hash of (seed, w*L + l). */

@@ -238,6 +238,32 @@ __global__ __launch_bounds__(CB) void compact_write_kernel(const int64_t* __rest
     }
 }
 
+// ---- the endpoint lists of a batch in one launch each (they were 2 cat + 3 gather + 3 cast launches of stock ops) ----
+// src / dst = column 0 / 1 of [pos (na rows) ; neg (nb rows)], both row-major [*, 2] int64
+__global__ __launch_bounds__(256) void edge_endpoints_kernel(const int64_t* __restrict__ a, int64_t na,
+                                                             const int64_t* __restrict__ b, int64_t nb,
+                                                             int64_t* __restrict__ src, int64_t* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= na + nb) return;
+    const int64_t* row = i < na ? a + 2 * i : b + 2 * (i - na);
+    src[i] = row[0];
+    dst[i] = row[1];
+}
+// endpoints and the incidence lists' other endpoints as rows of the matrix that holds only the touched nodes
+__global__ __launch_bounds__(256) void compact_endpoints_kernel(const int32_t* __restrict__ node_map,
+                                                                const int64_t* __restrict__ src,
+                                                                const int64_t* __restrict__ dst, int64_t n_edges,
+                                                                const int32_t* __restrict__ item_other, int64_t n_items,
+                                                                int64_t* __restrict__ src_c, int64_t* __restrict__ dst_c,
+                                                                int32_t* __restrict__ other_c) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_edges) {
+        src_c[i] = (int64_t)node_map[src[i]];
+        dst_c[i] = (int64_t)node_map[dst[i]];
+    }
+    if (i < n_items) other_c[i] = node_map[item_other[i]];
+}
+
 static inline int bits_for(int64_t n) {  // smallest b with (1 << b) >= n
     int b = 0;
     while (((int64_t)1 << b) < n) ++b;
@@ -284,6 +310,32 @@ extern "C" int plnlp_incidence_build(const int64_t* src, const int64_t* dst, int
     if (err != hipSuccess) return (int)err;
     hipLaunchKernelGGL(incidence_items_kernel, dim3(blocks), dim3(256), 0, s, keys_b, src, dst, n_edges, n_nodes,
                        shift, item_edge, item_other, seg_ptr);
+    return launch_status();
+}
+
+extern "C" int plnlp_edge_endpoints(const int64_t* pos, int64_t n_pos, const int64_t* neg, int64_t n_neg,
+                                    int64_t* src, int64_t* dst, void* stream) {
+    using namespace plnlp;
+    if (n_pos < 0 || n_neg < 0 || n_pos + n_neg >= (1ll << 31)) return PLNLP_E_SHAPE;
+    if (n_pos + n_neg == 0) return 0;
+    if ((n_pos > 0 && !pos) || (n_neg > 0 && !neg) || !src || !dst) return PLNLP_E_NULL;
+    const int64_t n = n_pos + n_neg;
+    hipLaunchKernelGGL(edge_endpoints_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos,
+                       n_pos, neg, n_neg, src, dst);
+    return launch_status();
+}
+
+extern "C" int plnlp_compact_endpoints(const int32_t* node_map, const int64_t* src, const int64_t* dst, int64_t n_edges,
+                                       const int32_t* item_other, int64_t n_items, int64_t* src_c, int64_t* dst_c,
+                                       int32_t* other_c, void* stream) {
+    using namespace plnlp;
+    if (n_edges < 0 || n_items < 0 || n_edges >= (1ll << 31) || n_items >= (1ll << 31)) return PLNLP_E_SHAPE;
+    const int64_t n = n_edges > n_items ? n_edges : n_items;
+    if (n == 0) return 0;
+    if (!node_map || (n_edges > 0 && (!src || !dst || !src_c || !dst_c)) || (n_items > 0 && (!item_other || !other_c)))
+        return PLNLP_E_NULL;
+    hipLaunchKernelGGL(compact_endpoints_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       node_map, src, dst, n_edges, item_other, n_items, src_c, dst_c, other_c);
     return launch_status();
 }
 

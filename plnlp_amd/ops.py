@@ -1891,18 +1891,48 @@ class EdgeBatch:
         else:
             self._produce(src_parts, dst_parts, n_nodes, build, compact)
 
+    @staticmethod
+    def _column_pair(s, d) -> bool:
+        """s, d = columns 0 and 1 of one row-major [n, 2] int64 device tensor (`edge[:, 0]`, `edge[:, 1]`)"""
+        return (s.is_cuda and s.dtype == torch.int64 and d.dtype == torch.int64 and s.dim() == 1 and d.dim() == 1
+                and s.numel() == d.numel() and (s.numel() <= 1 or (s.stride(0) == 2 and d.stride(0) == 2))
+                and d.data_ptr() == s.data_ptr() + 8)
+
     def _produce(self, src_parts, dst_parts, n_nodes, build, compact):
-        self.src = torch.cat(src_parts) if len(src_parts) > 1 else src_parts[0].contiguous()
-        self.dst = torch.cat(dst_parts) if len(dst_parts) > 1 else dst_parts[0].contiguous()
+        if (len(src_parts) == 2 and len(dst_parts) == 2 and self._column_pair(src_parts[0], dst_parts[0])
+                and self._column_pair(src_parts[1], dst_parts[1])):
+            # [pos ; neg] -> src, dst in one launch (plnlp_edge_endpoints) instead of two torch.cat
+            n_pos, n_neg = src_parts[0].numel(), src_parts[1].numel()
+            both = torch.empty(2, n_pos + n_neg, dtype=torch.int64, device=src_parts[0].device)
+            self.src, self.dst = both[0], both[1]
+            L.check(L.load().plnlp_edge_endpoints(src_parts[0].data_ptr(), n_pos, src_parts[1].data_ptr(), n_neg,
+                                                  self.src.data_ptr(), self.dst.data_ptr(), L.stream_ptr()),
+                    "plnlp_edge_endpoints")
+        else:
+            self.src = torch.cat(src_parts) if len(src_parts) > 1 else src_parts[0].contiguous()
+            self.dst = torch.cat(dst_parts) if len(dst_parts) > 1 else dst_parts[0].contiguous()
         self.incidence = None
         self.src_c = self.dst_c = None
         if build and self.src.numel() > 0:
             self.incidence = prepare_edge_backward(self.src, self.dst, n_nodes, compact, self._count_host)
             if self._compact_endpoints:
                 inc = self.incidence
-                inc.prepare_compact_columns()
-                self.src_c = inc.node_map.index_select(0, self.src).long()
-                self.dst_c = inc.node_map.index_select(0, self.dst).long()
+                if self.src.is_cuda:
+                    # the endpoints and the lists' other endpoints as compact row ids: one launch
+                    # (plnlp_compact_endpoints) instead of three gathers and three casts
+                    e = self.src.numel()
+                    both_c = torch.empty(2, e, dtype=torch.int64, device=self.src.device)
+                    inc._other_c = torch.empty_like(inc.item_other)
+                    self.src_c, self.dst_c = both_c[0], both_c[1]
+                    L.check(L.load().plnlp_compact_endpoints(inc.node_map.data_ptr(), self.src.data_ptr(),
+                                                             self.dst.data_ptr(), e, inc.item_other.data_ptr(),
+                                                             inc.item_other.numel(), self.src_c.data_ptr(),
+                                                             self.dst_c.data_ptr(), inc._other_c.data_ptr(),
+                                                             L.stream_ptr()), "plnlp_compact_endpoints")
+                else:
+                    inc.prepare_compact_columns()
+                    self.src_c = inc.node_map.index_select(0, self.src).long()
+                    self.dst_c = inc.node_map.index_select(0, self.dst).long()
 
     def _tensors(self):
         out = [self.src, self.dst]

@@ -670,3 +670,32 @@ def test_sqnorm_with_the_sum_in_the_same_launch(P):
             assert torch.equal(one, two)
         ref = sum(float((t.double() ** 2).sum()) for t in ts)
         assert abs(float(one) - ref) <= 1e-5 * ref
+
+
+def test_edge_batch_endpoint_lists_in_one_launch_each(P):
+    """plnlp_edge_endpoints / plnlp_compact_endpoints (what EdgeBatch now builds its lists with) == the stock-op
+    formulation they replace: src / dst = columns of [pos ; neg], src_c / dst_c / other_c = node_map[...]; also with an
+    empty negative part, one edge, and column views that are NOT a [n, 2] pair (falls back to torch.cat)"""
+    from plnlp_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    n_nodes = 5000
+    for n_pos, k in ((1000, 3), (1, 1), (257, 0)):
+        pos = torch.randint(0, n_nodes, (n_pos, 2), generator=gen).cuda()
+        neg = torch.randint(0, n_nodes, (n_pos * k, 2), generator=gen).cuda()
+        b = ops.EdgeBatch([pos[:, 0], neg[:, 0]], [pos[:, 1], neg[:, 1]], n_nodes, build=True, compact=True,
+                          overlap=False, compact_endpoints=True)
+        src = torch.cat([pos[:, 0], neg[:, 0]])
+        dst = torch.cat([pos[:, 1], neg[:, 1]])
+        assert torch.equal(b.src, src) and torch.equal(b.dst, dst)
+        inc = b.incidence
+        nm = inc.node_map.long()
+        assert torch.equal(b.src_c, nm[src]) and torch.equal(b.dst_c, nm[dst])
+        assert int(b.src_c.min()) >= 0 and int(b.dst_c.min()) >= 0          # every endpoint is a touched node
+        assert torch.equal(inc._other_c.long(), nm[inc.item_other.long()])
+        assert b.src_c.dtype == torch.int64 and inc._other_c.dtype == torch.int32
+    # not a column pair of one tensor: the general path
+    a0, a1 = torch.randint(0, n_nodes, (300,), generator=gen).cuda(), torch.randint(0, n_nodes, (300,), generator=gen).cuda()
+    c0, c1 = torch.randint(0, n_nodes, (50,), generator=gen).cuda(), torch.randint(0, n_nodes, (50,), generator=gen).cuda()
+    b = ops.EdgeBatch([a0, c0], [a1, c1], n_nodes, build=True, compact=True, overlap=False, compact_endpoints=True)
+    assert torch.equal(b.src, torch.cat([a0, c0])) and torch.equal(b.dst, torch.cat([a1, c1]))
+    assert torch.equal(b.src_c, b.incidence.node_map.long()[b.src])
