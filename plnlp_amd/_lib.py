@@ -183,7 +183,14 @@ def check(rc: int, what: str) -> None:
         raise PlnlpHipError(f"{what}: {msg} (code {rc})")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
+    """hipStream_t of the current device's current stream.  (A step asks ~11 times; the Stream object that
+    torch.cuda.current_stream() builds per call was 0.15 ms of the host's ~0.9 ms per step, the raw query is ~1 us.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
