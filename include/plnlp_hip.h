@@ -28,6 +28,10 @@
 extern "C" {
 #endif
 
+/* 7 (round 3): plnlp_rmat_edges, plnlp_host_randperm_*, plnlp_adam_step_scalars, device-side step scalars in
+ *              plnlp_epilogue / plnlp_adam_tensor; the short-rows aggregation form retired.
+ * 8 (round 3): plnlp_row_split.seg_* (explicit chunks), PLNLP_AGG_SLABS_XCD / _HUB_XCD / _FUSED_PASSES,
+ *              plnlp_pairwise_loss_tail_f32, plnlp_sqnorm_multi_sum_f32, plnlp_edge_endpoints, plnlp_compact_endpoints. */
 #define PLNLP_ABI_VERSION 8
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
