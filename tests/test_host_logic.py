@@ -437,3 +437,24 @@ def test_source_ordered_split_tables_cover_every_long_row_entry_once():
     # no long row at all
     sp3 = SourceOrderedSplit(rowptr, col, 1000)
     assert not sp3.active
+
+
+def test_aggregation_form_helpers():
+    """host-side form bookkeeping of the aggregation tuner (no GPU): the range rule of the source-ordered hub split,
+    the form a mapped launch runs, and the words the bench line prints for a form"""
+    from plnlp_amd import ops, _lib as L
+    old = dict(ops.HUB_RANGES)
+    try:
+        ops.HUB_RANGES.update(part_rows=65536, max_len=256, max_ranges=8)
+        assert ops.hub_ranges(235868) == (65536, 256)                  # collab: 4 ranges of the floor size
+        assert ops.hub_ranges(12_500_000) == (1_562_500, 256)          # R-MAT x0.25: capped at 8 ranges
+        assert ops.hub_ranges(10) == (65536, 256)
+    finally:
+        ops.HUB_RANGES.update(old)
+    hub = L.AGG_HUB_XCD | ops.AGG_HUB_RANGES
+    assert ops.mapped_form(hub) == 0 and ops.mapped_form(L.AGG_SLABS_128) == L.AGG_SLABS_128
+    assert ops.mapped_form(hub | L.AGG_FUSED_PASSES) == L.AGG_FUSED_PASSES
+    assert "source range" in ops.describe_form(hub) and "128-column slab" in ops.describe_form(L.AGG_SLABS_128)
+    assert "position chunks" in ops.describe_form(0) and "pinned" in ops.describe_form(L.AGG_HUB_XCD)
+    # the host-side bit never reaches the library's flag word
+    assert ops.AGG_HUB_RANGES > 0xFFFF and (hub & 0xFFFF) == L.AGG_HUB_XCD
