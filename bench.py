@@ -33,8 +33,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# before anything initialises the HIP runtime (plnlp_amd/__init__.py explains): replayed hipGraphs need it
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import torch
 
 WORKLOADS = {
@@ -78,6 +76,12 @@ def parse():
                     help="launcher check without GPUs: the ranks rendezvous over gloo, do one all-reduce and rank 0 "
                          "prints a JSON line (no kernels run; not a measurement)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--as-rank", default="",
+                    help="rmat only, one process: 'R/W' = do what rank R of a W-rank job does at --scale 1.0 -- its "
+                         "destination-row block of the 50 M x 1 B R-MAT graph gathering from the full replicated "
+                         "50 M x 512 source (102 GB): layer 1's aggregation and GEMM on its 6.25 M rows.  No "
+                         "collective runs (the other ranks do not exist); reports the aggregation kernel on the "
+                         "source size config 5 really has")
     ap.add_argument("--batch-mult", type=int, default=1,
                     help="multiply the per-GPU batch (debug: the per-rank cost of an N-rank 'scores' job is about the "
                          "1-GPU step at N times the batch; invalidates the number)")
@@ -274,6 +278,88 @@ def run_rmat_stress(args, P, world, rank, device, pg):
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
+
+
+def run_rmat_as_rank(args, P, device):
+    """BASELINE.json config 5 at ONE RANK'S TRUE SHARE: rank R of W builds its destination-row block of the full
+    R-MAT graph (N = 50 M, 1 B edges) and gathers from the full replicated source X [50 M, 512] (102 GB, generated in
+    place) -- the geometry the aggregation kernel meets on an 8-GPU node, which no --scale run reaches (a source 18x
+    the one behind the default `roofline`, offsets beyond 2^32 bytes, TLB reach).  Layer 1 on the rank's rows:
+    mean aggregation, then the concat-K GEMM with bias + relu.  One process, no collective."""
+    from plnlp_amd import synthetic, shard
+    R, Wd = (int(v) for v in args.as_rank.split("/"))
+    F = 512
+    n = max(1024, int(round(50_000_000 * args.scale)))
+    nnz = max(4096, int(round(1_000_000_000 * args.scale)))
+    rscale = max(10, (n - 1).bit_length())
+    part = shard.RowPartition(n, Wd, R)
+    S, npad = part.rows, part.padded
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    blk = synthetic.rmat_row_block(rscale, nnz, n, part.lo, S, npad, device, seed=11)
+    torch.cuda.synchronize()
+    t_graph = time.perf_counter() - t0
+    gen = torch.Generator(device=device).manual_seed(12)
+    x = torch.empty(npad, F, device=device)
+    for lo in range(0, npad, 1 << 20):
+        x[lo:lo + (1 << 20)].normal_(generator=gen)
+    w_l = torch.randn(F, F, device=device, generator=gen) * 0.03
+    w_r = torch.randn(F, F, device=device, generator=gen) * 0.03
+    bias = torch.zeros(F, device=device)
+    agg = torch.empty(S, F, device=device)
+    y = torch.empty(S, F, device=device)
+    P.ops.tune_aggregation(blk, [F])
+    epi = P._lib.make_epilogue(bias=bias, relu=True)
+    K, W = args.steps, args.warmup
+
+    def layer():
+        P.ops.csr_aggregate(blk, x, "mean", False, out=agg)
+        P.ops.gemm([(agg, w_l), (x[part.lo:part.lo + S], w_r)], False, True, out=y, epilogue=epi)
+    for _ in range(W):
+        layer()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        layer()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    t_agg = time_kernel(lambda: P.ops.csr_aggregate(blk, x, "mean", False, out=agg), iters=max(3, K), warm=1)
+    t_gemm = time_kernel(lambda: P.ops.gemm([(agg, w_l), (x[part.lo:part.lo + S], w_r)], False, True, out=y, epilogue=epi),
+                         iters=max(3, K), warm=1)
+    by = agg_bytes(blk.nnz, S, F)
+    # what MUST cross the HBM pins for this launch: every index once, every DISTINCT source row once, the result once
+    distinct = int(torch.unique(blk.col).numel())
+    compulsory = blk.nnz * 4 + (S + 1) * 8 + (distinct + S) * 4 * F
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(prof):
+        traffic = json.load(open(prof)).get("rmat_as_rank_%d_of_%d" % (R, Wd))
+    result = {
+        "metric": "edges aggregated/sec, R-MAT config 5, ONE rank's share of layer 1", "value": blk.nnz / dt,
+        "unit": "edges/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt * 1e3, "higher_is_better": True,
+        "scaling": "unmeasured (one process doing rank %d of %d's work; no collective)" % (R, Wd), "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "R-MAT (.57,.19,.19,.05) N=%d, 1e9 x %g edges; rank %d of %d: rows [%d, %d), %d entries, "
+                               "source X [%d, %d] = %.1f GB" % (n, args.scale, R, Wd, part.lo, part.lo + S, blk.nnz, npad, F,
+                                                               npad * F * 4 / 1e9),
+                   "scale": args.scale, "rows_per_rank": S, "as_rank": args.as_rank},
+        "roofline": {"bound": "hbm", "kernel": "csr aggregation (mean, F = 512), form: " + P.ops.describe_form(
+                         getattr(blk, "_agg_tune", {}).get(F, 0)) if hasattr(P.ops, "describe_form") else "csr aggregation",
+                     "subject": "this rank's row block gathering from the full 102 GB source",
+                     "kernel_ms": t_agg * 1e3, "peak": 8000.0, "unit": "GB/s",
+                     "algorithmic_bytes_gather_model": by, "effective_GBps": by / t_agg / 1e9,
+                     "compulsory_bytes": compulsory, "distinct_source_rows": distinct,
+                     "achieved": compulsory / t_agg / 1e9, "frac": compulsory / t_agg / 8e12,
+                     "traffic": None, "traffic_from_profile": traffic,
+                     "frac_from_counter_bytes": (traffic["bytes"] / t_agg / 8e12) if traffic else None,
+                     "note": "frac = COMPULSORY bytes (indices + every distinct source row once + the result) / time / 8 TB/s "
+                             "-- a lower bound on the kernel's HBM efficiency: rows re-read after falling out of the caches "
+                             "cross the pins again; frac_from_counter_bytes uses the PMC-measured bytes of the same launch "
+                             "(scripts/pmc_agg.sh, profiles/traffic.json) when a profile exists"},
+        "gemm_layer1_ms": t_gemm * 1e3, "gemm_TFLOPs_f32_equivalent": 2.0 * S * F * 2 * F / t_gemm / 1e12,
+        "graph_build_s": t_graph, "output_checksum": float(y.double().sum().item()), "rccl_ranks": 1,
+    }
+    print(json.dumps(result), flush=True)
 
 
 def agg_bytes(nnz, n_out, feat, weighted=False):
@@ -675,6 +761,8 @@ def main():
     P._lib.load()
     from plnlp_amd.utils import limit_host_threads
     limit_host_threads(world)      # stay inside the container's CPU quota (utils.host_cpu_budget)
+    if args.workload == "rmat" and args.as_rank:
+        return run_rmat_as_rank(args, P, device)
     if args.workload == "rmat":
         return run_rmat_stress(args, P, world, rank, device, pg)
 

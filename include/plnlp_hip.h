@@ -31,8 +31,9 @@ extern "C" {
 /* 7 (round 3): plnlp_rmat_edges, plnlp_host_randperm_*, plnlp_adam_step_scalars, device-side step scalars in
  *              plnlp_epilogue / plnlp_adam_tensor; the short-rows aggregation form retired.
  * 8 (round 3): plnlp_row_split.seg_* (explicit chunks), PLNLP_AGG_SLABS_XCD / _HUB_XCD / _FUSED_PASSES,
- *              plnlp_pairwise_loss_tail_f32, plnlp_sqnorm_multi_sum_f32, plnlp_edge_endpoints, plnlp_compact_endpoints. */
-#define PLNLP_ABI_VERSION 8
+ *              plnlp_pairwise_loss_tail_f32, plnlp_sqnorm_multi_sum_f32, plnlp_edge_endpoints, plnlp_compact_endpoints.
+ * 9 (round 4): plnlp_gemm_operand.b_terms / b_terms_bytes + plnlp_gemm_b_terms_bytes (the stationary-weights GEMM). */
+#define PLNLP_ABI_VERSION 9
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -233,7 +234,20 @@ typedef struct plnlp_gemm_operand {
                                  of MLPPredictor's first linear instead of being written out and read back       */
     const int32_t* b_index2;  /* nullable, with b_index: likewise for B's row of reduction index j (the weight
                                  gradient of that linear, dz^T (h[src] * h[dst]))                                */
+    void* b_terms;            /* nullable (read from segs[0]), BF16X3 and a_trans = 0: DEVICE scratch of at least
+                                 plnlp_gemm_b_terms_bytes(m, n, k0, k1) bytes, 16-byte aligned, that the launch may
+                                 overwrite: B -- the weights of the layer -- is split into its three bf16 terms ONCE
+                                 into this buffer instead of once per row panel, and the product runs on the
+                                 stationary-weights kernel (csrc/gemm_x3s.hip).  Same result bits either way; launches
+                                 the form does not cover (gathered B rows, unaligned operands, m < 16384) ignore it.   */
+    int64_t b_terms_bytes;
 } plnlp_gemm_operand;
+
+/* bytes of scratch plnlp_gemm_operand.b_terms needs for an [m, n] result over K-segments k0 (+ k1, 0 = one segment) */
+int64_t plnlp_gemm_b_terms_bytes(int64_t m, int64_t n, int64_t k0, int64_t k1);
+/* measurement knob of the stationary-weights form (process-global; A/B runs only, not for concurrent launches):
+ * nb = 1 / 2 / 4 / 7 / 8 forces the column-tile width (x 32 columns), 0 = automatic; `reserved` is ignored */
+void plnlp_gemm_stationary_tuning(int nb, int reserved);
 
 /* how the products are formed.  Both take and return fp32 and accumulate in fp32:
  *   F32    -- v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain over k (157 TFLOP/s peak)

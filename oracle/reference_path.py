@@ -24,6 +24,7 @@ __all__ = [
     "perm_copy_ref", "structured_negative_sampling_ref", "global_neg_sample_ref",
     "pos_neg_edges_ref", "hits_at_k", "mrr_list", "evaluate_hits_ref",
     "evaluate_mrr_ref", "clip_grad_norm_ref", "TrainerRef", "adjust_lr_ref", "collab_graph_prep_ref",
+    "random_walk_pairs_ref", "LoggerRef", "run_loop_ref",
 ]
 
 
@@ -802,3 +803,117 @@ def collab_graph_prep_ref(train_edge, train_w, train_year, valid_edge, valid_w, 
         te = pairs
         tw = dis[pairs[:, 0]] * weights * dis[pairs[:, 1]]
     return {"adj": adj, "edge_index_keys": keys, "train_edge": te, "train_weight": tw, "train_year": ty}
+
+
+# --------------------------------------------------------------------------
+# the driver's run loop (main.py:228-305)
+# --------------------------------------------------------------------------
+def random_walk_pairs_ref(walk: torch.Tensor, walk_length: int):
+    """main.py:243-253: training pairs (start, j-th hop), j = 1 .. L, concatenated HOP-MAJOR (all walks' first hop,
+    then all second hops, ...), weight 1 / j, pairs whose two ends coincide removed -- the order matters: it is the
+    order the epoch's batch permutation indexes."""
+    pairs, weights = [], []
+    for j in range(walk_length):
+        pairs.append(walk[:, [0, j + 1]])
+        weights.append(torch.ones((walk.size(0),), dtype=torch.float) / (j + 1))
+    pairs = torch.cat(pairs, dim=0)
+    weights = torch.cat(weights, dim=0)
+    mask = (pairs[:, 0] - pairs[:, 1]) != 0
+    return torch.masked_select(pairs, mask.view(-1, 1)).view(-1, 2), torch.masked_select(weights, mask)
+
+
+class LoggerRef:
+    """plnlp/logger.py:6-50 restated (pinned by fixture G9 through tests/test_oracle.py): per run the test score at
+    the best-validation evaluation point, over runs mean and unbiased std of those picks; returns the text."""
+
+    def __init__(self, runs):
+        self.results = [[] for _ in range(runs)]
+
+    def add_result(self, run, result):
+        assert len(result) == 2 and 0 <= run < len(self.results)
+        self.results[run].append(result)
+
+    @staticmethod
+    def _best(r, last_best):
+        v = r[:, 0]
+        at = v.size(0) - int(v.flip(dims=[0]).argmax()) - 1 if last_best else int(v.argmax())
+        return at
+
+    def statistics(self, run=None, last_best=False) -> List[str]:
+        if run is not None:
+            r = 100 * torch.tensor(self.results[run])
+            at = self._best(r, last_best)
+            return [f"Run {run + 1:02d}:", f"Highest Valid: {r[:, 0].max():.2f}", f"Highest Eval Point: {at + 1}",
+                    f"   Final Test: {r[at, 1]:.2f}"]
+        best = []
+        for r in 100 * torch.tensor(self.results):
+            at = self._best(r, last_best)
+            best.append((r[:, 0].max().item(), r[at, 1].item()))
+        b = torch.tensor(best)
+        return ["All runs:", f"Highest Valid: {b[:, 0].mean():.2f}  {b[:, 0].std():.2f}",
+                f"   Final Test: {b[:, 1].mean():.2f}  {b[:, 1].std():.2f}"]
+
+
+def run_loop_ref(trainer: "TrainerRef", split_edge: dict, *, num_nodes: int, runs: int, epochs: int, batch_size: int,
+                 neg_sampler: str, num_neg: int, lr: float, eval_steps: int = 1, log_steps: int = 1,
+                 use_lr_decay: bool = False, eval_metric: str = "hits", eval_last_best: bool = False,
+                 random_walk_augment: bool = False, walk_length: int = 5, rw_adj: Optional["CSR"] = None,
+                 rw_start: Optional[torch.Tensor] = None, rw_seed: int = 0, edge_index=None,
+                 on_run_start: Optional[Callable] = None, on_epoch: Optional[Callable] = None) -> dict:
+    """main.py:235-305, the run / epoch / eval / logging loop, around a TrainerRef.
+
+    Per epoch: (random_walk_augment) a fresh set of walks -> pairs + weights (main.py:241-253; the walks come from
+    random_walk_ref under seed rw_seed + epoch count, the counter stream the HIP kernel shares -- torch_cluster's own
+    stream is third-party and unpinned), `model.train` (negatives drawn, then the DataLoader permutation: both from the
+    default CPU generator, in that order), every eval_steps epochs `model.test` + Logger.add_result + the epoch line
+    (main.py:260-286), then adjust_lr (main.py:288-291: AFTER the epoch, so epoch 1 trains at the full rate).
+    on_run_start(run, trainer): called where main.py calls model.param_init() (main.py:236) -- the caller installs the
+    run's initial weights (and RNG state) there.  Returns dict(lines, losses, lrs, results, logger_text)."""
+    keys = ["Hits@20", "Hits@50", "Hits@100"] if eval_metric == "hits" else ["MRR"]
+    loggers = {k: LoggerRef(runs) for k in keys}
+    out = {"lines": [], "losses": [], "lrs": [], "results": [], "logger_text": []}
+    split_edge = {k: dict(v) for k, v in split_edge.items()}
+    walks_drawn = 0
+    for run in range(runs):
+        if on_run_start is not None:
+            on_run_start(run, trainer)
+        else:
+            trainer.param_init()
+        # main.py:236-239: param_init() re-draws the weights only -- the optimiser (Adam moments, step count, and the
+        # learning rate adjust_lr left behind) carries over from the previous run, while the PRINTED rate restarts
+        cur_lr = lr
+        for epoch in range(1, 1 + epochs):
+            if random_walk_augment:
+                walks_drawn += 1
+                walk = random_walk_ref(rw_adj, rw_start, walk_length, rw_seed + walks_drawn)
+                split_edge["train"]["edge"], split_edge["train"]["weight"] = random_walk_pairs_ref(walk, walk_length)
+            pos, neg = pos_neg_edges_ref("train", split_edge, edge_index=edge_index, num_nodes=num_nodes,
+                                         neg_sampler_name=neg_sampler, num_neg=num_neg)
+            weight = split_edge["train"].get("weight")
+            loss = trainer.train_epoch(pos, neg.view(-1, num_neg, 2), batch_size, num_neg, weight)
+            out["losses"].append(loss)
+            out["lrs"].append(cur_lr)
+            if epoch % eval_steps == 0:
+                hh = trainer.embed_for_eval()
+                pv, nv = pos_neg_edges_ref("valid", split_edge)
+                pt, nt = pos_neg_edges_ref("test", split_edge)
+                spv, snv = trainer.score(hh, pv, batch_size), trainer.score(hh, nv, batch_size)
+                spt, snt = trainer.score(hh, pt, batch_size), trainer.score(hh, nt, batch_size)
+                results = (evaluate_hits_ref if eval_metric == "hits" else evaluate_mrr_ref)(spv, snv, spt, snt)
+                out["results"].append(results)
+                for key, result in results.items():
+                    loggers[key].add_result(run, result)
+                if epoch % log_steps == 0:
+                    for key, (valid_res, test_res) in results.items():
+                        out["lines"] += [key, (f"Run: {run + 1:02d}, Epoch: {epoch:02d}, Loss: {loss:.4f}, "
+                                               f"Learning Rate: {cur_lr:.4f}, Valid: {100 * valid_res:.2f}%, "
+                                               f"Test: {100 * test_res:.2f}%")]
+            if on_epoch is not None:
+                on_epoch(run, epoch, trainer)
+            if use_lr_decay:
+                cur_lr = adjust_lr_ref(trainer.optimizer, epoch / epochs, lr)
+        for key in loggers:
+            out["logger_text"] += [key] + loggers[key].statistics(run, last_best=eval_last_best)
+    for key in loggers:
+        out["logger_text"] += [key] + loggers[key].statistics(last_best=eval_last_best)
+    return out

@@ -43,7 +43,8 @@ class GemmOperand(C.Structure):
     """mirror of plnlp_gemm_operand"""
     _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64),
                 ("k", C.c_int64), ("b_index", C.c_void_p), ("a_index", C.c_void_p),
-                ("math", C.c_int32), ("reserved", C.c_int32), ("a_index2", C.c_void_p), ("b_index2", C.c_void_p)]
+                ("math", C.c_int32), ("reserved", C.c_int32), ("a_index2", C.c_void_p), ("b_index2", C.c_void_p),
+                ("b_terms", C.c_void_p), ("b_terms_bytes", C.c_int64)]
 
 
 class AdamTensor(C.Structure):
@@ -100,6 +101,8 @@ SIGNATURES = {
                                                   C.c_void_p, c_i64, C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p]),
     "plnlp_gemm_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
                                  c_i64, C.POINTER(Epilogue), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_gemm_b_terms_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
+    "plnlp_gemm_stationary_tuning": (None, [C.c_int, C.c_int]),
     "plnlp_gemm_split_out_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64,
                                            C.c_void_p, c_i64, c_i64, c_i64, c_i64, C.POINTER(Epilogue),
                                            C.c_void_p]),
@@ -171,7 +174,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.plnlp_abi_version() != 8:
+    if lib.plnlp_abi_version() != 9:
         raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

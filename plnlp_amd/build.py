@@ -34,6 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # (-fno-slp-vectorize: packed f32 adds formed from the operand split cost issue slots beside the MFMAs and
     # sent the split's residuals through scratch memory)
     units.append(("gemm_f32.hip", "gemm_f32_x3.o", ["-DPLNLP_GEMM_BK=16", "-DPLNLP_GEMM_X3=1", "-fno-slp-vectorize"]))
+    units.append(("gemm_x3s.hip", "gemm_x3s.o", ["-fno-slp-vectorize"]))
     for src, oname, extra in units:
         obj = os.path.join(HERE, "build", oname)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",

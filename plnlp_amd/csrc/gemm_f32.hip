@@ -974,6 +974,29 @@ int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_tra
 namespace x16 {      // the split-bf16 translation unit
 int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_trans, hipStream_t s, const Epi& e);
 }
+namespace x3s {      // gemm_x3s.hip: the split-bf16 form with a stationary, pre-split weight operand
+struct Args {
+    const float* a[2]; int64_t lda[2]; int k[2]; const int32_t* a_index[2];
+    int nseg;
+    int ks0, ks_total;
+    const void* image;
+    float* c; int64_t ldc; float* c2; int64_t ldc2; int n_split;
+    int64_t m; int n;
+    int64_t gm; int gn;
+    int64_t row_lo;
+};
+struct SplitArgs {
+    const float* b[2]; int64_t ldb[2]; int k[2];
+    const float* b2; int64_t ldb2; int nb_split;
+    int b_trans;
+    int nseg, ks0, ks_total, n, wn, gn;
+    void* image;
+};
+int pick_nb(int64_t m, int64_t n);
+void set_tuning(int nb, int tail);
+int64_t image_bytes(int64_t n, const int64_t* k, int nseg, int nb);
+int launch(const SplitArgs& sp, const Args& a, int nb, const Epi& e, hipStream_t s);
+}
 
 // sum split-K slices in slice order, apply the epilogue.  16 bytes per thread, 8 slices in flight.
 // c2 != nullptr: result columns >= n_split go to c2[:, col - n_split] (the pair form; no epilogue there)
@@ -1070,6 +1093,20 @@ extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_t
                      workspace_floats, stream);
 }
 
+extern "C" void plnlp_gemm_stationary_tuning(int nb, int tail) { plnlp::x3s::set_tuning(nb, tail); }
+
+extern "C" int64_t plnlp_gemm_b_terms_bytes(int64_t m, int64_t n, int64_t k0, int64_t k1) {
+    if (m <= 0 || n <= 0 || k0 <= 0 || k1 < 0) return 0;
+    const int64_t k[2] = {k0, k1};
+    int64_t need = 0;                       // whatever tile width the launch picks (or a measurement forces)
+    for (int nb : {8, 7, 4, 2, 1}) {
+        const int64_t b = plnlp::x3s::image_bytes(n, k, k1 > 0 ? 2 : 1, nb);
+        need = b > need ? b : need;
+    }
+    (void)m;
+    return need;
+}
+
 extern "C" int plnlp_gemm_split_out_f32(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans,
                                         float* c, int64_t ldc, float* c2, int64_t ldc2, int64_t n_split,
                                         int64_t m, int64_t n, const plnlp_epilogue* epi, void* stream) {
@@ -1154,6 +1191,38 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     if (a_trans) aligned = aligned && (m % 4 == 0) && m >= 4;    // row-contiguous operands move 4 rows per load
     if (!b_trans) aligned = aligned && (n % 4 == 0) && n >= 4;
     int mode = !aligned ? 0 : (ragged ? 2 : 1);
+    // ---- the stationary-weights form (gemm_x3s.hip): A an activation matrix with K-contiguous rows, B the weights, the
+    // caller lent a buffer for B's pre-split image.  Same bits as the kernels below (same split, same six products in the
+    // same order per K-step of 16), so which one runs is a pure speed choice.
+    if (math == PLNLP_GEMM_MATH_BF16X3 && !a_trans && segs[0].b_terms && m >= 16384 && n % 4 == 0 && n >= 16) {
+        bool ok = g.vec_store && (!c2 || n_split % 4 == 0);
+        int64_t ks[2] = {0, 0};
+        for (int si = 0; si < n_seg && ok; ++si) {
+            const Seg& d = g.seg[si];
+            ok = d.a_vec && d.k % 4 == 0 && !d.b_index && !d.a_index2 && !d.b_index2 && (d.a_index == nullptr || b_trans);
+            ks[si] = d.k;
+        }
+        if (ok) {
+            const int nb = x3s::pick_nb(m, n);
+            if (segs[0].b_terms_bytes >= x3s::image_bytes(n, ks, n_seg, nb) && ((uintptr_t)segs[0].b_terms % 16 == 0)) {
+                x3s::SplitArgs sp{};
+                x3s::Args xa{};
+                for (int si = 0; si < n_seg; ++si) {
+                    const Seg& d = g.seg[si];
+                    sp.b[si] = d.b; sp.ldb[si] = d.ldb; sp.k[si] = d.k;
+                    xa.a[si] = d.a; xa.lda[si] = d.lda; xa.k[si] = d.k; xa.a_index[si] = d.a_index;
+                }
+                sp.b2 = b2; sp.ldb2 = ldb2; sp.nb_split = b2 ? (int)nb_split : (int)n;
+                sp.b_trans = b_trans; sp.nseg = n_seg; sp.n = (int)n; sp.image = segs[0].b_terms;
+                sp.ks0 = (int)((ks[0] + 15) / 16);
+                sp.ks_total = sp.ks0 + (n_seg > 1 ? (int)((ks[1] + 15) / 16) : 0);
+                xa.nseg = n_seg; xa.ks0 = sp.ks0; xa.ks_total = sp.ks_total; xa.image = segs[0].b_terms;
+                xa.c = c; xa.ldc = ldc; xa.c2 = c2; xa.ldc2 = ldc2; xa.n_split = c2 ? (int)n_split : (int)n;
+                xa.m = m; xa.n = (int)n;
+                return x3s::launch(sp, xa, nb, e, s);
+            }
+        }
+    }
     const int reduce_slices = split_k;
     g.mt0 = 0; g.nt0 = 0; g.gm = gm; g.gn = (int)gn; g.z0 = 0;
     auto launch_grid = [&](const GemmArgs& ga, int md, dim3 grid) -> int {

@@ -158,9 +158,6 @@ class Graph:
         if self._split is None or self._split.threshold != threshold:
             self._split = RowSplit(self.rowptr, self.nnz, threshold, exact=True)
         return self._split
-        if self._split is None or self._split.threshold != threshold or hasattr(self._split, "_key"):
-            self._split = RowSplit(self.rowptr, self.nnz, threshold, exact=True)
-        return self._split
 
     # ---- construction ---------------------------------------------------------
     @classmethod

@@ -375,6 +375,25 @@ SPLIT_K_SLOTS = {"slots": int(os.environ.get("PLNLP_SPLIT_K_SLOTS", "512"))}
 GEMM_MATH = {"mode": os.environ.get("PLNLP_GEMM_MATH", "bf16x3")}
 
 
+# the stationary-weights form of the split-bf16 GEMM (csrc/gemm_x3s.hip): the weights are split into their bf16 terms
+# once per launch into a lent buffer instead of once per row panel.  Bit-identical to the 128 x 128 kernels; off =
+# those kernels everywhere (A/B runs, tests of both)
+GEMM_STATIONARY_B = {"enabled": os.environ.get("PLNLP_GEMM_STATIONARY_B", "1") != "0"}
+
+
+def _lend_b_terms(op, m: int, n: int, ks, device):
+    """lend the launch a scratch buffer for B's pre-split image (plnlp_gemm_operand.b_terms) where the form applies:
+    split-bf16 products, A not transposed, enough rows for the one-off split to pay.  Returns the tensor to keep alive."""
+    if not GEMM_STATIONARY_B["enabled"] or op.math != L.GEMM_MATH_BF16X3 or m < 16384:
+        return None
+    need = L.load().plnlp_gemm_b_terms_bytes(m, n, ks[0], ks[1] if len(ks) > 1 else 0)
+    if need <= 0:
+        return None
+    buf = torch.empty(need, dtype=torch.uint8, device=device)
+    op.b_terms, op.b_terms_bytes = buf.data_ptr(), need
+    return buf
+
+
 def _gemm_math() -> int:
     mode = GEMM_MATH["mode"]
     if mode == "bf16x3":
@@ -436,6 +455,10 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     if split_k is None:
         split_k = _pick_split_k(m, n, ktiles)
     split_k = max(1, min(split_k, ktiles))
+    if not a_trans and b_index is None and a_index2 is None:
+        keep.append(_lend_b_terms(ops[0], m, n, [int(ops[i].k) for i in range(len(segs))], out.device))
+        if keep[-1] is not None:
+            split_k = 1          # (the form never cuts K: few row panels get narrower column tiles instead)
     ws = torch.empty(split_k * m * n, dtype=torch.float32, device=out.device) if split_k > 1 else None
     rc = lib.plnlp_gemm_f32(ops, len(segs), int(a_trans), int(b_trans), out.data_ptr(), _ld(out), m, n,
                             C.byref(epilogue) if epilogue is not None else None, split_k,
@@ -499,6 +522,7 @@ def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool
     c1 = out1 if out1 is not None else torch.empty(m, n1, dtype=torch.float32, device=a.device)
     assert c1.shape == (m, n1) and c1.is_contiguous()
     c2 = torch.empty(m, n2, dtype=torch.float32, device=a.device)
+    lent = _lend_b_terms(ops[0], m, n, [k], a.device) if (not a_trans and rows is None) else None
     ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device) if split_k > 1 else None
     L.check(lib.plnlp_gemm_pair_f32(ops, b2.data_ptr(), _ld(b2), n1, int(rows_on), int(a_trans), 0, c1.data_ptr(), _ld(c1),
                                     c2.data_ptr(), _ld(c2), n1, m, n, split_k, L.ptr(ws),
@@ -521,6 +545,7 @@ def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool
     c1 = out1 if out1 is not None else torch.empty(m, n_split, dtype=torch.float32, device=a.device)
     assert c1.shape == (m, n_split) and c1.is_contiguous()
     c2 = torch.empty(m, n - n_split, dtype=torch.float32, device=a.device)
+    lent = _lend_b_terms(ops[0], m, n, [k], a.device)
     L.check(lib.plnlp_gemm_split_out_f32(ops, 1, 0, int(b_trans), c1.data_ptr(), _ld(c1), c2.data_ptr(), _ld(c2),
                                          n_split, m, n, None, L.stream_ptr()), "plnlp_gemm_split_out_f32")
     return c1, c2
@@ -926,13 +951,17 @@ TAIL_LOSS, TAIL_SQNORM = 0, 1
 
 
 def tail_counter(device, slot: int) -> int:
-    """device pointer of the `slot`-th persistent zero word on this device (64 bytes apart)"""
+    """device pointer of the `slot`-th persistent zero word of (this device, the CURRENT stream), 64 bytes apart.
+    include/plnlp_hip.h asks for one zeroed word per caller AND stream (last_workgroup()): two loss or clip-norm launches
+    in flight on different streams of one device -- a second model on a side stream -- must not share a ticket counter.
+    A captured graph keeps the word of the stream it was captured on."""
     key = torch.device(device)
     if key.index is None and key.type == "cuda":
         key = torch.device("cuda", torch.cuda.current_device())
+    key = (key, L.stream_ptr() if key.type == "cuda" else 0)
     buf = _tail_words.get(key)
     if buf is None:
-        buf = _tail_words[key] = torch.zeros(16 * 8, dtype=torch.int32, device=key)
+        buf = _tail_words[key] = torch.zeros(16 * 8, dtype=torch.int32, device=key[0])
     return buf.data_ptr() + 64 * slot
 
 

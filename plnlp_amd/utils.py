@@ -50,7 +50,7 @@ def batch_permutation(n: int, batch_size: int, shuffle: bool) -> List[torch.Tens
     return list(order.split(batch_size))
 
 
-_perm_host = {"buf": None}
+_perm_host = {"buf": None, "owner": None}
 
 
 class StreamedPermutation:
@@ -80,6 +80,10 @@ class StreamedPermutation:
         torch.empty((), dtype=torch.int64).random_()                                   # the loader's base-seed draw
         seed = int(torch.empty((), dtype=torch.int64).random_().item())               # the sampler's seed
         self.sizes = [min(self.batch_size, self.n - lo) for lo in range(0, self.n, self.batch_size)]
+        prev = _perm_host.get("owner")        # an epoch that ended in an exception left its thread shuffling into the
+        if prev is not None:                  # pinned buffer this instance is about to re-initialise: stop it first
+            prev.stop()
+        _perm_host["owner"] = self
         buf = _perm_host["buf"]
         if buf is None or buf.numel() < self.n:
             buf = _perm_host["buf"] = torch.empty(max(self.n, 1 << 20), dtype=torch.int64, pin_memory=True)
@@ -90,6 +94,10 @@ class StreamedPermutation:
         L.check(self._lib.plnlp_host_randperm_init(seed & 0xFFFFFFFFFFFFFFFF, self.n, self._host.data_ptr(),
                                                    self._mt.data_ptr()), "plnlp_host_randperm_init")
         self.order = torch.empty(self.n, dtype=torch.int64, device=self.device)
+        # `order` was allocated on the caller's stream and is first WRITTEN on the copy stream: whatever that stream still
+        # has queued on a recycled allocator block must run before the copies do
+        self._copy.wait_stream(torch.cuda.current_stream(self.device))
+        self._stop = threading.Event()
         self._chunk = max(1, int(chunk_batches)) * self.batch_size
         self._cv = threading.Condition()
         self._chunks = []                     # (end index, event of its copy), in order
@@ -103,7 +111,7 @@ class StreamedPermutation:
         try:
             torch.cuda.set_device(self.device)
             pos = 0
-            while pos < self.n:
+            while pos < self.n and not self._stop.is_set():
                 # the first slice is one batch (the first step can start at once), the rest a few batches each
                 to = min(self.n, pos + (self.batch_size if pos == 0 else self._chunk))
                 self._L.check(self._lib.plnlp_host_randperm_advance(self.n, self._host.data_ptr(), self._mt.data_ptr(),
@@ -141,8 +149,17 @@ class StreamedPermutation:
             self._seen[key] = need
         return self.order[lo:hi]
 
+    def stop(self):
+        """abandon the shuffle (checked per slice) and wait for the thread"""
+        self._stop.set()
+        self._thread.join()
+        if _perm_host.get("owner") is self:
+            _perm_host["owner"] = None
+
     def join(self):
         self._thread.join()
+        if _perm_host.get("owner") is self:
+            _perm_host["owner"] = None
         if self._error is not None:
             raise self._error
 

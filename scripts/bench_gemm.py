@@ -24,6 +24,10 @@ SHAPES = {
     # tail quantisation probes: 3584 tiles = exactly 7 rounds of the 512 workgroup slots, vs 7.2 rounds above
     "collab_fwd_7rounds": (229376, 256, [256, 256], False, True, True),
     "collab_fwd_plain_7rounds": (229376, 256, [256, 256], False, True, False),
+    # the collab STEP's own launches: the conv at the ~132 K touched rows (root rows gathered from the 235 868-row table)
+    "collab_step_fwd": (132224, 256, [256, 256], False, True, "gather"),
+    "collab_step_dgrad": (132224, 512, [256], False, False, False),
+    "ddi_pred_dgrad": (262144, 512, [512], False, False, False),
     "collab_dgrad_T": (131072, 512, [256], False, False, False),
     "collab_wgrad_T": (256, 512, [131072], True, False, False),
 }
@@ -34,7 +38,7 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=3, help="timed blocks per shape; the median is reported")
-    ap.add_argument("--math", default="env", choices=["env", "f32", "bf16x3", "ab"],
+    ap.add_argument("--math", default="env", choices=["env", "f32", "bf16x3", "ab", "st", "nb"],
                     help="how the products are formed (ops.GEMM_MATH); ab = measure both, interleaved")
     ap.add_argument("--error", action="store_true",
                     help="also report max |C - C_fp64| / sum_k |a||b| over 64 sampled result rows (no epilogue)")
@@ -59,34 +63,52 @@ def main():
             e = _lib.make_epilogue(bias=bias, relu=True)
         elif epi:
             e = _lib.make_epilogue(bias=bias, relu=True, dropout_p=0.3, dropout_seed=1)
+        a_index = None
+        if epi == "gather":           # the second segment's A rows gathered from a larger table
+            table = torch.randn(235868, ks[1], device=dev)
+            rows = torch.randperm(235868, device=dev)[:m].sort().values.to(torch.int32)
+            segs[1] = (table, segs[1][1])
+            a_index = [None, rows]
         out = torch.empty(m, n, device=dev)
         flop = 2.0 * m * n * sum(ks)
-        maths = {"env": [None], "f32": ["f32"], "bf16x3": ["bf16x3"], "ab": ["f32", "bf16x3"]}[args.math]
+        maths = {"env": [None], "f32": ["f32"], "bf16x3": ["bf16x3"], "ab": ["f32", "bf16x3"], "st": [], "nb": []}[args.math]
         modes = [(mt, None) for mt in maths]
+        if args.math == "st":         # split-bf16 products: the 128 x 128 kernels vs the stationary-weights kernel
+            modes = [("bf16x3", False), ("bf16x3", True)]
+        if args.math == "nb":         # the stationary-weights kernel by column-tile width, tail launch on / off, vs the tile kernel
+            modes = [("bf16x3", False)] + [("bf16x3", (nb, 0)) for nb in (0, 8, 7, 4)]
         ts = {md: [] for md in modes}
 
         def arm(md):
             if md[0] is not None:
                 P.ops.GEMM_MATH["mode"] = md[0]
+            if md[1] is not None:
+                P.ops.GEMM_STATIONARY_B["enabled"] = bool(md[1])
+                nb, tail = md[1] if isinstance(md[1], tuple) else (0, 1)
+                _lib.load().plnlp_gemm_stationary_tuning(nb, tail)
         for _ in range(args.repeats):                     # interleaved: every arm sees the same clocks
             for md in modes:
                 arm(md)
-                ts[md].append(time_kernel(lambda: P.ops.gemm(segs, at, bt, out=out, epilogue=e), iters=args.iters))
+                ts[md].append(time_kernel(lambda: P.ops.gemm(segs, at, bt, out=out, epilogue=e, a_index=a_index), iters=args.iters))
         for md in modes:
             t = sorted(ts[md])[len(ts[md]) // 2]
             rec = {"shape": name, "M": m, "N": n, "K": ks, "ms": round(t * 1e3, 4),
                    "TFLOPs": round(flop / t / 1e12, 2), "frac_of_157": round(flop / t / 157.3e12, 3),
                    "math": md[0] or P.ops.GEMM_MATH["mode"]}
+            if md[1] is not None:
+                rec["stationary_b"] = md[1]
             if md[0] == "bf16x3" or (md[0] is None and P.ops.GEMM_MATH["mode"] == "bf16x3"):
                 rec["bf16_TFLOPs_executed"] = round(6 * flop / t / 1e12, 1)
                 rec["frac_of_2500"] = round(6 * flop / t / 2.5e15, 3)
             if args.error:
                 arm(md)
-                got = P.ops.gemm(segs, at, bt)
+                got = P.ops.gemm(segs, at, bt, a_index=a_index)
                 rows = torch.randperm(m, device=dev)[:64]
                 ref = torch.zeros(rows.numel(), n, dtype=torch.float64, device=dev)
                 mag = torch.zeros_like(ref)
                 for a, b in segs:
+                    if a_index is not None and a is segs[1][0]:
+                        a = a[a_index[1].long()]
                     a64 = (a[:, rows].T if at else a[rows]).double()
                     b64 = (b.T if bt else b).double()
                     ref += a64 @ b64

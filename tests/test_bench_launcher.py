@@ -29,6 +29,17 @@ def test_bench_starts_its_own_ranks():
             "all_to_all_single_uneven", "barrier"} <= set(out["collective_self_test"])
 
 
+def test_bench_eight_ranks_dry_run():
+    """what the driver's SCALE run launches, minus the GPUs: `bench.py --gpus 8` starts 8 ranks that rendezvous, run the
+    collective self-test and an all-reduce over gloo, and rank 0 prints ONE line"""
+    r = _run({}, ["--gpus", "8", "--dry-run-cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["rccl_ranks"] == 8 and out["n_gpus"] == 8 and out["all_reduce_ok"] and out["dry_run"]
+
+
 def test_a_failing_rank_stops_its_siblings():
     """rank 1 dies before the rendezvous: the launcher must notice, end rank 0 (which would otherwise wait in the
     rendezvous for minutes) and return the failure -- quickly, with rank 1's message relayed"""

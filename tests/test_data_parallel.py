@@ -131,6 +131,27 @@ def test_uneven_last_batch_and_empty_slice(exchange):
     np.testing.assert_array_equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("world,exchange", [(4, "grads"), (8, "grads"), (4, "scores")])
+def test_four_and_eight_ranks_equal_one_process(world, exchange):
+    """the node the path is meant for has 8 GPUs: the same equivalence at world 4 and 8 (N = 120 nodes, so row / edge
+    slices are uneven), weak scaling -- W ranks each bringing B positives == one process on W x B -- and a last global
+    batch that leaves most ranks without an edge"""
+    B = 16
+    ref_losses, ref_flat = _run(0, 1, 0, world * B, "weak", "WeightedHingeAUC", "DOT", None)
+    res = _spawn(world, B, "weak", "WeightedHingeAUC", "DOT", exchange)
+    assert len(res) == world
+    for rank, losses, flat in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-9, err_msg=f"rank {rank}")
+        np.testing.assert_allclose(flat, ref_flat, rtol=1e-6, atol=1e-9)
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][2], r[2])            # bit-identical replicas
+    n = _problem()[1].size(0)
+    ref_losses, _ = _run(0, 1, 0, n - 1, "strong", "AUC", "DOT", None)        # second global batch: ONE edge
+    res = _spawn(world, n - 1, "strong", "AUC", "DOT", exchange)
+    for rank, losses, flat in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-9)
+
+
 def _tuner_rank(rank, world, port, out_q):
     """the aggregation autotuner under a process group: the op never communicates; the ranks agree only in
     ops.tune_aggregation (a rank-0-only aggregation used to broadcast into its idle peers)"""

@@ -412,3 +412,68 @@ def test_rmat_reference_stream_properties():
     # a different seed is a different stream
     r3, _ = O.rmat_edges_ref(14, 10_000, 0, 1000, 10)
     assert not np.array_equal(r3, r[:1000])
+
+
+# ------------------------------------------------------------------ the driver's run loop (main.py:228-305) ----
+def test_logger_ref_reproduces_the_reference_logger_text(golden):
+    """LoggerRef (oracle) against the text the reference's own plnlp/logger.py printed (fixture G9)"""
+    g = golden("g9_logger")
+    res = g["results"]
+    lg = O.LoggerRef(3)
+    for r in range(3):
+        for e in range(5):
+            lg.add_result(r, (float(res[r, e, 0]), float(res[r, e, 1])))
+    calls = {"run1": dict(run=1), "run1_last": dict(run=1, last_best=True), "all": dict(), "all_last": dict(last_best=True)}
+    for key, want in zip(g["keys"].tolist(), g["texts"].tolist()):
+        assert "\n".join(lg.statistics(**calls[key])) + "\n" == want, key
+
+
+def test_random_walk_pairs_ref_by_hand():
+    """main.py:243-253 on a walk table small enough to write the answer down: hop-major order, weights 1 / hop,
+    pairs whose ends coincide removed"""
+    walk = torch.tensor([[0, 1, 0], [2, 2, 3], [4, 5, 4]])
+    pairs, w = O.random_walk_pairs_ref(walk, 2)
+    assert pairs.tolist() == [[0, 1], [4, 5], [2, 3]]          # hop 1: (0,1), (2,2) dropped, (4,5); hop 2: (0,0), (2,3), (4,4)
+    assert w.tolist() == [1.0, 1.0, 0.5]
+    assert pairs.dtype == torch.int64 and w.dtype == torch.float32
+
+
+def test_run_loop_ref_follows_the_reference_schedule():
+    """the restated loop's bookkeeping: adjust_lr AFTER each epoch (epoch 1 runs at the full rate, main.py:288-291), the
+    printed rate restarts per run while the optimiser -- Adam state and the decayed rate -- carries over (param_init
+    only re-draws weights, main.py:236; model.py:92-96), eval every eval_steps, fresh walks per epoch with seeds that
+    keep counting across runs, the epoch's pairs = random_walk_pairs_ref of those walks"""
+    torch.manual_seed(0)
+    n, h = 60, 8
+    csr = _rand_graph(n, 400, 3, weighted=False)
+    enc = O.GNNRef("SAGE", h, h, h, 1, 0.0)
+    emb = torch.nn.Embedding(n, h)
+    tr = O.TrainerRef(enc, O.DotPredictorRef(), emb, csr, loss_name="WeightedHingeAUC", lr=0.1, clip_norm=1.0)
+    gen = torch.Generator().manual_seed(1)
+    e = torch.randint(0, n, (80, 2), generator=gen)
+    split = {"train": {"edge": e, "weight": torch.ones(80)},
+             "valid": {"edge": e[:20], "edge_neg": torch.randint(0, n, (50, 2), generator=gen)},
+             "test": {"edge": e[20:40], "edge_neg": torch.randint(0, n, (50, 2), generator=gen)}}
+    seen = []
+
+    def on_epoch(run, epoch, trainer):
+        seen.append((run, epoch, trainer.optimizer.param_groups[0]["lr"],
+                     trainer.optimizer.state[trainer.params[0]]["step"].item()))
+    out = O.run_loop_ref(tr, split, num_nodes=n, runs=2, epochs=4, batch_size=64, neg_sampler="local", num_neg=1, lr=0.1,
+                         eval_steps=2, use_lr_decay=True, random_walk_augment=True, walk_length=2, rw_adj=csr,
+                         rw_start=e.reshape(-1), rw_seed=10, on_epoch=on_epoch)
+    assert [s[:2] for s in seen] == [(r, ep) for r in range(2) for ep in range(1, 5)]
+    # the rate each epoch TRAINED at: 0.1, then 0.1 (1 - (epoch - 1) / 4); run 2 starts at the floor run 1 ended on
+    want = [0.1, 0.075, 0.05, 0.025, 0.1 * 1e-4, 0.075, 0.05, 0.025]
+    np.testing.assert_allclose([s[2] for s in seen], want, rtol=1e-12)
+    np.testing.assert_allclose(out["lrs"], [0.1, 0.075, 0.05, 0.025] * 2, rtol=1e-12)       # what main.py PRINTS
+    steps = [s[3] for s in seen]
+    assert steps == sorted(steps) and steps[4] > steps[3]         # Adam's step count keeps counting through run 2
+    assert len(out["results"]) == 4 and len(out["lines"]) == 2 * 3 * 4
+    assert out["lines"][1].startswith("Run: 01, Epoch: 02, Loss: ") and "Learning Rate: 0.0750" in out["lines"][1]
+    assert out["logger_text"][0] == "Hits@20" and out["logger_text"][1] == "Run 01:"
+    assert out["logger_text"][-4] == "Hits@100" and out["logger_text"][-3] == "All runs:"
+    # the last epoch's training pairs are the pairs of walk number 8 (seed 10 + 8)
+    walk = O.random_walk_ref(csr, e.reshape(-1), 2, 18)
+    pairs, w = O.random_walk_pairs_ref(walk, 2)
+    assert pairs.size(0) > 0 and float(w.min()) == 0.5

@@ -90,7 +90,9 @@ def _run(rank, world, port, batch, scaling, loss_name, predictor, layers, out_q,
                     process_group=pg, dp_scaling=scaling, dp_exchange="shard" if world > 1 else "auto")
     if world > 1:
         assert m.dp_mode() == "shard"
-        assert m._emb_shard.shape[0] == 64 and m._emb_full.shape[0] == 128
+        from plnlp_amd.shard import RowPartition
+        part_ = RowPartition(N, world, rank)
+        assert m._emb_shard.shape[0] == part_.rows and m._emb_full.shape[0] == part_.padded
     m.emb.double()
     if world > 1:            # .double() re-seated the table: put the float64 table back on the sharded layout
         full = torch.zeros(m._emb_full.shape, dtype=torch.float64)
@@ -174,6 +176,29 @@ def test_sharded_uneven_last_batch_and_empty_slice():
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-9)
         np.testing.assert_allclose(table, ref_table, rtol=1e-6, atol=1e-9)
     np.testing.assert_array_equal(res[0][3], res[1][3])
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_four_and_eight_ranks_equal_one_process(world):
+    """the row-sharded step at world 4 and 8: N is not a multiple of the world (blocks of uneven real height, the last
+    ones partly padding), weak scaling, and a last global batch of one edge (empty slices on all ranks but one)"""
+    B = 16
+    ref_losses, ref_small, ref_table = _run(0, 1, 0, world * B, "weak", "WeightedHingeAUC", "DOT", 2, None)
+    res = _spawn(world, B, "weak", "WeightedHingeAUC", "DOT", 2)
+    assert len(res) == world
+    for rank, losses, small, table in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-9, err_msg=f"rank {rank}")
+        np.testing.assert_allclose(small, ref_small, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(table, ref_table, rtol=1e-6, atol=1e-9)
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][2], r[2])
+        np.testing.assert_array_equal(res[0][3], r[3])
+    n_pos = _problem()[2].size(0)
+    ref_losses, _, ref_table = _run(0, 1, 0, n_pos - 1, "strong", "AUC", "DOT", 1, None)
+    res = _spawn(world, n_pos - 1, "strong", "AUC", "DOT", 1)
+    for rank, losses, small, table in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-9)
+        np.testing.assert_allclose(table, ref_table, rtol=1e-6, atol=1e-9)
 
 
 def test_shard_plan_lists_exactly_the_touched_rows():

@@ -11,10 +11,9 @@ available, `load_dataset` is the only function to replace.
 """
 import argparse
 import os
+import sys
 import time
 
-# before anything initialises the HIP runtime (plnlp_amd/__init__.py explains): replayed hipGraphs need it
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import torch
 
 import plnlp_amd as P
@@ -160,8 +159,13 @@ def prepare_graph(args, data, split_edge, num_nodes):
             split_edge['train']['weight'] = dis[full_ei[0]] * full_w * dis[full_ei[1]]
 
 
-def main(argv=None):
+def main(argv=None, dataset=None, hooks=None):
+    """dataset: (data, split_edge, num_nodes) on the host instead of load_dataset's synthetic stand-in (tests hand a small
+    problem in).  hooks: optional callables -- on_run_start(run, model) right after model.param_init() (main.py:236),
+    on_epoch(run, epoch, model, loss) after the epoch's train / eval -- the seams the driver parity test uses to give the
+    CPU oracle the same initial weights and to read the per-epoch losses."""
     args = argument(argv)
+    hooks = hooks or {}
     group = None
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:      # one process per GPU (torch.distributed.run)
         args.device = int(os.environ.get('LOCAL_RANK', '0'))
@@ -178,7 +182,7 @@ def main(argv=None):
     if args.seed is not None:
         torch.manual_seed(args.seed)
         P.manual_seed(args.seed)
-    data, split_edge, num_nodes = load_dataset(args, device)
+    data, split_edge, num_nodes = dataset if dataset is not None else load_dataset(args, device)
     num_node_feats = getattr(data, 'num_features', 0) if data.x is not None else 0
     # under torch.distributed.run every rank runs this script: rank 0 alone prints and owns the log file (the
     # others would interleave duplicates, or split across files whose names differ by a second).  Evaluation still
@@ -242,6 +246,8 @@ def main(argv=None):
 
     for run in range(args.runs):
         model.param_init()
+        if 'on_run_start' in hooks:
+            hooks['on_run_start'](run, model)
         start_time = time.time()
         cur_lr = args.lr
         for epoch in range(1, 1 + args.epochs):
@@ -272,19 +278,21 @@ def main(argv=None):
                     _print(f'Training Time Per Epoch: {spent_time / args.eval_steps: .4f} s')
                     _print('---')
                     start_time = time.time()
+            if 'on_epoch' in hooks:
+                hooks['on_epoch'](run, epoch, model, loss)
             if args.use_lr_decay:
                 cur_lr = P.adjust_lr(model.optimizer, epoch / args.epochs, args.lr)
         for key in loggers:
             _print(key)
             if is_main:
-                loggers[key].print_statistics(run, last_best=args.eval_last_best)
+                loggers[key].print_statistics(run, f=sys.stdout, last_best=args.eval_last_best)
             with _Log() as f:
                 print(key, file=f)
                 loggers[key].print_statistics(run, f=f, last_best=args.eval_last_best)
     for key in loggers:
         _print(key)
         if is_main:
-            loggers[key].print_statistics(last_best=args.eval_last_best)
+            loggers[key].print_statistics(f=sys.stdout, last_best=args.eval_last_best)
         with _Log() as f:
             print(key, file=f)
             loggers[key].print_statistics(f=f, last_best=args.eval_last_best)
