@@ -809,24 +809,6 @@ def main():
 
     exchange = args.dp_exchange
     prediction = None
-    if pg is not None:
-        # which exchange form, from the cost model (plnlp_amd/shard.py::cost_model) fed with this workload's one-GPU
-        # measurements of round 3 (profiles/r03_bench_*.json); the prediction goes into the line so that the measured
-        # run can be held against it
-        from plnlp_amd import shard as _shard
-        one_gpu = {"collab": (1.58, 0.28), "ddi": (4.31, 0.01), "citation2": (29.3, 0.7)}[cfg["shape"]]
-        small = 4 * (cfg["gnn_layers"] * 3 * cfg["hidden"] * max(cfg["hidden"], cfg.get("emb", cfg["hidden"]) + feats)
-                     + (cfg["mlp_layers"] * cfg["hidden"] * cfg["hidden"] if cfg["predictor"] == "MLP" else 0))
-        prediction = _shard.cost_model(n_nodes=n, emb_width=cfg.get("emb", cfg["hidden"]), hidden=cfg["hidden"],
-                                       param_bytes_small=small, batch_per_rank=B, num_neg=k, world=world,
-                                       step_ms_1gpu=one_gpu[0], table_adam_ms=one_gpu[1],
-                                       scorer_has_params=cfg["predictor"] != "DOT")
-    if exchange == "default":
-        if prediction is not None and (cfg["encoder"] == "SAGE" or prediction["choice"] != "shard"):
-            exchange = prediction["choice"]
-        else:
-            exchange = "auto" if pg is None else "grads"
-
     def make_model(group, how):
         m = P.BaseModel(lr=1e-3, dropout=cfg["dropout"], grad_clip_norm=cfg["clip"],
                         gnn_num_layers=cfg["gnn_layers"], mlp_num_layers=cfg["mlp_layers"],
@@ -840,8 +822,7 @@ def main():
         m.predictor.train()
         return m
 
-    model = make_model(pg, exchange)
-    dp_mode = model.dp_mode()
+    model = None
 
     def sync():
         if pg is not None:
@@ -923,12 +904,77 @@ def main():
     host_busy_s = []
     last_pipe = []
     capture_flag = [None]          # None = the product default (plnlp_amd/capture.py: CAPTURE["enabled"])
+    phases = None
+    if pg is not None:
+        # ---- the cost model's inputs, MEASURED by this run on this rank's GPU: the plain one-process step, the table's
+        # Adam, and every exchange form's step through a ONE-rank process group (its whole host / plan / separate-
+        # optimiser overhead, every collective degenerate).  plnlp_amd/shard.py::cost_model returns these at world = 1.
+        from plnlp_amd import shard as _shard
+        Km, Wm = 8, 4
+        solo = make_model(None, "auto")
+        dt0, _ = timed_steps(solo, "none", 1, B, 0, collective=False, K=Km, W=Wm)
+        step_1gpu = dt0 / Km * 1e3
+        emb = solo.emb.weight
+        st = [torch.zeros_like(emb) for _ in range(3)]
+        table_adam = time_kernel(lambda: P.ops.adam_step(emb.detach(), st[0], st[1], st[2], lr=0.0, step=1), iters=5, warm=2) * 1e3
+        del solo, st, emb
+        mine = pg
+        if world > 1:                   # (every rank creates every group: new_group is collective)
+            mine = [torch.distributed.new_group([r]) for r in range(world)][rank]
+        forms = ["grads"] + (["scores"] if cfg["predictor"] == "DOT" else []) + (["shard"] if cfg["encoder"] == "SAGE" or feats else [])
+        step_1rank = {}
+        for form in forms:
+            m1 = make_model(mine, form)
+            dtf, _ = timed_steps(m1, m1.dp_mode(), 1, B, 0, collective=False, K=Km, W=Wm)
+            step_1rank[m1.dp_mode()] = dtf / Km * 1e3
+            del m1
+        torch.cuda.empty_cache()
+        small = 4 * (cfg["gnn_layers"] * 3 * cfg["hidden"] * max(cfg["hidden"], cfg.get("emb", cfg["hidden"]) + feats)
+                     + (cfg["mlp_layers"] * cfg["hidden"] * cfg["hidden"] if cfg["predictor"] == "MLP" else 0))
+        prediction = _shard.cost_model(n_nodes=n, emb_width=cfg.get("emb", cfg["hidden"]), hidden=cfg["hidden"],
+                                       param_bytes_small=small, batch_per_rank=B, num_neg=k, world=world,
+                                       step_ms_1gpu=step_1gpu, table_adam_ms=table_adam,
+                                       scorer_has_params=cfg["predictor"] != "DOT", step_ms_1rank=step_1rank)
+    if exchange == "default":
+        if prediction is not None and prediction["choice"] in prediction["inputs"]["measured_1rank_forms"]:
+            exchange = prediction["choice"]
+        else:
+            exchange = "auto" if pg is None else "grads"
+    model = make_model(pg, exchange)
+    dp_mode = model.dp_mode()
     if pg is not None and dp_mode != "shard":
         # all ranks agree on the aggregation kernel's form on the full graph NOW, collectively, so that the
         # rank-0-only measurements further down (roofline, control model) find the choice made: the op itself never
         # communicates (ops.tune_aggregation / ops._agg_tune)
         P.ops.tune_aggregation(g["adj_t"], [cfg["hidden"], cfg.get("emb", cfg["hidden"])], group=pg)
     dt, final_loss = timed_steps(model, dp_mode, n_ranks, B * world, rank)
+    if pg is not None:
+        # ---- what the step's time is made of, so that a SCALE run can be decomposed: compute = the same form's step
+        # through a one-rank group (same per-rank work, collectives degenerate); collective_alone = this form's payloads
+        # moved by the same collectives with nothing else running; exposed = step - compute (what the collectives cost
+        # the step after overlap).  At world = 1 exposed ~ 0 by construction.
+        table_floats = n * cfg.get("emb", cfg["hidden"])
+        buf = torch.empty(table_floats + small // 4, device=device)
+        shard_out = torch.empty((table_floats + world - 1) // world * world // world, device=device)
+
+        def coll():
+            if dp_mode == "grads":
+                torch.distributed.all_reduce(buf, group=pg)
+            elif dp_mode == "shard":
+                full = buf[: shard_out.numel() * world]
+                torch.distributed.reduce_scatter_tensor(shard_out, full, group=pg)
+                torch.distributed.all_gather_into_tensor(full, shard_out, group=pg)
+            else:
+                torch.distributed.all_reduce(buf[: 2 * B * world], group=pg)
+        coll_ms = time_kernel(coll, iters=5, warm=2) * 1e3
+        del buf, shard_out
+        compute_ms = prediction["inputs"]["step_ms_1rank"].get(dp_mode) if prediction else None
+        phases = {"step_ms": dt / K * 1e3, "compute_ms_1rank_group": compute_ms, "collective_alone_ms": coll_ms,
+                  "exposed_ms": (dt / K * 1e3 - compute_ms) if compute_ms is not None else None,
+                  "predicted_ms": prediction["ms_per_step_predicted"].get(dp_mode) if prediction else None,
+                  "note": "compute = this exchange form's step through a ONE-rank process group on this GPU (measured in "
+                          "this run); collective_alone = the form's table-sized payloads through the same RCCL collectives "
+                          "with nothing else running; exposed = step - compute"}
     host_ms_per_step = host_enqueue_s[0] / K * 1e3
     host_busy_ms_per_step = host_busy_s[0] / K * 1e3
     capture_info = None
@@ -987,6 +1033,9 @@ def main():
         finally:
             P.ops.GEMM_MATH["mode"] = old_math
         extra["ms_per_step_%s" % ("f32_mfma" if other_math == "f32" else "bf16x3")] = dtv / Kv * 1e3
+        # the same metric at the OTHER arithmetic, beside `value`: with the default split-bf16 products `value_f32_mfma` is
+        # the rate on the exact-f32 MFMA (bit-for-bit an fma chain -- the reference's sgemm arithmetic)
+        extra["value_%s" % ("f32_mfma" if other_math == "f32" else "bf16x3")] = B * (1 + k) * Kv / dtv
         if sparse_fwd:
             P.ops.SPARSE_FORWARD["enabled"] = False
             try:
@@ -1052,6 +1101,10 @@ def main():
         "metric": "pos+neg edges scored/sec", "value": edges_per_step * K / dt, "unit": "edges/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling_measured": bool(world > 1),
+        "scaling_note": ("per-GPU work fixed as N grows (weak).  No multi-GPU hardware was available to the build in any "
+                         "round: no N > 1 value of this metric has ever been measured by it -- dp_prediction / dp_phases in an "
+                         "N > 1 line are what to hold the driver's SCALE run against"),
         "gemm_math": P.ops.GEMM_MATH["mode"],
         "host_enqueue_ms_per_step": host_ms_per_step,
         "host_busy_ms_per_step": host_busy_ms_per_step,
@@ -1081,6 +1134,7 @@ def main():
     if pg is not None:
         result["collective_self_test"] = selftest
         result["dp_prediction"] = prediction
+        result["dp_phases"] = phases
     result.update(extra)
     if pg is not None:
         result["replicas_in_sync"] = model.check_replicas()

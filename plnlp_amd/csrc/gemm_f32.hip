@@ -1202,6 +1202,15 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
             ok = d.a_vec && d.k % 4 == 0 && !d.b_index && !d.a_index2 && !d.b_index2 && (d.a_index == nullptr || b_trans);
             ks[si] = d.k;
         }
+        // h = 200 (citation2): measured both ways on MI355X (profiles/r04_gemm_tile_width.jsonl) -- K a multiple of 16
+        // (the first layer's padded 192): the tile kernel 1.85 ms against 2.17 (its aligned loaders are at their best,
+        // the 224-column tile wastes 11 % of its MFMAs); ragged K (200): the tile kernel's select-zeroed loaders 2.22 ms
+        // against 1.94 here, where the padding lives in the weight image
+        if (ok && n > 192 && n <= 224) {
+            bool ragged_k = false;
+            for (int si = 0; si < n_seg; ++si) ragged_k |= (ks[si] % 16) != 0;
+            ok = ragged_k;
+        }
         if (ok) {
             const int nb = x3s::pick_nb(m, n);
             if (segs[0].b_terms_bytes >= x3s::image_bytes(n, ks, n_seg, nb) && ((uintptr_t)segs[0].b_terms % 16 == 0)) {

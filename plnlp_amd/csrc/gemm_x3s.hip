@@ -174,17 +174,37 @@ __device__ __forceinline__ void load_a(const Args& g, const float* p0, const flo
     }
 }
 
-template <int NB, bool RAGGED>
+// one untracked 16-byte global load: the compiler's wait-count bookkeeping does not see it, the K loop counts by hand
+// (deep variant below).  The destination must not be read before the covering s_waitcnt vmcnt.
+__device__ __forceinline__ void gload16_untracked(f32x4& dst, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// the same wait, naming the registers whose untracked loads it covers: to the compiler the statement REWRITES them, so
+// nothing that reads them can be scheduled above it (a plain asm wait orders memory, not register arithmetic: the split
+// of a raw set was hoisted above the wait that makes the set valid)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_for(f32x4& a, f32x4& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
+// DEEP = 0: the loads of a K-step have ONE step to land (two raw A sets, two LDS stages, __syncthreads drains them).
+// DEEP = 1: TWO steps (three raw sets, three LDS stages): A through untracked loads, the image through global_load_lds,
+//           one counted s_waitcnt vmcnt(loads of one step) + a bare s_barrier per step -- never vmcnt(0) inside the loop.
+//           The B fragments are then read one column block at a time (24 instead of 48 fragment registers).
+template <int NB, bool RAGGED, int DEEP = 0>
 __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s_kernel(Args g, Epi epi) {
     constexpr int WN = 32 * NB;
     constexpr int STAGE_UNITS = 6 * WN;                // 16-byte units of one K-step of the image
     constexpr int STAGE_BYTES = STAGE_UNITS * 16;
     constexpr int GLDS = STAGE_UNITS / 256;            // global_load_lds instructions per wave per stage (WN % 128 == 0 ...)
     constexpr int GLDS_REM = STAGE_UNITS % 256;        // ... or a partial last round (WN = 224: 1344 units = 5 x 256 + 64)
+    constexpr int NSTAGE = DEEP ? 3 : 2;
     // the C tile leaves through LDS in 64-column chunks, one private region per wave
     constexpr int CS = 64 + 4;
     constexpr int C_BYTES = 4 * 32 * CS * 4;
-    constexpr int LDS_BYTES = 2 * STAGE_BYTES > C_BYTES ? 2 * STAGE_BYTES : C_BYTES;
+    constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES > C_BYTES ? NSTAGE * STAGE_BYTES : C_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
     const int t = threadIdx.x;
@@ -230,22 +250,125 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
             __builtin_amdgcn_global_load_lds((glb_void*)(src + u), (lds_void*)(dst + u), 16, 0, 0);
         }
         if constexpr (GLDS_REM != 0) {
-            const int u = (GLDS * 4 + wave) * 1024;
-            if (wave * 64 < GLDS_REM)
+            if constexpr (DEEP) {       // every wave issues the same NUMBER of loads (the counted wait): the spare waves
+                                        // repeat the last live piece -- same bytes to the same place
+                const int w = wave * 64 < GLDS_REM ? wave : 0;
+                const int u = (GLDS * 4 + w) * 1024;
                 __builtin_amdgcn_global_load_lds((glb_void*)(src + u), (lds_void*)(dst + u), 16, 0, 0);
+            } else {
+                const int u = (GLDS * 4 + wave) * 1024;
+                if (wave * 64 < GLDS_REM)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(src + u), (lds_void*)(dst + u), 16, 0, 0);
+            }
         }
     };
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};       // hi lo, lo hi, mid mid, hi mid, mid hi, hi hi
+    u32x4 cur[3], nxt[3];
 
+    if constexpr (DEEP) {
+        constexpr int STEP_LOADS = 2 + GLDS + (GLDS_REM ? 1 : 0);          // VMEM operations a wave issues per K-step
+        f32x4 ra[3][2];
+        // where the 8 k of step ks live for this lane, and which of the two 16-byte halves are inside the segment
+        auto a_ptr = [&](int ks, bool& v0, bool& v1) -> const float* {
+            const bool s1 = g.nseg > 1 && ks >= g.ks0;
+            const float* p = s1 ? p1 : p0;
+            const int k0 = 16 * (ks - (s1 ? g.ks0 : 0)) + 8 * h;
+            v0 = v1 = true;
+            if constexpr (RAGGED) { const int kdim = s1 ? g.k[1] : g.k[0]; v0 = k0 < kdim; v1 = k0 + 4 < kdim; }
+            return p + (v0 ? k0 : 0);
+        };
+        auto load_raw = [&](int ks, f32x4 (&r)[2]) {
+            bool v0, v1;
+            const float* p = a_ptr(ks < KS ? ks : KS - 1, v0, v1);
+            gload16_untracked(r[0], p);
+            gload16_untracked(r[1], v1 ? p + 4 : p);
+        };
+        auto masked = [&](int ks, const f32x4 (&r)[2], f32x4& x0, f32x4& x1) {
+            x0 = r[0]; x1 = r[1];
+            if constexpr (RAGGED) {
+                bool v0, v1;
+                a_ptr(ks < KS ? ks : KS - 1, v0, v1);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                x0 = v0 ? x0 : zero; x1 = v1 ? x1 : zero;
+            }
+        };
+        // ---- prologue: raw A of steps 0..2, the image of steps 0 and 1; everything waited for once
+        load_raw(0, ra[0]); load_raw(1, ra[1]); load_raw(2, ra[2]);
+        stage_b(0, 0);
+        stage_b(KS > 1 ? 1 : 0, 1);
+        wait_vmcnt_for<0>(ra[0][0], ra[0][1]);
+        wait_vmcnt_for<0>(ra[1][0], ra[1][1]);
+        wait_vmcnt_for<0>(ra[2][0], ra[2][1]);
+        {
+            f32x4 x0, x1;
+            masked(0, ra[0], x0, x1);
+            split8(x0, x1, cur);
+        }
+        __builtin_amdgcn_s_barrier();
+        auto step = [&](int ks, auto dc) {
+            constexpr int D = decltype(dc)::value;                 // ks % 3
+            // this step's loads first: raw A of step + 3 into the set split two steps ago ... (D: raw(ks) was split during
+            // step ks - 1), the image of step + 2 into the stage read during step ks - 1.  They are waited for at the END of
+            // step ks + 1: two whole steps to land.
+            load_raw(ks + 3, ra[D]);
+            stage_b(ks + 2 < KS ? ks + 2 : KS - 1, (D + 2) % 3);
+            const u32x4* bt = reinterpret_cast<const u32x4*>(lds + D * STAGE_BYTES) + h * WN + l31;
+            bf16x8 fb[2][3];
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) fb[0][t3] = __builtin_bit_cast(bf16x8, bt[t3 * 2 * WN]);
+            SplitStages sp;
+            f32x4 x0, x1;
+            masked(ks + 1, ra[(D + 1) % 3], x0, x1);              // landed: covered by the wait that ended step ks - 1
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int SLOTS1 = 6 * NB;
+            static_for<SLOTS1>([&](auto sc) {
+                constexpr int slot = decltype(sc)::value;
+                constexpr int j = slot / 6, u = slot % 6;
+                if constexpr (u < 3 && j + 1 < NB)                  // the next column block's fragments, one per slot
+                    fb[(j + 1) & 1][u] = __builtin_bit_cast(bf16x8, bt[u * 2 * WN + (j + 1) * 32]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[TA[u]]), fb[j & 1][TB[u]],
+                                                                 acc[j], 0, 0, 0);
+                static_for<9>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    if constexpr (q * SLOTS1 / 9 == slot) {
+                        if constexpr (q < 4) sp.template first<q>(x0, x1);
+                        else if constexpr (q < 8) sp.template second<q - 4>();
+                        else sp.third(nxt);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // everything but THIS step's loads has landed: the image of step + 1, the raw A of step + 2 (the set the next
+            // step splits)
+            wait_vmcnt_for<STEP_LOADS>(ra[(D + 2) % 3][0], ra[(D + 2) % 3][1]);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
+        };
+        int ks = 0;
+        for (; ks + 3 <= KS; ks += 3) {
+            step(ks, std::integral_constant<int, 0>{});
+            step(ks + 1, std::integral_constant<int, 1>{});
+            step(ks + 2, std::integral_constant<int, 2>{});
+        }
+        if (ks < KS) step(ks, std::integral_constant<int, 0>{});
+        if (ks + 1 < KS) step(ks + 1, std::integral_constant<int, 1>{});
+        wait_vmcnt<0>();                                           // no LDS-DMA may still be in flight into the C staging area
+        // the last steps' raw sets are never split -- keep them "read" until here: a destination the compiler considers
+        // dead is reused at once (as an ADDRESS register in the very next instructions) while its untracked load is still
+        // in flight
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(ra[i][0]), "v"(ra[i][1]));
+        __builtin_amdgcn_s_barrier();
+    } else {
     // ---- prologue: A of step 0 split, A of step 1 in flight, B of step 0 resident
     f32x4 ra[2][2];                                            // two sets of raw A registers, used alternately
-    u32x4 cur[3], nxt[3];
     load_a<RAGGED>(g, p0, p1, 0, h, ra[0][0], ra[0][1]);
     stage_b(0, 0);
     split8(ra[0][0], ra[0][1], cur);
     load_a<RAGGED>(g, p0, p1, KS > 1 ? 1 : 0, h, ra[1][0], ra[1][1]);
     __syncthreads();
 
-    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};       // hi lo, lo hi, mid mid, hi mid, mid hi, hi hi
     constexpr int G = NB / 2 + (NB & 1);                       // column-block groups of 2 (the last may hold 1)
     constexpr int SLOTS = 6 * G;                               // one slot = the MFMAs of one term product of one group
     // one K-step: D = the parity of ks (which raw set holds step ks + 1, which LDS buffer holds this step's image).
@@ -301,6 +424,8 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
     }
     if (ks < KS) step(ks, std::integral_constant<int, 0>{});
 
+    }
+
     // ---- write back: 64 columns at a time through this wave's private LDS region (the MFMA C/D map -- col = lane & 31,
     // row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5) -- would leave as 4-byte scattered stores), then 16-byte row stores with
     // the epilogue on float4.  (The barrier that ended the K loop freed the image buffers.)
@@ -314,29 +439,65 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
 #pragma unroll
             for (int q = 0; q < 16; ++q)
                 cw[((q & 3) + 8 * (q >> 2) + 4 * h) * CS + jj * 32 + l31] = acc[j0 + jj][q];
-        // rows i * 4 + (lane >> 4), 16-byte column group lane & 15
+        // rows i * 4 + (lane >> 4), 16-byte column group lane & 15.  The epilogue's operands (bias once per chunk; gate and
+        // accumulate rows) are requested for all 8 rows BEFORE the first store: a load issued between stores waits for
+        // them (the compiler must assume the result aliases the operand), 8 dependent round trips per chunk.
+        const int c4 = (lane & 15) * 4;
+        const int col = n0 + j0 * 32 + c4;
+        const bool col_ok = c4 < NJ * 32 && col < g.n;
+        const bool second = col >= g.n_split;
+        const bool pre = epi.flags && epi.vec4 && !(epi.flags & PLNLP_EPI_ADDEND);
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col_ok && pre && (epi.flags & PLNLP_EPI_BIAS)) bias4 = *reinterpret_cast<const float4*>(epi.bias + col);
+        constexpr int RB = NB >= 7 ? 4 : 8;                    // rows per batch (the wide tiles have few registers to spare)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int rl = i * 4 + (lane >> 4);
-            const int c4 = (lane & 15) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(cw + rl * CS + c4);
-            const int64_t orow = row_w + rl;
-            const int col = n0 + j0 * 32 + c4;
-            if (c4 < NJ * 32 && orow < g.m && col < g.n) {
-                const bool second = col >= g.n_split;
-                float* op = second ? g.c2 + orow * g.ldc2 - g.n_split : g.c + orow * g.ldc;
-                const float4 y = epi_apply4(epi, v, orow, col, g.n, op);
-                *reinterpret_cast<float4*>(op + col) = y;
+        for (int i0 = 0; i0 < 8; i0 += RB) {
+            float4 g4[RB], p4[RB], v4[RB];
+            if (col_ok && pre && (epi.flags & (PLNLP_EPI_GATE | PLNLP_EPI_ACCUM))) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    int64_t orow = row_w + (i0 + i) * 4 + (lane >> 4);
+                    orow = orow < g.m ? orow : g.m - 1;
+                    if (epi.flags & PLNLP_EPI_GATE) {
+                        const int64_t gr = epi.gate_index ? (int64_t)epi.gate_index[orow] : orow;
+                        g4[i] = *reinterpret_cast<const float4*>(epi.gate + gr * epi.ld_gate + col);
+                    }
+                    if (epi.flags & PLNLP_EPI_ACCUM) {
+                        const float* pp = second ? g.c2 + orow * g.ldc2 - g.n_split : g.c + orow * g.ldc;
+                        p4[i] = *reinterpret_cast<const float4*>(pp + col);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) v4[i] = *reinterpret_cast<const float4*>(cw + ((i0 + i) * 4 + (lane >> 4)) * CS + c4);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int64_t orow = row_w + (i0 + i) * 4 + (lane >> 4);
+                if (col_ok && orow < g.m) {
+                    float* op = second ? g.c2 + orow * g.ldc2 - g.n_split : g.c + orow * g.ldc;
+                    float4 y = v4[i];
+                    if (pre) y = epi_apply4_pre(epi, y, orow, col, g.n, bias4, g4[i], p4[i]);
+                    else y = epi_apply4(epi, y, orow, col, g.n, op);
+                    *reinterpret_cast<float4*>(op + col) = y;
+                }
             }
         }
     });
 }
 
+static int g_deep = 1;
 template <int NB>
 static int launch_nb(const Args& a, const Epi& e, bool ragged, hipStream_t s) {
     dim3 grid((unsigned)(a.gm * a.gn));
-    if (ragged) hipLaunchKernelGGL((gemm_x3s_kernel<NB, true>), grid, dim3(256), 0, s, a, e);
-    else        hipLaunchKernelGGL((gemm_x3s_kernel<NB, false>), grid, dim3(256), 0, s, a, e);
+    if constexpr (NB >= 7) {            // (NB = 4 keeps three workgroups per CU: the deep loop's registers do not fit 168)
+        if (g_deep) {
+            if (ragged) hipLaunchKernelGGL((gemm_x3s_kernel<NB, true, 1>), grid, dim3(256), 0, s, a, e);
+            else        hipLaunchKernelGGL((gemm_x3s_kernel<NB, false, 1>), grid, dim3(256), 0, s, a, e);
+            return launch_status();
+        }
+    }
+    if (ragged) hipLaunchKernelGGL((gemm_x3s_kernel<NB, true, 0>), grid, dim3(256), 0, s, a, e);
+    else        hipLaunchKernelGGL((gemm_x3s_kernel<NB, false, 0>), grid, dim3(256), 0, s, a, e);
     return launch_status();
 }
 
@@ -345,24 +506,24 @@ static int slots_of(int nb) { return 256 * (nb >= 7 ? 2 : nb == 4 ? 3 : 4); }
 
 // measurement knob (plnlp_gemm_stationary_tuning): process-global, for A/B runs only
 static int g_force_nb = 0;
-void set_tuning(int nb, int) { g_force_nb = nb; }
+void set_tuning(int nb, int shallow) { g_force_nb = nb; g_deep = shallow ? 0 : 1; }
 
 // n-tile width (in 32-column blocks) of a launch.  A launch is rounds of slots_of(nb) workgroups; measured on MI355X
-// (profiles/r04_gemm_tile_width.jsonl) a round of 256-column tiles takes 1.28 x a round of 128-column tiles and does
-// twice the work, so wide tiles win -- unless the row panels leave their last round nearly empty (the step's forward
+// (profiles/r04_gemm_tile_width.jsonl) a round of 256-column tiles takes 1.2 .. 1.3 x a round of 128-column tiles and
+// does twice the work, so wide tiles win -- unless the row panels leave their last round nearly empty (the step's forward
 // GEMM: 1 033 panels on 512 slots = 2.02 rounds -> three; on 768 slots of narrow tiles 2.69 -> three SHORT ones).
 int pick_nb(int64_t m, int64_t n) {
     if (g_force_nb == 1 || g_force_nb == 2 || g_force_nb == 4 || g_force_nb == 7 || g_force_nb == 8) return g_force_nb;
     if (n <= 32) return 1;
     if (n <= 64) return 2;
     if (n <= 128) return 4;
-    if (n > 192 && n <= 224) return 7;        // h = 200 in one tile
+    if (n > 192 && n <= 224) return 7;        // h = 200 in one tile (gemm_impl sends only ragged K here, see there)
     const int64_t panels = (m + 127) / 128;
-    auto rounds = [&](int nb) {               // (workgroups do not run in lock step: a round 10 % over is not a new round)
-        const double r = (double)(panels * ((n + 32 * nb - 1) / (32 * nb))) / slots_of(nb);
-        return r - (int64_t)r > 0.1 ? (double)((int64_t)r + 1) : (r < 1.0 ? 1.0 : (double)(int64_t)r);
+    auto rounds = [&](int nb) {
+        const int64_t blocks = panels * ((n + 32 * nb - 1) / (32 * nb)), slots = slots_of(nb);
+        return (double)((blocks + slots - 1) / slots);
     };
-    return 1.28 * rounds(8) <= rounds(4) ? 8 : 4;
+    return 1.2 * rounds(8) <= rounds(4) ? 8 : 4;
 }
 
 int64_t image_bytes(int64_t n, const int64_t* k, int nseg, int nb) {

@@ -33,16 +33,16 @@ import os
 
 # single process, SAGE on the raw embedding table: the table's Adam step rides in the epilogue of the kernel that
 # finishes its gradient (BaseModel._embedding_grad_sink); PLNLP_FUSE_EMBEDDING_ADAM=0 keeps gradient and update apart
-FUSE_EMBEDDING_ADAM = {"enabled": os.environ.get("PLNLP_FUSE_EMBEDDING_ADAM", "1") != "0"}
+FUSE_EMBEDDING_ADAM = {"enabled": True}
 # the epoch's batch permutation shuffled a few batches ahead of the GPU by a host thread (utils.StreamedPermutation);
 # PLNLP_STREAM_PERMUTATION=0: the whole torch.randperm before the first step, as the reference's DataLoader does
-STREAM_PERMUTATION = {"enabled": os.environ.get("PLNLP_STREAM_PERMUTATION", "1") != "0"}
+STREAM_PERMUTATION = {"enabled": True}
 # the epoch's running sum of loss * examples (model.py:169) fed by the loss kernel's own tail (ops.LOSS_ACC) in a
 # one-process run; PLNLP_FUSE_LOSS_ACC=0: three element-wise launches per step, as the reference's line does it
-FUSE_LOSS_ACC = {"enabled": os.environ.get("PLNLP_FUSE_LOSS_ACC", "1") != "0"}
+FUSE_LOSS_ACC = {"enabled": True}
 # row-sharded data parallelism: the last SAGE layer evaluated / back-propagated only at the rows of the rank's block that
 # the global batch touches (PLNLP_SHARD_SPARSE=0: every row of the block)
-SHARD_SPARSE = {"enabled": os.environ.get("PLNLP_SHARD_SPARSE", "1") != "0"}
+SHARD_SPARSE = {"enabled": True}
 
 
 class BaseModel(object):

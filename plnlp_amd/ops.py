@@ -72,7 +72,7 @@ def _ld(t: torch.Tensor) -> int:
 # edges = 2 900 chunks of 256 for 256 CUs) -- 128-edge chunks: collab step -2.7 %, ddi step -3.4 %, ddi aggregation
 # -23 %; on citation2 / R-MAT-23 (sources far beyond the caches) there are waves enough and fewer, longer chunks
 # save partial sums: 1024 vs 256: citation2 step -1.1 %, R-MAT-23 aggregation -5.7 %; 128 costs 1 %, 64 costs 6 %.
-SPLIT_THRESHOLD = int(os.environ.get("PLNLP_SPLIT_THRESHOLD", "0"))
+SPLIT_THRESHOLD = 0
 
 
 def split_threshold(n_source_rows: int) -> int:
@@ -105,7 +105,7 @@ HUB_RANGES = {"part_rows": 65536, "max_len": 256, "max_ranges": 8}
 
 # the long rows' chunk pass inside the main pass's launch (PLNLP_AGG_FUSED_PASSES): the same sums in the same order --
 # not a tuned form, a launch shape; PLNLP_AGG_FUSED=0 restores the three-launch sequence for A/B runs
-AGG_FUSED = {"enabled": os.environ.get("PLNLP_AGG_FUSED", "1") != "0"}
+AGG_FUSED = {"enabled": True}
 
 
 def hub_ranges(n_source_rows: int):
@@ -116,7 +116,7 @@ def hub_ranges(n_source_rows: int):
 # kernels would otherwise time differently from the run they are meant to explain)
 AGG_AUTOTUNE = {"enabled": os.environ.get("PLNLP_AGG_AUTOTUNE", "1") != "0", "min_feat": 256,
                 "candidates": (0, L.AGG_SLABS_128, L.AGG_SLABS_256, L.AGG_HUB_XCD | AGG_HUB_RANGES),
-                "force": int(os.environ["PLNLP_AGG_FORM"]) if os.environ.get("PLNLP_AGG_FORM") else None}
+                "force": int(os.environ["PLNLP_AGG_FORM"]) if os.environ.get("PLNLP_AGG_FORM") else None}   # (counter runs pin the form)
 
 
 def describe_form(tune: int) -> str:
@@ -367,7 +367,7 @@ def _pick_split_k(m: int, n: int, ktiles: int) -> int:
 
 # workgroup slots one round of a split-K launch should fill (256 CUs x 2; the split-bf16 kernels run 3 per CU, but
 # 768 slots measured +5 % on ddi's 512x512 weight gradient and -6 % on collab's 256x256 -- profiles/r02_gemm_x3_splitk.txt)
-SPLIT_K_SLOTS = {"slots": int(os.environ.get("PLNLP_SPLIT_K_SLOTS", "512"))}
+SPLIT_K_SLOTS = {"slots": 512}
 
 # how every dense product of the path is formed (include/plnlp_hip.h, PLNLP_GEMM_MATH_*): 'f32' = the f32-input
 # MFMA (an fmaf chain), 'bf16x3' = operands split into three bf16 terms in the loader, six bf16 MFMAs per block
@@ -840,13 +840,13 @@ class SparseGradChannel:
         return g
 
 
-SPARSE_BACKWARD = {"enabled": os.environ.get("PLNLP_SPARSE_BACKWARD", "1") != "0",
+SPARSE_BACKWARD = {"enabled": True,
                    # use the channel when the batch can touch at most this fraction of the nodes in
                    # expectation (1 - exp(-endpoints / nodes)); a batch that touches everything (ddi)
                    # gains nothing from the indirection.  Measured on collab at 1/2/3/4/6/8x the batch
                    # (expectation 0.67 / 0.89 / 0.96 / 0.99 / ~1 / ~1; degree-biased positives touch fewer):
                    # row-sparse vs dense 2.52/3.15, 2.90/3.14, 3.10/3.18, 3.24/3.24, 3.41/3.38, 3.59/3.54 ms
-                   "max_expected_fraction": float(os.environ.get("PLNLP_SPARSE_MAX_FRACTION", "0.97"))}
+                   "max_expected_fraction": 0.97}
 
 
 def sparse_backward_pays(n_endpoints: int, n_nodes: int) -> bool:
@@ -1590,7 +1590,7 @@ def _padded_operand(x: torch.Tensor):
     return xp, k
 
 
-GCN_INPUT_FUSION = {"enabled": os.environ.get("PLNLP_GCN_INPUT_FUSION", "1") != "0"}
+GCN_INPUT_FUSION = {"enabled": True}
 
 
 class GCNInputConvFn(torch.autograd.Function):
@@ -1836,7 +1836,7 @@ def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, co
     return inc
 
 
-PROLOGUE_OVERLAP = {"enabled": os.environ.get("PLNLP_PROLOGUE_OVERLAP", "1") != "0"}
+PROLOGUE_OVERLAP = {"enabled": True}
 
 
 JOIN_STATS = {"waited": 0, "skipped": 0}        # EdgeBatch.join: stream waits enqueued / found unnecessary
@@ -1874,7 +1874,7 @@ class StepThrottle:
                 StepThrottle.waited_s += time.perf_counter() - t0
 
 
-STEP_THROTTLE = {"depth": int(os.environ.get("PLNLP_STEP_THROTTLE", "2"))}
+STEP_THROTTLE = {"depth": 2}
 
 
 class EdgeBatch:
@@ -2107,7 +2107,7 @@ class EdgeHadamardFn(torch.autograd.Function):
 # bytes of each gathered row, so the two loaders issue 32 scattered 64-byte gathers per instruction where the
 # stand-alone kernel reads whole 2 KB rows: the first linear's forward goes 0.39 -> 0.90 ms, its weight
 # gradient 0.78 -> 1.05 ms.
-FUSE_EDGE_MLP = {"enabled": os.environ.get("PLNLP_FUSE_EDGE_MLP", "0") == "1"}
+FUSE_EDGE_MLP = {"enabled": False}
 
 
 def edge_mlp_fusable(h: torch.Tensor, params) -> bool:
