@@ -174,33 +174,17 @@ __device__ __forceinline__ void load_a(const Args& g, const float* p0, const flo
     }
 }
 
-// one untracked 16-byte global load: the compiler's wait-count bookkeeping does not see it, the K loop counts by hand
-// (deep variant below).  The destination must not be read before the covering s_waitcnt vmcnt.
-__device__ __forceinline__ void gload16_untracked(f32x4& dst, const float* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// the same wait, naming the registers whose untracked loads it covers: to the compiler the statement REWRITES them, so
-// nothing that reads them can be scheduled above it (a plain asm wait orders memory, not register arithmetic: the split
-// of a raw set was hoisted above the wait that makes the set valid)
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_for(f32x4& a, f32x4& b) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
-}
-
-// DEEP = 0: the loads of a K-step have ONE step to land (two raw A sets, two LDS stages, __syncthreads drains them).
-// DEEP = 1: TWO steps (three raw sets, three LDS stages): A through untracked loads, the image through global_load_lds,
-//           one counted s_waitcnt vmcnt(loads of one step) + a bare s_barrier per step -- never vmcnt(0) inside the loop.
-//           The B fragments are then read one column block at a time (24 instead of 48 fragment registers).
-template <int NB, bool RAGGED, int DEEP = 0>
+// (A K loop with TWO steps of load look-ahead was built and measured in round 4 -- three raw A sets through untracked inline-asm
+// loads, three LDS stages, one counted s_waitcnt vmcnt + a bare s_barrier per step, the B fragments read one column block
+// at a time to fit the registers: 2-4 % SLOWER than this one on every shape (profiles/r04_gemm_deep_loop.jsonl), removed.)
+template <int NB, bool RAGGED>
 __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s_kernel(Args g, Epi epi) {
     constexpr int WN = 32 * NB;
     constexpr int STAGE_UNITS = 6 * WN;                // 16-byte units of one K-step of the image
     constexpr int STAGE_BYTES = STAGE_UNITS * 16;
     constexpr int GLDS = STAGE_UNITS / 256;            // global_load_lds instructions per wave per stage (WN % 128 == 0 ...)
     constexpr int GLDS_REM = STAGE_UNITS % 256;        // ... or a partial last round (WN = 224: 1344 units = 5 x 256 + 64)
-    constexpr int NSTAGE = DEEP ? 3 : 2;
+    constexpr int NSTAGE = 2;
     // the C tile leaves through LDS in 64-column chunks, one private region per wave
     constexpr int CS = 64 + 4;
     constexpr int C_BYTES = 4 * 32 * CS * 4;
@@ -250,117 +234,14 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
             __builtin_amdgcn_global_load_lds((glb_void*)(src + u), (lds_void*)(dst + u), 16, 0, 0);
         }
         if constexpr (GLDS_REM != 0) {
-            if constexpr (DEEP) {       // every wave issues the same NUMBER of loads (the counted wait): the spare waves
-                                        // repeat the last live piece -- same bytes to the same place
-                const int w = wave * 64 < GLDS_REM ? wave : 0;
-                const int u = (GLDS * 4 + w) * 1024;
+            const int u = (GLDS * 4 + wave) * 1024;
+            if (wave * 64 < GLDS_REM)
                 __builtin_amdgcn_global_load_lds((glb_void*)(src + u), (lds_void*)(dst + u), 16, 0, 0);
-            } else {
-                const int u = (GLDS * 4 + wave) * 1024;
-                if (wave * 64 < GLDS_REM)
-                    __builtin_amdgcn_global_load_lds((glb_void*)(src + u), (lds_void*)(dst + u), 16, 0, 0);
-            }
         }
     };
     constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};       // hi lo, lo hi, mid mid, hi mid, mid hi, hi hi
     u32x4 cur[3], nxt[3];
 
-    if constexpr (DEEP) {
-        constexpr int STEP_LOADS = 2 + GLDS + (GLDS_REM ? 1 : 0);          // VMEM operations a wave issues per K-step
-        f32x4 ra[3][2];
-        // where the 8 k of step ks live for this lane, and which of the two 16-byte halves are inside the segment
-        auto a_ptr = [&](int ks, bool& v0, bool& v1) -> const float* {
-            const bool s1 = g.nseg > 1 && ks >= g.ks0;
-            const float* p = s1 ? p1 : p0;
-            const int k0 = 16 * (ks - (s1 ? g.ks0 : 0)) + 8 * h;
-            v0 = v1 = true;
-            if constexpr (RAGGED) { const int kdim = s1 ? g.k[1] : g.k[0]; v0 = k0 < kdim; v1 = k0 + 4 < kdim; }
-            return p + (v0 ? k0 : 0);
-        };
-        auto load_raw = [&](int ks, f32x4 (&r)[2]) {
-            bool v0, v1;
-            const float* p = a_ptr(ks < KS ? ks : KS - 1, v0, v1);
-            gload16_untracked(r[0], p);
-            gload16_untracked(r[1], v1 ? p + 4 : p);
-        };
-        auto masked = [&](int ks, const f32x4 (&r)[2], f32x4& x0, f32x4& x1) {
-            x0 = r[0]; x1 = r[1];
-            if constexpr (RAGGED) {
-                bool v0, v1;
-                a_ptr(ks < KS ? ks : KS - 1, v0, v1);
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                x0 = v0 ? x0 : zero; x1 = v1 ? x1 : zero;
-            }
-        };
-        // ---- prologue: raw A of steps 0..2, the image of steps 0 and 1; everything waited for once
-        load_raw(0, ra[0]); load_raw(1, ra[1]); load_raw(2, ra[2]);
-        stage_b(0, 0);
-        stage_b(KS > 1 ? 1 : 0, 1);
-        wait_vmcnt_for<0>(ra[0][0], ra[0][1]);
-        wait_vmcnt_for<0>(ra[1][0], ra[1][1]);
-        wait_vmcnt_for<0>(ra[2][0], ra[2][1]);
-        {
-            f32x4 x0, x1;
-            masked(0, ra[0], x0, x1);
-            split8(x0, x1, cur);
-        }
-        __builtin_amdgcn_s_barrier();
-        auto step = [&](int ks, auto dc) {
-            constexpr int D = decltype(dc)::value;                 // ks % 3
-            // this step's loads first: raw A of step + 3 into the set split two steps ago ... (D: raw(ks) was split during
-            // step ks - 1), the image of step + 2 into the stage read during step ks - 1.  They are waited for at the END of
-            // step ks + 1: two whole steps to land.
-            load_raw(ks + 3, ra[D]);
-            stage_b(ks + 2 < KS ? ks + 2 : KS - 1, (D + 2) % 3);
-            const u32x4* bt = reinterpret_cast<const u32x4*>(lds + D * STAGE_BYTES) + h * WN + l31;
-            bf16x8 fb[2][3];
-#pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) fb[0][t3] = __builtin_bit_cast(bf16x8, bt[t3 * 2 * WN]);
-            SplitStages sp;
-            f32x4 x0, x1;
-            masked(ks + 1, ra[(D + 1) % 3], x0, x1);              // landed: covered by the wait that ended step ks - 1
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr int SLOTS1 = 6 * NB;
-            static_for<SLOTS1>([&](auto sc) {
-                constexpr int slot = decltype(sc)::value;
-                constexpr int j = slot / 6, u = slot % 6;
-                if constexpr (u < 3 && j + 1 < NB)                  // the next column block's fragments, one per slot
-                    fb[(j + 1) & 1][u] = __builtin_bit_cast(bf16x8, bt[u * 2 * WN + (j + 1) * 32]);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[TA[u]]), fb[j & 1][TB[u]],
-                                                                 acc[j], 0, 0, 0);
-                static_for<9>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    if constexpr (q * SLOTS1 / 9 == slot) {
-                        if constexpr (q < 4) sp.template first<q>(x0, x1);
-                        else if constexpr (q < 8) sp.template second<q - 4>();
-                        else sp.third(nxt);
-                    }
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            // everything but THIS step's loads has landed: the image of step + 1, the raw A of step + 2 (the set the next
-            // step splits)
-            wait_vmcnt_for<STEP_LOADS>(ra[(D + 2) % 3][0], ra[(D + 2) % 3][1]);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
-        };
-        int ks = 0;
-        for (; ks + 3 <= KS; ks += 3) {
-            step(ks, std::integral_constant<int, 0>{});
-            step(ks + 1, std::integral_constant<int, 1>{});
-            step(ks + 2, std::integral_constant<int, 2>{});
-        }
-        if (ks < KS) step(ks, std::integral_constant<int, 0>{});
-        if (ks + 1 < KS) step(ks + 1, std::integral_constant<int, 1>{});
-        wait_vmcnt<0>();                                           // no LDS-DMA may still be in flight into the C staging area
-        // the last steps' raw sets are never split -- keep them "read" until here: a destination the compiler considers
-        // dead is reused at once (as an ADDRESS register in the very next instructions) while its untracked load is still
-        // in flight
-#pragma unroll
-        for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(ra[i][0]), "v"(ra[i][1]));
-        __builtin_amdgcn_s_barrier();
-    } else {
     // ---- prologue: A of step 0 split, A of step 1 in flight, B of step 0 resident
     f32x4 ra[2][2];                                            // two sets of raw A registers, used alternately
     load_a<RAGGED>(g, p0, p1, 0, h, ra[0][0], ra[0][1]);
@@ -424,8 +305,6 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
     }
     if (ks < KS) step(ks, std::integral_constant<int, 0>{});
 
-    }
-
     // ---- write back: 64 columns at a time through this wave's private LDS region (the MFMA C/D map -- col = lane & 31,
     // row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5) -- would leave as 4-byte scattered stores), then 16-byte row stores with
     // the epilogue on float4.  (The barrier that ended the K loop freed the image buffers.)
@@ -485,19 +364,11 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
     });
 }
 
-static int g_deep = 1;
 template <int NB>
 static int launch_nb(const Args& a, const Epi& e, bool ragged, hipStream_t s) {
     dim3 grid((unsigned)(a.gm * a.gn));
-    if constexpr (NB >= 7) {            // (NB = 4 keeps three workgroups per CU: the deep loop's registers do not fit 168)
-        if (g_deep) {
-            if (ragged) hipLaunchKernelGGL((gemm_x3s_kernel<NB, true, 1>), grid, dim3(256), 0, s, a, e);
-            else        hipLaunchKernelGGL((gemm_x3s_kernel<NB, false, 1>), grid, dim3(256), 0, s, a, e);
-            return launch_status();
-        }
-    }
-    if (ragged) hipLaunchKernelGGL((gemm_x3s_kernel<NB, true, 0>), grid, dim3(256), 0, s, a, e);
-    else        hipLaunchKernelGGL((gemm_x3s_kernel<NB, false, 0>), grid, dim3(256), 0, s, a, e);
+    if (ragged) hipLaunchKernelGGL((gemm_x3s_kernel<NB, true>), grid, dim3(256), 0, s, a, e);
+    else        hipLaunchKernelGGL((gemm_x3s_kernel<NB, false>), grid, dim3(256), 0, s, a, e);
     return launch_status();
 }
 
@@ -506,7 +377,7 @@ static int slots_of(int nb) { return 256 * (nb >= 7 ? 2 : nb == 4 ? 3 : 4); }
 
 // measurement knob (plnlp_gemm_stationary_tuning): process-global, for A/B runs only
 static int g_force_nb = 0;
-void set_tuning(int nb, int shallow) { g_force_nb = nb; g_deep = shallow ? 0 : 1; }
+void set_tuning(int nb, int) { g_force_nb = nb; }
 
 // n-tile width (in 32-column blocks) of a launch.  A launch is rounds of slots_of(nb) workgroups; measured on MI355X
 // (profiles/r04_gemm_tile_width.jsonl) a round of 256-column tiles takes 1.2 .. 1.3 x a round of 128-column tiles and

@@ -271,38 +271,3 @@ def describe(name: str, c: dict) -> str:
             f" oracle f32 median {np.median(c['epochs_f32']):.0f} mean {c['epochs_f32'].mean():.2f};"
             f" reached by {100 * c['reached_hip']:.0f} % / {100 * c['reached_f32']:.0f} % of the seeds;"
             f" Mann-Whitney p = {c['mw_p']:.3f}")
-
-
-# ------------------------------------------------------------------ worker processes --
-def run_hip_parallel(recipe: str, math: str, seeds, mutation: str = "none", workers: int = 4):
-    """run_hip over `seeds` in `workers` child processes sharing the GPU (a run is host-bound: ~50 launches per step of a
-    toy-sized problem), each a fresh interpreter running this file as a script.  Returns (hits [n, epochs, 3, 2],
-    losses [n, epochs]) in seed order."""
-    import subprocess
-    import tempfile
-    seeds = list(seeds)
-    chunks = [seeds[i::workers] for i in range(workers) if seeds[i::workers]]
-    with tempfile.TemporaryDirectory() as tmp:
-        procs = []
-        for i, chunk in enumerate(chunks):
-            out = os.path.join(tmp, f"w{i}.npz")
-            cmd = [sys.executable, os.path.abspath(__file__), recipe, math, mutation, out] + [str(s) for s in chunk]
-            procs.append((chunk, out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        got = {}
-        for chunk, out, p in procs:
-            log, _ = p.communicate()
-            if p.returncode != 0:
-                raise RuntimeError(f"trained-parity worker failed ({recipe}, {math}, {mutation}):\n{log[-3000:]}")
-            z = np.load(out)
-            for j, s in enumerate(chunk):
-                got[s] = (z["hits"][j], z["losses"][j])
-    return np.stack([got[s][0] for s in seeds]), np.stack([got[s][1] for s in seeds])
-
-
-if __name__ == "__main__":
-    _recipe, _math, _mutation, _out = sys.argv[1:5]
-    _seeds = [int(v) for v in sys.argv[5:]]
-    import plnlp_amd as _P
-    _P._lib.load()
-    _runs = [run_hip(_P, _recipe, s, _math, _mutation) for s in _seeds]
-    np.savez(_out, hits=np.stack([h for h, _ in _runs]), losses=np.stack([l for _, l in _runs]))
