@@ -16,13 +16,13 @@ import torch as _torch
 # `.item()`, the touched-row count) faults with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- reproduced on MI355X
 # with nothing but torch.cuda.CUDAGraph + our kernels, gone with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 # (profiles/r03_capture_debug.md).  The HIP runtime reads the flag when it initialises, so it is set here, at import --
-# but ONLY when the captured loop was asked for (PLNLP_CAPTURE=1) and the process has not touched the GPU yet: the flag is
+# but ONLY when the captured loop was asked for (PLNLP_CAPTURE=1, or =available: the flag alone) and the process has not touched the GPU yet: the flag is
 # a process-wide runtime switch that an embedding application and its children inherit, and the captured loop is opt-in.
 # Otherwise the environment is left alone and the step pipeline stays eager (StepPipeline.why_eager says why).
 _PACKET_FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 _preset = _os.environ.get(_PACKET_FLAG)
 _early = not _torch.cuda.is_initialized()
-if _preset is None and _early and _os.environ.get("PLNLP_CAPTURE") == "1":
+if _preset is None and _early and _os.environ.get("PLNLP_CAPTURE") in ("1", "available"):     # "available": flag only, loop stays eager
     _os.environ[_PACKET_FLAG] = "0"
 GRAPH_REPLAY_SAFE = _os.environ.get(_PACKET_FLAG) == "0" and (_preset == "0" or _early)
 

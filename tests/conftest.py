@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+# the captured step loop (plnlp_amd/capture.py) is opt-in: the product only flips ROCm's graph-packet-capture switch when
+# PLNLP_CAPTURE=1 is in the environment at import.  The suite TESTS that loop (tests/test_hip_round3.py), so the test
+# session asks for it here, before anything has touched the GPU -- a choice of this test environment, not of the library.
+os.environ.setdefault("PLNLP_CAPTURE", "available")     # the runtime flag only: the default loop stays eager
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -584,8 +584,11 @@ def test_gemm_pair_gathered_operands_equal_materialised_hadamard(P, n, k, e, nou
     dz = torch.randn(e, nout, generator=gen)
     had = dev(h)[dev(src)] * dev(h)[dev(dst)]
     s32, d32 = dev(src).to(torch.int32), dev(dst).to(torch.int32)
-    old = P.ops.GEMM_MATH["mode"]
+    old, old_st = P.ops.GEMM_MATH["mode"], P.ops.GEMM_STATIONARY_B["enabled"]
     P.ops.GEMM_MATH["mode"] = "bf16x3"
+    # (the pair loaders live in the 128 x 128 kernels: the bit-for-bit reference is the SAME kernel on the materialised
+    #  operand -- the stationary-weights kernel sums the same products in another order, tests/test_hip_round4.py)
+    P.ops.GEMM_STATIONARY_B["enabled"] = False
     try:
         y = P.ops.gemm([(dev(h), dev(w))], False, True, a_index=[s32], a_index2=d32)
         y_ref = P.ops.gemm([(had, dev(w))], False, True)
@@ -595,7 +598,7 @@ def test_gemm_pair_gathered_operands_equal_materialised_hadamard(P, n, k, e, nou
         with pytest.raises(Exception):          # the f32-MFMA form has no pair loader: it must refuse, not ignore
             P.ops.gemm([(dev(h), dev(w))], False, True, a_index=[s32], a_index2=d32)
     finally:
-        P.ops.GEMM_MATH["mode"] = old
+        P.ops.GEMM_MATH["mode"], P.ops.GEMM_STATIONARY_B["enabled"] = old, old_st
     assert torch.equal(y, y_ref) and torch.equal(gw, gw_ref)
     had64 = h.double()[src] * h.double()[dst]
     close(y, had64 @ w.double().T, atol=2e-5 * np.sqrt(k))
