@@ -447,6 +447,13 @@ def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
                       "no-reuse HBM fraction -- that one is taken on the uniform graph (default workload's `roofline`)"))}
 
 
+def _x3_kernel_name(P, m):
+    """which split-bf16 kernel a launch with K-contiguous A and m rows runs (csrc/gemm_f32.hip::gemm_impl)"""
+    if P.ops.GEMM_STATIONARY_B["enabled"] and m >= 16384:
+        return "x3s::gemm_x3s_kernel (stationary pre-split weights; tile kernel x16::gemm_f32_kernel where the form does not apply)"
+    return "x16::gemm_f32_kernel"
+
+
 def measure_gemm_roofline(P, n_rows, k_in, hidden, device, sage=True):
     """the other hot kernel: the encoder's forward linear on the f32-input MFMA (SAGE: lin_l(agg) + lin_r(x)
     as one concat-K product with bias/relu/dropout in the epilogue), timed live like the aggregation"""
@@ -474,7 +481,7 @@ def measure_gemm_roofline(P, n_rows, k_in, hidden, device, sage=True):
                 "unit": "TFLOP/s", "frac": flop / times["f32"] / 157.3e12, "kernel_ms": times["f32"] * 1e3,
                 "note": "v_mfma_f32_32x32x2_f32 (an fmaf chain; gfx950 has no TF32), peak = 256 CUs x 256 FLOP/clk x 2.4 GHz"}
     t = times["bf16x3"]
-    x3_form = {"kernel": "x16::gemm_f32_kernel (%s)" % kname, "achieved": 6 * flop / t / 1e12, "peak": 2500.0,
+    x3_form = {"kernel": "%s (%s)" % (_x3_kernel_name(P, n_rows), kname), "achieved": 6 * flop / t / 1e12, "peak": 2500.0,
                "unit": "TFLOP/s", "frac": 6 * flop / t / 2.5e15, "kernel_ms": t * 1e3,
                "f32_equivalent_TFLOPs": flop / t / 1e12, "f32_equivalent_over_f32_mfma_peak": flop / t / 157.3e12,
                "note": "fp32 in / fp32 out; every operand element split in the loader into three bf16 terms, six "
@@ -546,7 +553,7 @@ def measure_step_launches(P, model, data, pos_b, neg_b, cfg, device):
     f32_form = {"math": "f32", "kernel": "g16::gemm_f32_kernel (%s)" % kname, "achieved": flop / times["f32"] / 1e12,
                 "peak": 157.3, "unit": "TFLOP/s", "frac": flop / times["f32"] / 157.3e12, "kernel_ms": times["f32"] * 1e3}
     tx = times["bf16x3"]
-    x3_form = {"math": "bf16x3", "kernel": "x16::gemm_f32_kernel (%s)" % kname, "achieved": 6 * flop / tx / 1e12,
+    x3_form = {"math": "bf16x3", "kernel": "%s (%s)" % (_x3_kernel_name(P, Tp), kname), "achieved": 6 * flop / tx / 1e12,
                "peak": 2500.0, "unit": "TFLOP/s", "frac": 6 * flop / tx / 2.5e15, "kernel_ms": tx * 1e3,
                "f32_equivalent_TFLOPs": flop / tx / 1e12,
                "note": "fp32 in / fp32 out; operands split into three bf16 terms, six bf16 MFMAs per block (executed flops = "
