@@ -290,7 +290,7 @@ __device__ __forceinline__ void vec_body(
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
     int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, int64_t row_base, int slab_feat,
-    const int32_t* __restrict__ row_index, int xcd_slabs) {
+    const int32_t* __restrict__ row_index, int xcd_slabs, const int32_t* __restrict__ out_map) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (xcd_slabs > 0) {
@@ -323,7 +323,17 @@ __device__ __forceinline__ void vec_body(
     }
     const int nslots = feat >> 2;
     const int64_t beg = rowptr[rg], end = rowptr[rg + 1];
-    if (skip_above > 0 && end - beg > skip_above) return;
+    if (skip_above > 0 && end - beg > skip_above) {
+        // a long row belongs to the split pass, which writes the ONE result row out_map names.  A row-indexed launch
+        // may name the CSR row again (CompactIncidence pads its row list to a multiple of 32 with row id 0): those
+        // result rows are defined as zero, never left unwritten -- the weight-gradient GEMM reduces over them
+        // (against a zero gradient row, and 0 x stale memory is not always 0)
+        if (row_index && out_map && (int64_t)out_map[rg] != r) {
+            const f32x4n zero = {0.f, 0.f, 0.f, 0.f};
+            for (int c = lane; c < nslots; c += 64) reinterpret_cast<f32x4n*>(out + r * ldo)[c] = zero;
+        }
+        return;
+    }
     EpiPre<VPL> pre;
     pre.valid = false;
     if (LPR == 64 || grp == 0) epi_prefetch<VPL, LPR>(pre, epi, r, nslots, sub, out, ldo);
@@ -344,10 +354,10 @@ __global__ __launch_bounds__(256) void csr_agg_vec_kernel(
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
     int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, int64_t row_base, int slab_feat,
-    const int32_t* __restrict__ row_index, int xcd_slabs) {
+    const int32_t* __restrict__ row_index, int xcd_slabs, const int32_t* __restrict__ out_map) {
     vec_body<VPL, LPR, WEIGHTED, CHX, NT>((int64_t)blockIdx.x, (int)blockIdx.y, rowptr, col, val, val_index, src_scale, src_map,
                                           x, ldx, out, ldo, n_rows, feat, mean, skip_above, epi, row_base, slab_feat,
-                                          row_index, xcd_slabs);
+                                          row_index, xcd_slabs, out_map);
 }
 
 // LDS-staged form for SMALL, DENSE graphs (ogbl-ddi: 4 267 nodes, ~500 neighbours per row).  The
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(256) void csr_agg_fused_kernel(
     const float* __restrict__ src_scale, const int32_t* __restrict__ src_map,
     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
     int64_t n_rows, int feat, int mean, int64_t skip_above, Epi epi, const int32_t* __restrict__ row_index,
-    SplitArgs sp, int chunk_slab_feat, int chunk_xcd_slabs, int64_t chunk_blocks) {
+    SplitArgs sp, int chunk_slab_feat, int chunk_xcd_slabs, int64_t chunk_blocks, const int32_t* __restrict__ out_map) {
     const int64_t bx = blockIdx.x;
     if (bx < chunk_blocks) {       // block-uniform
         chunk_body<CVPL, CLPR, WEIGHTED>(bx, 0, rowptr, col, val, val_index, src_scale, src_map, x, ldx, feat, sp,
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(256) void csr_agg_fused_kernel(
         return;
     }
     vec_body<VPL, LPR, WEIGHTED>(bx - chunk_blocks, 0, rowptr, col, val, val_index, src_scale, src_map, x, ldx, out, ldo,
-                                 n_rows, feat, mean, skip_above, epi, 0, 0, row_index, 0);
+                                 n_rows, feat, mean, skip_above, epi, 0, 0, row_index, 0, out_map);
 }
 
 // split pass 2: one BLOCK per long row.  Its 4 waves take the row's chunk sums round-robin (wave w:
@@ -693,7 +703,7 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
                 const dim3 g((unsigned)(cblocks + (int64_t)grid.x));
 #define PLNLP_FUSED(CV, CL, W, CSLAB, CXCD) \
     hipLaunchKernelGGL((csr_agg_fused_kernel<VPL, LPR, CV, CL, W>), g, dim3(256), 0, s, rowptr, col, val, val_index, \
-                       src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, row_index, *sp, CSLAB, CXCD, cblocks)
+                       src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, row_index, *sp, CSLAB, CXCD, cblocks, out_map)
                 if (!pin) { if (weighted) PLNLP_FUSED(VPL, LPR, true, 0, 0); else PLNLP_FUSED(VPL, LPR, false, 0, 0); }
                 else if (feat == 256) { if (weighted) PLNLP_FUSED(1, 8, true, 32, 8); else PLNLP_FUSED(1, 8, false, 32, 8); }
                 else if (feat == 512) { if (weighted) PLNLP_FUSED(1, 16, true, 64, 8); else PLNLP_FUSED(1, 16, false, 64, 8); }
@@ -716,11 +726,11 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
         if (weighted)
             hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, true, CHX, NT>), g, dim3(256), 0, s, rowptr, col, val,
                                val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4,
-                               slab_feat, row_index, xcd_slabs);
+                               slab_feat, row_index, xcd_slabs, out_map);
         else
             hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false, CHX, NT>), g, dim3(256), 0, s, rowptr, col, val,
                                val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4,
-                               slab_feat, row_index, xcd_slabs);
+                               slab_feat, row_index, xcd_slabs, out_map);
         if (int rc = launch_status()) return rc;
     }
     if (hub_xcd && slab_feat == 0 && (feat == 256 || feat == 512 || feat == 1024)) {

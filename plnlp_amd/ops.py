@@ -736,6 +736,56 @@ class CompactIncidence:
         self.val = None
         self._split = None
 
+    @classmethod
+    def build_fused(cls, src: torch.Tensor, dst: torch.Tensor, n_nodes: int, count_host: Optional[torch.Tensor] = None,
+                    compact_endpoints: bool = True):
+        """Incidence(src, dst, n).compact() -- and, compact_endpoints, the endpoint / other-endpoint lists as compact rows --
+        through plnlp_edge_lists_build: the same tensors bit for bit in seven hand-written launches instead of a library
+        radix sort, its fills, and eight index kernels (csrc/edge_lists.hip).  Returns (lists, src_c, dst_c)."""
+        lib = L.load()
+        L.require_device(src, dst)
+        src, dst = _edge_idx(src), _edge_idx(dst)
+        e, n, dev = src.numel(), int(n_nodes), src.device
+        inc = Incidence.__new__(Incidence)
+        inc.n_nodes = inc.n_rows = inc.n_cols = n
+        inc.item_edge = torch.empty(2 * e, dtype=torch.int32, device=dev)
+        inc.item_other = torch.empty(2 * e, dtype=torch.int32, device=dev)
+        inc.seg_ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        inc.rowptr, inc.col, inc.val, inc.val_index, inc._split = inc.seg_ptr, inc.item_other, None, inc.item_edge, None
+        self = cls.__new__(cls)
+        self._rows_cap = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self.node_map = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self._rowptr_cap = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        self._count_dev = torch.empty(1, dtype=torch.int64, device=dev)
+        both_c = other_c = None
+        if compact_endpoints:
+            both_c = torch.empty(2, e, dtype=torch.int64, device=dev)
+            other_c = torch.empty(2 * e, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.plnlp_edge_lists_workspace(e, n), dtype=torch.int32, device=dev)
+        L.check(lib.plnlp_edge_lists_build(src.data_ptr(), dst.data_ptr(), e, n, inc.item_edge.data_ptr(),
+                                           inc.item_other.data_ptr(), inc.seg_ptr.data_ptr(), self._rows_cap.data_ptr(),
+                                           self.node_map.data_ptr(), self._rowptr_cap.data_ptr(), self._count_dev.data_ptr(),
+                                           L.ptr(both_c[0]) if both_c is not None else None,
+                                           L.ptr(both_c[1]) if both_c is not None else None, L.ptr(other_c),
+                                           ws.data_ptr(), ws.numel(), L.stream_ptr()), "plnlp_edge_lists_build")
+        self._host = _pinned_count_buffer() if count_host is None else count_host
+        self._host.copy_(self._count_dev, non_blocking=True)
+        self._ready = None
+        if count_host is None:
+            self._ready = torch.cuda.Event()
+            self._ready.record()
+        self._count = None
+        self._base = inc
+        self.n_cols = self.n_nodes = n
+        self.col = self.item_other = inc.item_other
+        self.val_index = self.item_edge = inc.item_edge
+        self.val = None
+        self._split = None
+        self._ws = ws                      # (lives as long as the lists: the launches above read it)
+        if other_c is not None:
+            self._other_c = other_c
+        return self, (both_c[0] if both_c is not None else None), (both_c[1] if both_c is not None else None)
+
     @property
     def count(self) -> int:
         if self._count is None:
@@ -1837,6 +1887,8 @@ def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, co
 
 
 PROLOGUE_OVERLAP = {"enabled": True}
+# the batch's index structures through plnlp_edge_lists_build (False: the sort-based entry points; A/B and the equality test)
+EDGE_LISTS_FUSED = {"enabled": True}
 
 
 JOIN_STATS = {"waited": 0, "skipped": 0}        # EdgeBatch.join: stream waits enqueued / found unnecessary
@@ -1942,7 +1994,12 @@ class EdgeBatch:
             self.dst = torch.cat(dst_parts) if len(dst_parts) > 1 else dst_parts[0].contiguous()
         self.incidence = None
         self.src_c = self.dst_c = None
-        if build and self.src.numel() > 0:
+        if (build and compact and self._compact_endpoints and self.src.is_cuda and EDGE_LISTS_FUSED["enabled"]
+                and L.load().plnlp_edge_lists_supported(self.src.numel(), int(n_nodes))):
+            # lists, compaction and compact ids in one call (csrc/edge_lists.hip): no library sort on the step's side stream
+            self.incidence, self.src_c, self.dst_c = CompactIncidence.build_fused(self.src, self.dst, n_nodes, self._count_host)
+            self.incidence.row_split(split_threshold(n_nodes))
+        elif build and self.src.numel() > 0:
             self.incidence = prepare_edge_backward(self.src, self.dst, n_nodes, compact, self._count_host)
             if self._compact_endpoints:
                 inc = self.incidence
@@ -1969,7 +2026,7 @@ class EdgeBatch:
         if self.src_c is not None:
             out += [self.src_c, self.dst_c, inc._other_c]
         if inc is not None:
-            for name in ("item_edge", "item_other", "seg_ptr", "_rows_cap", "node_map", "_rowptr_cap", "_count_dev"):
+            for name in ("item_edge", "item_other", "seg_ptr", "_rows_cap", "node_map", "_rowptr_cap", "_count_dev", "_ws"):
                 t = getattr(inc, name, None)
                 if isinstance(t, torch.Tensor):
                     out.append(t)
