@@ -94,11 +94,13 @@ class GCNConv(torch.nn.Module):
             emb_weight, feats, cache = parts
             return ops.GCNInputConvFn.apply(emb_weight, self.lin.weight, self.bias, _require_graph(adj_t), act, feats,
                                             cache)
+        x = ops.materialize_concat(x)
         return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act, in_act, channel, out_rows)
 
     def forward_block(self, x_full, adj_block, row_lo: int, act: _Act = None):
         """this conv on one destination-row block of a row-sharded encoder (ops.GCNConvBlockFn)"""
         act = act if act is not None else _Act(False, 0.0, False)
+        x_full = ops.materialize_concat(x_full)
         return ops.GCNConvBlockFn.apply(x_full, self.lin.weight, self.bias, _require_graph(adj_block), act)
 
 

@@ -215,7 +215,11 @@ class BaseModel(object):
                 from .ops import concat_features
                 if not hasattr(self, "_feat_cache"):
                     self._feat_cache = {}
-                return concat_features(self.emb.weight, feat, self._feat_cache)
+                # (a first GCNConv takes the two parts and never reads the matrix: no per-step copy then)
+                from .layer import GCNConv
+                defer = (len(self.encoder.convs) > 0 and isinstance(self.encoder.convs[0], GCNConv)
+                         and ops.GCN_INPUT_FUSION["enabled"])
+                return concat_features(self.emb.weight, feat, self._feat_cache, defer=defer)
             feat = torch.cat([self.emb.weight, feat], dim=-1)
         return feat
 
