@@ -383,7 +383,8 @@ int plnlp_compact_endpoints(const int32_t* node_map, const int64_t* src, const i
  * seg_ptr AND the compaction, a scatter by arrival ticket, and a pass that puts every segment into increasing item order
  * (one thread for the short ones, a workgroup with an LDS bitmap over the item ids for the hubs).  Replaces what the
  * backward of `h[edge]` (plnlp/model.py:155-156: index_put_(accumulate=True), an unordered scatter-add in the reference)
- * needs to be a deterministic gather.  workspace: int32 [plnlp_edge_lists_workspace(n_edges, n_nodes)], uninitialised.
+ * needs to be a deterministic gather.  rows == NULL (then node_map, rowptr_c, count, src_c, dst_c, other_c NULL too): the lists
+ * alone, for a batch whose backward is not row-sparse.  workspace: int32 [plnlp_edge_lists_workspace(n_edges, n_nodes)], uninitialised.
  * plnlp_edge_lists_supported: 0 when a batch is too large for the bitmap (n_edges > 2^19): use the entry points above. */
 int64_t plnlp_edge_lists_workspace(int64_t n_edges, int64_t n_nodes);
 int plnlp_edge_lists_supported(int64_t n_edges, int64_t n_nodes);

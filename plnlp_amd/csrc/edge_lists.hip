@@ -99,7 +99,7 @@ __global__ __launch_bounds__(CB) void scan_parts_kernel(int32_t* __restrict__ pa
         if (tid == CB - 1) { carry[0] = e0 + v[0]; carry[1] = e1 + v[1]; }
         __syncthreads();
     }
-    if (tid == 0) *count = carry[1];
+    if (tid == 0 && count) *count = carry[1];
 }
 
 // seg_ptr, the compaction (the exact layout plnlp_compact_rows writes: touched rows first, then empty padding rows whose
@@ -131,21 +131,22 @@ __global__ __launch_bounds__(CB) void segments_kernel(const int32_t* __restrict_
     const int64_t beg = (int64_t)part[2 * blockIdx.x] + ioff + x - c;
     const int idx = part[2 * blockIdx.x + 1] + roff + lanes_below(m);
     seg_ptr[r] = beg;
+    if (f) {
+        if (c > WAVE_MAX) long_list[atomicAdd(&n_lists[0], 1)] = (int32_t)r;
+        else if (c > 2) med_list[atomicAdd(&n_lists[1], 1)] = (int32_t)r;
+    }
+    if (r == n_nodes - 1) seg_ptr[n_nodes] = n_items;
+    if (!rows) return;                      // the lists alone (no touched-node compaction asked for)
     node_map[r] = f ? idx : -1;
     if (f) {
         rows[idx] = (int32_t)r;
         rowptr_c[idx] = beg;
-        if (c > WAVE_MAX) long_list[atomicAdd(&n_lists[0], 1)] = (int32_t)r;
-        else if (c > 2) med_list[atomicAdd(&n_lists[1], 1)] = (int32_t)r;
     } else {
         const int64_t cn = *count, u = r - idx;
         rows[cn + u] = 0;
         rowptr_c[cn + 1 + u] = n_items;
     }
-    if (r == n_nodes - 1) {
-        seg_ptr[n_nodes] = n_items;
-        rowptr_c[idx + (f ? 1 : 0)] = n_items;
-    }
+    if (r == n_nodes - 1) rowptr_c[idx + (f ? 1 : 0)] = n_items;
 }
 
 // item i -> its node's segment at the arrival slot; the edges' endpoints as compact rows
@@ -297,7 +298,9 @@ extern "C" int plnlp_edge_lists_build(const int64_t* src, const int64_t* dst, in
     using namespace plnlp;
     using namespace plnlp::el;
     if (!plnlp_edge_lists_supported(n_edges, n_nodes)) return PLNLP_E_UNSUPPORTED;
-    if (!src || !dst || !item_edge || !item_other || !seg_ptr || !rows || !node_map || !rowptr_c || !count || !workspace)
+    if (!src || !dst || !item_edge || !item_other || !seg_ptr || !workspace) return PLNLP_E_NULL;
+    // rows == NULL: the node-sorted lists alone (a batch whose backward is not row-sparse); then no compaction output at all
+    if (rows ? (!node_map || !rowptr_c || !count) : (node_map || rowptr_c || count || src_c || dst_c || other_c))
         return PLNLP_E_NULL;
     if ((src_c == nullptr) != (dst_c == nullptr)) return PLNLP_E_NULL;
     if (workspace_ints < plnlp_edge_lists_workspace(n_edges, n_nodes)) return PLNLP_E_WORKSPACE;
@@ -324,12 +327,14 @@ extern "C" int plnlp_edge_lists_build(const int64_t* src, const int64_t* dst, in
                        tmp, src_c, dst_c);
     const int words = (int)((n_items + 31) / 32);
     const unsigned order_blocks = (unsigned)(LONG_BLOCKS + MED_BLOCKS + (n_nodes + 255) / 256);
-    static bool big_lds = false;       // (idempotent: a race sets it twice)
-    if (!big_lds) {
+    static unsigned long long big_lds = 0;       // per device (bit = device ordinal; idempotent: a race sets a bit twice)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PLNLP_E_UNSUPPORTED;
+    if (dev < 0 || dev >= 64 || !((big_lds >> dev) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 128 * 1024) != hipSuccess)
             return PLNLP_E_UNSUPPORTED;
-        big_lds = true;
+        if (dev >= 0 && dev < 64) big_lds |= 1ull << dev;
     }
     hipLaunchKernelGGL(order_kernel, dim3(order_blocks), dim3(256), (size_t)words * 4, s, src, dst, n_edges, n_nodes, cnt,
                        seg_ptr, node_map, long_list, med_list, n_lists, tmp, item_edge, item_other, other_c, words);

@@ -658,6 +658,18 @@ class Incidence:
         self.item_edge = torch.empty(2 * e, dtype=torch.int32, device=dev)
         self.item_other = torch.empty(2 * e, dtype=torch.int32, device=dev)
         self.seg_ptr = torch.empty(n_nodes + 1, dtype=torch.int64, device=dev)
+        self.rowptr, self.col = self.seg_ptr, self.item_other
+        self.val = None            # set to the per-edge gradient g; indexed through val_index
+        self.val_index = self.item_edge
+        self._split = None
+        if EDGE_LISTS_FUSED["enabled"] and src.is_cuda and lib.plnlp_edge_lists_supported(e, int(n_nodes)):
+            # the same lists without the library sort (csrc/edge_lists.hip; rows = NULL: no touched-node compaction)
+            self._ws = torch.empty(lib.plnlp_edge_lists_workspace(e, int(n_nodes)), dtype=torch.int32, device=dev)
+            L.check(lib.plnlp_edge_lists_build(src.data_ptr(), dst.data_ptr(), e, int(n_nodes), self.item_edge.data_ptr(),
+                                               self.item_other.data_ptr(), self.seg_ptr.data_ptr(), None, None, None, None,
+                                               None, None, None, self._ws.data_ptr(), self._ws.numel(), L.stream_ptr()),
+                    "plnlp_edge_lists_build")
+            return
         keys = torch.empty(2, max(2 * e, 1), dtype=torch.int64, device=dev)
         tbytes = lib.plnlp_incidence_temp_bytes(e)
         temp = torch.empty(max(tbytes, 8), dtype=torch.uint8, device=dev)
@@ -665,10 +677,6 @@ class Incidence:
                                           keys[1].data_ptr(), temp.data_ptr(), temp.numel(),
                                           self.item_edge.data_ptr(), self.item_other.data_ptr(),
                                           self.seg_ptr.data_ptr(), L.stream_ptr()), "plnlp_incidence_build")
-        self.rowptr, self.col = self.seg_ptr, self.item_other
-        self.val = None            # set to the per-edge gradient g; indexed through val_index
-        self.val_index = self.item_edge
-        self._split = None
 
     def row_split(self, threshold: int):
         """hot nodes of the batch (tables built on the device, upper-bound sizes)"""

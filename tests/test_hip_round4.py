@@ -681,6 +681,19 @@ def test_config5_one_ranks_true_share_of_the_full_problem(P):
 
 
 # ------------------------------------------------ the batch's index structures without a library sort ----
+def _sort_based_lists(ops, src, dst, n_nodes):
+    """the reference structures: plnlp_incidence_build (rocPRIM radix sort) + plnlp_compact_rows + compact columns"""
+    ops.EDGE_LISTS_FUSED["enabled"] = False
+    try:
+        base = ops.Incidence(src, dst, n_nodes)
+        assert not hasattr(base, "_ws")
+        inc = base.compact()
+        inc.prepare_compact_columns()
+    finally:
+        ops.EDGE_LISTS_FUSED["enabled"] = True
+    return inc
+
+
 @pytest.mark.parametrize("n_nodes,n_pos,k,hub", [(235_868, 65_536, 1, 3000), (4267, 65_536, 3, 0), (2_927_963, 65_536, 3, 0),
                                                  (50, 7, 1, 0), (1000, 1, 1, 0), (70_000, 40_000, 2, 20_000)])
 def test_edge_lists_build_equals_the_sort_based_structures(P, n_nodes, n_pos, k, hub):
@@ -698,9 +711,12 @@ def test_edge_lists_build_equals_the_sort_based_structures(P, n_nodes, n_pos, k,
         src[:hub] = 7 % n_nodes
         dst[hub // 2: hub // 2 + hub] = 11 % n_nodes
         src[-hub // 4:] = n_nodes - 1
-    inc = ops.Incidence(src, dst, n_nodes).compact()
-    inc.prepare_compact_columns()
+    inc = _sort_based_lists(ops, src, dst, n_nodes)
     want_src_c, want_dst_c = inc.node_map[src].long(), inc.node_map[dst].long()
+    plain = ops.Incidence(src, dst, n_nodes)            # rows = NULL: the lists alone (the non-compact backward, ddi)
+    assert hasattr(plain, "_ws")
+    assert torch.equal(plain.seg_ptr, inc._base.seg_ptr)
+    assert torch.equal(plain.item_edge, inc.item_edge) and torch.equal(plain.item_other, inc.item_other)
     for _ in range(2):
         got, src_c, dst_c = ops.CompactIncidence.build_fused(src, dst, n_nodes)
         assert got.count == inc.count
@@ -723,8 +739,7 @@ def test_edge_lists_build_at_the_segment_class_boundaries(P):
     nodes = nodes[torch.randperm(nodes.numel(), generator=gen)]
     e = nodes.numel() // 2
     src, dst = nodes[:e].cuda(), nodes[e:2 * e].cuda()
-    inc = ops.Incidence(src, dst, n_nodes).compact()
-    inc.prepare_compact_columns()
+    inc = _sort_based_lists(ops, src, dst, n_nodes)
     for _ in range(3):
         got, src_c, dst_c = ops.CompactIncidence.build_fused(src, dst, n_nodes)
         assert got.count == inc.count
