@@ -334,9 +334,12 @@ __device__ __forceinline__ void vec_body(
         }
         return;
     }
+    // (the narrow forms run without the epilogue-operand prefetch: its twelve registers cost them waves of occupancy, and
+    // their launches are bound by rows in flight -- see the dispatch of the weighted <1, 16> form)
+    constexpr bool PREFETCH = LPR > 16;
     EpiPre<VPL> pre;
     pre.valid = false;
-    if (LPR == 64 || grp == 0) epi_prefetch<VPL, LPR>(pre, epi, r, nslots, sub, out, ldo);
+    if constexpr (PREFETCH) { if (LPR == 64 || grp == 0) epi_prefetch<VPL, LPR>(pre, epi, r, nslots, sub, out, ldo); }
 
     float4 acc[VPL];
 #pragma unroll
@@ -344,7 +347,7 @@ __device__ __forceinline__ void vec_body(
     agg_range<VPL, LPR, WEIGHTED, CHX, NT>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
-    finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi, &pre);
+    finish_row<VPL, LPR>(acc, r, end - beg, mean, feat, nslots, sub, out, ldo, epi, PREFETCH ? &pre : nullptr);
 }
 
 template <int VPL, int LPR, bool WEIGHTED, int CHX = 0, bool NT = false>
@@ -884,6 +887,10 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
         if (nt) PLNLP_AGGX(2, 64, 0, true);
         if (few) PLNLP_AGGX(2, 64, 4, false);
     }
+    // the weighted narrow form with 4 instead of 8 neighbour groups in flight: 53 instead of 84 VGPRs, 7 instead of 5 waves per
+    // SIMD -- these launches (citation2's 52-wide embedding block, forward and transposed) are bound by rows in flight:
+    // 3.54 ms at 4 waves (97 VGPRs), 2.99 at 5, 2.91 at 6 (two spills), 2.80 here; same sums in the same order
+    if (weighted && nslots > 8 && nslots <= 16) PLNLP_AGGX(1, 16, 4, false);
     if (nslots <= 8) PLNLP_AGG(1, 8);
     if (nslots <= 16) PLNLP_AGG(1, 16);
     if (nslots <= 32) PLNLP_AGG(1, 32);

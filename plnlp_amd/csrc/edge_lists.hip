@@ -39,6 +39,17 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
+// slot of this lane's item in a list that grows by one atomic per wave (want: wave-wide predicate; all active lanes call)
+__device__ __forceinline__ int wave_append(int32_t* counter, bool want, int lane) {
+    const uint64_t m = __ballot(want);
+    if (m == 0) return 0;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + lanes_below(m);
+}
+
 __global__ __launch_bounds__(256) void zero_kernel(int32_t* __restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
 }
@@ -131,10 +142,13 @@ __global__ __launch_bounds__(CB) void segments_kernel(const int32_t* __restrict_
     const int64_t beg = (int64_t)part[2 * blockIdx.x] + ioff + x - c;
     const int idx = part[2 * blockIdx.x + 1] + roff + lanes_below(m);
     seg_ptr[r] = beg;
-    if (f) {
-        if (c > WAVE_MAX) long_list[atomicAdd(&n_lists[0], 1)] = (int32_t)r;
-        else if (c > 2) med_list[atomicAdd(&n_lists[1], 1)] = (int32_t)r;
-    }
+    // (one atomic per wave and list, written out: left to the compiler, the two appends were merged into a single per-lane
+    // atomic on a lane-dependent address once the statements around them moved -- ~25 000 serialised atomics, the kernel 3x
+    // longer and 0.14 ms on the collab step it overlaps, profiles/r04_same_box_ab.txt)
+    const int at_long = wave_append(&n_lists[0], c > WAVE_MAX, lane);
+    const int at_med = wave_append(&n_lists[1], c > 2 && c <= WAVE_MAX, lane);
+    if (c > WAVE_MAX) long_list[at_long] = (int32_t)r;
+    else if (c > 2) med_list[at_med] = (int32_t)r;
     if (r == n_nodes - 1) seg_ptr[n_nodes] = n_items;
     if (!rows) return;                      // the lists alone (no touched-node compaction asked for)
     node_map[r] = f ? idx : -1;
