@@ -1912,7 +1912,11 @@ def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, co
 
 PROLOGUE_OVERLAP = {"enabled": True}
 # the batch's index structures through plnlp_edge_lists_build (False: the sort-based entry points; A/B and the equality test)
-EDGE_LISTS_FUSED = {"enabled": True}
+# Measured on one box, interleaved (profiles/r04_same_box_ab.txt): with the sort-free lists the step has 10 launches fewer and is
+# SLOWER -- collab 1.57 vs 1.54 ms, ddi and citation2 within 1 % -- its denser side-stream kernels disturb the step's own launches
+# more than the library sort's many short ones do.  So the sort-based entry points stay the default and the sort-free builder is the
+# opt-in (PLNLP_EDGE_LISTS=1): same tensors bit for bit, tested both ways.
+EDGE_LISTS_FUSED = {"enabled": os.environ.get("PLNLP_EDGE_LISTS", "0") == "1"}
 
 
 JOIN_STATS = {"waited": 0, "skipped": 0}        # EdgeBatch.join: stream waits enqueued / found unnecessary

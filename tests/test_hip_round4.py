@@ -681,16 +681,24 @@ def test_config5_one_ranks_true_share_of_the_full_problem(P):
 
 
 # ------------------------------------------------ the batch's index structures without a library sort ----
+@contextlib.contextmanager
+def _edge_lists(ops, fused: bool):
+    """ops.EDGE_LISTS_FUSED for the duration (True: plnlp_edge_lists_build, False: the sort-based entry points)"""
+    was = ops.EDGE_LISTS_FUSED["enabled"]
+    ops.EDGE_LISTS_FUSED["enabled"] = fused
+    try:
+        yield
+    finally:
+        ops.EDGE_LISTS_FUSED["enabled"] = was
+
+
 def _sort_based_lists(ops, src, dst, n_nodes):
     """the reference structures: plnlp_incidence_build (rocPRIM radix sort) + plnlp_compact_rows + compact columns"""
-    ops.EDGE_LISTS_FUSED["enabled"] = False
-    try:
+    with _edge_lists(ops, False):
         base = ops.Incidence(src, dst, n_nodes)
         assert not hasattr(base, "_ws")
         inc = base.compact()
         inc.prepare_compact_columns()
-    finally:
-        ops.EDGE_LISTS_FUSED["enabled"] = True
     return inc
 
 
@@ -713,7 +721,8 @@ def test_edge_lists_build_equals_the_sort_based_structures(P, n_nodes, n_pos, k,
         src[-hub // 4:] = n_nodes - 1
     inc = _sort_based_lists(ops, src, dst, n_nodes)
     want_src_c, want_dst_c = inc.node_map[src].long(), inc.node_map[dst].long()
-    plain = ops.Incidence(src, dst, n_nodes)            # rows = NULL: the lists alone (the non-compact backward, ddi)
+    with _edge_lists(ops, True):
+        plain = ops.Incidence(src, dst, n_nodes)        # rows = NULL: the lists alone (the non-compact backward, ddi)
     assert hasattr(plain, "_ws")
     assert torch.equal(plain.seg_ptr, inc._base.seg_ptr)
     assert torch.equal(plain.item_edge, inc.item_edge) and torch.equal(plain.item_other, inc.item_other)
@@ -763,8 +772,7 @@ def test_training_steps_with_the_fused_edge_lists_are_bit_identical(P):
     w = (g["weight"][:3 * 8192] / 5.0).cuda()
     out = {}
     for fused in (True, False):
-        ops.EDGE_LISTS_FUSED["enabled"] = fused
-        try:
+        with _edge_lists(ops, fused):
             torch.manual_seed(9)
             P.manual_seed(9)
             m = P.BaseModel(lr=0.01, dropout=0.3, grad_clip_norm=1.0, gnn_num_layers=1, mlp_num_layers=2,
@@ -777,8 +785,6 @@ def test_training_steps_with_the_fused_edge_lists_are_bit_identical(P):
                                          w[i * 8192:(i + 1) * 8192])) for i in range(3)]
             torch.cuda.synchronize()
             out[fused] = (losses, [p.detach().clone() for p in m.para_list])
-        finally:
-            ops.EDGE_LISTS_FUSED["enabled"] = True
     assert out[True][0] == out[False][0]
     for a, b in zip(out[True][1], out[False][1]):
         assert torch.isfinite(a).all()
@@ -821,12 +827,13 @@ def test_full_size_steps_do_not_depend_on_stale_memory(P, name):
         torch.cuda.synchronize()
         return [float(l) for l in losses], [p.detach().clone() for p in m.para_list]
     l1, p1 = run()
-    with _stale_memory_is_nan():
-        l2, p2 = run()
-    assert all(np.isfinite(l1)) and l1 == l2, (l1, l2)
-    for a, b in zip(p1, p2):
-        assert torch.isfinite(b).all()
-        assert torch.equal(a, b)
+    for fused in (False, True):            # ... with the sort-based index preparation and with plnlp_edge_lists_build
+        with _stale_memory_is_nan(), _edge_lists(P.ops, fused):
+            l2, p2 = run()
+        assert all(np.isfinite(l1)) and l1 == l2, (fused, l1, l2)
+        for a, b in zip(p1, p2):
+            assert torch.isfinite(b).all()
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("feat", [64, 256])
