@@ -532,7 +532,9 @@ __device__ __forceinline__ void chunk_body(
     float4 acc[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    agg_range<VPL, LPR, WEIGHTED>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
+    // (the weighted narrow form with 4 groups in flight, as in the main pass: 83 -> ~55 VGPRs, 5 -> 7 waves per SIMD)
+    constexpr int CHC = (WEIGHTED && VPL == 1 && LPR == 16) ? 4 : 0;
+    agg_range<VPL, LPR, WEIGHTED, CHC>(acc, beg, end, col, val, val_index, src_scale, src_map, x, ldx, lane, sub, grp, nslots);
     fold_groups<VPL, LPR>(acc);
     if (LPR < 64 && grp != 0) return;
     float* w = sp.ws + slot * (int64_t)feat_full + c0;

@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256) void edge_scatter_bwd_kernel(const float* __re
 
 // ---------------- backward: deterministic segmented gather-reduce -----------------
 // one wave per node slot; items are (edge id, other endpoint).
-template <bool GVEC, bool VEC>
+// NK: float4 slots per lane and pass (a pass covers 256 NK columns).  Rows of up to 256 floats take NK = 1: the launch is a chain
+// of dependent round trips per segment (node -> segment -> items -> rows), bound by waves in flight, and the second slot's
+// registers (x, gg: 32 VGPRs that hold zeros at F = 200) cost the vector-gradient form three of its eight waves per SIMD.
+template <bool GVEC, bool VEC, int NK = 2>
 __global__ __launch_bounds__(256) void edge_segment_bwd_kernel(
     const float* __restrict__ h, int64_t ldh, const int64_t* __restrict__ seg_ptr,
     const int64_t* __restrict__ seg_node, int64_t n_seg, const int32_t* __restrict__ item_edge,
@@ -117,8 +120,10 @@ __global__ __launch_bounds__(256) void edge_segment_bwd_kernel(
     float* orow = gh + node * ldgh;
     if constexpr (VEC) {
         const int nslots = feat >> 2;
-        for (int s0 = 0; s0 < nslots; s0 += 128) {
-            float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        for (int s0 = 0; s0 < nslots; s0 += 64 * NK) {
+            float4 acc[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int64_t i0 = beg; i0 < end; i0 += 64) {
                 const int n = (int)((end - i0) < 64 ? (end - i0) : 64);
                 int ev = 0, ov = 0;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void edge_segment_bwd_kernel(
                     if constexpr (!GVEC) gv = g[ev];
                 }
                 for (int j = 0; j < n; j += 4) {
-                    float4 x[4][2], gg[4][2];
+                    float4 x[4][NK], gg[4][NK];
                     float w[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void edge_segment_bwd_kernel(
                                 const int ed = __builtin_amdgcn_readlane(ev, j + u);
                                 const float4* q = reinterpret_cast<const float4*>(g + (int64_t)ed * ldg);
 #pragma unroll
-                                for (int k = 0; k < 2; ++k) {
+                                for (int k = 0; k < NK; ++k) {
                                     const int sl = s0 + lane + 64 * k;
                                     gg[u][k] = sl < nslots ? q[sl] : make_float4(0.f, 0.f, 0.f, 0.f);
                                 }
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void edge_segment_bwd_kernel(
                                 w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), j + u));
                             }
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) {
+                            for (int k = 0; k < NK; ++k) {
                                 const int sl = s0 + lane + 64 * k;
                                 x[u][k] = sl < nslots ? p[sl] : make_float4(0.f, 0.f, 0.f, 0.f);
                             }
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void edge_segment_bwd_kernel(
                     for (int u = 0; u < 4; ++u) {
                         if (j + u < n) {
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) {
+                            for (int k = 0; k < NK; ++k) {
                                 if constexpr (GVEC) {
                                     acc[k].x = fmaf(gg[u][k].x, x[u][k].x, acc[k].x);
                                     acc[k].y = fmaf(gg[u][k].y, x[u][k].y, acc[k].y);
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void edge_segment_bwd_kernel(
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < NK; ++k) {
                 const int sl = s0 + lane + 64 * k;
                 if (sl < nslots) {
                     const float4 y = epi_apply4(epi, acc[k], node, (int64_t)sl * 4, feat, orow);
@@ -301,11 +306,12 @@ extern "C" int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh, const int
                      (!(e.flags & PLNLP_EPI_GATE) || true);
     dim3 grid((unsigned)((n_seg + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
-#define L(GV, V)                                                                                                  \
-    hipLaunchKernelGGL((edge_segment_bwd_kernel<GV, V>), grid, dim3(256), 0, s, h, ldh, seg_ptr, seg_node, n_seg, \
+#define L(GV, V, NK)                                                                                                  \
+    hipLaunchKernelGGL((edge_segment_bwd_kernel<GV, V, NK>), grid, dim3(256), 0, s, h, ldh, seg_ptr, seg_node, n_seg, \
                        item_edge, item_other, (int)feat, g, ldg, gh, ldgh, e)
-    if (g_is_vector) { if (vec) L(true, true); else L(true, false); }
-    else             { if (vec) L(false, true); else L(false, false); }
+    const bool narrow = feat <= 256;
+    if (g_is_vector) { if (vec) { if (narrow) L(true, true, 1); else L(true, true, 2); } else L(true, false, 2); }
+    else             { if (vec) { if (narrow) L(false, true, 1); else L(false, true, 2); } else L(false, false, 2); }
 #undef L
     return launch_status();
 }
