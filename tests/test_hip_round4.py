@@ -862,3 +862,56 @@ def test_row_indexed_aggregation_writes_every_result_row(P, feat):
         ops.csr_aggregate(graph, x, "mean", use_values=False, row_index=rows, out_map=dev(out_map), out=out)
         assert torch.equal(out[:t], full[dev(touched.long())])
         assert torch.equal(out[t:], torch.zeros_like(out[t:]))
+
+
+def test_deferred_concat_is_written_only_when_it_is_read(P):
+    """create_input_feat with a GCN encoder (ops.concat_features(defer=True)): a first GCNConv that takes the parts
+    (GCNInputConvFn) never reads the concatenated [emb | x] matrix, so the per-step copy of the embedding block is skipped --
+    the buffer's embedding columns stay STALE -- and the output, the embedding gradient and the weight gradients are the bits
+    of the materialised path; a consumer that does read the matrix (input fusion off; the row-sharded block conv) gets it
+    written first"""
+    from plnlp_amd import ops
+    torch.manual_seed(11)
+    n, e, f, h = 900, 50, 128, 64
+    g = to_graph(P, O.gcn_norm_csr(rand_csr(n, 9000, 17, weighted=False)))
+    enc = P.GCN(e + f, h, h, 2, 0.0).cuda()
+    feats = torch.randn(n, f).cuda()
+    emb = torch.randn(n, e).cuda().requires_grad_(True)
+    go = torch.randn(n, h).cuda()
+
+    def run(defer, cache):
+        for p_ in list(enc.parameters()) + [emb]:
+            p_.grad = None
+        x = ops.concat_features(emb, feats, cache, defer=defer)
+        out = enc(x, g)
+        out.backward(go)
+        return x, out.detach().clone(), emb.grad.clone(), [p_.grad.clone() for p_ in enc.parameters()]
+
+    c0, c1 = {}, {}
+    x0, out0, ge0, gw0 = run(False, c0)
+    with torch.no_grad():
+        ops.concat_features(emb, feats, c1)                            # the buffer exists and holds the CURRENT embedding ...
+        emb_before = emb.detach().clone()
+        emb.add_(0.5)                                                    # ... which then moves on
+    x0, out0, ge0, gw0 = run(False, c0)
+    x1, out1, ge1, gw1 = run(True, c1)
+    assert getattr(x1, "_plnlp_stale", False)
+    assert torch.equal(out0, out1) and torch.equal(ge0, ge1)
+    for a, b in zip(gw0, gw1):
+        assert torch.equal(a, b)
+    # the deferred buffer was NOT rewritten: its embedding block is still the old embedding
+    assert torch.equal(c1["buf"][:, :e], emb_before) and not torch.equal(emb_before, emb.detach())
+    assert torch.equal(c0["buf"][:, :e], emb.detach())
+    # a reader of the matrix itself gets it materialised
+    xm = ops.materialize_concat(x1)
+    assert not getattr(xm, "_plnlp_stale", False) and torch.equal(xm, torch.cat([emb.detach(), feats], -1))
+    old = ops.GCN_INPUT_FUSION["enabled"]
+    try:
+        ops.GCN_INPUT_FUSION["enabled"] = False
+        with torch.no_grad():
+            emb.add_(0.25)
+        out_plain = enc(ops.concat_features(emb, feats, c0), g)
+        out_lazy = enc(ops.concat_features(emb, feats, c1, defer=True), g)      # GCNConv.forward materialises it
+    finally:
+        ops.GCN_INPUT_FUSION["enabled"] = old
+    assert torch.equal(out_plain, out_lazy)
