@@ -247,8 +247,9 @@ typedef struct plnlp_gemm_operand {
 /* bytes of scratch plnlp_gemm_operand.b_terms needs for an [m, n] result over K-segments k0 (+ k1, 0 = one segment) */
 int64_t plnlp_gemm_b_terms_bytes(int64_t m, int64_t n, int64_t k0, int64_t k1);
 /* measurement knob of the stationary-weights form (process-global; A/B runs only, not for concurrent launches):
- * nb = 1 / 2 / 4 / 7 / 8 forces the column-tile width (x 32 columns), 0 = automatic; `reserved` is ignored */
-void plnlp_gemm_stationary_tuning(int nb, int reserved);
+ * nb = 1 / 2 / 4 / 7 / 8 forces the column-tile width (x 32 columns), 0 = automatic; min_rows > 0 changes the number of
+ * rows of A from which the form is used at all (default 16 384; the caller must lend b_terms for such launches too) */
+void plnlp_gemm_stationary_tuning(int nb, int min_rows);
 
 /* how the products are formed.  Both take and return fp32 and accumulate in fp32:
  *   F32    -- v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain over k (157 TFLOP/s peak)

@@ -993,7 +993,8 @@ struct SplitArgs {
     void* image;
 };
 int pick_nb(int64_t m, int64_t n);
-void set_tuning(int nb, int tail);
+void set_tuning(int nb, int min_rows);
+int min_rows();
 int64_t image_bytes(int64_t n, const int64_t* k, int nseg, int nb);
 int launch(const SplitArgs& sp, const Args& a, int nb, const Epi& e, hipStream_t s);
 }
@@ -1093,7 +1094,7 @@ extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_t
                      workspace_floats, stream);
 }
 
-extern "C" void plnlp_gemm_stationary_tuning(int nb, int tail) { plnlp::x3s::set_tuning(nb, tail); }
+extern "C" void plnlp_gemm_stationary_tuning(int nb, int min_rows) { plnlp::x3s::set_tuning(nb, min_rows); }
 
 extern "C" int64_t plnlp_gemm_b_terms_bytes(int64_t m, int64_t n, int64_t k0, int64_t k1) {
     if (m <= 0 || n <= 0 || k0 <= 0 || k1 < 0) return 0;
@@ -1194,7 +1195,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     // ---- the stationary-weights form (gemm_x3s.hip): A an activation matrix with K-contiguous rows, B the weights, the
     // caller lent a buffer for B's pre-split image.  Same bits as the kernels below (same split, same six products in the
     // same order per K-step of 16), so which one runs is a pure speed choice.
-    if (math == PLNLP_GEMM_MATH_BF16X3 && !a_trans && segs[0].b_terms && m >= 16384 && n % 4 == 0 && n >= 16) {
+    if (math == PLNLP_GEMM_MATH_BF16X3 && !a_trans && segs[0].b_terms && m >= x3s::min_rows() && n % 4 == 0 && n >= 16) {
         bool ok = g.vec_store && (!c2 || n_split % 4 == 0);
         int64_t ks[2] = {0, 0};
         for (int si = 0; si < n_seg && ok; ++si) {

@@ -377,7 +377,9 @@ static int slots_of(int nb) { return 256 * (nb >= 7 ? 2 : nb == 4 ? 3 : 4); }
 
 // measurement knob (plnlp_gemm_stationary_tuning): process-global, for A/B runs only
 static int g_force_nb = 0;
-void set_tuning(int nb, int) { g_force_nb = nb; }
+static int g_min_rows = 16384;      // rows of A from which the form applies (gemm_impl); the knob's second argument, > 0, changes it
+void set_tuning(int nb, int min_rows) { g_force_nb = nb; if (min_rows > 0) g_min_rows = min_rows; }
+int min_rows() { return g_min_rows; }
 
 // n-tile width (in 32-column blocks) of a launch.  A launch is rounds of slots_of(nb) workgroups; measured on MI355X
 // (profiles/r04_gemm_tile_width.jsonl) a round of 256-column tiles takes 1.2 .. 1.3 x a round of 128-column tiles and

@@ -378,13 +378,13 @@ GEMM_MATH = {"mode": os.environ.get("PLNLP_GEMM_MATH", "bf16x3")}
 # the stationary-weights form of the split-bf16 GEMM (csrc/gemm_x3s.hip): the weights are split into their bf16 terms
 # once per launch into a lent buffer instead of once per row panel.  Bit-identical to the 128 x 128 kernels; off =
 # those kernels everywhere (A/B runs, tests of both)
-GEMM_STATIONARY_B = {"enabled": os.environ.get("PLNLP_GEMM_STATIONARY_B", "1") != "0"}
+GEMM_STATIONARY_B = {"enabled": os.environ.get("PLNLP_GEMM_STATIONARY_B", "1") != "0", "min_rows": 16384}
 
 
 def _lend_b_terms(op, m: int, n: int, ks, device):
     """lend the launch a scratch buffer for B's pre-split image (plnlp_gemm_operand.b_terms) where the form applies:
     split-bf16 products, A not transposed, enough rows for the one-off split to pay.  Returns the tensor to keep alive."""
-    if not GEMM_STATIONARY_B["enabled"] or op.math != L.GEMM_MATH_BF16X3 or m < 16384:
+    if not GEMM_STATIONARY_B["enabled"] or op.math != L.GEMM_MATH_BF16X3 or m < GEMM_STATIONARY_B["min_rows"]:
         return None
     need = L.load().plnlp_gemm_b_terms_bytes(m, n, ks[0], ks[1] if len(ks) > 1 else 0)
     if need <= 0:

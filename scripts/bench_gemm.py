@@ -16,6 +16,8 @@ SHAPES = {
     "ddi_pred_fwd": (262144, 512, [512], False, True, True),
     "ddi_pred_wgrad": (512, 512, [262144], True, False, False),
     "ddi_enc_fwd": (4267, 512, [512, 512], False, True, True),
+    "ddi_enc_dgrad": (4267, 1024, [512], False, False, False),
+    "ddi_enc_fwd_l1": (4267, 512, [512, 512], False, True, "bias_relu"),
     "square4k": (4096, 4096, [4096], False, True, False),
     # citation2 (GCN h=200): first layer over [A emb | A x] (52 + 128 = 180 columns), padded to 192, second layer
     "cit_in_fwd_k180": (2927963, 200, [180], False, True, "bias_relu"),
@@ -37,6 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--min-rows", type=int, default=0, help="nb mode: rows of A from which the stationary-weights form applies (0: the default 16384)")
     ap.add_argument("--repeats", type=int, default=3, help="timed blocks per shape; the median is reported")
     ap.add_argument("--math", default="env", choices=["env", "f32", "bf16x3", "ab", "st", "nb"],
                     help="how the products are formed (ops.GEMM_MATH); ab = measure both, interleaved")
@@ -76,7 +79,7 @@ def main():
         if args.math == "st":         # split-bf16 products: the 128 x 128 kernels vs the stationary-weights kernel
             modes = [("bf16x3", False), ("bf16x3", True)]
         if args.math == "nb":         # the stationary-weights kernel by column-tile width, tail launch on / off, vs the tile kernel
-            modes = [("bf16x3", False)] + [("bf16x3", (nb, 0)) for nb in (0, 8, 7, 4)]
+            modes = [("bf16x3", False)] + [("bf16x3", (nb, args.min_rows)) for nb in (0, 8, 4, 2, 1)]
         ts = {md: [] for md in modes}
 
         def arm(md):
@@ -86,6 +89,8 @@ def main():
                 P.ops.GEMM_STATIONARY_B["enabled"] = bool(md[1])
                 nb, tail = md[1] if isinstance(md[1], tuple) else (0, 1)
                 _lib.load().plnlp_gemm_stationary_tuning(nb, tail)
+                if tail > 0:
+                    P.ops.GEMM_STATIONARY_B["min_rows"] = tail
         for _ in range(args.repeats):                     # interleaved: every arm sees the same clocks
             for md in modes:
                 arm(md)
