@@ -309,6 +309,8 @@ extern "C" int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh, const int
 #define L(GV, V, NK)                                                                                                  \
     hipLaunchKernelGGL((edge_segment_bwd_kernel<GV, V, NK>), grid, dim3(256), 0, s, h, ldh, seg_ptr, seg_node, n_seg, \
                        item_edge, item_other, (int)feat, g, ldg, gh, ldgh, e)
+    // (wider rows keep two slots and one pass: at F = 512 -- ddi, long segments, bandwidth-bound -- one slot and two passes
+    // measured the same 0.29 ms)
     const bool narrow = feat <= 256;
     if (g_is_vector) { if (vec) { if (narrow) L(true, true, 1); else L(true, true, 2); } else L(true, false, 2); }
     else             { if (vec) { if (narrow) L(false, true, 1); else L(false, true, 2); } else L(false, false, 2); }
