@@ -150,6 +150,10 @@ def _time_agg_forms(graph, x, out, reduce, use_values, src_scale, epilogue) -> i
     if AGG_AUTOTUNE["force"] is not None:
         return int(AGG_AUTOTUNE["force"])
     cands = list(AGG_AUTOTUNE["candidates"])
+    # nothing else should run beside the measurement (a trainer reaches this point with the next batch's index preparation
+    # queued on the side stream).  (On the collab graph the weighted full-graph launch timed here is a near-tie between the
+    # plain and the hub-by-source-range form -- fresh processes pick either; the step differs by ~5 us between them.)
+    torch.cuda.synchronize(x.device)
 
     def run(cand):
         csr_aggregate(graph, x, reduce, use_values, src_scale=src_scale, out=out, epilogue=epilogue, tune=cand)
