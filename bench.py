@@ -351,11 +351,15 @@ def run_rmat_as_rank(args, P, device):
                      "compulsory_bytes": compulsory, "distinct_source_rows": distinct,
                      "achieved": compulsory / t_agg / 1e9, "frac": compulsory / t_agg / 8e12,
                      "traffic": None, "traffic_from_profile": traffic,
-                     "frac_from_counter_bytes": (traffic["bytes"] / t_agg / 8e12) if traffic else None,
+                     "fabric_side_rate_over_8TBps": (traffic["bytes"] / t_agg / 8e12) if traffic else None,
                      "note": "frac = COMPULSORY bytes (indices + every distinct source row once + the result) / time / 8 TB/s "
                              "-- a lower bound on the kernel's HBM efficiency: rows re-read after falling out of the caches "
-                             "cross the pins again; frac_from_counter_bytes uses the PMC-measured bytes of the same launch "
-                             "(scripts/pmc_agg.sh, profiles/traffic.json) when a profile exists"},
+                             "cross the pins again.  fabric_side_rate_over_8TBps = the PMC-measured bytes of the same launch "
+                             "(scripts/pmc_agg.sh, profiles/traffic.json) / time / 8 TB/s: those counters sit on the FABRIC side "
+                             "and include Infinity-Cache hits (R-MAT's hub rows live there), so this is NOT an HBM fraction -- "
+                             "it can exceed the ~0.79 any kernel pulls from the HBM pins.  The kernel's HBM efficiency on this "
+                             "graph lies between frac (compulsory) and fabric-bound; the no-reuse HBM fraction is the default "
+                             "workload's `roofline` (uniform graph)"},
         "gemm_layer1_ms": t_gemm * 1e3, "gemm_TFLOPs_f32_equivalent": 2.0 * S * F * 2 * F / t_gemm / 1e12,
         "graph_build_s": t_graph, "output_checksum": float(y.double().sum().item()), "rccl_ranks": 1,
     }
@@ -936,6 +940,17 @@ def main():
             step_1rank[m1.dp_mode()] = dtf / Km * 1e3
             del m1
         torch.cuda.empty_cache()
+        last_pipe.clear()               # (the solo / one-rank models of this phase are gone: no capture_info about them)
+        if world > 1:
+            # every rank must reach the SAME choice: each measured on its own GPU with its own noise, and on a near-tie two
+            # ranks would build different models and issue mismatched collectives.  The inputs are made rank-identical
+            # (MAX over ranks: the slowest GPU paces a data-parallel step), and the choice is checked below
+            names = sorted(step_1rank)
+            v = torch.tensor([step_1gpu, table_adam] + [step_1rank[f] for f in names], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX, group=pg)
+            v = v.tolist()
+            step_1gpu, table_adam = v[0], v[1]
+            step_1rank = dict(zip(names, v[2:]))
         small = 4 * (cfg["gnn_layers"] * 3 * cfg["hidden"] * max(cfg["hidden"], cfg.get("emb", cfg["hidden"]) + feats)
                      + (cfg["mlp_layers"] * cfg["hidden"] * cfg["hidden"] if cfg["predictor"] == "MLP" else 0))
         prediction = _shard.cost_model(n_nodes=n, emb_width=cfg.get("emb", cfg["hidden"]), hidden=cfg["hidden"],
@@ -947,14 +962,25 @@ def main():
             exchange = prediction["choice"]
         else:
             exchange = "auto" if pg is None else "grads"
+    if pg is not None and world > 1:
+        agreed = [exchange]
+        torch.distributed.broadcast_object_list(agreed, src=0, group=pg)
+        if agreed[0] != exchange:
+            raise RuntimeError(f"rank {rank} chose exchange form {exchange!r}, rank 0 chose {agreed[0]!r}")
     model = make_model(pg, exchange)
     dp_mode = model.dp_mode()
+    if pg is not None and world > 1:
+        modes = [None] * world
+        torch.distributed.all_gather_object(modes, dp_mode, group=pg)
+        assert len(set(modes)) == 1, f"the ranks run different exchange forms: {modes}"
     if pg is not None and dp_mode != "shard":
         # all ranks agree on the aggregation kernel's form on the full graph NOW, collectively, so that the
         # rank-0-only measurements further down (roofline, control model) find the choice made: the op itself never
         # communicates (ops.tune_aggregation / ops._agg_tune)
         P.ops.tune_aggregation(g["adj_t"], [cfg["hidden"], cfg.get("emb", cfg["hidden"])], group=pg)
     dt, final_loss = timed_steps(model, dp_mode, n_ranks, B * world, rank)
+    host_ms_per_step = host_enqueue_s[-1] / K * 1e3          # (of THIS call: a process group's first calls are the cost model's)
+    host_busy_ms_per_step = host_busy_s[-1] / K * 1e3
     if pg is not None:
         # ---- what the step's time is made of, so that a SCALE run can be decomposed: compute = the same form's step
         # through a one-rank group (same per-rank work, collectives degenerate); collective_alone = this form's payloads
@@ -982,8 +1008,6 @@ def main():
                   "note": "compute = this exchange form's step through a ONE-rank process group on this GPU (measured in "
                           "this run); collective_alone = the form's table-sized payloads through the same RCCL collectives "
                           "with nothing else running; exposed = step - compute"}
-    host_ms_per_step = host_enqueue_s[0] / K * 1e3
-    host_busy_ms_per_step = host_busy_s[0] / K * 1e3
     capture_info = None
     if last_pipe:
         pp = last_pipe[0]

@@ -33,8 +33,10 @@ extern "C" {
  * 8 (round 3): plnlp_row_split.seg_* (explicit chunks), PLNLP_AGG_SLABS_XCD / _HUB_XCD / _FUSED_PASSES,
  *              plnlp_pairwise_loss_tail_f32, plnlp_sqnorm_multi_sum_f32, plnlp_edge_endpoints, plnlp_compact_endpoints.
  * 9 (round 4): plnlp_gemm_operand.b_terms / b_terms_bytes + plnlp_gemm_b_terms_bytes (the stationary-weights GEMM);
- *              plnlp_edge_lists_build / _workspace / _supported (the batch's index structures without a library sort). */
-#define PLNLP_ABI_VERSION 9
+ *              plnlp_edge_lists_build / _workspace / _supported (the batch's index structures without a library sort).
+ * 10 (round 5): plnlp_gemm_stationary_applies (the host asks the library's own rule before it lends b_terms and drops
+ *              split-K), plnlp_launch_counts / plnlp_launch_kind_name (which kernel families have been launched). */
+#define PLNLP_ABI_VERSION 10
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -246,6 +248,13 @@ typedef struct plnlp_gemm_operand {
 
 /* bytes of scratch plnlp_gemm_operand.b_terms needs for an [m, n] result over K-segments k0 (+ k1, 0 = one segment) */
 int64_t plnlp_gemm_b_terms_bytes(int64_t m, int64_t n, int64_t k0, int64_t k1);
+/* 1 when plnlp_gemm_f32 / _pair_f32 / _split_out_f32 / _concat_b_f32 called with these arguments (and a b_terms buffer of
+ * plnlp_gemm_b_terms_bytes) run the stationary-weights kernel, else 0: the library's OWN rule (csrc/gemm_f32.hip::
+ * stationary_form), so a host that lends the buffer and leaves K uncut only when this says 1 cannot disagree with the
+ * launch (the rule reads segs[].a / lda / k / math / the index pointers, c / ldc / c2 / ldc2 / n_split, m, n; it replaces the
+ * host-side mirror of it that `F.linear`'s callers kept, plnlp/layer.py:83,86).  No launch, no device access. */
+int plnlp_gemm_stationary_applies(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, const float* c,
+                                  int64_t ldc, int64_t m, int64_t n, const float* c2, int64_t ldc2, int64_t n_split);
 /* measurement knob of the stationary-weights form (process-global; A/B runs only, not for concurrent launches):
  * nb = 1 / 2 / 4 / 7 / 8 forces the column-tile width (x 32 columns), 0 = automatic; min_rows > 0 changes the number of
  * rows of A from which the form is used at all (default 16 384; the caller must lend b_terms for such launches too) */
@@ -532,6 +541,17 @@ int plnlp_dropout_f32(const float* x, float* y, int64_t n_rows, int64_t n_cols,
                       float p, uint64_t seed, void* stream);
 int plnlp_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy,
                         int64_t n_rows, int64_t n_cols, void* stream);
+
+/* ---- diagnostics: which kernel families this process has launched -------------- */
+/* Process-wide counters (relaxed atomics; a count, not a synchronisation), one per kernel FAMILY an entry point can choose
+ * between: the stationary-weights / tile split-bf16 GEMMs, the f32 tile GEMM, the aggregation's one-wave-per-row, slab,
+ * XCD-pinned, fused (main + hub chunks in one launch), chunk, finalize, LDS-staged and scalar forms.  The reference has no
+ * counterpart (its kernels are chosen inside torch / torch_sparse); the parity tests use it to assert that a multi-step run
+ * went through the forms the benchmark measures (tests/test_hip_round5.py).
+ * plnlp_launch_counts copies min(n, kinds) counters into out (nullable) and returns the number of kinds;
+ * plnlp_launch_kind_name(i) names kind i (NULL past the end). */
+int         plnlp_launch_counts(int64_t* out /* HOST */, int n);
+const char* plnlp_launch_kind_name(int kind);
 
 #ifdef __cplusplus
 }

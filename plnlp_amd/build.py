@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplnlp_hip.so")
 SOURCES = ["csr_aggregate.hip", "csr_aggregate_max.hip", "gemm_f32.hip", "edge_ops.hip", "train_ops.hip", "incidence.hip",
-           "edge_lists.hip", "host_perm.hip"]
+           "edge_lists.hip", "host_perm.hip", "launch_log.hip"]
 
 
 def needs_build() -> bool:
@@ -24,7 +24,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    import time
+    started = time.time()        # the library is stamped with the time its sources were READ: an edit made while the
+    objs = []                    # compilers run must count as newer than the result
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     # gemm_f32.hip is compiled three times: K-tile depth 32 (with the host entry points), depth 16 (kernels
@@ -52,6 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if failed:
         raise RuntimeError("hipcc failed")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    os.utime(LIB, (started, started))
     return LIB
 
 

@@ -287,6 +287,27 @@ __device__ __forceinline__ bool last_workgroup(unsigned int* counter, unsigned i
     return last;
 }
 
+// ---- which kernel families this process has launched (plnlp_launch_counts; csrc/launch_log.hip).  Diagnostics only: the
+// trained-regime tests assert with them that the forms the benchmark runs are the forms they exercised.
+enum LaunchKind : int {
+    LK_GEMM_X3S = 0,          // split-bf16, stationary pre-split weights (gemm_x3s.hip)
+    LK_GEMM_TILE_X3,          // split-bf16, 128 x 128 tile kernel
+    LK_GEMM_TILE_F32,         // f32-input MFMA, 128 x 128 tile kernel
+    LK_GEMM_SPLITK_REDUCE,    // the split-K slices' reduction
+    LK_AGG_VEC,               // aggregation: one wave per row, full width
+    LK_AGG_VEC_SLABS,         //   one wave per (row, 128- / 256-column slab)
+    LK_AGG_VEC_XCD,           //   one wave per (row, F/8-column slab pinned to an XCD)
+    LK_AGG_FUSED,             //   main pass + the long rows' chunk pass in ONE launch
+    LK_AGG_FUSED_HUB_XCD,     //   ... with the chunks in eight XCD-pinned column slabs
+    LK_AGG_CHUNK,             //   the long rows' chunk pass as its own launch
+    LK_AGG_CHUNK_XCD,         //   ... in XCD-pinned slabs
+    LK_AGG_FINALIZE,          //   the long rows' partial sums -> result rows
+    LK_AGG_LDS,               //   LDS-staged feature slabs (small dense graphs)
+    LK_AGG_SCALAR,            //   any width / alignment
+    LK_COUNT
+};
+void count_launch(int kind);
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

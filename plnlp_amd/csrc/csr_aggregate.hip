@@ -471,6 +471,7 @@ static int launch_lds(bool weighted, hipStream_t s, const int64_t* rowptr, const
         hipLaunchKernelGGL((csr_agg_lds_kernel<S, false>), grid, dim3(LDS_THREADS), lds_bytes, s, rowptr, col, val,
                            val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, n_src, feat, mean, rows_per_block, e);
     }
+    count_launch(LK_AGG_LDS);
     return launch_status();
 }
 
@@ -714,6 +715,8 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
                 else if (feat == 512) { if (weighted) PLNLP_FUSED(1, 16, true, 64, 8); else PLNLP_FUSED(1, 16, false, 64, 8); }
                 else { if (weighted) PLNLP_FUSED(1, 32, true, 128, 8); else PLNLP_FUSED(1, 32, false, 128, 8); }
 #undef PLNLP_FUSED
+                count_launch(pin ? LK_AGG_FUSED_HUB_XCD : LK_AGG_FUSED);
+                count_launch(LK_AGG_FINALIZE);
                 if (int rc = launch_status()) return rc;
                 hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)sp->n_long), dim3(256), 0, s, rowptr,
                                    feat, mean, *sp, out, ldo, e, out_map);
@@ -736,6 +739,7 @@ static int launch_vec(bool weighted, dim3 grid, hipStream_t s, const int64_t* ro
             hipLaunchKernelGGL((csr_agg_vec_kernel<VPL, LPR, false, CHX, NT>), g, dim3(256), 0, s, rowptr, col, val,
                                val_index, src_scale, src_map, x, ldx, out, ldo, n_rows, feat, mean, skip, e, b0 * 4,
                                slab_feat, row_index, xcd_slabs, out_map);
+        count_launch(xcd_slabs > 0 ? LK_AGG_VEC_XCD : (slab_feat > 0 ? LK_AGG_VEC_SLABS : LK_AGG_VEC));
         if (int rc = launch_status()) return rc;
     }
     if (hub_xcd && slab_feat == 0 && (feat == 256 || feat == 512 || feat == 1024)) {
@@ -775,8 +779,10 @@ static int launch_split(bool weighted, hipStream_t s, const int64_t* rowptr, con
         else
             hipLaunchKernelGGL((csr_agg_chunk_kernel<VPL, LPR, false>), cgrid, dim3(256), 0, s, rowptr, col, val,
                                val_index, src_scale, src_map, x, ldx, feat, *sp, slab_feat, xcd_slabs, b0 * 4);
+        count_launch(xcd_slabs > 0 ? LK_AGG_CHUNK_XCD : LK_AGG_CHUNK);
         if (int rc = launch_status()) return rc;
     }
+    count_launch(LK_AGG_FINALIZE);
     hipLaunchKernelGGL(csr_agg_finalize_kernel, dim3((unsigned)sp->n_long), dim3(256), 0, s, rowptr,
                        feat, mean, *sp, out, ldo, e, out_map);
     return launch_status();
@@ -837,6 +843,7 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
             else
                 hipLaunchKernelGGL((csr_agg_scalar_kernel<false>), g, dim3(256), 0, s, rowptr, col, val, val_index,
                                    src_scale, src_map, x, ldx, out, ldo, n_rows, (int)feat, mean, e, b0 * 4, row_index);
+            count_launch(LK_AGG_SCALAR);
             if (int rc = launch_status()) return rc;
         }
         return 0;

@@ -26,7 +26,7 @@
 // result): grid.z slices write raw partial tiles to a workspace and a second
 // kernel adds them in slice order -- deterministic, no atomics.
 #include "common.hip.h"
-#include "gemm_ablation.hip.h"     // ABL_* timing switches: inert unless built with -DPLNLP_ABLATION
+#include "gemm_x3s.hip.h"     // the stationary-weights form (its own translation unit, gemm_x3s.hip)
 #include <utility>
 
 namespace plnlp {
@@ -315,27 +315,17 @@ struct X3Split {
             if constexpr (ROWC) { v.x *= (*y)[0][Q]; v.y *= (*y)[1 % NP][Q]; }
             else { v.x *= (*y)[(Q >> 1) % NP][2 * (Q & 1)]; v.y *= (*y)[(Q >> 1) % NP][2 * (Q & 1) + 1]; }
         }
-#ifdef ABL_X3_NOSPLIT      // ablation: timing without the split arithmetic (wrong numbers)
-        hi[Q] = __float_as_uint(v.x); mid[Q] = __float_as_uint(v.y); lo[Q] = hi[Q]; r[Q] = v;
-        return;
-#endif
         hi[Q] = pk(v);
         r[Q].x = v.x - __uint_as_float(hi[Q] << 16);
         r[Q].y = v.y - __uint_as_float(hi[Q] & 0xffff0000u);
     }
     template <int Q>
     __device__ __forceinline__ void second() {
-#ifdef ABL_X3_NOSPLIT
-        return;
-#endif
         mid[Q] = pk(r[Q]);
         r[Q].x -= __uint_as_float(mid[Q] << 16);
         r[Q].y -= __uint_as_float(mid[Q] & 0xffff0000u);
     }
     __device__ __forceinline__ void third() {
-#ifdef ABL_X3_NOSPLIT
-        return;
-#endif
         lo[0] = pk(r[0]); lo[1] = pk(r[1]); lo[2] = pk(r[2]); lo[3] = pk(r[3]);
     }
     template <bool ROWC>
@@ -343,9 +333,6 @@ struct X3Split {
         u32x4* u = reinterpret_cast<u32x4*>(tile) + (ROWC ? (t >> 5) * 32 + (t & 31) : (t & 1) * X3_KG + (t >> 1));
         const u32x4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]},
                     l4 = {lo[0], lo[1], lo[2], lo[3]};
-#ifdef ABL_X3_NOSTORE      // ablation: no LDS writes (an impossible condition keeps three of the terms live)
-        if (hi[0] != 0x12345678u || lo[3] != 0x9abcdef0u || mid[1] != 0x0fedcba9u) return;
-#endif
         u[0] = h4; u[X3_TERM] = m4; u[2 * X3_TERM] = l4;
     }
 };
@@ -501,11 +488,6 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, con
                                            const f32x4 (&rb)[NP], int t) {
     float* at = lds + buf * TILE_FLOATS;
     float* bt = lds + (2 + buf) * TILE_FLOATS;
-#ifdef ABL_NOSTAGE
-    // ablation: consume the loaded registers without the LDS writes (an impossible condition keeps them live)
-    if (ra[0].x == 123.456f && rb[NP - 1].w == 654.321f) { at[t] = ra[1].y + ra[NP - 1].w; bt[t] = rb[0].x + rb[1].y; }
-    return;
-#endif
     if constexpr (X3) {
         if constexpr (A_T) store_rc_x3(at, ra, t); else store_kc_x3(at, ra, t);
         if constexpr (B_T) store_kc_x3(bt, rb, t); else store_rc_x3(bt, rb, t);
@@ -522,7 +504,6 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, int buf, con
 #ifndef PLNLP_GEMM_PF
 #define PLNLP_GEMM_PF 2
 #endif
-#ifndef ABL_CLAMPED_LOOP
 template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
                                        int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
@@ -554,12 +535,8 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
                 const int tile = base + d;
                 const int buf = (tile - tb) & 1;
                 stage_tile<A_T, B_T>(lds, buf, ra[d], rb[d], t);
-#ifndef ABL_NOBARRIER
                 __syncthreads();
-#endif
-#ifndef ABL_NOGLOAD
                 load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t, arow0, arow1);
-#endif
                 mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
             }
             base += PF;
@@ -577,83 +554,21 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], f
             if (tile < te) {                                   // block-uniform
                 const int buf = (tile - tb) & 1;
                 stage_tile<A_T, B_T>(lds, buf, ra[d], rb[d], t);
-#ifndef ABL_NOBARRIER
                 __syncthreads();
-#endif
-#ifndef ABL_NOGLOAD
                 if (tile + PF < te) load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tile + PF, ra[d], rb[d], m0, n0, t, arow0, arow1);
-#endif
                 mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
             }
         }
     }
 }
 
-#else
-// ablation (measured on MI355X, profiles/r02_gemm_ab_loop.txt): one loop without a drain phase, every
-// look-ahead load unconditional with its tile index clamped to the slice's last tile.  1-3 % SLOWER than the
-// steady + drain form above on the 8..16-tile shapes of this path (the two `if (live)` regions cost more
-// than the two conditional loads of the drain), so it is not the default.
-template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX = false>
-__device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
-                                       int64_t m0, int n0, int tb, int te, int t, int wm, int wn, int l31,
-                                       int h) {
-    constexpr int PF = PLNLP_GEMM_PF;
-    f32x4 ra[PF][NP], rb[PF][NP];
-    int arow0[NP], arow1[NP];
-    if constexpr (AIDX) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            int64_t row = m0 + kc_row(t, p);
-            row = row < g.m ? row : g.m - 1;
-            arow0[p] = g.seg[0].a_index ? g.seg[0].a_index[row] : (int)row;
-            arow1[p] = (g.nseg > 1 && g.seg[1].a_index) ? g.seg[1].a_index[row] : (int)row;
-        }
-    }
-    // Every global load of the loop is UNCONDITIONAL: a load under a branch (`if (tile + PF < te)`) makes
-    // the compiler assume the younger register sets may never have been issued and wait for vmcnt(0)
-    // before staging the oldest one -- i.e. for the younger sets too, which halves the look-ahead.  The
-    // tile index of a look-ahead load is CLAMPED to the slice's last tile instead: past the end the same
-    // tile is simply fetched again (an L2 hit) and never staged.  Short reductions (K = 180 .. 512: 6 to
-    // 16 tiles, the forward and data-gradient shapes of this path) used to spend a third to a half of their
-    // tiles in a drain loop full of vmcnt(0) waits.
-    const int last = te - 1;          // te >= 1 (a launch has at least one K-tile); an empty slice reloads it, stages nothing
-#pragma unroll
-    for (int d = 0; d < PF; ++d) {
-        const int tl = tb + d < last ? tb + d : last;
-        load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tl, ra[d], rb[d], m0, n0, t, arow0, arow1);
-    }
-    for (int base = tb; base < te; base += PF) {
-#pragma unroll
-        for (int d = 0; d < PF; ++d) {
-            const int tile = base + d;
-            const bool live = tile < te;                       // block-uniform; guards no global load
-            const int buf = (tile - tb) & 1;
-            if (live) {
-                stage_tile<A_T, B_T>(lds, buf, ra[d], rb[d], t);
-#ifndef ABL_NOBARRIER
-                __syncthreads();
-#endif
-            }
-#ifndef ABL_NOGLOAD
-            {
-                const int tn = tile + PF < last ? tile + PF : last;
-                load_tile<A_T, B_T, MODE, BIDX, AIDX>(g, tn, ra[d], rb[d], m0, n0, t, arow0, arow1);
-            }
-#endif
-            if (live) mma_tile<A_T, B_T>(acc, lds + buf * TILE_FLOATS, lds + (2 + buf) * TILE_FLOATS, wm, wn, l31, h);
-        }
-    }
-}
-
-#endif
 // K loop of the split-bf16 form.  A K-tile is only 24 MFMAs (768 cycles) next to ~110 VALU instructions of
 // operand splitting and addressing, so the two must overlap INSIDE a wave: the registers of tile i+1 (loaded one
 // iteration earlier) are split and written to the other LDS buffer while the MFMAs of tile i run -- one basic
 // block per tile (every look-ahead load unconditional, its tile index clamped to the slice's last tile; the junk
 // it stages past the end is never read), the instruction mix pinned with sched_group_barrier: MFMA, then a few
 // VALU, ... (a bf16 32x32x16 MFMA leaves ~7 issue slots before the next one can start).  One barrier per tile.
-#if PLNLP_GEMM_X3 && !defined(ABL_X3_PLAIN_LOOP)
+#if PLNLP_GEMM_X3
 #define PLNLP_X3_PIPELINED 1
 template <bool A_T, bool B_T, int MODE, bool BIDX, bool AIDX, bool PAIR, int D>
 __device__ __forceinline__ void x3_step(const GemmArgs& g, f32x16 (&acc)[2][2], float* __restrict__ lds,
@@ -672,9 +587,7 @@ __device__ __forceinline__ void x3_step(const GemmArgs& g, f32x16 (&acc)[2][2], 
         for (int j = 0; j < 2; ++j) b[j][s] = frag_x3<!B_T>(bt, s, wn * 64 + j * 32 + l31, h);
     }
     // the set staged one step ago is free: fetch the tile two ahead into it
-#ifndef ABL_X3_NOGLOAD     // ablation: the staging registers keep the first tiles (no loads, no address arithmetic)
     load_tile<A_T, B_T, MODE, BIDX, AIDX, PAIR>(g, next_tile, ra[D], rb[D], m0, n0, t, arow0, arow1, &r2[D]);
-#endif
     // the other set holds the next tile: it is split into the other LDS buffer BETWEEN the MFMAs -- region q of
     // the block = MFMA q + one 5-instruction stage of the split of one element pair (nothing crosses a
     // sched_barrier, so the wave always has VALU work to issue while the matrix pipe runs the MFMA)
@@ -890,9 +803,6 @@ void gemm_f32_kernel(GemmArgs g, Epi epi) {
             if (row >= g.m) continue;
             float4 v = *reinterpret_cast<const float4*>(lds + (SPLIT_C ? rl - 64 * half : rl) * CS + c4);
             float* orow = second_col ? g.c2 + row * g.ldc2 - g.n_split : cbase + row * ldc;   // index with the global column
-#ifdef ABL_NOSTORE
-            if (v.x != 123.456f) continue;
-#endif
             if (colvec) {
                 if (pre) v = epi_apply4_pre(epi, v, row, col, g.n, bias4, g4[ue], p4[ue]);
                 else if (!raw) v = epi_apply4(epi, v, row, col, g.n, orow);
@@ -974,30 +884,6 @@ int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_tra
 namespace x16 {      // the split-bf16 translation unit
 int launch_kernels(const GemmArgs& ga, int md, dim3 grid, int a_trans, int b_trans, hipStream_t s, const Epi& e);
 }
-namespace x3s {      // gemm_x3s.hip: the split-bf16 form with a stationary, pre-split weight operand
-struct Args {
-    const float* a[2]; int64_t lda[2]; int k[2]; const int32_t* a_index[2];
-    int nseg;
-    int ks0, ks_total;
-    const void* image;
-    float* c; int64_t ldc; float* c2; int64_t ldc2; int n_split;
-    int64_t m; int n;
-    int64_t gm; int gn;
-    int64_t row_lo;
-};
-struct SplitArgs {
-    const float* b[2]; int64_t ldb[2]; int k[2];
-    const float* b2; int64_t ldb2; int nb_split;
-    int b_trans;
-    int nseg, ks0, ks_total, n, wn, gn;
-    void* image;
-};
-int pick_nb(int64_t m, int64_t n);
-void set_tuning(int nb, int min_rows);
-int min_rows();
-int64_t image_bytes(int64_t n, const int64_t* k, int nseg, int nb);
-int launch(const SplitArgs& sp, const Args& a, int nb, const Epi& e, hipStream_t s);
-}
 
 // sum split-K slices in slice order, apply the epilogue.  16 bytes per thread, 8 slices in flight.
 // c2 != nullptr: result columns >= n_split go to c2[:, col - n_split] (the pair form; no epilogue there)
@@ -1054,6 +940,42 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 }  // namespace plnlp
+
+// Does this launch run the stationary-weights form (given a large enough b_terms buffer)?  Returns the column-tile width
+// (x 32 columns) it would use, 0 when the tile kernels take it; ks[] = the K of each segment.  Everything the decision
+// depends on is an argument of the launch -- the Python host asks the same question through plnlp_gemm_stationary_applies
+// BEFORE it decides about split-K and lends the buffer, so the two sides cannot disagree.
+static int stationary_form(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, const float* c, int64_t ldc,
+                           int64_t m, int64_t n, const float* c2, int64_t ldc2, int64_t n_split, int64_t (&ks)[2]) {
+    using namespace plnlp;
+    ks[0] = ks[1] = 0;
+    if (!segs || n_seg < 1 || n_seg > 2 || segs[0].math != PLNLP_GEMM_MATH_BF16X3 || a_trans) return 0;
+    if (m < x3s::min_rows() || n % 4 != 0 || n < 16) return 0;
+    const bool vec_store = (ldc % 4 == 0) && ((uintptr_t)c % 16 == 0) &&
+                           (!c2 || ((n_split % 4 == 0) && (ldc2 % 4 == 0) && ((uintptr_t)c2 % 16 == 0)));
+    if (!vec_store) return 0;
+    bool ragged_k = false;
+    for (int si = 0; si < n_seg; ++si) {
+        const plnlp_gemm_operand& o = segs[si];
+        const bool a_vec = ((uintptr_t)o.a % 16 == 0) && (o.lda % 4 == 0);
+        if (!a_vec || o.k <= 0 || o.k % 4 != 0 || o.b_index || o.a_index2 || o.b_index2 || (o.a_index && !b_trans)) return 0;
+        ks[si] = o.k;
+        ragged_k |= (o.k % 16) != 0;
+    }
+    // h = 200 (citation2): measured both ways on MI355X (profiles/r04_gemm_tile_width.jsonl) -- K a multiple of 16
+    // (the first layer's padded 192): the tile kernel 1.85 ms against 2.17 (its aligned loaders are at their best,
+    // the 224-column tile wastes 11 % of its MFMAs); ragged K (200): the tile kernel's select-zeroed loaders 2.22 ms
+    // against 1.94 here, where the padding lives in the weight image
+    if (n > 192 && n <= 224 && !ragged_k) return 0;
+    return x3s::pick_nb(m, n);
+}
+
+extern "C" int plnlp_gemm_stationary_applies(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans,
+                                             const float* c, int64_t ldc, int64_t m, int64_t n, const float* c2,
+                                             int64_t ldc2, int64_t n_split) {
+    int64_t ks[2];
+    return stationary_form(segs, n_seg, a_trans, b_trans, c, ldc, m, n, c2, ldc2, n_split, ks) > 0 ? 1 : 0;
+}
 
 static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, float* c, int64_t ldc,
                      int64_t m, int64_t n, float* c2, int64_t ldc2, int64_t n_split, const plnlp_epilogue* epi,
@@ -1194,43 +1116,28 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     int mode = !aligned ? 0 : (ragged ? 2 : 1);
     // ---- the stationary-weights form (gemm_x3s.hip): A an activation matrix with K-contiguous rows, B the weights, the
     // caller lent a buffer for B's pre-split image.  Same bits as the kernels below (same split, same six products in the
-    // same order per K-step of 16), so which one runs is a pure speed choice.
-    if (math == PLNLP_GEMM_MATH_BF16X3 && !a_trans && segs[0].b_terms && m >= x3s::min_rows() && n % 4 == 0 && n >= 16) {
-        bool ok = g.vec_store && (!c2 || n_split % 4 == 0);
+    // same order per K-step of 16), so which one runs is a pure speed choice (stationary_form: ONE rule, also behind
+    // plnlp_gemm_stationary_applies).
+    if (segs[0].b_terms && ((uintptr_t)segs[0].b_terms % 16 == 0)) {
         int64_t ks[2] = {0, 0};
-        for (int si = 0; si < n_seg && ok; ++si) {
-            const Seg& d = g.seg[si];
-            ok = d.a_vec && d.k % 4 == 0 && !d.b_index && !d.a_index2 && !d.b_index2 && (d.a_index == nullptr || b_trans);
-            ks[si] = d.k;
-        }
-        // h = 200 (citation2): measured both ways on MI355X (profiles/r04_gemm_tile_width.jsonl) -- K a multiple of 16
-        // (the first layer's padded 192): the tile kernel 1.85 ms against 2.17 (its aligned loaders are at their best,
-        // the 224-column tile wastes 11 % of its MFMAs); ragged K (200): the tile kernel's select-zeroed loaders 2.22 ms
-        // against 1.94 here, where the padding lives in the weight image
-        if (ok && n > 192 && n <= 224) {
-            bool ragged_k = false;
-            for (int si = 0; si < n_seg; ++si) ragged_k |= (ks[si] % 16) != 0;
-            ok = ragged_k;
-        }
-        if (ok) {
-            const int nb = x3s::pick_nb(m, n);
-            if (segs[0].b_terms_bytes >= x3s::image_bytes(n, ks, n_seg, nb) && ((uintptr_t)segs[0].b_terms % 16 == 0)) {
-                x3s::SplitArgs sp{};
-                x3s::Args xa{};
-                for (int si = 0; si < n_seg; ++si) {
-                    const Seg& d = g.seg[si];
-                    sp.b[si] = d.b; sp.ldb[si] = d.ldb; sp.k[si] = d.k;
-                    xa.a[si] = d.a; xa.lda[si] = d.lda; xa.k[si] = d.k; xa.a_index[si] = d.a_index;
-                }
-                sp.b2 = b2; sp.ldb2 = ldb2; sp.nb_split = b2 ? (int)nb_split : (int)n;
-                sp.b_trans = b_trans; sp.nseg = n_seg; sp.n = (int)n; sp.image = segs[0].b_terms;
-                sp.ks0 = (int)((ks[0] + 15) / 16);
-                sp.ks_total = sp.ks0 + (n_seg > 1 ? (int)((ks[1] + 15) / 16) : 0);
-                xa.nseg = n_seg; xa.ks0 = sp.ks0; xa.ks_total = sp.ks_total; xa.image = segs[0].b_terms;
-                xa.c = c; xa.ldc = ldc; xa.c2 = c2; xa.ldc2 = ldc2; xa.n_split = c2 ? (int)n_split : (int)n;
-                xa.m = m; xa.n = (int)n;
-                return x3s::launch(sp, xa, nb, e, s);
+        const int nb = stationary_form(segs, n_seg, a_trans, b_trans, c, ldc, m, n, c2, ldc2, n_split, ks);
+        if (nb > 0 && segs[0].b_terms_bytes >= x3s::image_bytes(n, ks, n_seg, nb)) {
+            x3s::SplitArgs sp{};
+            x3s::Args xa{};
+            for (int si = 0; si < n_seg; ++si) {
+                const Seg& d = g.seg[si];
+                sp.b[si] = d.b; sp.ldb[si] = d.ldb; sp.k[si] = d.k;
+                xa.a[si] = d.a; xa.lda[si] = d.lda; xa.k[si] = d.k; xa.a_index[si] = d.a_index;
             }
+            sp.b2 = b2; sp.ldb2 = ldb2; sp.nb_split = b2 ? (int)nb_split : (int)n;
+            sp.b_trans = b_trans; sp.nseg = n_seg; sp.n = (int)n; sp.image = segs[0].b_terms;
+            sp.ks0 = (int)((ks[0] + 15) / 16);
+            sp.ks_total = sp.ks0 + (n_seg > 1 ? (int)((ks[1] + 15) / 16) : 0);
+            xa.nseg = n_seg; xa.ks0 = sp.ks0; xa.ks_total = sp.ks_total; xa.image = segs[0].b_terms;
+            xa.c = c; xa.ldc = ldc; xa.c2 = c2; xa.ldc2 = ldc2; xa.n_split = c2 ? (int)n_split : (int)n;
+            xa.m = m; xa.n = (int)n;
+            count_launch(LK_GEMM_X3S);
+            return x3s::launch(sp, xa, nb, e, s);
         }
     }
     const int reduce_slices = split_k;
@@ -1244,8 +1151,10 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         dim3 grid((unsigned)(gm * gn), 1, (unsigned)slices);
         return launch_grid(ga, md, grid);
     };
+    count_launch(math == PLNLP_GEMM_MATH_BF16X3 ? LK_GEMM_TILE_X3 : LK_GEMM_TILE_F32);
     if (int rc = launch(g, mode, split_k)) return rc;
     if (split_k > 1) {
+        count_launch(LK_GEMM_SPLITK_REDUCE);
         const int64_t total = m * n;
         int64_t blocks = (total / 4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;

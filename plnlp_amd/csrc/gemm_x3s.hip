@@ -19,7 +19,7 @@
 //   * one barrier per K-step of 6 NB MFMAs per wave; the step's loads (A registers for step + 2, the B image of
 //     step + 1) are issued at its top and waited for at its bottom.
 // Block = 4 waves stacked along M (128 rows); two workgroups per CU (acc 16 NB registers per lane).
-#include "common.hip.h"
+#include "gemm_x3s.hip.h"
 #include <utility>
 
 namespace plnlp {
@@ -33,25 +33,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
-
-struct Args {
-    const float* a[2]; int64_t lda[2]; int k[2]; const int32_t* a_index[2];
-    int nseg;
-    int ks0, ks_total;            // K-steps (of 16) in segment 0 / in all segments
-    const u32x4* image;           // the pre-split B operand
-    float* c; int64_t ldc; float* c2; int64_t ldc2; int n_split;
-    int64_t m; int n;
-    int64_t gm; int gn;           // row panels (128 rows) x n-tiles of THIS launch
-    int64_t row_lo;               // its first row (a launch covers the row panels [row_lo / 128, row_lo / 128 + gm))
-};
-
-struct SplitArgs {                // what the image is made from
-    const float* b[2]; int64_t ldb[2]; int k[2];      // per K-segment
-    const float* b2; int64_t ldb2; int nb_split;      // columns >= nb_split come from b2 (segment 0 only; nb_split = n: unused)
-    int b_trans;                                      // 1: stored [N, K]   0: stored [K, N]
-    int nseg, ks0, ks_total, n, wn, gn;
-    u32x4* image;
-};
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
     const f32x2 v = {lo, hi};
@@ -113,7 +94,7 @@ struct SplitStages {
 __global__ __launch_bounds__(256) void split_b_kernel(SplitArgs g) {
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int wn = g.wn;
-    u32x4* image = g.image;
+    u32x4* image = reinterpret_cast<u32x4*>(g.image);
     if (id >= (int64_t)g.gn * g.ks_total * 2 * wn) return;
     const int c = (int)(id % wn);
     const int h = (int)((id / wn) & 1);

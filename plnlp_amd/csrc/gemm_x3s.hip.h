@@ -1,0 +1,35 @@
+// The interface between gemm_f32.hip (gemm_impl decides which kernel a launch runs) and gemm_x3s.hip (the split-bf16 GEMM
+// with a stationary, pre-split weight operand): ONE definition of the argument structs for both translation units.
+#pragma once
+#include "common.hip.h"
+
+namespace plnlp {
+namespace x3s {
+
+struct Args {
+    const float* a[2]; int64_t lda[2]; int k[2]; const int32_t* a_index[2];
+    int nseg;
+    int ks0, ks_total;            // K-steps (of 16) in segment 0 / in all segments
+    const void* image;            // the pre-split B operand (16-byte units, see split_b_kernel)
+    float* c; int64_t ldc; float* c2; int64_t ldc2; int n_split;
+    int64_t m; int n;
+    int64_t gm; int gn;           // row panels (128 rows) x n-tiles of THIS launch
+    int64_t row_lo;               // its first row (a launch covers the row panels [row_lo / 128, row_lo / 128 + gm))
+};
+
+struct SplitArgs {                // what the image is made from
+    const float* b[2]; int64_t ldb[2]; int k[2];      // per K-segment
+    const float* b2; int64_t ldb2; int nb_split;      // columns >= nb_split come from b2 (segment 0 only; nb_split = n: unused)
+    int b_trans;                                      // 1: stored [N, K]   0: stored [K, N]
+    int nseg, ks0, ks_total, n, wn, gn;
+    void* image;
+};
+
+int pick_nb(int64_t m, int64_t n);
+void set_tuning(int nb, int min_rows);
+int min_rows();
+int64_t image_bytes(int64_t n, const int64_t* k, int nseg, int nb);
+int launch(const SplitArgs& sp, const Args& a, int nb, const Epi& e, hipStream_t s);
+
+}  // namespace x3s
+}  // namespace plnlp

@@ -32,16 +32,16 @@ from .utils import StreamedPermutation, batch_permutation, evaluate_hits, evalua
 import os
 
 # single process, SAGE on the raw embedding table: the table's Adam step rides in the epilogue of the kernel that
-# finishes its gradient (BaseModel._embedding_grad_sink); PLNLP_FUSE_EMBEDDING_ADAM=0 keeps gradient and update apart
+# finishes its gradient (BaseModel._embedding_grad_sink); False keeps gradient and update apart (plnlp_amd/switches.py)
 FUSE_EMBEDDING_ADAM = {"enabled": True}
 # the epoch's batch permutation shuffled a few batches ahead of the GPU by a host thread (utils.StreamedPermutation);
-# PLNLP_STREAM_PERMUTATION=0: the whole torch.randperm before the first step, as the reference's DataLoader does
+# False: the whole torch.randperm before the first step, as the reference's DataLoader does
 STREAM_PERMUTATION = {"enabled": True}
 # the epoch's running sum of loss * examples (model.py:169) fed by the loss kernel's own tail (ops.LOSS_ACC) in a
-# one-process run; PLNLP_FUSE_LOSS_ACC=0: three element-wise launches per step, as the reference's line does it
+# one-process run; False: three element-wise launches per step, as the reference's line does it
 FUSE_LOSS_ACC = {"enabled": True}
 # row-sharded data parallelism: the last SAGE layer evaluated / back-propagated only at the rows of the rank's block that
-# the global batch touches (PLNLP_SHARD_SPARSE=0: every row of the block)
+# the global batch touches (False: every row of the block)
 SHARD_SPARSE = {"enabled": True}
 
 
@@ -205,7 +205,15 @@ class BaseModel(object):
                 torch.distributed.broadcast(p.data, 0, group=self.process_group)
 
     def create_input_feat(self, data):
-        """model.py:98-105"""
+        """model.py:98-105.  The public surface: always the real [emb.weight | data.x] matrix, with its autograd edge to
+        emb.weight -- whatever the caller does with it (slice, cast, a foreign conv) sees current values."""
+        return self._input_feat(data, defer=False)
+
+    def _input_feat(self, data, defer=True):
+        """create_input_feat for the trainer's own passes, which hand the result STRAIGHT to encoder.convs[0]: with
+        defer=True and a first GCNConv (which takes the two parts and never reads the concatenated matrix) the per-step copy
+        of the embedding block is skipped and the returned tensor is marked stale (ops.concat_features(defer=True)); never
+        returned to a caller outside this class."""
         if not self.use_node_feats:
             return self.emb.weight
         feat = data.x.to(self.device)
@@ -217,7 +225,7 @@ class BaseModel(object):
                     self._feat_cache = {}
                 # (a first GCNConv takes the two parts and never reads the matrix: no per-step copy then)
                 from .layer import GCNConv
-                defer = (len(self.encoder.convs) > 0 and isinstance(self.encoder.convs[0], GCNConv)
+                defer = (defer and len(self.encoder.convs) > 0 and isinstance(self.encoder.convs[0], GCNConv)
                          and ops.GCN_INPUT_FUSION["enabled"])
                 return concat_features(self.emb.weight, feat, self._feat_cache, defer=defer)
             feat = torch.cat([self.emb.weight, feat], dim=-1)
@@ -441,7 +449,7 @@ class BaseModel(object):
         dst_c address it) -- tell by `batch.src_c is not None`."""
         n_edges = pos_edge.size(0) + neg_flat.size(0)
         native = isinstance(self.encoder, BaseGNN)
-        x_in = self.create_input_feat(data)
+        x_in = self._input_feat(data)
         fused, use_channel, build, sparse_fwd = self._edge_flags(n_edges, x_in.is_cuda, rows_only)
         # a 1-layer encoder ends in relu+dropout (layer.py:24-26); with a fused scorer as the only
         # consumer of h, that activation's backward rides in the scorer's gather-reduce epilogue
@@ -946,7 +954,7 @@ class BaseModel(object):
         self.predictor.eval()
         self._table_wait()
 
-        h = self.encoder(self.create_input_feat(data), data.adj_t)
+        h = self.encoder(self._input_feat(data), data.adj_t)
         # index -1 = unseen node = mean of all seen representations (model.py:191-194)
         h = torch.cat([h, torch.mean(h, dim=0, keepdim=True)], dim=0)
 

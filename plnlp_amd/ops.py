@@ -104,7 +104,7 @@ HUB_RANGES = {"part_rows": 65536, "max_len": 256, "max_ranges": 8}
 
 
 # the long rows' chunk pass inside the main pass's launch (PLNLP_AGG_FUSED_PASSES): the same sums in the same order --
-# not a tuned form, a launch shape; PLNLP_AGG_FUSED=0 restores the three-launch sequence for A/B runs
+# not a tuned form, a launch shape; AGG_FUSED["enabled"] = False restores the three-launch sequence for A/B runs
 AGG_FUSED = {"enabled": True}
 
 
@@ -143,12 +143,49 @@ def _multi_rank() -> bool:
     return d.is_available() and d.is_initialized() and d.get_world_size() > 1
 
 
+# The forms differ in summation order, so a per-box measurement means per-box BITS.  The chosen form per (graph shape,
+# width) is therefore kept in a file that ships with the package: a shape found there is not measured again -- every box
+# then runs the same kernels on it and two boxes give the same bits.  A shape that is not in the file is measured as
+# before and remembered for the process only; scripts/pin_agg_forms.py measures the benchmark shapes and rewrites the file.
+# PLNLP_AGG_FORMS_FILE=none: measure per process.
+AGG_FORMS = {"path": os.environ.get("PLNLP_AGG_FORMS_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                            "agg_forms.json"),
+             "table": None, "hits": 0, "measured": {}}
+
+
+def agg_form_key(graph, feat: int) -> str:
+    """what a pinned form is keyed by: the static graph's shape (rows, source rows, entries) and the width.  A graph and
+    its transposed view share one choice (their passes cannot be timed apart), so the key is orientation-free."""
+    lo, hi = sorted((int(graph.n_rows), int(graph.n_cols)))
+    return "%d:%d:%d:f%d" % (lo, hi, int(graph.col.numel()), int(feat))
+
+
+def pinned_agg_form(graph, feat: int):
+    """the form the shipped table names for this shape, or None"""
+    if AGG_FORMS["path"] in (None, "", "none"):
+        return None
+    if AGG_FORMS["table"] is None:
+        import json
+        try:
+            with open(AGG_FORMS["path"]) as f:
+                AGG_FORMS["table"] = {k: int(v) for k, v in json.load(f).get("forms", {}).items()}
+        except (OSError, ValueError):
+            AGG_FORMS["table"] = {}
+    hit = AGG_FORMS["table"].get(agg_form_key(graph, feat))
+    if hit is not None:
+        AGG_FORMS["hits"] += 1
+    return hit
+
+
 def _time_agg_forms(graph, x, out, reduce, use_values, src_scale, epilogue) -> int:
     """which candidate form is fastest on this graph, by measurement on this rank: every form is launched once untimed
     (its tables get built, the clocks come up), then five timed rounds go over the forms in turn -- a cold or drifting
     clock then biases no form -- and each form keeps its best time; a form other than the default must win by 3 %"""
     if AGG_AUTOTUNE["force"] is not None:
         return int(AGG_AUTOTUNE["force"])
+    pinned = pinned_agg_form(graph, x.shape[1])
+    if pinned is not None:
+        return pinned
     cands = list(AGG_AUTOTUNE["candidates"])
     # nothing else should run beside the measurement (a trainer reaches this point with the next batch's index preparation
     # queued on the side stream).  (On the collab graph the weighted full-graph launch timed here is a near-tie between the
@@ -174,6 +211,7 @@ def _time_agg_forms(graph, x, out, reduce, use_values, src_scale, epilogue) -> i
     for cand in cands[1:]:
         if best_t[cand] < 0.97 * best_t[best]:
             best = cand
+    AGG_FORMS["measured"][agg_form_key(graph, x.shape[1])] = {"form": int(best), "ms": {str(c): round(best_t[c], 4) for c in cands}}
     return best
 
 
@@ -382,20 +420,37 @@ GEMM_MATH = {"mode": os.environ.get("PLNLP_GEMM_MATH", "bf16x3")}
 # the stationary-weights form of the split-bf16 GEMM (csrc/gemm_x3s.hip): the weights are split into their bf16 terms
 # once per launch into a lent buffer instead of once per row panel.  Bit-identical to the 128 x 128 kernels; off =
 # those kernels everywhere (A/B runs, tests of both)
-GEMM_STATIONARY_B = {"enabled": os.environ.get("PLNLP_GEMM_STATIONARY_B", "1") != "0", "min_rows": 16384}
+GEMM_STATIONARY_B = {"enabled": os.environ.get("PLNLP_GEMM_STATIONARY_B", "1") != "0",
+                     "min_rows": 16384}     # (informational: the rule itself lives in the library, plnlp_gemm_stationary_applies)
 
 
-def _lend_b_terms(op, m: int, n: int, ks, device):
-    """lend the launch a scratch buffer for B's pre-split image (plnlp_gemm_operand.b_terms) where the form applies:
-    split-bf16 products, A not transposed, enough rows for the one-off split to pay.  Returns the tensor to keep alive."""
-    if not GEMM_STATIONARY_B["enabled"] or op.math != L.GEMM_MATH_BF16X3 or m < GEMM_STATIONARY_B["min_rows"]:
+def _lend_b_terms(ops, n_seg: int, a_trans: bool, b_trans: bool, out: torch.Tensor, m: int, n: int,
+                  out2: Optional[torch.Tensor] = None, n_split: Optional[int] = None):
+    """lend the launch a scratch buffer for B's pre-split image (plnlp_gemm_operand.b_terms) exactly where the library will
+    run the stationary-weights form with it -- plnlp_gemm_stationary_applies is the launch's own rule (shape, alignment,
+    gathered operands, the h = 200 exception): a launch that declines the form keeps its split-K and gets no buffer.
+    `ops` must be filled in (pointers, leading dimensions, K, index pointers, math).  Returns the tensor to keep alive."""
+    if not GEMM_STATIONARY_B["enabled"] or ops[0].math != L.GEMM_MATH_BF16X3:
         return None
-    need = L.load().plnlp_gemm_b_terms_bytes(m, n, ks[0], ks[1] if len(ks) > 1 else 0)
+    lib = L.load()
+    if not lib.plnlp_gemm_stationary_applies(ops, n_seg, int(a_trans), int(b_trans), out.data_ptr(), _ld(out), m, n,
+                                             L.ptr(out2), 0 if out2 is None else _ld(out2), n if n_split is None else n_split):
+        return None
+    need = lib.plnlp_gemm_b_terms_bytes(m, n, int(ops[0].k), int(ops[1].k) if n_seg > 1 else 0)
     if need <= 0:
         return None
-    buf = torch.empty(need, dtype=torch.uint8, device=device)
-    op.b_terms, op.b_terms_bytes = buf.data_ptr(), need
+    buf = torch.empty(need, dtype=torch.uint8, device=out.device)
+    ops[0].b_terms, ops[0].b_terms_bytes = buf.data_ptr(), need
     return buf
+
+
+def launch_counts() -> dict:
+    """{kernel family: launches so far in this process} (plnlp_launch_counts) -- which forms a run went through"""
+    lib = L.load()
+    n = lib.plnlp_launch_counts(None, 0)
+    buf = (C.c_int64 * n)()
+    lib.plnlp_launch_counts(C.cast(buf, C.c_void_p), n)
+    return {lib.plnlp_launch_kind_name(i).decode(): int(buf[i]) for i in range(n)}
 
 
 def _gemm_math() -> int:
@@ -459,10 +514,9 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     if split_k is None:
         split_k = _pick_split_k(m, n, ktiles)
     split_k = max(1, min(split_k, ktiles))
-    if not a_trans and b_index is None and a_index2 is None:
-        keep.append(_lend_b_terms(ops[0], m, n, [int(ops[i].k) for i in range(len(segs))], out.device))
-        if keep[-1] is not None:
-            split_k = 1          # (the form never cuts K: few row panels get narrower column tiles instead)
+    keep.append(_lend_b_terms(ops, len(segs), a_trans, b_trans, out, m, n))
+    if keep[-1] is not None:
+        split_k = 1              # (the form never cuts K: few row panels get narrower column tiles instead)
     ws = torch.empty(split_k * m * n, dtype=torch.float32, device=out.device) if split_k > 1 else None
     rc = lib.plnlp_gemm_f32(ops, len(segs), int(a_trans), int(b_trans), out.data_ptr(), _ld(out), m, n,
                             C.byref(epilogue) if epilogue is not None else None, split_k,
@@ -526,7 +580,7 @@ def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool
     c1 = out1 if out1 is not None else torch.empty(m, n1, dtype=torch.float32, device=a.device)
     assert c1.shape == (m, n1) and c1.is_contiguous()
     c2 = torch.empty(m, n2, dtype=torch.float32, device=a.device)
-    lent = _lend_b_terms(ops[0], m, n, [k], a.device) if (not a_trans and rows is None) else None
+    lent = _lend_b_terms(ops, 1, a_trans, False, c1, m, n, out2=c2, n_split=n1)
     ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device) if split_k > 1 else None
     L.check(lib.plnlp_gemm_pair_f32(ops, b2.data_ptr(), _ld(b2), n1, int(rows_on), int(a_trans), 0, c1.data_ptr(), _ld(c1),
                                     c2.data_ptr(), _ld(c2), n1, m, n, split_k, L.ptr(ws),
@@ -549,7 +603,7 @@ def gemm_split_out(a: torch.Tensor, b: torch.Tensor, n_split: int, b_trans: bool
     c1 = out1 if out1 is not None else torch.empty(m, n_split, dtype=torch.float32, device=a.device)
     assert c1.shape == (m, n_split) and c1.is_contiguous()
     c2 = torch.empty(m, n - n_split, dtype=torch.float32, device=a.device)
-    lent = _lend_b_terms(ops[0], m, n, [k], a.device)
+    lent = _lend_b_terms(ops, 1, False, b_trans, c1, m, n, out2=c2, n_split=n_split)
     L.check(lib.plnlp_gemm_split_out_f32(ops, 1, 0, int(b_trans), c1.data_ptr(), _ld(c1), c2.data_ptr(), _ld(c2),
                                          n_split, m, n, None, L.stream_ptr()), "plnlp_gemm_split_out_f32")
     return c1, c2

@@ -26,8 +26,10 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     """GPU tests must fail loudly (not skip) when asked for explicitly with -m gpu on a
     box without the HIP library / device; without -m they are deselected by the driver's
-    `-m "not gpu"`."""
-    return
+    `-m "not gpu"`.
+    Order: tests/test_hip_multirank.py first -- it starts child processes that use the GPU, and the parent should not have
+    initialised the GPU itself when it does (stable sort: everything else keeps its order)."""
+    items.sort(key=lambda it: 0 if "test_hip_multirank" in it.nodeid else 1)
 
 
 @pytest.fixture(scope="session")

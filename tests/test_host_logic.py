@@ -3,6 +3,8 @@ edge plumbing, batch permutation, evaluator, logger, factories, Graph) against t
 captured from the reference and against the oracle.  No kernels are launched here."""
 import io
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -458,3 +460,165 @@ def test_aggregation_form_helpers():
     assert "position chunks" in ops.describe_form(0) and "pinned" in ops.describe_form(L.AGG_HUB_XCD)
     # the host-side bit never reaches the library's flag word
     assert ops.AGG_HUB_RANGES > 0xFFFF and (hub & 0xFFFF) == L.AGG_HUB_XCD
+
+
+def test_switch_tables_match_the_code():
+    """INTEGRATION.md section 5 is generated from plnlp_amd/switches.py, and that table is the code's: every PLNLP_* variable
+    the host reads from the environment is listed, nothing listed is unread, every in-process switch named exists with the
+    default stated, and no document or comment offers an environment variable that nothing reads (a dozen
+    documented switches had silently stopped working)."""
+    import re
+    import importlib
+    from plnlp_amd import switches
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert switches.BEGIN in doc and switches.END in doc
+    section = doc[doc.index(switches.BEGIN):doc.index(switches.END) + len(switches.END)]
+    assert section == switches.markdown(), "regenerate: python -m plnlp_amd.switches (INTEGRATION.md section 5)"
+    # environment reads in the product and the bench
+    read = set()
+    files = [os.path.join(root, "plnlp_amd", f) for f in os.listdir(os.path.join(root, "plnlp_amd")) if f.endswith(".py")]
+    files += [os.path.join(root, "bench.py"), os.path.join(root, "train.py")]
+    for path in files:
+        if path.endswith("switches.py") or path.endswith("build.py"):
+            continue
+        src = open(path).read()
+        read |= set(re.findall(r"environ(?:\.get\(|\[)\s*[\"'](PLNLP_[A-Z0-9_]+)[\"']", src))
+    listed = {row[0] for row in switches.ENV}
+    assert read == listed, (sorted(read - listed), sorted(listed - read))
+    # the in-process switches exist and hold the defaults the table states
+    for attr, default, _ in switches.MODULE:
+        for part, want in zip(attr.split(" / "), default.split(" / ")):
+            mod_name, rest = part.split(".", 1) if not part.startswith("[") else (last_mod, last_name + part)
+            m = re.match(r"([A-Z_]+)(?:\['([a-z_]+)'\])?$", rest)
+            assert m, part
+            last_mod, last_name = mod_name, m.group(1)
+            obj = getattr(importlib.import_module("plnlp_amd." + mod_name), m.group(1))
+            val = obj[m.group(2)] if m.group(2) else obj
+            assert str(val) == want, (part, val, want)
+    # nowhere else: a PLNLP_* name in the documents / host comments is an ABI constant of the header, a build macro, or listed
+    header = set(re.findall(r"PLNLP_[A-Z0-9_]+", open(os.path.join(root, "include", "plnlp_hip.h")).read()))
+    build_macros = {"PLNLP_GEMM_BK", "PLNLP_GEMM_X3"}
+    for path in files + [os.path.join(root, "INTEGRATION.md"), os.path.join(root, "README.md")]:
+        for name in set(re.findall(r"PLNLP_[A-Z0-9_]+", open(path).read())):
+            name = name.rstrip("_")
+            assert name in header or name in listed or name in build_macros or any(h.startswith(name) for h in header), \
+                f"{os.path.basename(path)} names {name}: not an environment switch the code reads (plnlp_amd/switches.py)"
+
+
+def test_pinned_aggregation_forms_are_looked_up_not_measured(tmp_path):
+    """ops.AGG_FORMS: a (graph shape, width) found in the shipped table is not measured -- two boxes then run the same
+    kernels and give the same bits; the key is the same for a graph and its transposed view"""
+    import json
+    import plnlp_amd as P
+    from plnlp_amd import ops
+    g = torch.Generator().manual_seed(1)
+    row, col = torch.randint(0, 50, (400,), generator=g), torch.randint(0, 70, (400,), generator=g)
+    graph = P.Graph.from_coo(row, col, None, 50, 70)
+    key = ops.agg_form_key(graph, 256)
+    assert key == "50:70:400:f256" and ops.agg_form_key(graph.t(), 256) == key
+    path = tmp_path / "forms.json"
+    path.write_text(json.dumps({"forms": {key: 16}}))
+    old = dict(ops.AGG_FORMS)
+    try:
+        ops.AGG_FORMS.update(path=str(path), table=None, hits=0)
+        assert ops.pinned_agg_form(graph, 256) == 16 and ops.pinned_agg_form(graph, 512) is None
+        # the measurement entry point returns the pinned form without launching anything (CPU tensors would raise)
+        x = torch.zeros(70, 256)
+        assert ops._time_agg_forms(graph, x, torch.zeros(50, 256), "mean", False, None, None) == 16
+        ops.AGG_FORMS.update(path="none", table=None)
+        assert ops.pinned_agg_form(graph, 256) is None
+    finally:
+        ops.AGG_FORMS.clear()
+        ops.AGG_FORMS.update(old)
+    # the shipped table parses and every form in it is a combination of known flag bits
+    shipped = json.load(open(os.path.join(os.path.dirname(ops.__file__), "agg_forms.json")))
+    known = (P._lib.AGG_SLABS_128 | P._lib.AGG_SLABS_256 | P._lib.AGG_SLABS_XCD | P._lib.AGG_HUB_XCD | ops.AGG_HUB_RANGES)
+    for k, v in shipped["forms"].items():
+        assert re_key(k) and int(v) & ~known == 0, (k, v)
+
+
+def re_key(k):
+    import re
+    return re.match(r"\d+:\d+:\d+:f\d+$", k) is not None
+
+
+@pytest.mark.parametrize("name,ext", [("ogbl-collab", "pt"), ("ogbl-ddi", "npz"), ("ogbl-citation2", "pt")])
+def test_data_path_reads_ogbs_raw_layout(tmp_path, name, ext):
+    """train.py --data_path (main.py:74-95): a 200-node dataset written in OGB's on-disk layout (raw/edge.csv.gz,
+    raw/edge_weight.csv.gz, raw/node-feat.csv.gz, split/<type>/{train,valid,test}.pt of numpy arrays) is read back without
+    the ogb wheel into what main.py holds after line 95 -- inverse edges added for the undirected datasets with their
+    per-edge attributes, adj_t = the transposed adjacency carrying edge_weight, edge_index rebuilt from it, the split
+    dictionary as tensors -- and the driver falls back to the synthetic stand-in when the directory is absent."""
+    import train as driver
+    from plnlp_amd import ogb_raw
+    gen = torch.Generator().manual_seed(7)
+    n, e = 200, 900
+    edge = torch.randint(0, n, (e, 2), generator=gen)
+    edge = edge[edge[:, 0] != edge[:, 1]]
+    e = edge.shape[0]
+    weight = torch.randint(1, 6, (e,), generator=gen).float() if name == "ogbl-collab" else None
+    year = torch.randint(2000, 2018, (e,), generator=gen) if name == "ogbl-collab" else None
+    x = torch.randn(n, 16, generator=gen) if name == "ogbl-citation2" else None
+    cut = [0, e * 8 // 10, e * 9 // 10, e]
+    split = {}
+    for i, s in enumerate(("train", "valid", "test")):
+        part = edge[cut[i]:cut[i + 1]]
+        if name == "ogbl-citation2":
+            split[s] = {"source_node": part[:, 0].clone(), "target_node": part[:, 1].clone()}
+            if s != "train":
+                split[s]["target_node_neg"] = torch.randint(0, n, (part.shape[0], 10), generator=gen)
+        else:
+            split[s] = {"edge": part.clone()}
+            if s != "train":
+                split[s]["edge_neg"] = torch.randint(0, n, (50, 2), generator=gen)
+            if weight is not None:
+                split[s]["weight"] = weight[cut[i]:cut[i + 1]].clone()
+                split[s]["year"] = year[cut[i]:cut[i + 1]].clone()
+    root = str(tmp_path / "dataset")
+    assert not ogb_raw.available(name, root)
+    ogb_raw.write_link_dataset(name, root, edge, n, split, edge_weight=weight, edge_year=year, x=x, split_ext=ext)
+    assert ogb_raw.available(name, root) and os.path.isdir(os.path.join(root, name.replace("-", "_"), "raw"))
+    data, split_r, num_nodes = ogb_raw.read_link_dataset(name, root)
+    assert num_nodes == n and data.num_nodes == n
+    for s in split:
+        assert set(split_r[s]) == set(split[s])
+        for k in split[s]:
+            assert torch.equal(split_r[s][k], split[s][k]), (s, k)
+    # the graph: what T.ToSparseTensor() makes of the (inverse-augmented) edge list -- checked against dense matrices
+    undirected = name != "ogbl-citation2"
+    ei = torch.cat([edge.t(), edge.t().flip(0)], 1) if undirected else edge.t()
+    w = None if weight is None else (torch.cat([weight, weight]) if undirected else weight)
+    dense = torch.zeros(n, n, dtype=torch.float64)
+    dense.index_put_((ei[1], ei[0]), torch.ones(ei.shape[1], dtype=torch.float64) if w is None else w.double(), accumulate=True)
+    row, col, val = data.adj_t.coo()
+    got = torch.zeros(n, n, dtype=torch.float64)
+    got.index_put_((row, col), torch.ones(row.numel(), dtype=torch.float64) if val is None else val.double(), accumulate=True)
+    assert torch.equal(got, dense) and row.numel() == ei.shape[1]          # duplicates kept, like SparseTensor
+    assert (val is None) == (weight is None)
+    assert torch.equal(data.edge_index, torch.stack([col, row]))            # main.py:82-83
+    if x is not None:
+        assert data.num_features == 16 and torch.allclose(data.x, x, rtol=1e-6) and data.x.dtype == torch.float32
+    else:
+        assert data.x is None
+    assert hasattr(data, "edge_year") == (name == "ogbl-collab")
+    # the driver: reads the directory when it is there, else the synthetic stand-in of the same shape
+    args = driver.argument(["--data_name", name, "--data_path", root, "--data_scale", "0.002"])
+    d2, s2, n2 = driver.load_dataset(args, "cpu")
+    assert n2 == n and torch.equal(d2.adj_t.col, data.adj_t.col)
+    args = driver.argument(["--data_name", name, "--data_path", str(tmp_path / "nowhere"), "--data_scale", "0.002"])
+    d3, s3, n3 = driver.load_dataset(args, "cpu")
+    assert n3 != n and "train" in s3
+    # and main.py:109-150's preparation runs on what was read (collab: year filter + validation edges as input)
+    if name == "ogbl-collab":
+        args = driver.argument(["--data_name", name, "--year", "2008", "--use_valedges_as_input", "True"])
+        driver.prepare_graph(args, data, split_r, n)
+        assert int(split_r["train"]["year"].min()) >= 2008 or split_r["train"]["year"].numel() == 0
+        assert split_r["train"]["edge"].shape[0] == split_r["train"]["weight"].shape[0]
+    if name == "ogbl-citation2":
+        args = driver.argument(["--data_name", name])
+        driver.prepare_graph(args, data, split_r, n)
+        r2, c2, _ = data.adj_t.coo()
+        sym = torch.zeros(n, n, dtype=torch.bool)
+        sym[r2, c2] = True
+        assert torch.equal(sym, sym.t())

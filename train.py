@@ -1,9 +1,11 @@
 """train.py -- experiment driver with the command line of the reference's main.py
 (same 36 flags, same run / epoch / eval / logging loop: main.py:16-305), running the
-MI355X path.  The OGB datasets cannot be downloaded here (no network, `ogb` absent), so
-`--data_name` selects a synthetic OGB-SHAPED dataset (`ogbl-ddi`, `ogbl-collab`,
-`ogbl-citation2`; `--data_scale` shrinks it); if a directory with real OGB tensors is ever
-available, `load_dataset` is the only function to replace.
+MI355X path.  `--data_path` is read like the reference's (main.py:74): when it holds the dataset
+in OGB's raw on-disk layout (`<data_path>/ogbl_collab/raw/edge.csv.gz`, `split/time/train.pt`,
+...: plnlp_amd/ogb_raw.py reads it without the `ogb` / PyG wheels) that data is used; nothing is
+ever downloaded (no network here), so when the directory is absent `--data_name` selects a
+synthetic OGB-SHAPED dataset instead (`ogbl-ddi`, `ogbl-collab`, `ogbl-citation2`;
+`--data_scale` shrinks it).
 
     python train.py --data_name=ogbl-collab --predictor=DOT --use_valedges_as_input=True \
         --epochs=3 --runs=1 --eval_steps=1 --dropout=0.3 --gnn_num_layers=1 --grad_clip_norm=1 \
@@ -68,6 +70,19 @@ class Data:
 
 
 def load_dataset(args, device):
+    """PygLinkPropPredDataset(name=args.data_name, root=args.data_path) + get_edge_split (main.py:74-95): read from OGB's raw
+    on-disk layout when `--data_path` holds the dataset (plnlp_amd/ogb_raw.py: no ogb / PyG wheel needed), else the
+    synthetic stand-in of the same shape (no network here: nothing is ever downloaded)."""
+    from plnlp_amd import ogb_raw
+    if ogb_raw.available(args.data_name, args.data_path):
+        print(f'reading {args.data_name} from {ogb_raw.dataset_dir(args.data_name, args.data_path)}')
+        return ogb_raw.read_link_dataset(args.data_name, args.data_path)
+    print(f'{ogb_raw.dataset_dir(args.data_name, args.data_path)} not found: synthetic {args.data_name}-shaped data '
+          f'(scale {args.data_scale})')
+    return synthetic_dataset(args, device)
+
+
+def synthetic_dataset(args, device):
     """Synthetic stand-in for PygLinkPropPredDataset + get_edge_split (main.py:74-95)."""
     shape = {'ogbl-ddi': 'ddi', 'ogbl-collab': 'collab', 'ogbl-citation2': 'citation2'}[args.data_name]
     g = synthetic.make_graph(shape, seed=0, device='cpu', scale=args.data_scale, weighted=(shape == 'collab'))
