@@ -798,10 +798,12 @@ extern "C" int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col
                                        int flags, const plnlp_epilogue* epi, const plnlp_row_split* split,
                                        void* stream) {
     using namespace plnlp;
-    if (!rowptr || !x || !out) return PLNLP_E_NULL;
     if (n_rows < 0 || feat <= 0 || ldx < feat || ldo < feat || feat > (1 << 20)) return PLNLP_E_SHAPE;
     if (reduce != PLNLP_REDUCE_SUM && reduce != PLNLP_REDUCE_MEAN) return PLNLP_E_UNSUPPORTED;
+    // nothing to produce: an empty result has no storage, so its pointer may be NULL (a rank of a row-sharded step whose
+    // block no edge of the batch touches -- found by the world-2 run of tests/test_hip_multirank.py)
     if (n_rows == 0) return 0;
+    if (!rowptr || !x || !out) return PLNLP_E_NULL;
     if (!col) return PLNLP_E_NULL;
     Epi e;
     if (int rc = make_epi(epi, &e, /*allow_adam=*/true)) return rc;

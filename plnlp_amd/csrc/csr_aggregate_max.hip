@@ -331,9 +331,9 @@ extern "C" int plnlp_csr_aggregate_max_f32(const int64_t* rowptr, const int32_t*
                                            int64_t ld_arg, int64_t n_rows, int64_t feat,
                                            const plnlp_row_split* split, int32_t* arg_workspace, void* stream) {
     using namespace plnlp;
-    if (!rowptr || !x || !out || !arg) return PLNLP_E_NULL;
     if (n_rows < 0 || feat <= 0 || ldx < feat || ldo < feat || ld_arg < feat || feat > (1 << 20)) return PLNLP_E_SHAPE;
     if (n_rows == 0) return 0;
+    if (!rowptr || !x || !out || !arg) return PLNLP_E_NULL;
     if (!col) return PLNLP_E_NULL;
     if (n_rows > (int64_t)4 * 0x7FFFFFFF) return PLNLP_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -388,9 +388,9 @@ extern "C" int plnlp_csr_aggregate_max_bwd_f32(const int64_t* rowptr_t, const in
                                                int64_t ld_arg, float* gx, int64_t ldgx, int64_t n_src, int64_t feat,
                                                void* stream) {
     using namespace plnlp;
-    if (!rowptr_t || !gy || !arg || !gx) return PLNLP_E_NULL;
     if (n_src < 0 || feat <= 0 || ldg < feat || ld_arg < feat || ldgx < feat || feat > (1 << 20)) return PLNLP_E_SHAPE;
     if (n_src == 0) return 0;
+    if (!rowptr_t || !gy || !arg || !gx) return PLNLP_E_NULL;
     if (!col_t || !pos_t) return PLNLP_E_NULL;
     hipStream_t s = (hipStream_t)stream;
     const bool weighted = val_t != nullptr;

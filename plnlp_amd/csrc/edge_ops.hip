@@ -226,9 +226,9 @@ extern "C" int plnlp_edge_dot_fwd_f32(const float* h, int64_t ldh, int64_t n_row
                                       const int64_t* dst, int64_t n_edges, int64_t feat, float* out,
                                       void* stream) {
     using namespace plnlp;
-    if (!h || !out) return PLNLP_E_NULL;
     if (n_edges < 0 || feat <= 0 || ldh < feat || n_rows <= 0 || feat > (1 << 20)) return PLNLP_E_SHAPE;
     if (n_edges == 0) return 0;
+    if (!h || !out) return PLNLP_E_NULL;
     if (!src || !dst) return PLNLP_E_NULL;
     const bool vec = feat % 4 == 0 && ldh % 4 == 0 && (uintptr_t)h % 16 == 0;
     const int lpr = pick_lpr(feat, vec);
@@ -248,9 +248,9 @@ extern "C" int plnlp_edge_hadamard_fwd_f32(const float* h, int64_t ldh, int64_t 
                                            const int64_t* dst, int64_t n_edges, int64_t feat, float* out,
                                            int64_t ldo, void* stream) {
     using namespace plnlp;
-    if (!h || !out) return PLNLP_E_NULL;
     if (n_edges < 0 || feat <= 0 || ldh < feat || ldo < feat || n_rows <= 0 || feat > (1 << 20)) return PLNLP_E_SHAPE;
     if (n_edges == 0) return 0;
+    if (!h || !out) return PLNLP_E_NULL;
     if (!src || !dst) return PLNLP_E_NULL;
     const bool vec = feat % 4 == 0 && ldh % 4 == 0 && ldo % 4 == 0 && (uintptr_t)h % 16 == 0 &&
                      (uintptr_t)out % 16 == 0;
@@ -271,9 +271,9 @@ extern "C" int plnlp_edge_scatter_bwd_f32(const float* h, int64_t ldh, const int
                                           int64_t n_edges, int64_t feat, const float* g, int64_t ldg,
                                           int g_is_vector, float* gh, int64_t ldgh, void* stream) {
     using namespace plnlp;
-    if (!h || !g || !gh) return PLNLP_E_NULL;
     if (n_edges < 0 || feat <= 0 || ldh < feat || ldgh < feat || (g_is_vector && ldg < feat)) return PLNLP_E_SHAPE;
     if (n_edges == 0) return 0;
+    if (!h || !g || !gh) return PLNLP_E_NULL;
     if (!src || !dst) return PLNLP_E_NULL;
     const int lpr = pick_lpr(feat, false);
     dim3 grid(edge_grid(n_edges, lpr));
@@ -294,10 +294,10 @@ extern "C" int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh, const int
                                           int g_is_vector, float* gh, int64_t ldgh, const plnlp_epilogue* epi,
                                           void* stream) {
     using namespace plnlp;
-    if (!h || !g || !gh || !seg_ptr) return PLNLP_E_NULL;
     if (n_seg < 0 || feat <= 0 || ldh < feat || ldgh < feat || (g_is_vector && ldg < feat) || feat > (1 << 20))
         return PLNLP_E_SHAPE;
     if (n_seg == 0) return 0;
+    if (!h || !g || !gh || !seg_ptr) return PLNLP_E_NULL;
     if (!item_edge || !item_other) return PLNLP_E_NULL;
     Epi e;
     if (int rc = make_epi(epi, &e)) return rc;

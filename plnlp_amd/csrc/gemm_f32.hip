@@ -1044,9 +1044,9 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
                      int split_k, float* workspace, int64_t workspace_floats, void* stream, const float* b2,
                      int64_t ldb2, int64_t nb_split, int bidx_mask) {
     using namespace plnlp;
-    if (!segs || !c) return PLNLP_E_NULL;
     if (n_seg < 1 || n_seg > 2 || m < 0 || n < 0 || n > 0x7FFFFFF0) return PLNLP_E_SHAPE;
-    if (m == 0 || n == 0) return 0;
+    if (m == 0 || n == 0) return 0;           // (an empty result has no storage: its pointer may be NULL)
+    if (!segs || !c) return PLNLP_E_NULL;
     if (split_k < 1) split_k = 1;
     // K-tile depth of this launch: the weight gradients (row-contiguous A, a reduction over 10^5 .. 10^6 rows cut
     // along K) keep 32; everything else runs the depth-16 kernels, three workgroups per CU

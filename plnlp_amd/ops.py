@@ -402,7 +402,7 @@ def _pick_split_k(m: int, n: int, ktiles: int) -> int:
     second, partly filled round leaves SIMDs with one wave (measured: 768 blocks -> 1.27 waves/SIMD,
     58 % MFMA utilisation; 512 blocks -> one full round)."""
     blocks = ((m + 127) // 128) * ((n + 127) // 128)
-    if blocks >= 384 or ktiles <= 1:
+    if blocks == 0 or blocks >= 384 or ktiles <= 1:
         return 1
     return max(1, min(ktiles, SPLIT_K_SLOTS["slots"] // blocks))
 

@@ -221,7 +221,10 @@ class ShardPlan:
             segs = [rows_v[offs[q * W + me]:offs[q * W + me + 1]] for q in range(W)]
             self.send_rows = (torch.cat(segs) if W > 1 else segs[0]).remainder(S)
             # ---- the touched rows of my block as a compact row set (global ids, increasing), padded to 32 rows
-            pad = min(part.padded, (self.block_count + 31) // 32 * 32)
+            # (at least one group of 32: a rank whose block no edge of the batch touches still launches the layer -- over
+            # padding rows only -- instead of handing zero-row operands to every kernel of it; found by the world-2 HIP run,
+            # tests/test_hip_multirank.py::empty_slice_shard)
+            pad = min(part.padded, max(32, (self.block_count + 31) // 32 * 32))
             local = torch.nonzero(self._any).reshape(-1)                               # block-local ids, sorted
             rows_g = torch.zeros(max(pad, 1), dtype=torch.int32, device=self._dev)
             rows_g[:self.block_count] = (local + part.lo).to(torch.int32)

@@ -256,3 +256,54 @@ def geometric_graph(num_nodes: int = 3000, avg_degree: float = 30.0, softness: f
     return dict(num_nodes=n, train=torch.stack([lo, hi], 1), valid=held[: n_hold // 2].clone(),
                 test=held[n_hold // 2:].clone(), valid_neg=negs[:n_neg], test_neg=negs[n_neg:], adj_t=adj, data=data,
                 pos=z)
+
+
+def geometric_graph_blocked(num_nodes: int = 40000, avg_degree: float = 20.0, softness: float = 0.15, holdout: float = 0.15,
+                            n_neg: int = 10000, seed: int = 0, n_hubs: int = 0, hub_degree: float = 1500.0,
+                            block: int = 1000) -> Dict:
+    """geometric_graph for tens of thousands of nodes (the all-pairs pass goes block of rows by block of rows, so memory
+    is O(block * n) instead of O(n^2)), optionally with HUBS: `n_hubs` nodes whose connection radius is scaled so that
+    their expected degree is `hub_degree` -- a pair's radius is the larger of its endpoints' -- which gives the
+    aggregation kernel rows beyond its long-row threshold while every edge still follows the latent geometry.  Same
+    problem statement and return value as geometric_graph; a different random stream (not the same graph at equal
+    arguments).  2-d torus."""
+    gen = torch.Generator().manual_seed(889_000 + seed)
+    n = int(num_nodes)
+    z = torch.rand(n, 2, generator=gen, dtype=torch.float64)
+    r0 = (avg_degree / (math.pi * n)) ** 0.5
+    rad = torch.full((n,), r0, dtype=torch.float64)
+    if n_hubs > 0:
+        hubs = torch.randperm(n, generator=gen)[:n_hubs]
+        rad[hubs] = (hub_degree / (math.pi * n)) ** 0.5
+    aa, bb = [], []
+    for lo_i in range(0, n, block):
+        hi_i = min(n, lo_i + block)
+        d = (z[lo_i:hi_i, None, :] - z[None, :, :]).abs()
+        d = torch.minimum(d, 1.0 - d).pow(2).sum(2).sqrt()                    # [block, n]
+        rr = torch.maximum(rad[lo_i:hi_i, None], rad[None, :])
+        p = torch.sigmoid((rr - d) / (softness * rr)) if softness > 0 else (d < rr).double()
+        keep = torch.rand(d.shape, generator=gen, dtype=torch.float64) < p
+        i, j = keep.nonzero(as_tuple=True)
+        i = i + lo_i
+        up = i < j                                                             # each unordered pair is decided once
+        aa.append(i[up])
+        bb.append(j[up])
+    a, b = torch.cat(aa), torch.cat(bb)
+    perm = torch.randperm(a.numel(), generator=gen)
+    a, b = a[perm], b[perm]
+    n_hold = int(a.numel() * holdout) // 2 * 2
+    held = torch.stack([a[:n_hold], b[:n_hold]], 1)
+    lo, hi = a[n_hold:], b[n_hold:]
+    adj = Graph.from_coo(torch.cat([lo, hi]), torch.cat([hi, lo]), None, n, n)
+    rr_, cc_, _ = adj.coo()
+    data = SyntheticData(adj_t=adj, edge_index=torch.stack([cc_, rr_]).cpu(), num_nodes=n)
+    cand = torch.randint(0, n, (3 * n_neg, 2), generator=gen)
+    cl, ch = torch.minimum(cand[:, 0], cand[:, 1]), torch.maximum(cand[:, 0], cand[:, 1])
+    known = torch.unique(a * n + b)
+    ck = cl * n + ch
+    at = torch.searchsorted(known, ck).clamp_(max=known.numel() - 1)
+    negs = cand[(known[at] != ck) & (cl != ch)][: 2 * n_neg]
+    assert negs.size(0) == 2 * n_neg
+    return dict(num_nodes=n, train=torch.stack([lo, hi], 1), valid=held[: n_hold // 2].clone(),
+                test=held[n_hold // 2:].clone(), valid_neg=negs[:n_neg], test_neg=negs[n_neg:], adj_t=adj, data=data,
+                pos=z)

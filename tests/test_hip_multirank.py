@@ -66,9 +66,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _one_case(P, torch, dist, cfg, pg, world):
-    """build the case's model on cuda:0 with the real modules, train, return what the parent compares"""
+def _one_case(P, torch, dist, cfg, pg, world, resummed=False):
+    """build the case's model on cuda:0 with the real modules, train, return what the parent compares.
+    resummed (one process only): the same run with the dense products on the f32-input MFMA instead of the split-bf16
+    terms -- both within ~1e-7 of the exact product sums, i.e. a perturbation of the size the ranks' all-reduce
+    introduces by re-associating the gradient sums.  How far THAT moves the parameters is the yardstick the W-rank runs
+    are held to where Adam amplifies round-off: the pairwise losses are invariant under a shift of all scores, so the
+    gradient of the MLP scorer's output bias is exactly zero and -- while the scores are still nearly the same constant
+    for every edge, i.e. at initialisation -- the common part of the hidden biases' gradient cancels too; what is left is
+    round-off, and Adam's 1 / sqrt(v) turns its sign into a move of +-lr per step.  The oracle's own float32 and float64
+    runs part the same way (profiles/r03_trajectory_drift.txt)."""
     from plnlp_amd import ops, synthetic
+    if resummed:
+        old_math = ops.GEMM_MATH["mode"]
+        ops.GEMM_MATH["mode"] = "f32" if old_math == "bf16x3" else "bf16x3"
+        try:
+            return _one_case(P, torch, dist, cfg, pg, world)
+        finally:
+            ops.GEMM_MATH["mode"] = old_math
     g = synthetic.make_graph("collab", seed=4, device="cpu", num_nodes=cfg["n"], num_edges=cfg["m"],
                              weighted=cfg["weighted"])
     feats, emb_w = cfg.get("feats", 0), cfg.get("emb", cfg["h"])
@@ -112,22 +127,42 @@ def _one_case(P, torch, dist, cfg, pg, world):
         dist.all_reduce = native_all_reduce
     torch.cuda.synchronize()
     small = torch.cat([p.detach().reshape(-1) for p in list(m.encoder.parameters()) + list(m.predictor.parameters())])
+    named = {("encoder." + k): v.detach().cpu().numpy() for k, v in m.encoder.named_parameters()}
+    named.update({("predictor." + k): v.detach().cpu().numpy() for k, v in m.predictor.named_parameters()})
     th = getattr(m, "_step_throttle", None)
     return {"losses": losses, "small": small.cpu().numpy(), "table": m.emb.weight.detach().cpu().numpy().reshape(-1),
             "steps": m.last_epoch["steps"] * cfg["epochs"], "async_table_allreduce": early["async_table_allreduce"],
             "throttle_ticks": 0 if th is None else len(th.events),
-            "replicas_equal": bool(m.check_replicas()),
+            "replicas_equal": bool(m.check_replicas()), "named": named,
             "agg_forms": {int(f): int(v) for f, v in getattr(data.adj_t, "_agg_tune", {}).items()}}
 
 
+CASE_DEADLINE_S = 240        # a rank stuck in one case for this long dumps every thread's stack and exits
+
+
+def _log_path(world, rank):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out", "multirank") if os.path.isdir(os.path.join(root, "gpurun_out")) else "/tmp"
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, f"w{world}_r{rank}.log")
+
+
 def _rank(rank, world, port, names, q):
+    import faulthandler
+    import time
     res = {}
+    log = open(_log_path(world, rank), "w")
+
+    def say(msg):
+        log.write(f"{time.strftime('%H:%M:%S')} {msg}\n")
+        log.flush()
     try:
+        faulthandler.dump_traceback_later(CASE_DEADLINE_S, exit=True, file=log)
         import torch
         import torch.distributed as dist
         import plnlp_amd as P
         from plnlp_amd import _lib
-        from gloo_device_shim import STAGED_CALLS, install
+        from gloo_device_shim import NATIVE_CALLS, NEEDS_STAGING, STAGED_CALLS, install
         torch.cuda.set_device(0)
         _lib.load()
         pg = None
@@ -135,24 +170,34 @@ def _rank(rank, world, port, names, q):
             dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
             install()
             pg = dist.group.WORLD
+        say(f"process group up: world {world}")
         for name in names:
+            faulthandler.cancel_dump_traceback_later()
+            faulthandler.dump_traceback_later(CASE_DEADLINE_S, exit=True, file=log)
+            say(f"case {name} ...")
             try:
                 res[name] = _one_case(P, torch, dist, CASES[name], pg, world)
+                say(f"case {name} done: losses {res[name]['losses']}")
+                if world == 1 and CASES[name]["pred"] == "MLP":
+                    res[name + "/resummed"] = _one_case(P, torch, dist, CASES[name], pg, world, resummed=True)
             except Exception:              # noqa: BLE001 -- reported to the parent, which fails the test
                 res[name] = {"error": traceback.format_exc()}
+                say(f"case {name} FAILED:\n{res[name]['error']}")
                 break                      # (a rank that left a collective half way cannot rejoin its peers)
-        res["_staged"] = dict(STAGED_CALLS)
+        faulthandler.cancel_dump_traceback_later()
+        res["_staged"] = {k: STAGED_CALLS[k] + NATIVE_CALLS[k] for k in STAGED_CALLS}
+        res["_needs_staging"] = dict(NEEDS_STAGING)
         res["_lib"] = _lib.LIB_PATH
     except Exception:                      # noqa: BLE001
         res["_fatal"] = traceback.format_exc()
+        say("FATAL:\n" + res["_fatal"])
     q.put((rank, res))
-    if world > 1:
-        try:
-            import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
-        except Exception:                  # noqa: BLE001
-            pass
+    say("reported")
+    if world > 1 and "_fatal" not in res and all("error" not in v for k, v in res.items() if not k.startswith("_")):
+        import torch.distributed as dist
+        faulthandler.dump_traceback_later(60, exit=True, file=log)
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def _spawn(world, names, timeout):
@@ -172,16 +217,31 @@ def _spawn(world, names, timeout):
             os.environ.pop("PYTHONPATH", None)
         else:
             os.environ["PYTHONPATH"] = old
-    out = []
+    import queue
+    import time
+    out, deadline = [], time.monotonic() + timeout
     try:
-        for _ in procs:
-            out.append(q.get(timeout=timeout))
+        while len(out) < world and time.monotonic() < deadline:
+            try:
+                out.append(q.get(timeout=5))
+            except queue.Empty:
+                if not any(p.is_alive() for p in procs) and q.empty():
+                    break              # every child is gone and nothing is left to read
     finally:
         for p in procs:
             p.join(timeout=30)
             if p.is_alive():
                 p.kill()           # the exact child this test started
-    assert len(out) == world, f"only {len(out)} of {world} ranks reported"
+    if len(out) != world:
+        told = "".join(f"\n--- rank {r} reported: " + "; ".join(f"{k}: {v.get('error', 'ok') if isinstance(v, dict) else v}"
+                                                                for k, v in res.items()) for r, res in sorted(out))
+        logs = ""
+        for r in range(world):
+            try:
+                logs += f"\n--- {_log_path(world, r)}:\n" + open(_log_path(world, r)).read()[-6000:]
+            except OSError:
+                pass
+        raise AssertionError(f"only {len(out)} of {world} ranks reported (exit codes {[p.exitcode for p in procs]}){told}{logs}")
     return [r for _, r in sorted(out, key=lambda t: t[0])]
 
 
@@ -192,10 +252,20 @@ def _run(world):
     """one spawn per world size for the whole file (each child imports torch and initialises HIP once)"""
     if world not in _RUNS:
         names = list(CASES) if world == 1 else WORLDS[world]
-        _RUNS[world] = _spawn(world, names, timeout=900)
+        _RUNS[world] = _spawn(world, names, timeout=CASE_DEADLINE_S * 2 + 120 * len(names))
         for r, res in enumerate(_RUNS[world]):
             assert "_fatal" not in res, f"world {world} rank {r}:\n{res.get('_fatal')}"
     return _RUNS[world]
+
+
+def _describe(res, ref):
+    """per-parameter deviation table for a failure message"""
+    rows = []
+    for k in ref["named"]:
+        d = np.abs(res["named"][k].astype(np.float64) - ref["named"][k].astype(np.float64))
+        rows.append(f"{k:32s} {str(d.shape):14s} max {d.max():.2e}  median {np.median(d):.2e}  > 5e-5: {np.mean(d > 5e-5):.3f}"
+                    f"   |ref| median {np.median(np.abs(ref['named'][k])):.2e}")
+    return "\n".join(rows)
 
 
 def _close_after_adam(got, ref, steps, what):
@@ -216,12 +286,35 @@ def test_w_ranks_on_one_gpu_equal_the_one_process_hip_step(world, name):
         assert res is not None, f"rank {r} never reached case {name} (an earlier case failed on it)"
         assert "error" not in res, f"rank {r}:\n{res.get('error')}"
     cfg = CASES[name]
+    alt = _run(1)[0].get(name + "/resummed")
     for r, res in enumerate(ranks):
         # epoch losses: the all-reduced sum over ranks of the slice losses == the one-process loss of the whole batch
-        np.testing.assert_allclose(res["losses"][0], ref["losses"][0], rtol=1e-5, err_msg=f"rank {r} first epoch")
-        np.testing.assert_allclose(res["losses"], ref["losses"], rtol=2e-4, err_msg=f"rank {r}")
-        _close_after_adam(res["small"], ref["small"], ref["steps"], f"rank {r} encoder/predictor weights")
-        _close_after_adam(res["table"], ref["table"], ref["steps"], f"rank {r} embedding table")
+        np.testing.assert_allclose(res["losses"][0], ref["losses"][0], rtol=1e-5 if cfg["pred"] == "DOT" else 5e-5,
+                                   err_msg=f"rank {r} first epoch")
+        # later epochs: the reassociated gradient sum perturbs round-off-sized gradients, Adam's 1/sqrt(v) amplifies them;
+        # an MLP scorer's biases feel it most (the same bound as the one-process trajectory tests: test_hip_round4.py)
+        np.testing.assert_allclose(res["losses"], ref["losses"], rtol=5e-3 if cfg["pred"] == "MLP" else 2e-4,
+                                   err_msg=f"rank {r}")
+        if alt is None:
+            try:
+                _close_after_adam(res["small"], ref["small"], ref["steps"], f"rank {r} encoder/predictor weights")
+            except AssertionError as exc:
+                raise AssertionError(f"{exc}\n{_describe(res, ref)}\nlosses {res['losses']} vs {ref['losses']}") from None
+            _close_after_adam(res["table"], ref["table"], ref["steps"], f"rank {r} embedding table")
+        else:
+            # Adam-amplified round-off: the W ranks may sit as far from the one-process run as that run sits from ITSELF
+            # with its sums re-associated (a few times that: two runs' worth of independent noise), never further than
+            # Adam can carry an element
+            for what in ("small", "table"):
+                dev = np.abs(res[what].astype(np.float64) - ref[what].astype(np.float64))
+                noise = np.abs(alt[what].astype(np.float64) - ref[what].astype(np.float64))
+                msg = (f"rank {r} {what}: median |W ranks - one process| {np.median(dev):.2e} (90 % {np.quantile(dev, 0.9):.2e}) vs "
+                       f"the one-process run re-summed {np.median(noise):.2e} (90 % {np.quantile(noise, 0.9):.2e})\n"
+                       f"{_describe(res, ref)}\n-- re-summed one-process run:\n{_describe(alt, ref)}")
+                assert np.median(dev) <= 4.0 * np.median(noise) + 2e-5, msg
+                assert np.quantile(dev, 0.9) <= 4.0 * np.quantile(noise, 0.9) + 2e-5, msg
+                assert dev.max() <= 2 * ref["steps"] * LR + 1e-6, msg      # (two runs, each carried at most ~lr per step)
+            np.testing.assert_allclose(alt["losses"], ref["losses"], rtol=5e-3)
         assert res["replicas_equal"]
         assert res["steps"] == ref["steps"] and res["throttle_ticks"] > 0
     # replicas: the same bits on every rank (small weights in every mode; the table too -- 'shard' all-gathers it)
@@ -236,10 +329,10 @@ def test_w_ranks_on_one_gpu_equal_the_one_process_hip_step(world, name):
         assert all(res["agg_forms"] == ranks[0]["agg_forms"] for res in ranks) and ranks[0]["agg_forms"]
 
 
-def test_the_children_ran_the_hip_library_and_the_staged_collectives():
+def test_the_children_ran_the_hip_library_and_every_collective():
     for world in sorted(WORLDS):
         for res in _run(world):
             assert res["_lib"].endswith("libplnlp_hip.so")
             st = res["_staged"]
-            # 'shard' needs all three; 'scores' the all-gather
+            # device-tensor calls of each collective, native or staged: 'shard' needs all three; 'scores' the all-gather
             assert st["all_gather_into_tensor"] > 0 and st["reduce_scatter_tensor"] > 0 and st["all_to_all_single"] > 0, st

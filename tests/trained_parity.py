@@ -41,6 +41,15 @@ if ROOT not in sys.path:
 PROBLEMS = {
     "geometric": dict(num_nodes=3000, avg_degree=30.0, softness=0.15, holdout=0.15, n_neg=10000, seed=3),
     "sbm": dict(num_nodes=2000, community=50, p_in=0.97, cross_per_node=1.0, seed=3, unlearnable=0.1),
+    # the WIDE legs (round 5): the recipes at their own widths, on graphs big enough that every multi-step run goes through
+    # the kernels the benchmark measures -- the stationary-weights split-bf16 GEMM (>= 16 384 rows of A), the F = 256 / 512
+    # aggregation forms with hub rows beyond the long-row threshold (fused chunk pass), the touched-rows forward.
+    "geometric_wide": dict(num_nodes=40000, avg_degree=20.0, softness=0.15, holdout=0.15, n_neg=10000, seed=3, n_hubs=24,
+                           hub_degree=1500.0),
+    # ddi's own size and density: 4 267 nodes, ~450 neighbours each (README.md:24's graph has 2.1 M entries): the block
+    # model of the small ddi leg with eight communities of 500 (p_in 0.99: a dozen same-block non-edges among the 10 000
+    # negatives, fewer than K = 20, so a converged run sits on the 90 % plateau the 10 % unrankable positives leave)
+    "sbm_dense": dict(num_nodes=4267, community=500, p_in=0.99, cross_per_node=1.0, seed=3, unlearnable=0.1),
 }
 H = 64
 KS = ("Hits@20", "Hits@50", "Hits@100")
@@ -50,7 +59,41 @@ RECIPES = {
                    seeds=64),
     "ddi": dict(problem="sbm", layers=2, predictor="MLP", loss="AUC", k=3, lr=0.005, clip=2.0, epochs=60, batch=2048,
                 walk_length=0, decay=False, metric="Hits@20", level=88.0, center="median", seeds=48),
+    # README.md:35 at h = 256: batches of 32 768 pairs (+ as many negatives) touch ~96 % of the 40 000 nodes -- inside the
+    # row-sparse window (ops.SPARSE_BACKWARD), so the last conv runs at the ~38 000 touched rows, as on the real graph
+    "collab_wide": dict(problem="geometric_wide", h=256, layers=1, predictor="DOT", loss="WeightedHingeAUC", k=1, lr=0.01,
+                        clip=1.0, epochs=8, batch=32768, walk_length=1, decay=True, metric="Hits@50", level=None,
+                        center="mean", seeds=8),
+    # README.md:24 at h = 512: 8 192 positives + 3 x 8 192 negatives = 32 768 scorer rows per step; an epoch is the first
+    # `train_edges` training edges (the encoder still aggregates over the whole graph every step)
+    "ddi_wide": dict(problem="sbm_dense", h=512, layers=2, predictor="MLP", loss="AUC", k=3, lr=0.005, clip=2.0,
+                     epochs=6, batch=8192, walk_length=0, decay=False, metric="AUC", level=None, center="mean",
+                     seeds=8, train_edges=49152),
 }
+
+
+def width(recipe: str) -> int:
+    return RECIPES[recipe].get("h", H)
+
+
+WIDE = ("collab_wide", "ddi_wide")
+KS_WIDE = KS + ("AUC",)
+
+
+def metrics_of(recipe: str):
+    """the wide legs record, beside Hits@20/50/100, the AUC of the positives against the negatives (the share of
+    (positive, negative) pairs ranked the right way round, in percent): a metric that moves from the first step on -- the
+    ddi recipe at h = 512 is still near chance at Hits@20 after the few dozen steps the CPU oracle can afford"""
+    return KS_WIDE if recipe in WIDE else KS
+
+
+def auc_percent(pos: torch.Tensor, neg: torch.Tensor) -> float:
+    """100 * P(score(pos) > score(neg)) + 50 * P(equal), exact (sort + two binary searches), float64 counts"""
+    neg_sorted, _ = torch.sort(neg.reshape(-1).double())
+    p = pos.reshape(-1).double()
+    below = torch.searchsorted(neg_sorted, p, right=False)
+    upto = torch.searchsorted(neg_sorted, p, right=True)
+    return float(100.0 * (below.double() + 0.5 * (upto - below).double()).mean() / neg_sorted.numel())
 FINAL_EPOCHS = 3
 LEVEL_FRACTION = 0.9
 _problem = {}
@@ -60,8 +103,22 @@ def problem(recipe: str):
     name = RECIPES[recipe]["problem"]
     if name not in _problem:
         from plnlp_amd import synthetic
-        _problem[name] = (synthetic.geometric_graph(**PROBLEMS[name]) if name == "geometric"
-                          else synthetic.community_graph(device="cpu", **PROBLEMS[name]))
+        if name == "geometric_wide":          # (~1 minute of all-pairs blocks: kept on disk for the session's other processes)
+            cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "plnlp_geometric_wide_%d.pt" % os.getuid())
+            if os.path.exists(cache):
+                g = torch.load(cache, weights_only=False)
+            else:
+                g = synthetic.geometric_graph_blocked(**PROBLEMS[name])
+                torch.save(g, cache + ".%d" % os.getpid())
+                os.replace(cache + ".%d" % os.getpid(), cache)
+            _problem[name] = g
+        elif name.startswith("geometric"):
+            _problem[name] = synthetic.geometric_graph(**PROBLEMS[name])
+        else:
+            _problem[name] = synthetic.community_graph(device="cpu", **PROBLEMS[name])
+        te = RECIPES[recipe].get("train_edges")
+        if te:                                # the epoch's training edges: a fixed prefix (the graph keeps every train edge)
+            _problem[name] = dict(_problem[name], train=_problem[name]["train"][:te].clone())
     return _problem[name]
 
 
@@ -71,9 +128,10 @@ def initial_modules(recipe: str, seed: int):
     r = RECIPES[recipe]
     n = PROBLEMS[r["problem"]]["num_nodes"]
     torch.manual_seed(21 + 7919 * seed)
-    enc = O.GNNRef("SAGE", H, H, H, r["layers"], 0.0)
-    pred = O.MLPPredictorRef(H, H, 1, 2, 0.0) if r["predictor"] == "MLP" else O.DotPredictorRef()
-    emb = torch.nn.Embedding(n, H)
+    h = width(recipe)
+    enc = O.GNNRef("SAGE", h, h, h, r["layers"], 0.0)
+    pred = O.MLPPredictorRef(h, h, 1, 2, 0.0) if r["predictor"] == "MLP" else O.DotPredictorRef()
+    emb = torch.nn.Embedding(n, h)
     enc.reset_parameters()
     if r["predictor"] == "MLP":
         pred.reset_parameters()
@@ -98,7 +156,7 @@ def run_oracle(args):
     process pool can run the seeds side by side (one thread each)."""
     recipe, seed, dtype = args
     import oracle as O
-    torch.set_num_threads(1)
+    torch.set_num_threads(int(os.environ.get("PLNLP_ORACLE_THREADS", "1")))     # (results are thread-count independent only at 1)
     r = RECIPES[recipe]
     g = problem(recipe)
     n = g["num_nodes"]
@@ -124,8 +182,12 @@ def run_oracle(args):
             O.adjust_lr_ref(tr.optimizer, (epoch + 1) / r["epochs"], r["lr"])      # main.py:288-291
         hh = tr.embed_for_eval()
         B = r["batch"]
-        res = O.evaluate_hits_ref(tr.score(hh, pv, B), tr.score(hh, nv, B), tr.score(hh, pt, B), tr.score(hh, nt, B))
-        hits.append([[100.0 * res[k][0], 100.0 * res[k][1]] for k in KS])
+        spv, snv, spt, snt = tr.score(hh, pv, B), tr.score(hh, nv, B), tr.score(hh, pt, B), tr.score(hh, nt, B)
+        res = O.evaluate_hits_ref(spv, snv, spt, snt)
+        row = [[100.0 * res[k][0], 100.0 * res[k][1]] for k in KS]
+        if recipe in WIDE:
+            row.append([auc_percent(spv, snv), auc_percent(spt, snt)])
+        hits.append(row)
     return np.array(hits), np.array(losses)
 
 
@@ -174,7 +236,8 @@ def run_hip(P, recipe: str, seed: int, math: str, mutation: str = "none"):
     try:
         with Mutation(P, mutation):
             m = P.BaseModel(lr=r["lr"], dropout=0.0, grad_clip_norm=r["clip"], gnn_num_layers=r["layers"],
-                            mlp_num_layers=2, emb_hidden_channels=H, gnn_hidden_channels=H, mlp_hidden_channels=H,
+                            mlp_num_layers=2, emb_hidden_channels=width(recipe), gnn_hidden_channels=width(recipe),
+                            mlp_hidden_channels=width(recipe),
                             num_nodes=n, num_node_feats=0, gnn_encoder_name="SAGE", predictor_name=r["predictor"],
                             loss_func=r["loss"], optimizer_name="Adam", device="cuda", use_node_feats=False,
                             train_node_emb=True)
@@ -208,7 +271,14 @@ def run_hip(P, recipe: str, seed: int, math: str, mutation: str = "none"):
                 if r["decay"]:
                     P.adjust_lr(m.optimizer, (epoch + 1) / r["epochs"], r["lr"])
                 res = m.test(data, split, r["batch"], ev, "hits")
-                hits.append([[100.0 * res[k][0], 100.0 * res[k][1]] for k in KS])
+                row = [[100.0 * res[k][0], 100.0 * res[k][1]] for k in KS]
+                if recipe in WIDE:          # the scores themselves once more (BaseModel.test returns only Hits@K)
+                    with torch.no_grad():
+                        hh = m.encoder(m.create_input_feat(data), data.adj_t)
+                        hh = torch.cat([hh, hh.mean(0, keepdim=True)], 0)
+                        sc = [m.batch_predict(hh, e.to("cuda"), r["batch"], to_cpu=False) for e in (pv, nv, pt, nt)]
+                    row.append([auc_percent(sc[0], sc[1]), auc_percent(sc[2], sc[3])])
+                hits.append(row)
             return np.array(hits), np.array(losses)
     finally:
         P.ops.GEMM_MATH["mode"] = old
@@ -217,13 +287,13 @@ def run_hip(P, recipe: str, seed: int, math: str, mutation: str = "none"):
 # ------------------------------------------------------------------ statistics --
 def final_level(hits: np.ndarray, recipe: str) -> np.ndarray:
     """[..., epochs, 3, 2] -> [..., 2]: mean of the recipe's own Hits@K over the last FINAL_EPOCHS epochs (valid, test)"""
-    ki = KS.index(RECIPES[recipe]["metric"])
+    ki = metrics_of(recipe).index(RECIPES[recipe]["metric"])
     return hits[..., -FINAL_EPOCHS:, ki, :].mean(-2)
 
 
 def epochs_to_level(hits: np.ndarray, recipe: str, level: float) -> np.ndarray:
     """[seeds, epochs, 3, 2] -> [seeds]: first epoch (1-based) whose VALID Hits@K reaches `level`; epochs + 1 if never"""
-    ki = KS.index(RECIPES[recipe]["metric"])
+    ki = metrics_of(recipe).index(RECIPES[recipe]["metric"])
     reached = hits[:, :, ki, 0] >= level
     first = reached.argmax(1) + 1
     return np.where(reached.any(1), first, hits.shape[1] + 1)
