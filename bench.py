@@ -605,7 +605,8 @@ def measure_step_launches(P, model, data, pos_b, neg_b, cfg, device):
                         "ratio_to_algorithmic": tj[key] / out[obj]["algorithmic_bytes"],
                         "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/bench_step_launches.py (the same "
                                "launch on a real batch; counted on the fabric side of L2, so Infinity-Cache hits are "
-                               "included; an earlier run, NOT measured in this one)"}
+                               "included; taken on the round-5 tree -- profiles/r05_agg_pmc_step_launches.json -- in a "
+                               "separate counter run, NOT measured in this one)"}
         except Exception:
             pass
     return out
