@@ -35,7 +35,8 @@ extern "C" {
  * 9 (round 4): plnlp_gemm_operand.b_terms / b_terms_bytes + plnlp_gemm_b_terms_bytes (the stationary-weights GEMM);
  *              plnlp_edge_lists_build / _workspace / _supported (the batch's index structures without a library sort).
  * 10 (round 5): plnlp_gemm_stationary_applies (the host asks the library's own rule before it lends b_terms and drops
- *              split-K), plnlp_launch_counts / plnlp_launch_kind_name (which kernel families have been launched). */
+ *              split-K), plnlp_launch_counts / plnlp_launch_kind_name (which kernel families have been launched),
+ *              plnlp_mlp_head_backward_f32 (the 1-output head's backward in one pass over the hidden activation). */
 #define PLNLP_ABI_VERSION 10
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
@@ -331,6 +332,18 @@ int plnlp_matvec_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t feat,
 int plnlp_outer_f32(const float* g, const float* w, int64_t n_rows, int64_t feat,
                     float* dx, int64_t lddx, const plnlp_epilogue* epi /* nullable: GATE */,
                     void* stream);
+/* The whole backward of that head behind a relu / dropout hidden layer in ONE pass over the hidden activation a
+ * (plnlp/layer.py:82-86: x = dropout(relu(lin(x))); x = lins[-1](x) -- autograd's four passes over [rows, feat]):
+ *   dz[r,f] = a[r,f] > 0 ? g[r] w[f] gate_scale : 0      (= plnlp_outer_f32 with the GATE epilogue, same bits)
+ *   sums[0 .. feat)        = dw[f]  = sum_r g[r] a[r,f]  (= plnlp_colsum_f32(a, row_weight = g), same bits)
+ *   sums[feat .. 2 feat)   = dbp[f] = sum_r dz[r,f]      (= plnlp_colsum_f32(dz), same bits: the hidden layer's bias gradient)
+ *   sums[2 feat]           = db     = sum_r g[r]         (the head's bias gradient; sums has 2 feat + 4 floats)
+ * feat % 4 == 0, feat <= 1024, 16-byte aligned a / dz / w / workspace (else PLNLP_E_UNSUPPORTED / _ALIGN: the caller keeps
+ * the separate entry points); workspace: plnlp_mlp_head_backward_workspace_floats(n_rows, feat) floats. */
+int64_t plnlp_mlp_head_backward_workspace_floats(int64_t n_rows, int64_t feat);
+int plnlp_mlp_head_backward_f32(const float* a, int64_t lda, const float* g, const float* w, float gate_scale,
+                                int64_t n_rows, int64_t feat, float* dz, int64_t lddz, float* sums,
+                                float* workspace, int64_t workspace_floats, void* stream);
 
 /* ---- K3: edge endpoint gather + score --------------------------------------
  * Replaces h[edge[0]], h[edge[1]] (plnlp/model.py:155-156,179-180) fused with

@@ -37,20 +37,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # sent the split's residuals through scratch memory)
     units.append(("gemm_f32.hip", "gemm_f32_x3.o", ["-DPLNLP_GEMM_BK=16", "-DPLNLP_GEMM_X3=1", "-fno-slp-vectorize"]))
     units.append(("gemm_x3s.hip", "gemm_x3s.o", ["-fno-slp-vectorize"]))
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "plnlp_hip.h"))
+    newest_header = max(os.path.getmtime(h) for h in headers)
     for src, oname, extra in units:
         obj = os.path.join(HERE, "build", oname)
+        objs.append(obj)
+        # a unit is recompiled when its source or any header is newer than its object (the objects carry the time their
+        # sources were read, like the library)
+        if (not force and os.path.exists(obj)
+                and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(CSRC, src)), newest_header)):
+            continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj] + extra
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
-    for src, p in procs:
+    for src, obj, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0 or verbose:
             print(f"--- {src} ---\n{out}", file=sys.stderr)
         failed |= p.returncode != 0
+        if p.returncode == 0:
+            os.utime(obj, (started, started))
     if failed:
         raise RuntimeError("hipcc failed")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

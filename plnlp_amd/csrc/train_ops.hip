@@ -441,6 +441,64 @@ __global__ __launch_bounds__(256) void outer_vec_kernel(const float* __restrict_
     }
 }
 
+// ---------------- the backward of a 1-output head, in one pass -------------------------
+// MLPPredictor's last linear has ONE output (layer.py:73, 86): score[r] = <a[r, :], w> + b, a = dropout(relu(z)) the
+// hidden activation.  Given g[r] = d loss / d score[r], everything its backward needs from `a` comes out of ONE read of it:
+//     dz[r, f]  = a[r, f] > 0 ? g[r] w[f] gate_scale : 0        gradient of the hidden pre-activation (outer product + gate)
+//     dw[f]     = sum_r g[r] a[r, f]                             the head's weight gradient
+//     dbp[f]    = sum_r dz[r, f]                                 the hidden layer's bias gradient
+//     db        = sum_r g[r]                                     the head's bias gradient
+// instead of four passes (outer product, two column sums over [rows, feat], one over g): 262 144 x 512 on ddi is 537 MB
+// per pass.  Same row -> (block, lane) assignment and the same fold order as colsum_partial_vec_kernel, so dw and dbp are
+// the bits plnlp_colsum_f32 gives; dz the bits of plnlp_outer_f32 with the gate epilogue.
+__global__ __launch_bounds__(256) void mlp_head_bwd_kernel(const float* __restrict__ a, int64_t lda,
+                                                           const float* __restrict__ g, const float* __restrict__ w,
+                                                           float gate_scale, int64_t n_rows, int feat,
+                                                           float* __restrict__ dz, int64_t lddz,
+                                                           float* __restrict__ partial) {
+    __shared__ float4 sm[2][256];
+    __shared__ float sg[256];
+    const int q = feat >> 2;              // float4 per row
+    const int lanes = 256 / q;            // rows per step
+    const int c4 = threadIdx.x % q, rl = threadIdx.x / q;
+    const int64_t stride = 2 * (int64_t)feat + 4;
+    float4 acc_w = make_float4(0.f, 0.f, 0.f, 0.f), acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc_g = 0.f;
+    if (rl < lanes) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + c4 * 4);
+        for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < n_rows; r += (int64_t)gridDim.x * lanes) {
+            const float4 v = *reinterpret_cast<const float4*>(a + r * lda + c4 * 4);
+            const float gr = g[r];
+            float4 d = make_float4(gr * wv.x, gr * wv.y, gr * wv.z, gr * wv.w);
+            d.x = v.x > 0.f ? d.x * gate_scale : 0.f; d.y = v.y > 0.f ? d.y * gate_scale : 0.f;
+            d.z = v.z > 0.f ? d.z * gate_scale : 0.f; d.w = v.w > 0.f ? d.w * gate_scale : 0.f;
+            *reinterpret_cast<float4*>(dz + r * lddz + c4 * 4) = d;
+            acc_w.x = fmaf(gr, v.x, acc_w.x); acc_w.y = fmaf(gr, v.y, acc_w.y);
+            acc_w.z = fmaf(gr, v.z, acc_w.z); acc_w.w = fmaf(gr, v.w, acc_w.w);
+            acc_b.x += d.x; acc_b.y += d.y; acc_b.z += d.z; acc_b.w += d.w;
+            if (c4 == 0) acc_g += gr;
+        }
+        sm[0][rl * q + c4] = acc_w;
+        sm[1][rl * q + c4] = acc_b;
+        if (c4 == 0) sg[rl] = acc_g;
+    }
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < lanes; ++k) {
+            const float4 v = sm[0][k * q + c4], u = sm[1][k * q + c4];
+            acc_w.x += v.x; acc_w.y += v.y; acc_w.z += v.z; acc_w.w += v.w;
+            acc_b.x += u.x; acc_b.y += u.y; acc_b.z += u.z; acc_b.w += u.w;
+        }
+        float* row = partial + (int64_t)blockIdx.x * stride;
+        *reinterpret_cast<float4*>(row + c4 * 4) = acc_w;
+        *reinterpret_cast<float4*>(row + feat + c4 * 4) = acc_b;
+        if (c4 == 0) {
+            for (int k = 1; k < lanes; ++k) acc_g += sg[k];
+            *reinterpret_cast<float4*>(row + 2 * feat) = make_float4(acc_g, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
 static inline unsigned ew_grid(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (unsigned)(b < 2048 ? (b > 0 ? b : 1) : 2048);
@@ -627,6 +685,32 @@ extern "C" int plnlp_colsum_f32(const float* x, int64_t ldx, int64_t n_rows, int
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((feat + 3) / 4)), dim3(256), 0, s, workspace, blocks,
                        (int)feat, scale, out);
+    return launch_status();
+}
+
+extern "C" int64_t plnlp_mlp_head_backward_workspace_floats(int64_t n_rows, int64_t feat) {
+    return colsum_blocks(n_rows) * (2 * feat + 4);
+}
+
+extern "C" int plnlp_mlp_head_backward_f32(const float* a, int64_t lda, const float* g, const float* w, float gate_scale,
+                                           int64_t n_rows, int64_t feat, float* dz, int64_t lddz, float* sums,
+                                           float* workspace, int64_t workspace_floats, void* stream) {
+    using namespace plnlp;
+    if (n_rows <= 0 || feat <= 0 || lda < feat || lddz < feat) return PLNLP_E_SHAPE;
+    if (!a || !g || !w || !dz || !sums || !workspace) return PLNLP_E_NULL;
+    const int64_t q = feat / 4;
+    if (feat % 4 != 0 || q > 256) return PLNLP_E_UNSUPPORTED;
+    if (lda % 4 != 0 || lddz % 4 != 0 || (uintptr_t)a % 16 != 0 || (uintptr_t)dz % 16 != 0 || (uintptr_t)w % 16 != 0 ||
+        (uintptr_t)workspace % 16 != 0) return PLNLP_E_ALIGN;
+    const int64_t blocks = colsum_blocks(n_rows);
+    if (workspace_floats < blocks * (2 * feat + 4)) return PLNLP_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mlp_head_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, lda, g, w, gate_scale, n_rows,
+                       (int)feat, dz, lddz, workspace);
+    if (int rc = launch_status()) return rc;
+    const int64_t cols = 2 * feat + 4;          // [dw | dbp | db, 0, 0, 0]: one reduction over the blocks for all three
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, s, workspace, blocks, (int)cols,
+                       1.0f, sums);
     return launch_status();
 }
 

@@ -649,6 +649,31 @@ def outer(g: torch.Tensor, w: torch.Tensor, epilogue: Optional[L.Epilogue] = Non
     return dx
 
 
+FUSE_HEAD_BACKWARD = {"enabled": True}
+
+
+def mlp_head_backward(a: torch.Tensor, g: torch.Tensor, w: torch.Tensor, gate_scale: float):
+    """(dz, dw, dbp, db) of a 1-output linear head behind a relu / dropout hidden activation `a`, from ONE pass over `a`
+    (plnlp_mlp_head_backward_f32) -- or None where that form does not apply (width, alignment): the caller then runs the
+    four separate passes.  dz [rows, feat], dw [1, feat], dbp [feat], db [1]."""
+    lib = L.load()
+    L.require_device(a, g, w)
+    n, f = a.shape
+    if not FUSE_HEAD_BACKWARD["enabled"] or n == 0 or f % 4 != 0 or f > 1024:
+        return None
+    a, g, w = _f32c(a), _f32c(g.reshape(-1)), _f32c(w.reshape(-1))
+    if _ld(a) % 4 != 0 or a.data_ptr() % 16 != 0 or w.data_ptr() % 16 != 0:
+        return None
+    dz = torch.empty(n, f, dtype=torch.float32, device=a.device)
+    sums = torch.empty(2 * f + 4, dtype=torch.float32, device=a.device)
+    nws = lib.plnlp_mlp_head_backward_workspace_floats(n, f)
+    ws = torch.empty(nws, dtype=torch.float32, device=a.device)
+    L.check(lib.plnlp_mlp_head_backward_f32(a.data_ptr(), _ld(a), g.data_ptr(), w.data_ptr(), float(gate_scale), n, f,
+                                            dz.data_ptr(), _ld(dz), sums.data_ptr(), ws.data_ptr(), nws, L.stream_ptr()),
+            "plnlp_mlp_head_backward_f32")
+    return dz, sums[:f].reshape(1, f), sums[f:2 * f], sums[2 * f:2 * f + 1]
+
+
 def gate(g: torch.Tensor, y: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu+dropout backward: g * scale where the forward output y > 0, else 0."""
     lib = L.load()
@@ -1931,14 +1956,32 @@ class MLPStackFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         grads = [None] * (2 * nl)
         d = _f32c(g)
+        bias_grad_ready = None      # the bias gradient of layer i, already produced by the pass that made d
         for i in range(nl - 1, -1, -1):
             w, b = params[2 * i], params[2 * i + 1]
             xi = xs[i]
             head = (i == nl - 1) and w.shape[0] == 1
+            if head and i > 0 and ctx.acts[i - 1].active:
+                # the head behind a relu / dropout layer: its weight and bias gradients, the gradient of the hidden
+                # pre-activation and THAT layer's bias gradient from one pass over the hidden activation
+                fused = mlp_head_backward(xi, d, w, ctx.acts[i - 1].scale)
+                if fused is not None:
+                    d, gw, bias_grad_ready, gb = fused
+                    if need[3 + 2 * i]:
+                        grads[2 * i] = gw
+                    if b is not None and need[4 + 2 * i]:
+                        grads[2 * i + 1] = gb
+                    continue
+            if bias_grad_ready is not None:
+                if b is not None and need[4 + 2 * i]:
+                    grads[2 * i + 1] = bias_grad_ready
+                b_done, bias_grad_ready = True, None
+            else:
+                b_done = False
             if need[3 + 2 * i]:
                 grads[2 * i] = (colsum(xi, row_weight=d).reshape(1, -1) if head
                                 else gemm([(d, xi)], True, False))
-            if b is not None and need[4 + 2 * i]:
+            if b is not None and need[4 + 2 * i] and not b_done:
                 grads[2 * i + 1] = colsum(d.reshape(-1, 1)) if head else colsum(d)
             if i == 0 and not need[0]:
                 d = None

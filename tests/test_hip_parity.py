@@ -1052,10 +1052,15 @@ def test_row_sparse_backward_equals_dense_backward(P, enc, layers, pred, in_feat
     res = _sparse_vs_dense_step(P, enc, layers, pred, in_feats=in_feats)
     (ld, gd), (ls, gs) = res["dense"], res["sparse"]
     assert ld == ls
+    # (the scorer's output bias has an exactly-zero true gradient -- the pairwise losses are invariant under a shift of all
+    # scores -- so what is compared there is the round-off of a cancelling sum of O(1) terms: its tolerance is set by the
+    # size of the gradients that do NOT cancel, not by its own size)
+    biggest = max(float(v.abs().max()) for v in gd.values())
     for key in gd:
         scale = max(1e-6, float(gd[key].abs().max()))
         err = float((gd[key] - gs[key]).abs().max())
-        assert err <= 2e-6 * scale + 1e-7, (enc, layers, pred, key, err, scale)
+        floor = 1e-7 if scale > 1e-4 * biggest else 1e-6 * biggest
+        assert err <= 2e-6 * scale + floor, (enc, layers, pred, key, err, scale, biggest)
 
 
 def test_side_stream_prologue_gives_identical_training(P):

@@ -94,6 +94,59 @@ def test_zero_row_launches_are_defined(P):
     assert ops.edge_dot_fwd(x, e, e).numel() == 0 and ops.edge_hadamard_fwd(x, e, e).shape == (0, 64)
 
 
+# --------------------------------------------------- the 1-output head's backward in one pass ----
+@pytest.mark.parametrize("rows,feat,p", [(5000, 512, 0.3), (777, 64, 0.0), (262144, 512, 0.3), (33, 200, 0.5)])
+def test_fused_head_backward_is_the_four_separate_passes(P, rows, feat, p):
+    """plnlp_mlp_head_backward_f32 (MLPPredictor's last linear behind relu + dropout, layer.py:82-86): dz, the head's weight
+    gradient and the hidden layer's bias gradient are the BITS of the separate passes (outer product with the gate
+    epilogue, plnlp_colsum_f32 with / without row weights); the head's bias gradient -- a sum of `rows` numbers in another
+    association -- to round-off; the four against float64.  Then through MLPStackFn: same gradients with the fusion on
+    and off (ddi's full scorer shape among the cases)."""
+    ops = P.ops
+    gen = torch.Generator().manual_seed(rows + feat)
+    z = torch.randn(rows, feat, generator=gen)
+    keep = (torch.rand(rows, feat, generator=gen) >= p).float() / (1.0 - p)
+    a = (torch.relu(z) * keep).cuda()                     # what the forward stored: dropout(relu(z))
+    g = torch.randn(rows, generator=gen).cuda()
+    w = (torch.randn(1, feat, generator=gen) * 0.1).cuda()
+    scale = 1.0 / (1.0 - p)
+    dz, dw, dbp, db = ops.mlp_head_backward(a, g, w, scale)
+    from plnlp_amd import _lib
+    want_dz = ops.outer(g, w, epilogue=_lib.make_epilogue(gate=a, gate_scale=scale))
+    assert torch.equal(dz, want_dz)
+    assert torch.equal(dw, ops.colsum(a, row_weight=g).reshape(1, -1))
+    assert torch.equal(dbp, ops.colsum(want_dz))
+    a64, g64, w64 = a.double().cpu(), g.double().cpu(), w.double().cpu()
+    dz64 = (g64[:, None] * w64) * (a64 > 0) * scale
+    close(dz, dz64, rtol=2e-6)
+    close(dw.reshape(-1), (g64[:, None] * a64).sum(0), rtol=1e-5)
+    close(dbp, dz64.sum(0), rtol=1e-5, atol=1e-5 * float(dz64.abs().sum(0).max()))
+    assert abs(float(db) - float(g64.sum())) <= 1e-5 * float(g64.abs().sum())
+    # the stack: fusion on == fusion off
+    if rows <= 5000:
+        lin1 = torch.nn.Linear(feat, feat).cuda()
+        x = torch.randn(rows, feat, generator=gen).cuda().requires_grad_(True)
+        grads = {}
+        for on in (True, False):
+            ops.FUSE_HEAD_BACKWARD["enabled"] = on
+            try:
+                for t in (x, lin1.weight, lin1.bias, w):
+                    t.grad = None
+                wl = w.detach().clone().requires_grad_(True)
+                bl = torch.zeros(1, device="cuda", requires_grad=True)
+                ops.manual_seed(5)
+                out = ops.MLPStackFn.apply(x, p, True, lin1.weight, lin1.bias, wl, bl)
+                out.backward(g.reshape(-1, 1))
+                grads[on] = [t.grad.clone() for t in (x, lin1.weight, lin1.bias, wl, bl)]
+            finally:
+                ops.FUSE_HEAD_BACKWARD["enabled"] = True
+        for i_, (u, v) in enumerate(zip(grads[True], grads[False])):
+            if i_ < 4:
+                assert torch.equal(u, v), i_
+            else:
+                close(u, v, rtol=1e-5, atol=1e-5 * float(g.abs().sum()))
+
+
 # ------------------------------------------------------------------ create_input_feat (ADVICE r4) ----
 def test_public_create_input_feat_is_the_real_matrix_with_its_gradient(P):
     """BaseModel.create_input_feat mirrors model.py:98-105: a caller gets torch.cat([emb.weight, data.x], -1) -- current
