@@ -927,6 +927,8 @@ def main():
         dt0, _ = timed_steps(solo, "none", 1, B, 0, collective=False, K=Km, W=Wm)
         step_1gpu = dt0 / Km * 1e3
         emb = solo.emb.weight
+        if P.ops.padded_base(emb.detach()) is not None:      # (a table kept padded is stepped as its whole buffer)
+            emb = P.ops.padded_base(emb.detach())
         st = [torch.zeros_like(emb) for _ in range(3)]
         table_adam = time_kernel(lambda: P.ops.adam_step(emb.detach(), st[0], st[1], st[2], lr=0.0, step=1), iters=5, warm=2) * 1e3
         del solo, st, emb

@@ -1681,6 +1681,20 @@ class GCNConvBlockFn(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+def padded_base(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """t = buf[:, :e] of a contiguous [n, ep] buffer with ep = e rounded up to 4 floats (BaseModel keeps an embedding table of
+    an unaligned width that way: its rows then start on 16-byte boundaries and the two pad columns stay zero for ever --
+    their gradient is zero, so Adam never moves them) -> that [n, ep] buffer as a tensor over the same storage; None when t
+    is anything else (contiguous, another stride, an offset)."""
+    if t.dim() != 2 or t.is_contiguous() or t.stride(1) != 1 or t.storage_offset() != 0:
+        return None
+    n, e = t.shape
+    ep = t.stride(0)
+    if ep != _pad4(e) or t.untyped_storage().nbytes() < n * ep * t.element_size():
+        return None
+    return torch.as_strided(t, (n, ep), (ep, 1))
+
+
 def _pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 
@@ -1785,8 +1799,11 @@ class GCNInputConvFn(torch.autograd.Function):
                   # refreshed per step (two copies instead of a fresh zero-filled matrix)
                   "wa": torch.zeros(w.shape[0], kp, dtype=torch.float32, device=w.device)}
             cache["gcn_input"] = st
-        ax, emb_pad = st["ax"], st["emb_pad"]
-        emb_pad[:, :e].copy_(emb_weight.detach())
+        ax = st["ax"]
+        emb_pad = padded_base(emb_weight.detach())       # the table itself when it is kept padded (BaseModel): no copy
+        if emb_pad is None:
+            emb_pad = st["emb_pad"]
+            emb_pad[:, :e].copy_(emb_weight.detach())
         csr_aggregate(graph, emb_pad, "sum", use_values=True, out=ax[:, :ep])          # A_hat emb, every step
         wa = st["wa"]
         wa[:, :e].copy_(w[:, :e])
@@ -1795,6 +1812,9 @@ class GCNInputConvFn(torch.autograd.Function):
         y = gemm([(ax, wa)], False, True, epilogue=epi)
         ctx.graph, ctx.act, ctx.dims = graph, act, (e, f, ep, fp)
         ctx.ax = ax            # persistent buffer: this step's backward runs before the next forward rewrites it
+        # a padded table takes its gradient in the padded layout too, set on the parameter directly (autograd would copy a
+        # strided gradient into a contiguous one: the 0.18 ms this avoids on citation2)
+        ctx.direct_grad_to = emb_weight if (padded_base(emb_weight.detach()) is not None and emb_weight.is_leaf) else None
         ctx.save_for_backward(wa, y if act.active else None)
         return y
 
@@ -1813,7 +1833,11 @@ class GCNInputConvFn(torch.autograd.Function):
             gw = torch.cat([gwa[:, :e], gwa[:, ep:ep + f]], dim=1)
         if need[0]:
             g_aemb = gemm([(dz, wa[:, :ep].contiguous())], False, False)              # [N, ep]: embedding columns only
-            gemb = csr_aggregate(graph.t(), g_aemb, "sum", use_values=True)[:, :e].contiguous()
+            full = csr_aggregate(graph.t(), g_aemb, "sum", use_values=True)           # (its pad columns are exact zeros)
+            if ctx.direct_grad_to is not None and ctx.direct_grad_to.grad is None:
+                ctx.direct_grad_to.grad = full[:, :e]                                   # a view: no copy
+            else:
+                gemb = full[:, :e].contiguous()
         return gemb, gw, gb, None, None, None, None
 
 

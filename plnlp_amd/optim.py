@@ -22,24 +22,45 @@ class FusedAdam(torch.optim.Optimizer):
         """clip: id(param) -> (squared-norm device scalar of the param's clip group, max_norm)"""
         for group in self.param_groups:
             b1, b2 = group["betas"]
-            entries = []
+            entries, copy_back = [], []
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 st = self.state[p]
+                # a table kept padded to 16-byte rows (ops.padded_base) is stepped in that layout, gradient and moments
+                # too: its pad columns hold zeros and a zero gradient, which Adam leaves where they are
+                pd, gd = ops.padded_base(p.data), ops.padded_base(p.grad)
+                padded = pd is not None and gd is not None and pd.shape == gd.shape
                 if not st:
                     st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    like = pd if padded else p
+                    st["exp_avg"] = torch.zeros_like(like, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(like, memory_format=torch.contiguous_format)
                 st["step"] += 1
                 sq, max_norm = (clip or {}).get(id(p), (None, 0.0))
+                if padded and st["exp_avg"].shape == pd.shape:
+                    entries.append((pd, gd, st["exp_avg"], st["exp_avg_sq"], st["step"], sq, max_norm))
+                    continue
+                if st["exp_avg"].shape != p.shape:          # (moments in the padded layout, this gradient is not)
+                    pd = ops.padded_base(p.data)
+                    gd = torch.zeros_like(pd)
+                    gd[:, :p.shape[1]].copy_(p.grad)
+                    entries.append((pd, gd, st["exp_avg"], st["exp_avg_sq"], st["step"], sq, max_norm))
+                    continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not p.data.is_contiguous():              # a strided parameter with a plain gradient: step a copy
+                    pc = p.data.contiguous()
+                    entries.append((pc, g, st["exp_avg"], st["exp_avg_sq"], st["step"], sq, max_norm))
+                    copy_back.append((p, pc))
+                    continue
                 entries.append((p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], sq, max_norm))
             # all tensors of the group in one launch (per 16): the handful of small encoder / predictor
             # weights next to the embedding table would otherwise cost a launch each
             ops.adam_multi(entries, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
                            weight_decay=group["weight_decay"], decoupled=group["decoupled"],
                            grad_scale=grad_scale)
+            for p, pc in copy_back:
+                p.data.copy_(pc)
 
 
 def fused_adam_state(opt: "FusedAdam", p: torch.nn.Parameter) -> Optional[dict]:

@@ -181,6 +181,55 @@ def test_public_create_input_feat_is_the_real_matrix_with_its_gradient(P):
         assert torch.equal(m.encoder(xi, data.adj_t), m.encoder(m.create_input_feat(data), data.adj_t))
 
 
+def test_unaligned_embedding_table_is_kept_padded_and_trains_to_the_same_bits(P):
+    """citation2's recipe (README.md:40) trains a 50-wide table next to 128 features under a GCN: BaseModel keeps such a
+    table padded to 16-byte rows (emb.weight = the [:, :50] view of a zero-padded [N, 52] buffer), the 52-wide
+    aggregation gathers from it directly, the gradient arrives and Adam steps in that layout -- and nothing changes:
+    five steps end on the bits of the model whose table is a plain contiguous [N, 50] tensor (which pays the padded copy
+    and the strided -> contiguous gradient copy every step).  state_dict holds the [N, 50] parameter either way."""
+    from plnlp_amd import ops
+    n, e, f, h, B, k = 3000, 50, 16, 64, 512, 3
+    g = to_graph(P, O.gcn_norm_csr(rand_csr(n, 20000, 21, weighted=False)))
+
+    class D:
+        pass
+    data = D()
+    data.adj_t = g
+    data.x = torch.randn(n, f, generator=torch.Generator().manual_seed(2)).cuda()
+    gen = torch.Generator().manual_seed(3)
+    pos = torch.randint(0, n, (5 * B, 2), generator=gen).cuda()
+    neg = torch.randint(0, n, (5 * B, k, 2), generator=gen).cuda()
+    out = {}
+    for padded in (True, False):
+        torch.manual_seed(9)
+        m = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=1.0, gnn_num_layers=2, mlp_num_layers=2, emb_hidden_channels=e,
+                        gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n, num_node_feats=f, gnn_encoder_name="GCN",
+                        predictor_name="MLP", loss_func="AUC", optimizer_name="Adam", device="cuda", use_node_feats=True,
+                        train_node_emb=True)
+        assert ops.padded_base(m.emb.weight.detach()) is not None and m.emb.weight.shape == (n, e)
+        m.param_init()
+        if padded:
+            init = {"emb": m.emb.weight.detach().clone(), "enc": {k_: v.clone() for k_, v in m.encoder.state_dict().items()},
+                    "pred": {k_: v.clone() for k_, v in m.predictor.state_dict().items()}}
+        else:
+            m.emb.weight.data = init["emb"].clone()                     # a plain contiguous table: the old path
+            m.encoder.load_state_dict(init["enc"])
+            m.predictor.load_state_dict(init["pred"])
+            assert ops.padded_base(m.emb.weight.detach()) is None
+        m.encoder.train()
+        m.predictor.train()
+        losses = [float(m.train_step(data, pos[i * B:(i + 1) * B], neg[i * B:(i + 1) * B], k)) for i in range(5)]
+        torch.cuda.synchronize()
+        if padded:
+            base = ops.padded_base(m.emb.weight.detach())
+            assert torch.equal(base[:, e:], torch.zeros_like(base[:, e:]))        # the pad columns never moved
+            assert m.emb.state_dict()["weight"].shape == (n, e)
+        out[padded] = (losses, m.emb.weight.detach().clone().contiguous(),
+                       torch.cat([p.detach().reshape(-1) for p in list(m.encoder.parameters()) + list(m.predictor.parameters())]))
+    assert out[True][0] == out[False][0]
+    assert torch.equal(out[True][1], out[False][1]) and torch.equal(out[True][2], out[False][2])
+
+
 # --------------------------------------------------------------- teacher-forced ddi epoch ----
 def _copy_state(model, ref):
     """the oracle trainer's parameters and Adam state into the HIP model (same parameter order: encoder, predictor, emb)"""

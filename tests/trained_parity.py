@@ -129,7 +129,9 @@ def initial_modules(recipe: str, seed: int):
     n = PROBLEMS[r["problem"]]["num_nodes"]
     torch.manual_seed(21 + 7919 * seed)
     h = width(recipe)
-    enc = O.GNNRef("SAGE", h, h, h, r["layers"], 0.0)
+    # (the wide legs aggregate through torch's CSR product -- the formulation bench.py's cpu_baseline times: the
+    # transparent gather + index_add form materialises [entries, h], 7 GB per pass in float64 on the dense graph)
+    enc = O.GNNRef("SAGE", h, h, h, r["layers"], 0.0, spmm_impl="sparse_csr" if recipe in WIDE else "index_add")
     pred = O.MLPPredictorRef(h, h, 1, 2, 0.0) if r["predictor"] == "MLP" else O.DotPredictorRef()
     emb = torch.nn.Embedding(n, h)
     enc.reset_parameters()
