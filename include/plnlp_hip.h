@@ -337,7 +337,7 @@ int plnlp_outer_f32(const float* g, const float* w, int64_t n_rows, int64_t feat
  *   dz[r,f] = a[r,f] > 0 ? g[r] w[f] gate_scale : 0      (= plnlp_outer_f32 with the GATE epilogue, same bits)
  *   sums[0 .. feat)        = dw[f]  = sum_r g[r] a[r,f]  (= plnlp_colsum_f32(a, row_weight = g), same bits)
  *   sums[feat .. 2 feat)   = dbp[f] = sum_r dz[r,f]      (= plnlp_colsum_f32(dz), same bits: the hidden layer's bias gradient)
- *   sums[2 feat]           = db     = sum_r g[r]         (the head's bias gradient; sums has 2 feat + 4 floats)
+ * (sums has 2 feat floats; the head's own bias gradient sum_r g[r] stays plnlp_colsum_f32 on the [rows, 1] vector)
  * feat % 4 == 0, feat <= 1024, 16-byte aligned a / dz / w / workspace (else PLNLP_E_UNSUPPORTED / _ALIGN: the caller keeps
  * the separate entry points); workspace: plnlp_mlp_head_backward_workspace_floats(n_rows, feat) floats. */
 int64_t plnlp_mlp_head_backward_workspace_floats(int64_t n_rows, int64_t feat);

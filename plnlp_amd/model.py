@@ -43,6 +43,9 @@ FUSE_LOSS_ACC = {"enabled": True}
 # row-sharded data parallelism: the last SAGE layer evaluated / back-propagated only at the rows of the rank's block that
 # the global batch touches (False: every row of the block)
 SHARD_SPARSE = {"enabled": True}
+# a trainable embedding table of an unaligned width under a first GCN layer kept padded to 16-byte rows (BaseModel.__init__);
+# False: a plain contiguous [N, e] table, padded and un-padded by a copy each step
+PAD_EMBEDDING_TABLE = {"enabled": True}
 
 
 class BaseModel(object):
@@ -112,7 +115,8 @@ class BaseModel(object):
         # 52-wide aggregation then gathers from the table itself (no per-step padded copy: 0.35 ms on citation2), the
         # gradient arrives in the same layout and Adam steps it there (no strided -> contiguous copy: 0.18 ms); the pad
         # columns hold zeros and a zero gradient for ever.  state_dict / create_input_feat see the [N, e] parameter.
-        if (self.emb is not None and self.device.type == "cuda" and train_node_emb and use_node_feats
+        if (PAD_EMBEDDING_TABLE["enabled"] and self.emb is not None and self.device.type == "cuda" and train_node_emb
+                and use_node_feats
                 and isinstance(self.encoder, BaseGNN) and len(self.encoder.convs) > 0
                 and isinstance(self.encoder.convs[0], GCNConv) and self.emb.weight.shape[1] % 4 != 0
                 and self.emb.weight.requires_grad and dp_exchange != "shard"):

@@ -653,9 +653,9 @@ FUSE_HEAD_BACKWARD = {"enabled": True}
 
 
 def mlp_head_backward(a: torch.Tensor, g: torch.Tensor, w: torch.Tensor, gate_scale: float):
-    """(dz, dw, dbp, db) of a 1-output linear head behind a relu / dropout hidden activation `a`, from ONE pass over `a`
-    (plnlp_mlp_head_backward_f32) -- or None where that form does not apply (width, alignment): the caller then runs the
-    four separate passes.  dz [rows, feat], dw [1, feat], dbp [feat], db [1]."""
+    """(dz, dw, dbp, db) of a 1-output linear head behind a relu / dropout hidden activation `a`: the first three from ONE
+    pass over `a` (plnlp_mlp_head_backward_f32), db = the column sum of g -- or None where that form does not apply (width,
+    alignment): the caller then runs the separate passes.  dz [rows, feat], dw [1, feat], dbp [feat], db [1]."""
     lib = L.load()
     L.require_device(a, g, w)
     n, f = a.shape
@@ -665,13 +665,13 @@ def mlp_head_backward(a: torch.Tensor, g: torch.Tensor, w: torch.Tensor, gate_sc
     if _ld(a) % 4 != 0 or a.data_ptr() % 16 != 0 or w.data_ptr() % 16 != 0:
         return None
     dz = torch.empty(n, f, dtype=torch.float32, device=a.device)
-    sums = torch.empty(2 * f + 4, dtype=torch.float32, device=a.device)
+    sums = torch.empty(2 * f, dtype=torch.float32, device=a.device)
     nws = lib.plnlp_mlp_head_backward_workspace_floats(n, f)
     ws = torch.empty(nws, dtype=torch.float32, device=a.device)
     L.check(lib.plnlp_mlp_head_backward_f32(a.data_ptr(), _ld(a), g.data_ptr(), w.data_ptr(), float(gate_scale), n, f,
                                             dz.data_ptr(), _ld(dz), sums.data_ptr(), ws.data_ptr(), nws, L.stream_ptr()),
             "plnlp_mlp_head_backward_f32")
-    return dz, sums[:f].reshape(1, f), sums[f:2 * f], sums[2 * f:2 * f + 1]
+    return dz, sums[:f].reshape(1, f), sums[f:2 * f], colsum(g.reshape(-1, 1))
 
 
 def gate(g: torch.Tensor, y: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -49,6 +49,9 @@ MODULE = [
      "`False`: the epoch's loss sum as three element-wise launches per step, as `model.py:169` does it"),
     ("model.SHARD_SPARSE['enabled']", "True",
      "`False`: the sharded step (`dp_exchange='shard'`) runs its last layer over the whole row block"),
+    ("model.PAD_EMBEDDING_TABLE['enabled']", "True",
+     "`False`: an embedding table of an unaligned width under a first GCN layer (citation2: 50) is a plain contiguous tensor, "
+     "padded for the aggregation and un-padded for Adam by a copy each step, instead of living padded to 16-byte rows"),
     ("ops.STEP_THROTTLE['depth']", "2",
      "steps the host may run ahead of the GPU; `0`: unbounded, side-stream tensors handed over with `record_stream`"),
     ("ops.PROLOGUE_OVERLAP['enabled']", "True",

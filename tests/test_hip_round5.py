@@ -121,6 +121,7 @@ def test_fused_head_backward_is_the_four_separate_passes(P, rows, feat, p):
     close(dz, dz64, rtol=2e-6)
     close(dw.reshape(-1), (g64[:, None] * a64).sum(0), rtol=1e-5)
     close(dbp, dz64.sum(0), rtol=1e-5, atol=1e-5 * float(dz64.abs().sum(0).max()))
+    assert torch.equal(db, ops.colsum(g.reshape(-1, 1)))
     assert abs(float(db) - float(g64.sum())) <= 1e-5 * float(g64.abs().sum())
     # the stack: fusion on == fusion off
     if rows <= 5000:
@@ -141,10 +142,7 @@ def test_fused_head_backward_is_the_four_separate_passes(P, rows, feat, p):
             finally:
                 ops.FUSE_HEAD_BACKWARD["enabled"] = True
         for i_, (u, v) in enumerate(zip(grads[True], grads[False])):
-            if i_ < 4:
-                assert torch.equal(u, v), i_
-            else:
-                close(u, v, rtol=1e-5, atol=1e-5 * float(g.abs().sum()))
+            assert torch.equal(u, v), i_
 
 
 # ------------------------------------------------------------------ create_input_feat ----
@@ -249,30 +247,33 @@ def _copy_state(model, ref):
                 st["step"] = 0
 
 
-@pytest.mark.parametrize("math", ["bf16x3", "f32"])
-def test_teacher_forced_ddi_epoch_agrees_step_by_step(P, math):
+@pytest.mark.parametrize("recipe,math,max_steps", [("ddi", "bf16x3", 100), ("ddi", "f32", 100), ("ddi_wide", "bf16x3", 6),
+                                                   ("collab_wide", "bf16x3", 6)])
+def test_teacher_forced_epoch_agrees_step_by_step(P, recipe, math, max_steps):
     """The ddi recipe's free-running epoch-1 loss sits 1e-3 (median) to 2e-2 (worst seed) from the float32 oracle's -- and
     the oracle's own float32 and float64 runs sit exactly as far apart (6e-4 / 1.9e-2 over the same 48 seeds, fixture
-    g11).  Lottery or logic?  Here the HIP model is RESET to the oracle's state (parameters, Adam moments, step count)
-    before each of the epoch's 24 steps and takes the same batch: every step's loss then agrees to 1e-5 and every
-    parameter after the step to 2e-6 in the bulk -- the steps are the reference's steps; what remains after a step is the
-    handful of elements whose gradient is round-off (the scorer's output bias: the pairwise loss is invariant under a
-    shift of all scores, so its true gradient is zero), which Adam moves by up to lr in a direction round-off decides.
-    That is what compounds over a free-running epoch."""
+    g11; at h = 512 the two oracles part by 4.5e-2 in the first epoch, fixture g12).  Lottery or logic?  Here the HIP model
+    is RESET to the oracle's state (parameters, Adam moments, step count) before each step of the epoch and takes the
+    same batch: every step's loss then agrees to 1e-5 and every parameter after the step to 2e-5 in its 99 % quantile --
+    the steps are the reference's steps; what remains after a step is the share of elements whose gradient is round-off
+    (the scorer's output bias first of all: the pairwise loss is invariant under a shift of all scores, so its true
+    gradient is zero), which Adam moves by up to lr in a direction round-off decides.  That is what compounds over a
+    free-running epoch.  The WIDE cases take their steps through the kernels the benchmark runs (asserted by the launch
+    counters): the sharp per-step statement for the recipes at h = 256 / 512."""
     import trained_parity as T
-    recipe, seed = "ddi", 0
+    seed = 0
     r = T.RECIPES[recipe]
     g = T.problem(recipe)
-    n = g["num_nodes"]
+    n, h = g["num_nodes"], T.width(recipe)
     old = P.ops.GEMM_MATH["mode"]
     P.ops.GEMM_MATH["mode"] = math
     try:
         enc, pred, emb = T.initial_modules(recipe, seed)
         adj = g["adj_t"]
-        ref = O.TrainerRef(enc, pred, emb, O.CSR(adj.rowptr, adj.col.to(torch.int64), None, n), loss_name=r["loss"],
-                           lr=r["lr"], clip_norm=r["clip"])
+        csr = O.CSR(adj.rowptr, adj.col.to(torch.int64), None, n)
+        ref = O.TrainerRef(enc, pred, emb, csr, loss_name=r["loss"], lr=r["lr"], clip_norm=r["clip"])
         m = P.BaseModel(lr=r["lr"], dropout=0.0, grad_clip_norm=r["clip"], gnn_num_layers=r["layers"], mlp_num_layers=2,
-                        emb_hidden_channels=T.H, gnn_hidden_channels=T.H, mlp_hidden_channels=T.H, num_nodes=n,
+                        emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n,
                         num_node_feats=0, gnn_encoder_name="SAGE", predictor_name=r["predictor"], loss_func=r["loss"],
                         optimizer_name="Adam", device="cuda", use_node_feats=False, train_node_emb=True)
         m.encoder.train()
@@ -283,28 +284,38 @@ def test_teacher_forced_ddi_epoch_agrees_step_by_step(P, math):
         data = D()
         data.adj_t = adj.to("cuda")
         torch.manual_seed(T.epoch_seed(0, seed))
-        pos = g["train"]
+        pos, w = g["train"], None
+        if r["walk_length"]:
+            walk = O.random_walk_ref(csr, pos.reshape(-1), r["walk_length"], T.walk_seed(0, seed))
+            pos, w = O.random_walk_pairs_ref(walk, r["walk_length"])
         _, neg = O.pos_neg_edges_ref("train", {"train": {"edge": pos}}, num_nodes=n, neg_sampler_name="local", num_neg=r["k"])
-        batches = O.batch_permutation(pos.size(0), r["batch"], True)
-        assert len(batches) >= 20
+        batches = O.batch_permutation(pos.size(0), r["batch"], True)[:max_steps]
+        assert len(batches) >= min(6, max_steps)
+        c0 = P.ops.launch_counts()
         worst_loss, worst_bulk, lottery = 0.0, 0.0, []
         for perm in batches:
             _copy_state(m, ref)
-            loss_hip = float(m.train_step(data, pos[perm].cuda(), neg[perm].cuda(), r["k"]))
-            loss_ref = float(ref.step(pos[perm], neg[perm], r["k"])[0])
+            wb = None if w is None else w[perm]
+            loss_hip = float(m.train_step(data, pos[perm].cuda(), neg[perm].cuda(), r["k"], None if wb is None else wb.cuda()))
+            loss_ref = float(ref.step(pos[perm], neg[perm], r["k"], wb)[0])
             worst_loss = max(worst_loss, abs(loss_hip - loss_ref) / abs(loss_ref))
             assert abs(loss_hip - loss_ref) <= 1e-5 * abs(loss_ref), (loss_hip, loss_ref)
             # after the step, from identical state: the bulk of every tensor agrees tightly; the stragglers moved at most lr
             torch.cuda.synchronize()
             for p, q in zip(m.para_list, ref.params):
-                d = (p.detach().cpu().double() - q.detach().double()).abs()
-                worst_bulk = max(worst_bulk, float(d.flatten().quantile(0.99) if d.numel() > 100 else 0.0))
+                d = (p.detach().cpu().double() - q.detach().double()).abs().flatten()
+                if d.numel() > 100:
+                    worst_bulk = max(worst_bulk, float(d.kthvalue(int(0.99 * d.numel()))[0]))
                 lottery.append(float((d > 1e-4).double().mean()))
                 assert float(d.max()) <= 2.0 * r["lr"] + 1e-7
-        print(f"teacher-forced ddi epoch, HIP {math}: {len(batches)} steps, worst per-step loss deviation {worst_loss:.2e}, worst "
+        dlt = _delta(P, c0)
+        print(f"teacher-forced {recipe} epoch, HIP {math}: {len(batches)} steps, worst per-step loss deviation {worst_loss:.2e}, worst "
               f"99 % quantile of |parameter - oracle| after a step {worst_bulk:.2e}, share of elements moved > 1e-4 apart in one "
-              f"step {np.mean(lottery):.2e} (mean over tensors and steps)")
+              f"step {np.mean(lottery):.2e} (mean over tensors and steps); launches {({k: v for k, v in dlt.items() if v})}")
         assert worst_bulk <= 2e-5
+        if recipe in T.WIDE:
+            assert dlt["gemm_x3s"] >= 2 * len(batches), dlt
+            assert dlt["agg_fused"] + dlt["agg_fused_hub_xcd"] + dlt["agg_vec_slabs"] + dlt["agg_chunk"] >= len(batches), dlt
     finally:
         P.ops.GEMM_MATH["mode"] = old
 
@@ -335,8 +346,8 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
       ddi_wide     ddi's own size and density (4 267 nodes, ~450 neighbours each), SAGE x2 + MLP at h = 512, 8 192 x (1 + 3)
                    = 32 768 scorer rows per step.
     Asserted: (a) by the launch counters, that the runs went through gemm_x3s and the fused / slab aggregation forms;
-    (b) epoch-1 loss of every seed vs the float32 oracle: 1e-4 (collab), 5e-3 (ddi -- the lottery the teacher-forced test
-    pins down); every epoch's loss within 4 x the oracle's own float32-float64 gap (+ 0.2 %);
+    (b) epoch-1 loss of every seed vs the float32 oracle within twice the oracle's own float32-float64 gap there (+ 1e-4),
+    every epoch's loss within 4 x that gap (+ 0.2 %) -- the lottery the teacher-forced test pins down;
     (c) the final level of the recipe's metric (collab: Hits@50; ddi: AUC -- after the 36 steps the CPU oracle can afford
     this recipe is still near chance at Hits@20, recorded, not asserted) within 0.3 points + 2 s.e. of the float32 oracle's
     over the 8 seeds, on valid and test."""
@@ -360,7 +371,10 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
     text = (f"{recipe}: {n} seeds x {losses.shape[1]} epochs; epoch-1 loss vs oracle f32: median {np.median(rel1):.2e} max {rel1.max():.2e}; "
             f"all epochs: HIP vs f32 median {np.median(rel):.2e} max {rel.max():.2e}; oracle f32 vs f64 median {np.median(gap):.2e} "
             f"max {gap.max():.2e}; launches {({k: v for k, v in d.items() if v})}")
-    assert rel1.max() <= (1e-4 if recipe == "collab_wide" else 5e-3), text
+    # (the oracle's own float32 and float64 runs part by 2.6e-4 (collab_wide) / 4.5e-2 (ddi_wide) in the FIRST epoch and by up
+    # to 1.5e-2 / 0.3 later -- ddi at h = 512 crosses its steep phase at a different epoch per seed and arithmetic; the HIP
+    # run is held to twice / four times that spread.  The sharp statement is the teacher-forced test above.)
+    assert rel1.max() <= 2.0 * gap[:, 0].max() + 1e-4, text
     assert rel.max() <= 4.0 * gap.max() + 2e-3, text
     # (c) level
     c = T.compare(hip, ref32, ref64, recipe)
