@@ -231,7 +231,8 @@ def test_trained_regime_hits_parity(P, golden, recipe, math):
         gets there at all;
       * the epoch-1 loss of every seed agrees with the float32 oracle (same walks, negatives, batches): collab at 1e-4;
         ddi -- 24 Adam steps on an MLP scorer inside the number, Adam's sign lottery on its zero-gradient biases
-        (profiles/r03_trajectory_drift.txt) -- median 5e-3, every seed 5e-2."""
+        (profiles/r03_trajectory_drift.txt) -- within 4 x (median) / 1.6 x (worst seed) of the gap between the oracle's
+        OWN float32 and float64 runs (round 5; was a flat 5e-3 / 5e-2)."""
     import trained_parity as T
     n = _seeds_of(T, recipe)
     assert n >= 32
@@ -245,7 +246,15 @@ def test_trained_regime_hits_parity(P, golden, recipe, math):
     if recipe == "collab":
         assert rel.max() <= 1e-4, rel.max()
     else:
-        assert np.median(rel) <= 5e-3 and rel.max() <= 5e-2, (np.median(rel), rel.max())
+        # round 5: the bound is what the lottery needs, measured -- the ORACLE's own float32 and float64 runs of these 48
+        # seeds part by median 6.3e-4 / max 1.86e-2 in this number (fixture g11), the HIP runs by 1.1e-3 / 2.0e-2 from the
+        # float32 oracle (profiles/r04_trained_curves_ddi_*.npz); and with the state reset to the oracle's before every step
+        # each of the epoch's steps agrees to 2e-7 (tests/test_hip_round5.py, teacher-forced).  Bound: 4 x the oracle's own
+        # median, 1.6 x its own worst seed.
+        loss64 = golden("g11_trained_curves")[f"{recipe}_f64_loss"][:n]
+        own = np.abs(loss32[:, 0] - loss64[:, 0]) / loss64[:, 0]
+        assert np.median(rel) <= 4.0 * np.median(own) and rel.max() <= 1.6 * own.max(), (np.median(rel), rel.max(),
+                                                                                         np.median(own), own.max())
     if n >= 48:
         assert np.abs(c["diff_f32"]).max() <= 0.3, text
     else:
