@@ -72,6 +72,11 @@ def parse():
                          "gradients, or -- shard -- activations of a row-sharded encoder.  default: shard for the "
                          "SAGE-on-embedding workloads (collab, ddi), grads otherwise")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling and control measurements (N > 1)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="FUNCTIONAL run of the N-rank path on ONE GPU: every rank on cuda:0, gloo instead of RCCL (which refuses "
+                         "two ranks on one device).  Executes everything an N-GPU run executes -- the launcher, the ranks' agreement "
+                         "on the exchange form, the data-parallel steps, the phase timers -- but its numbers are N processes "
+                         "time-slicing one GPU: the line says so (`shared_gpu`) and is not a scaling point")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher check without GPUs: the ranks rendezvous over gloo, do one all-reduce and rank 0 "
                          "prints a JSON line (no kernels run; not a measurement)")
@@ -752,6 +757,8 @@ def main():
         sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     if args.dry_run_cpu:
         sys.exit(dry_run_cpu(world, rank, args.dry_run_fail_rank))
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
@@ -760,7 +767,10 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         import datetime
-        torch.distributed.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
+        if args.share_gpu:
+            torch.distributed.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
         pg = torch.distributed.group.WORLD
         # every collective the step will use, once, on a tiny tensor with a known answer -- BEFORE anything expensive:
         # a broken fabric / environment fails here, by name, on every rank (its stderr is kept per rank by the launcher)
@@ -1135,7 +1145,8 @@ def main():
         "metric": "pos+neg edges scored/sec", "value": edges_per_step * K / dt, "unit": "edges/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "scaling_measured": bool(world > 1),
+        "scaling_measured": bool(world > 1 and not args.share_gpu),
+        "shared_gpu": bool(args.share_gpu),
         "scaling_note": ("per-GPU work fixed as N grows (weak).  No multi-GPU hardware was available to the build in any "
                          "round: no N > 1 value of this metric has ever been measured by it -- dp_prediction / dp_phases in an "
                          "N > 1 line are what to hold the driver's SCALE run against"),

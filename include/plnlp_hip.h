@@ -34,7 +34,7 @@ extern "C" {
  *              plnlp_pairwise_loss_tail_f32, plnlp_sqnorm_multi_sum_f32, plnlp_edge_endpoints, plnlp_compact_endpoints.
  * 9 (round 4): plnlp_gemm_operand.b_terms / b_terms_bytes + plnlp_gemm_b_terms_bytes (the stationary-weights GEMM);
  *              plnlp_edge_lists_build / _workspace / _supported (the batch's index structures without a library sort).
- * 10 (round 5): plnlp_gemm_stationary_applies (the host asks the library's own rule before it lends b_terms and drops
+ * 10 (round 5): plnlp_edge_lists_* removed (the sort-free builder lost its third same-box A/B); plnlp_gemm_stationary_applies (the host asks the library's own rule before it lends b_terms and drops
  *              split-K), plnlp_launch_counts / plnlp_launch_kind_name (which kernel families have been launched),
  *              plnlp_mlp_head_backward_f32 (the 1-output head's backward in one pass over the hidden activation). */
 #define PLNLP_ABI_VERSION 10
@@ -398,23 +398,6 @@ int plnlp_edge_endpoints(const int64_t* pos, int64_t n_pos, const int64_t* neg, 
 int plnlp_compact_endpoints(const int32_t* node_map, const int64_t* src, const int64_t* dst, int64_t n_edges,
                             const int32_t* item_other, int64_t n_items, int64_t* src_c, int64_t* dst_c,
                             int32_t* other_c, void* stream);
-/* ALL of the above for one edge batch in seven hand-written launches and no library sort (ABI 9, csrc/edge_lists.hip): the
- * node-sorted incidence lists (== plnlp_incidence_build), the touched-node compaction (== plnlp_compact_rows over seg_ptr)
- * and -- src_c / dst_c / other_c nullable -- the compact endpoint ids (== plnlp_compact_endpoints), bit for bit.  A stable
- * sort by node of items generated in increasing item order is "per node, its items in increasing order": each item's rank
- * inside its node's segment is all that is needed -- counts by integer atomics (order-independent), one scan that yields
- * seg_ptr AND the compaction, a scatter by arrival ticket, and a pass that puts every segment into increasing item order
- * (one thread for the short ones, a workgroup with an LDS bitmap over the item ids for the hubs).  Replaces what the
- * backward of `h[edge]` (plnlp/model.py:155-156: index_put_(accumulate=True), an unordered scatter-add in the reference)
- * needs to be a deterministic gather.  rows == NULL (then node_map, rowptr_c, count, src_c, dst_c, other_c NULL too): the lists
- * alone, for a batch whose backward is not row-sparse.  workspace: int32 [plnlp_edge_lists_workspace(n_edges, n_nodes)], uninitialised.
- * plnlp_edge_lists_supported: 0 when a batch is too large for the bitmap (n_edges > 2^19): use the entry points above. */
-int64_t plnlp_edge_lists_workspace(int64_t n_edges, int64_t n_nodes);
-int plnlp_edge_lists_supported(int64_t n_edges, int64_t n_nodes);
-int plnlp_edge_lists_build(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
-                           int32_t* item_edge, int32_t* item_other, int64_t* seg_ptr, int32_t* rows, int32_t* node_map,
-                           int64_t* rowptr_c, int64_t* count, int64_t* src_c, int64_t* dst_c, int32_t* other_c,
-                           int32_t* workspace, int64_t workspace_ints, void* stream);
 /* uniform random walks for the random-walk pair augmentation (main.py:241-253; replaces
  * torch_cluster.random_walk): walks[w, 0] = start[w], walks[w, l+1] = a uniformly chosen neighbour of
  * walks[w, l] (the node itself if it has none).  Randomness: counter hash of (seed, w*L + l). */

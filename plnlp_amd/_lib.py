@@ -88,9 +88,6 @@ SIGNATURES = {
     "plnlp_edge_endpoints": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plnlp_compact_endpoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
-    "plnlp_edge_lists_workspace": (c_i64, [c_i64, c_i64]),
-    "plnlp_edge_lists_supported": (C.c_int, [c_i64, c_i64]),
-    "plnlp_edge_lists_build": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64] + [C.c_void_p] * 11 + [c_i64, C.c_void_p]),
     "plnlp_compact_rows": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "plnlp_csr_aggregate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

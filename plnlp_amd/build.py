@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplnlp_hip.so")
 SOURCES = ["csr_aggregate.hip", "csr_aggregate_max.hip", "gemm_f32.hip", "edge_ops.hip", "train_ops.hip", "incidence.hip",
-           "edge_lists.hip", "host_perm.hip", "launch_log.hip"]
+           "host_perm.hip", "launch_log.hip"]
 
 
 def needs_build() -> bool:

@@ -221,7 +221,10 @@ class BaseModel(object):
         if self.process_group is not None:       # replicas must start identical
             for p in self.para_list:
                 dense = ops.padded_base(p.data)          # (a table kept padded travels as its whole buffer)
-                torch.distributed.broadcast(p.data if dense is None else dense, 0, group=self.process_group)
+                # (source = the group's first rank by its GLOBAL number: a sub-group need not contain global rank 0 --
+                # bench.py's one-rank groups on ranks >= 1 failed here until the shared-GPU run of round 5 executed them)
+                torch.distributed.broadcast(p.data if dense is None else dense,
+                                            torch.distributed.get_global_rank(self.process_group, 0), group=self.process_group)
 
     def create_input_feat(self, data):
         """model.py:98-105.  The public surface: always the real [emb.weight | data.x] matrix, with its autograd edge to
@@ -773,7 +776,7 @@ class BaseModel(object):
             # replicated encoder passes must draw the same dropout masks: rank 0's stream state wins
             st = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in ops.seed_state()], dtype=torch.int64,
                               device=self.device)
-            torch.distributed.broadcast(st, 0, group=self.process_group)
+            torch.distributed.broadcast(st, torch.distributed.get_global_rank(self.process_group, 0), group=self.process_group)
             base, counter = (int(v) for v in st.tolist())
             ops.set_seed_state(base, counter)
 

@@ -626,6 +626,46 @@ def colsum(x: torch.Tensor, scale: float = 1.0, row_weight: Optional[torch.Tenso
     return out
 
 
+# a conv's bias gradient (the column sums of dz: a 22 us bandwidth-bound pair of launches on collab) beside the weight-gradient
+# GEMM and the transposed aggregation instead of between them: nothing on the main stream needs it before the optimiser
+COLSUM_SIDE_STREAM = {"enabled": True, "min_rows": 16384}
+
+
+class SideColsum:
+    """colsum(x) started on the device's second side stream; `join()` -- to be called AFTER the launches it should overlap
+    have been enqueued and before the backward function returns -- makes the main stream wait for it and hands out the
+    result.  The buffers are allocated on the main stream (they outlive the side kernels through the join), x is kept
+    alive by the caller until join()."""
+
+    def __init__(self, x: torch.Tensor):
+        self.side = None
+        if (not COLSUM_SIDE_STREAM["enabled"] or not x.is_cuda or x.shape[0] < COLSUM_SIDE_STREAM["min_rows"]
+                or _step_scalars["active"] is not None):
+            self.out = colsum(x)
+            return
+        lib = L.load()
+        x = _f32c(x)
+        n, f = x.shape
+        self.out = torch.empty(f, dtype=torch.float32, device=x.device)
+        nws = lib.plnlp_colsum_workspace_floats(n, f)
+        self.ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+        main = torch.cuda.current_stream(x.device)
+        self.side = side_stream(x.device, 1)
+        self.side.wait_stream(main)                       # x is the output of work queued on the main stream
+        with torch.cuda.stream(self.side):
+            L.check(lib.plnlp_colsum_f32(x.data_ptr(), _ld(x), n, f, None, 1.0, self.out.data_ptr(), self.ws.data_ptr(), nws,
+                                         L.stream_ptr()), "plnlp_colsum_f32")
+            self.done = torch.cuda.Event()
+            self.done.record(self.side)
+        self.x = x
+
+    def join(self) -> torch.Tensor:
+        if self.side is not None:
+            torch.cuda.current_stream(self.out.device).wait_event(self.done)
+            self.side = self.x = self.ws = None
+        return self.out
+
+
 def matvec(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[r] = <x[r,:], w> + bias  (plnlp_matvec_f32)"""
     lib = L.load()
@@ -745,14 +785,6 @@ class Incidence:
         self.val = None            # set to the per-edge gradient g; indexed through val_index
         self.val_index = self.item_edge
         self._split = None
-        if EDGE_LISTS_FUSED["enabled"] and src.is_cuda and lib.plnlp_edge_lists_supported(e, int(n_nodes)):
-            # the same lists without the library sort (csrc/edge_lists.hip; rows = NULL: no touched-node compaction)
-            self._ws = torch.empty(lib.plnlp_edge_lists_workspace(e, int(n_nodes)), dtype=torch.int32, device=dev)
-            L.check(lib.plnlp_edge_lists_build(src.data_ptr(), dst.data_ptr(), e, int(n_nodes), self.item_edge.data_ptr(),
-                                               self.item_other.data_ptr(), self.seg_ptr.data_ptr(), None, None, None, None,
-                                               None, None, None, self._ws.data_ptr(), self._ws.numel(), L.stream_ptr()),
-                    "plnlp_edge_lists_build")
-            return
         keys = torch.empty(2, max(2 * e, 1), dtype=torch.int64, device=dev)
         tbytes = lib.plnlp_incidence_temp_bytes(e)
         temp = torch.empty(max(tbytes, 8), dtype=torch.uint8, device=dev)
@@ -826,56 +858,6 @@ class CompactIncidence:
         self.val_index = self.item_edge = inc.item_edge
         self.val = None
         self._split = None
-
-    @classmethod
-    def build_fused(cls, src: torch.Tensor, dst: torch.Tensor, n_nodes: int, count_host: Optional[torch.Tensor] = None,
-                    compact_endpoints: bool = True):
-        """Incidence(src, dst, n).compact() -- and, compact_endpoints, the endpoint / other-endpoint lists as compact rows --
-        through plnlp_edge_lists_build: the same tensors bit for bit in seven hand-written launches instead of a library
-        radix sort, its fills, and eight index kernels (csrc/edge_lists.hip).  Returns (lists, src_c, dst_c)."""
-        lib = L.load()
-        L.require_device(src, dst)
-        src, dst = _edge_idx(src), _edge_idx(dst)
-        e, n, dev = src.numel(), int(n_nodes), src.device
-        inc = Incidence.__new__(Incidence)
-        inc.n_nodes = inc.n_rows = inc.n_cols = n
-        inc.item_edge = torch.empty(2 * e, dtype=torch.int32, device=dev)
-        inc.item_other = torch.empty(2 * e, dtype=torch.int32, device=dev)
-        inc.seg_ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
-        inc.rowptr, inc.col, inc.val, inc.val_index, inc._split = inc.seg_ptr, inc.item_other, None, inc.item_edge, None
-        self = cls.__new__(cls)
-        self._rows_cap = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        self.node_map = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        self._rowptr_cap = torch.empty(n + 1, dtype=torch.int64, device=dev)
-        self._count_dev = torch.empty(1, dtype=torch.int64, device=dev)
-        both_c = other_c = None
-        if compact_endpoints:
-            both_c = torch.empty(2, e, dtype=torch.int64, device=dev)
-            other_c = torch.empty(2 * e, dtype=torch.int32, device=dev)
-        ws = torch.empty(lib.plnlp_edge_lists_workspace(e, n), dtype=torch.int32, device=dev)
-        L.check(lib.plnlp_edge_lists_build(src.data_ptr(), dst.data_ptr(), e, n, inc.item_edge.data_ptr(),
-                                           inc.item_other.data_ptr(), inc.seg_ptr.data_ptr(), self._rows_cap.data_ptr(),
-                                           self.node_map.data_ptr(), self._rowptr_cap.data_ptr(), self._count_dev.data_ptr(),
-                                           L.ptr(both_c[0]) if both_c is not None else None,
-                                           L.ptr(both_c[1]) if both_c is not None else None, L.ptr(other_c),
-                                           ws.data_ptr(), ws.numel(), L.stream_ptr()), "plnlp_edge_lists_build")
-        self._host = _pinned_count_buffer() if count_host is None else count_host
-        self._host.copy_(self._count_dev, non_blocking=True)
-        self._ready = None
-        if count_host is None:
-            self._ready = torch.cuda.Event()
-            self._ready.record()
-        self._count = None
-        self._base = inc
-        self.n_cols = self.n_nodes = n
-        self.col = self.item_other = inc.item_other
-        self.val_index = self.item_edge = inc.item_edge
-        self.val = None
-        self._split = None
-        self._ws = ws                      # (lives as long as the lists: the launches above read it)
-        if other_c is not None:
-            self._other_c = other_c
-        return self, (both_c[0] if both_c is not None else None), (both_c[1] if both_c is not None else None)
 
     @property
     def count(self) -> int:
@@ -1309,15 +1291,18 @@ def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
     """second HIP stream per device: bandwidth-bound backward kernels (transposed aggregation) run
     there next to the MFMA-bound weight-gradient GEMMs instead of after them.  which = 1: a further one (the
     embedding's update), so that it does not queue behind the next batch's index preparation"""
-    key = (torch.device(device).index or 0, which)
+    key = (torch.device(device).index or 0, which, SIDE_STREAM_PRIORITY["value"])
     if key not in _side_streams:
         # high priority: HIP hands out hardware queues per priority class, so this stream does not end
         # up multiplexed onto the main stream's hardware queue once a process group has created its own
         # streams (measured: as the 7th normal-priority stream it ran strictly AFTER the main stream's
         # queued kernels, i.e. no overlap at all), and its short kernels are dispatched promptly
         # next to the long ones
-        _side_streams[key] = torch.cuda.Stream(device=device, priority=-1)
+        _side_streams[key] = torch.cuda.Stream(device=device, priority=SIDE_STREAM_PRIORITY["value"])
     return _side_streams[key]
+
+
+SIDE_STREAM_PRIORITY = {"value": -1}      # (low / normal measured +0.5 %: profiles/r05_same_box_ab.txt)
 
 
 class GradSink:
@@ -1535,6 +1520,7 @@ class SAGEConvFn(torch.autograd.Function):
                 # the input is the embedding table and nothing but Adam consumes its gradient: update it in the
                 # epilogue of the aggregation that finishes that gradient (no 242 MB gradient written and read
                 # back).  The weight gradients read the OLD table, so they go first.
+                bias_sum = SideColsum(dz) if need[2] else None      # beside the weight gradients and the aggregation below
                 if need[1] and need[3]:
                     gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows, x1_compact=compact_fwd)
                 else:
@@ -1542,8 +1528,6 @@ class SAGEConvFn(torch.autograd.Function):
                         gwl = gemm([(dz, agg)], True, False, b_index=None if compact_fwd else sg.rows)
                     if need[3]:
                         gwr = gemm([(dz, x)], True, False, b_index=sg.rows)
-                if need[2]:
-                    gbl = colsum(dz)
                 ad = sink.adam
                 sc = _step_scalars["active"]
                 epi = L.make_epilogue(addend=gx_c, addend_index=sg.node_map,
@@ -1553,6 +1537,8 @@ class SAGEConvFn(torch.autograd.Function):
                 csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=x.data,
                               epilogue=epi)
                 sink.adam_applied = True
+                if bias_sum is not None:
+                    gbl = bias_sum.join()
                 return None, gwl, gbl, gwr, None, None, None, None, None, None
             out = sink.buffer if sink is not None else torch.empty(x.shape[0], cin, dtype=torch.float32,
                                                                    device=x.device)
@@ -2036,12 +2022,11 @@ def prepare_edge_backward(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, co
 
 
 PROLOGUE_OVERLAP = {"enabled": True}
-# the batch's index structures through plnlp_edge_lists_build (False: the sort-based entry points; A/B and the equality test)
-# Measured on one box, interleaved (profiles/r04_same_box_ab.txt): with the sort-free lists the step has 10 launches fewer and is
-# SLOWER -- collab 1.57 vs 1.54 ms, ddi and citation2 within 1 % -- its denser side-stream kernels disturb the step's own launches
-# more than the library sort's many short ones do.  So the sort-based entry points stay the default and the sort-free builder is the
-# opt-in (PLNLP_EDGE_LISTS=1): same tensors bit for bit, tested both ways.
-EDGE_LISTS_FUSED = {"enabled": os.environ.get("PLNLP_EDGE_LISTS", "0") == "1"}
+# (Rounds 4-5 built and measured a sort-free builder of the batch's index structures -- counts by atomics, a scan fused with the
+# compaction, scatter, per-segment ordering: the same tensors bit for bit in 10 launches fewer -- and removed it: on three same-box
+# A/B runs the collab step was 1.6-2.1 % SLOWER with it, at every side-stream priority (profiles/r04_same_box_ab.txt,
+# profiles/r05_same_box_ab.txt): its denser side-stream kernels disturb the step's own launches more than the library sort's many
+# short ones do.)
 
 
 JOIN_STATS = {"waited": 0, "skipped": 0}        # EdgeBatch.join: stream waits enqueued / found unnecessary
@@ -2147,12 +2132,7 @@ class EdgeBatch:
             self.dst = torch.cat(dst_parts) if len(dst_parts) > 1 else dst_parts[0].contiguous()
         self.incidence = None
         self.src_c = self.dst_c = None
-        if (build and compact and self._compact_endpoints and self.src.is_cuda and EDGE_LISTS_FUSED["enabled"]
-                and L.load().plnlp_edge_lists_supported(self.src.numel(), int(n_nodes))):
-            # lists, compaction and compact ids in one call (csrc/edge_lists.hip): no library sort on the step's side stream
-            self.incidence, self.src_c, self.dst_c = CompactIncidence.build_fused(self.src, self.dst, n_nodes, self._count_host)
-            self.incidence.row_split(split_threshold(n_nodes))
-        elif build and self.src.numel() > 0:
+        if build and self.src.numel() > 0:
             self.incidence = prepare_edge_backward(self.src, self.dst, n_nodes, compact, self._count_host)
             if self._compact_endpoints:
                 inc = self.incidence

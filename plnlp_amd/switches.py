@@ -28,9 +28,6 @@ ENV = [
      "`1`: `BaseModel.train` / `bench.py` replay the step from two hipGraphs (`plnlp_amd/capture.py`): host work per step "
      "1.06 -> 0.25 ms, GPU time +2 %, bit-identical results; `available`: only flips ROCm's graph-packet-capture flag at "
      "import (the test session)"),
-    ("PLNLP_EDGE_LISTS", "ops.EDGE_LISTS_FUSED['enabled']", "0",
-     "`1`: a batch's edge lists through `plnlp_edge_lists_build` (no library sort); same tensors, measured 1.6-2 % slower "
-     "per collab step"),
     ("PLNLP_HIP_LIB", "_lib.LIB_PATH", "plnlp_amd/libplnlp_hip.so",
      "path of another build of the same ABI (same-box A/B runs of a kernel variant)"),
     ("PLNLP_BENCH_DEADLINE_S", "bench.py launcher", "1500",
@@ -69,6 +66,11 @@ MODULE = [
     ("ops.FUSE_HEAD_BACKWARD['enabled']", "True",
      "`False`: the backward of MLPPredictor's 1-output head as four passes over the hidden activation (outer product, three "
      "column sums) instead of one (`plnlp_mlp_head_backward_f32`)"),
+    ("ops.COLSUM_SIDE_STREAM['enabled']", "True",
+     "`False`: a conv's bias gradient (column sums of dz) in line on the main stream instead of on the second side stream "
+     "beside the weight-gradient GEMM (-1.0 % on the collab step)"),
+    ("ops.SIDE_STREAM_PRIORITY['value']", "-1",
+     "HIP priority of the side streams (`0` normal, `1` low: both measured +0.5 %)"),
     ("ops.SPLIT_K_SLOTS['slots']", "512",
      "workgroup slots one round of a split-K launch fills (768 measured +-5 % depending on the shape)"),
     ("ops.EDGE_BACKWARD['mode']", "segment",

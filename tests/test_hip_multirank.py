@@ -338,3 +338,25 @@ def test_the_children_ran_the_hip_library_and_every_collective():
             st = res["_staged"]
             # device-tensor calls of each collective, native or staged: 'shard' needs all three; 'scores' the all-gather
             assert st["all_gather_into_tensor"] > 0 and st["reduce_scatter_tensor"] > 0 and st["all_to_all_single"] > 0, st
+
+
+def test_bench_runs_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2 --share-gpu`: the driver's multi-GPU command line, executed -- launcher, rendezvous, collective
+    self-test, every rank MEASURING the one-rank forms and the ranks AGREEING on the exchange form (they used to
+    choose each from its own noisy timings), the data-parallel timed steps, the phase timers, one JSON line from rank 0 --
+    with both ranks on cuda:0 over gloo.  Its numbers are two processes time-slicing one GPU (`shared_gpu`), not a scaling
+    point; what it proves is that the N > 1 path runs end to end on the HIP kernels."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLNLP_BENCH_DEADLINE_S="600")
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "6", "--warmup",
+                          "3", "--scale", "0.25", "--no-strong"], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-4000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["shared_gpu"] is True and line["scaling_measured"] is False
+    assert line["value"] > 0 and line["config"]["parallelism"].startswith("dp2")
+    assert line["rccl_ranks"] == 2
+    pred = line.get("dp_prediction") or {}
+    assert pred.get("choice") in ("grads", "scores", "shard"), pred

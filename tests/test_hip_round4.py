@@ -689,117 +689,6 @@ def test_config5_one_ranks_true_share_of_the_full_problem(P):
         assert float((agg[r].double() - ref).abs().max()) <= 1e-5 * max(scale, 1e-3), r
 
 
-# ------------------------------------------------ the batch's index structures without a library sort ----
-@contextlib.contextmanager
-def _edge_lists(ops, fused: bool):
-    """ops.EDGE_LISTS_FUSED for the duration (True: plnlp_edge_lists_build, False: the sort-based entry points)"""
-    was = ops.EDGE_LISTS_FUSED["enabled"]
-    ops.EDGE_LISTS_FUSED["enabled"] = fused
-    try:
-        yield
-    finally:
-        ops.EDGE_LISTS_FUSED["enabled"] = was
-
-
-def _sort_based_lists(ops, src, dst, n_nodes):
-    """the reference structures: plnlp_incidence_build (rocPRIM radix sort) + plnlp_compact_rows + compact columns"""
-    with _edge_lists(ops, False):
-        base = ops.Incidence(src, dst, n_nodes)
-        assert not hasattr(base, "_ws")
-        inc = base.compact()
-        inc.prepare_compact_columns()
-    return inc
-
-
-@pytest.mark.parametrize("n_nodes,n_pos,k,hub", [(235_868, 65_536, 1, 3000), (4267, 65_536, 3, 0), (2_927_963, 65_536, 3, 0),
-                                                 (50, 7, 1, 0), (1000, 1, 1, 0), (70_000, 40_000, 2, 20_000)])
-def test_edge_lists_build_equals_the_sort_based_structures(P, n_nodes, n_pos, k, hub):
-    """plnlp_edge_lists_build (counts by atomics, one scan, scatter, per-segment ordering: csrc/edge_lists.hip) against
-    what it replaces -- plnlp_incidence_build (rocPRIM radix sort) + plnlp_compact_rows + plnlp_compact_endpoints -- on
-    the three recipes' batch geometries, tiny batches and a batch with 20 000-item hub segments: every tensor the backward
-    of the edge gathers reads, element for element (the order of a node's items decides the bits of its gradient sum),
-    twice (the arrival order of the atomics differs from launch to launch; the result must not)."""
-    from plnlp_amd import ops
-    gen = torch.Generator(device="cuda").manual_seed(n_nodes + n_pos)
-    e = n_pos * (1 + k)
-    src = torch.randint(0, n_nodes, (e,), device="cuda", generator=gen)
-    dst = torch.randint(0, n_nodes, (e,), device="cuda", generator=gen)
-    if hub:                                            # a few nodes that collect thousands of items, on both sides
-        src[:hub] = 7 % n_nodes
-        dst[hub // 2: hub // 2 + hub] = 11 % n_nodes
-        src[-hub // 4:] = n_nodes - 1
-    inc = _sort_based_lists(ops, src, dst, n_nodes)
-    want_src_c, want_dst_c = inc.node_map[src].long(), inc.node_map[dst].long()
-    with _edge_lists(ops, True):
-        plain = ops.Incidence(src, dst, n_nodes)        # rows = NULL: the lists alone (the non-compact backward, ddi)
-    assert hasattr(plain, "_ws")
-    assert torch.equal(plain.seg_ptr, inc._base.seg_ptr)
-    assert torch.equal(plain.item_edge, inc.item_edge) and torch.equal(plain.item_other, inc.item_other)
-    for _ in range(2):
-        got, src_c, dst_c = ops.CompactIncidence.build_fused(src, dst, n_nodes)
-        assert got.count == inc.count
-        assert torch.equal(got._base.seg_ptr, inc._base.seg_ptr)
-        assert torch.equal(got.item_edge, inc.item_edge) and torch.equal(got.item_other, inc.item_other)
-        assert torch.equal(got.node_map, inc.node_map)
-        assert torch.equal(got._rows_cap, inc._rows_cap) and torch.equal(got._rowptr_cap, inc._rowptr_cap)
-        assert torch.equal(got._other_c, inc._other_c)
-        assert torch.equal(src_c, want_src_c) and torch.equal(dst_c, want_dst_c)
-
-
-def test_edge_lists_build_at_the_segment_class_boundaries(P):
-    """segments of exactly 1, 2, 3, 63, 64, 65, 1023, 1024, 1025 and 5000 items (thread / wave / workgroup rank sort /
-    bitmap: csrc/edge_lists.hip order_kernel) next to each other, items interleaved in a random order"""
-    from plnlp_amd import ops
-    sizes = [1, 2, 3, 63, 64, 65, 1023, 1024, 1025, 5000, 2, 64, 1, 1024]
-    n_nodes = 400
-    nodes = torch.repeat_interleave(torch.arange(len(sizes)) * 7 + 5, torch.tensor(sizes))
-    gen = torch.Generator().manual_seed(1)
-    nodes = nodes[torch.randperm(nodes.numel(), generator=gen)]
-    e = nodes.numel() // 2
-    src, dst = nodes[:e].cuda(), nodes[e:2 * e].cuda()
-    inc = _sort_based_lists(ops, src, dst, n_nodes)
-    for _ in range(3):
-        got, src_c, dst_c = ops.CompactIncidence.build_fused(src, dst, n_nodes)
-        assert got.count == inc.count
-        assert torch.equal(got._base.seg_ptr, inc._base.seg_ptr)
-        assert torch.equal(got.item_edge, inc.item_edge) and torch.equal(got.item_other, inc.item_other)
-        assert torch.equal(got._other_c, inc._other_c)
-        assert torch.equal(got._rows_cap, inc._rows_cap) and torch.equal(got._rowptr_cap, inc._rowptr_cap)
-
-
-def test_training_steps_with_the_fused_edge_lists_are_bit_identical(P):
-    """three collab-recipe steps (row-sparse forward / backward, the table's Adam in the aggregation epilogue, dropout on)
-    with the batch's index structures from plnlp_edge_lists_build and from the sort-based entry points: the same losses
-    and the same parameters, bit for bit"""
-    from plnlp_amd import ops, synthetic
-    g = synthetic.make_graph("collab", seed=4, device="cpu", num_nodes=20_000, num_edges=150_000, weighted=True)
-    data = g["data"]
-    data.adj_t = g["adj_t"].to("cuda")
-    gen = torch.Generator().manual_seed(3)
-    pos = g["edges"][torch.randint(0, g["edges"].size(0), (3 * 8192,), generator=gen)].cuda()
-    neg = torch.randint(0, 20_000, (3 * 8192, 1, 2), generator=gen).cuda()
-    w = (g["weight"][:3 * 8192] / 5.0).cuda()
-    out = {}
-    for fused in (True, False):
-        with _edge_lists(ops, fused):
-            torch.manual_seed(9)
-            P.manual_seed(9)
-            m = P.BaseModel(lr=0.01, dropout=0.3, grad_clip_norm=1.0, gnn_num_layers=1, mlp_num_layers=2,
-                            emb_hidden_channels=64, gnn_hidden_channels=64, mlp_hidden_channels=64, num_nodes=20_000,
-                            num_node_feats=0, gnn_encoder_name="SAGE", predictor_name="DOT", loss_func="WeightedHingeAUC",
-                            optimizer_name="Adam", device="cuda", use_node_feats=False, train_node_emb=True)
-            m.param_init()
-            m.encoder.train()
-            losses = [float(m.train_step(data, pos[i * 8192:(i + 1) * 8192], neg[i * 8192:(i + 1) * 8192], 1,
-                                         w[i * 8192:(i + 1) * 8192])) for i in range(3)]
-            torch.cuda.synchronize()
-            out[fused] = (losses, [p.detach().clone() for p in m.para_list])
-    assert out[True][0] == out[False][0]
-    for a, b in zip(out[True][1], out[False][1]):
-        assert torch.isfinite(a).all()
-        assert torch.equal(a, b)
-
-
 @contextlib.contextmanager
 def _stale_memory_is_nan():
     """every float tensor the host side takes from torch.empty / torch.empty_like on the GPU arrives full of NaN (what a
@@ -836,13 +725,12 @@ def test_full_size_steps_do_not_depend_on_stale_memory(P, name):
         torch.cuda.synchronize()
         return [float(l) for l in losses], [p.detach().clone() for p in m.para_list]
     l1, p1 = run()
-    for fused in (False, True):            # ... with the sort-based index preparation and with plnlp_edge_lists_build
-        with _stale_memory_is_nan(), _edge_lists(P.ops, fused):
-            l2, p2 = run()
-        assert all(np.isfinite(l1)) and l1 == l2, (fused, l1, l2)
-        for a, b in zip(p1, p2):
-            assert torch.isfinite(b).all()
-            assert torch.equal(a, b)
+    with _stale_memory_is_nan():
+        l2, p2 = run()
+    assert all(np.isfinite(l1)) and l1 == l2, (l1, l2)
+    for a, b in zip(p1, p2):
+        assert torch.isfinite(b).all()
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("feat", [64, 256])
