@@ -36,7 +36,8 @@ extern "C" {
  *              plnlp_edge_lists_build / _workspace / _supported (the batch's index structures without a library sort).
  * 10 (round 5): plnlp_edge_lists_* removed (the sort-free builder lost its third same-box A/B); plnlp_gemm_stationary_applies (the host asks the library's own rule before it lends b_terms and drops
  *              split-K), plnlp_launch_counts / plnlp_launch_kind_name (which kernel families have been launched),
- *              plnlp_mlp_head_backward_f32 (the 1-output head's backward in one pass over the hidden activation). */
+ *              plnlp_mlp_head_backward_f32 (the 1-output head's backward in one pass over the hidden activation),
+ *              PLNLP_EPI_ROWDOT + plnlp_gemm_rowdot_tiles / plnlp_rowdot_finish_f32 (its forward in the hidden GEMM's epilogue). */
 #define PLNLP_ABI_VERSION 10
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
@@ -61,6 +62,7 @@ const char* plnlp_error_string(int code);
                                     applied where PLNLP_EPI_ACCUM is */
 #define PLNLP_EPI_ADAM     64u   /* the result is the gradient of the parameter `out`: one Adam step on it instead of
                                     a store (see the adam_* fields; plnlp_csr_aggregate_f32 only) */
+#define PLNLP_EPI_ROWDOT 128u   /* also emit per-tile row dot products with rowdot_w (see plnlp_epilogue; the stationary GEMM only) */
 
 typedef struct plnlp_epilogue {
     uint32_t     flags;
@@ -95,6 +97,15 @@ typedef struct plnlp_epilogue {
      *                      (overrides adam_lr / adam_step)                                                        */
     const uint64_t* dropout_seed_ptr;
     const float*    adam_scalars;
+    /* PLNLP_EPI_ROWDOT (plnlp_gemm_f32 on the stationary-weights kernel only, else PLNLP_E_UNSUPPORTED): besides storing the
+     * result, the launch writes, per column tile t of the result, the partial row dot products
+     *     rowdot_out[t * rowdot_ld + r] = sum_{c in tile t} y[r, c] * rowdot_w[c]        (y = the stored, post-epilogue value)
+     * -- MLPPredictor's 1-output last linear (plnlp/layer.py:86) evaluated in the epilogue of the hidden layer's product
+     * instead of by a second pass over the [rows, hidden] activation.  plnlp_gemm_rowdot_tiles(m, n) = the number of
+     * tiles t (0: the form does not apply to this shape); plnlp_rowdot_finish_f32 adds the tiles in order (+ the bias). */
+    const float*    rowdot_w;      /* [n_cols] */
+    float*          rowdot_out;    /* [tiles, rowdot_ld] */
+    int64_t         rowdot_ld;     /* >= n_rows */
 } plnlp_epilogue;
 
 /* ---- K1/K2: CSR neighbour gather-and-reduce --------------------------------
@@ -256,6 +267,12 @@ int64_t plnlp_gemm_b_terms_bytes(int64_t m, int64_t n, int64_t k0, int64_t k1);
  * host-side mirror of it that `F.linear`'s callers kept, plnlp/layer.py:83,86).  No launch, no device access. */
 int plnlp_gemm_stationary_applies(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, const float* c,
                                   int64_t ldc, int64_t m, int64_t n, const float* c2, int64_t ldc2, int64_t n_split);
+/* column tiles of the stationary-weights kernel's result for an [m, n] product = rows of plnlp_epilogue.rowdot_out that a
+ * PLNLP_EPI_ROWDOT launch writes; 0 when the row-dot epilogue is not available for this shape (tile widths 128 / 256 only) */
+int plnlp_gemm_rowdot_tiles(int64_t m, int64_t n);
+/* out[r] = (bias ? *bias : 0) + sum_t partial[t * ld + r], t = 0 .. tiles-1 in order (the tail of PLNLP_EPI_ROWDOT) */
+int plnlp_rowdot_finish_f32(const float* partial, int64_t ld, int tiles, int64_t n_rows, const float* bias /* nullable, DEVICE */,
+                            float* out, void* stream);
 /* measurement knob of the stationary-weights form (process-global; A/B runs only, not for concurrent launches):
  * nb = 1 / 2 / 4 / 7 / 8 forces the column-tile width (x 32 columns), 0 = automatic; min_rows > 0 changes the number of
  * rows of A from which the form is used at all (default 16 384; the caller must lend b_terms for such launches too) */

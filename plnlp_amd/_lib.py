@@ -28,7 +28,8 @@ class Epilogue(C.Structure):
                 ("ld_addend", C.c_int64), ("addend_index", C.c_void_p), ("dropout_row_index", C.c_void_p),
                 ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_step", C.c_int64),
                 ("adam_lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
-                ("dropout_seed_ptr", C.c_void_p), ("adam_scalars", C.c_void_p)]
+                ("dropout_seed_ptr", C.c_void_p), ("adam_scalars", C.c_void_p),
+                ("rowdot_w", C.c_void_p), ("rowdot_out", C.c_void_p), ("rowdot_ld", C.c_int64)]
 
 
 class RowSplit(C.Structure):
@@ -56,7 +57,7 @@ class AdamTensor(C.Structure):
 
 MULTI_MAX = 16
 GEMM_MATH_F32, GEMM_MATH_BF16X3 = 0, 1
-EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND, EPI_ADAM = 1, 2, 4, 8, 16, 32, 64
+EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND, EPI_ADAM, EPI_ROWDOT = 1, 2, 4, 8, 16, 32, 64, 128
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 AGG_LDS_STAGE = 2
 AGG_NT_LOADS = 4
@@ -103,6 +104,8 @@ SIGNATURES = {
                                  c_i64, C.POINTER(Epilogue), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
     "plnlp_gemm_b_terms_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "plnlp_gemm_stationary_tuning": (None, [C.c_int, C.c_int]),
+    "plnlp_gemm_rowdot_tiles": (C.c_int, [c_i64, c_i64]),
+    "plnlp_rowdot_finish_f32": (C.c_int, [C.c_void_p, c_i64, C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plnlp_gemm_stationary_applies": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
                                                 c_i64, C.c_void_p, c_i64, c_i64]),
     "plnlp_mlp_head_backward_workspace_floats": (c_i64, [c_i64, c_i64]),

@@ -89,6 +89,10 @@ struct Epi {
     float        adam_lr, adam_b1, adam_b2, adam_eps, adam_bc1, adam_bc2_sqrt;
     const float* adam_scalars;  // nullable: {lr, 1 - beta1^t, sqrt(1 - beta2^t)} of THIS step in device memory
                                 // (plnlp_adam_step_scalars); overrides adam_lr / adam_bc1 / adam_bc2_sqrt
+    // PLNLP_EPI_ROWDOT (gemm_x3s only)
+    const float* rowdot_w;
+    float*       rowdot_out;
+    int64_t      rowdot_ld;
 };
 
 // the dropout seed of this launch: from device memory when the caller put it there
@@ -113,12 +117,18 @@ __device__ __forceinline__ void adam_update(float& pi, float gi, float& mi, floa
     pi = pi - step * (mi / denom);
 }
 
-inline int make_epi(const plnlp_epilogue* e, Epi* out, bool allow_adam = false) {
+inline int make_epi(const plnlp_epilogue* e, Epi* out, bool allow_adam = false, bool allow_rowdot = false) {
     Epi d{};
     d.keep_scale = 1.f;
     d.gate_scale = 1.f;
     if (e) {
         d.flags = e->flags;
+        if (d.flags & PLNLP_EPI_ROWDOT) {
+            if (!allow_rowdot) return PLNLP_E_UNSUPPORTED;
+            if (!e->rowdot_w || !e->rowdot_out) return PLNLP_E_NULL;
+            if ((uintptr_t)e->rowdot_w % 16) return PLNLP_E_ALIGN;
+            d.rowdot_w = e->rowdot_w; d.rowdot_out = e->rowdot_out; d.rowdot_ld = e->rowdot_ld;
+        }
         if (d.flags & PLNLP_EPI_ADAM) {
             if (!allow_adam || (d.flags & PLNLP_EPI_ACCUM)) return PLNLP_E_UNSUPPORTED;
             if (!e->adam_m || !e->adam_v) return PLNLP_E_NULL;

@@ -1018,6 +1018,13 @@ extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_t
 
 extern "C" void plnlp_gemm_stationary_tuning(int nb, int min_rows) { plnlp::x3s::set_tuning(nb, min_rows); }
 
+extern "C" int plnlp_gemm_rowdot_tiles(int64_t m, int64_t n) {
+    if (m <= 0 || n <= 0) return 0;
+    const int nb = plnlp::x3s::pick_nb(m, n);
+    if (nb != 4 && nb != 8) return 0;
+    return (int)((n + 32 * nb - 1) / (32 * nb));
+}
+
 extern "C" int64_t plnlp_gemm_b_terms_bytes(int64_t m, int64_t n, int64_t k0, int64_t k1) {
     if (m <= 0 || n <= 0 || k0 <= 0 || k1 < 0) return 0;
     const int64_t k[2] = {k0, k1};
@@ -1088,7 +1095,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
                   (!c2 || ((n_split % 4 == 0) && (ldc2 % 4 == 0) && ((uintptr_t)c2 % 16 == 0))) &&
                   (split_k <= 1 || ((uintptr_t)workspace % 16 == 0));
     Epi e;
-    if (int rc = make_epi(epi, &e)) return rc;
+    if (int rc = make_epi(epi, &e, /*allow_adam=*/false, /*allow_rowdot=*/true)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int64_t gm = (m + BM - 1) / BM, gn = (n + BN - 1) / BN;
     if (gm > 0x7FFFFFFF || gn > 65535 || split_k > 65535) return PLNLP_E_SHAPE;
@@ -1140,6 +1147,7 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
             return x3s::launch(sp, xa, nb, e, s);
         }
     }
+    if (e.flags & PLNLP_EPI_ROWDOT) return PLNLP_E_UNSUPPORTED;      // the row-dot epilogue lives in the stationary kernel only
     const int reduce_slices = split_k;
     g.mt0 = 0; g.nt0 = 0; g.gm = gm; g.gn = (int)gn; g.z0 = 0;
     auto launch_grid = [&](const GemmArgs& ga, int md, dim3 grid) -> int {

@@ -158,7 +158,9 @@ __device__ __forceinline__ void load_a(const Args& g, const float* p0, const flo
 // (A K loop with TWO steps of load look-ahead was built and measured in round 4 -- three raw A sets through untracked inline-asm
 // loads, three LDS stages, one counted s_waitcnt vmcnt + a bare s_barrier per step, the B fragments read one column block
 // at a time to fit the registers: 2-4 % SLOWER than this one on every shape (profiles/r04_gemm_deep_loop.jsonl), removed.)
-template <int NB, bool RAGGED>
+// ROWDOT (PLNLP_EPI_ROWDOT, NB = 4 / 8): the write-back also forms, per row, the dot product of this tile's stored values with
+// rowdot_w -- a 1-output linear on top of this layer (MLPPredictor's head) without a second pass over the activation.
+template <int NB, bool RAGGED, bool ROWDOT = false>
 __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s_kernel(Args g, Epi epi) {
     constexpr int WN = 32 * NB;
     constexpr int STAGE_UNITS = 6 * WN;                // 16-byte units of one K-step of the image
@@ -291,6 +293,9 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
     // the epilogue on float4.  (The barrier that ended the K loop freed the image buffers.)
     float* cw = reinterpret_cast<float*>(lds) + wave * 32 * CS;
     const int n0 = nt * WN;
+    float rd[8];                                               // ROWDOT: this lane's share of rows i * 4 + (lane >> 4)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rd[i] = 0.f;
     static_for<NB / 2 + (NB & 1)>([&](auto jc) {
         constexpr int j0 = 2 * decltype(jc)::value;
         constexpr int NJ = (j0 + 1 < NB) ? 2 : 1;
@@ -309,6 +314,8 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
         const bool pre = epi.flags && epi.vec4 && !(epi.flags & PLNLP_EPI_ADDEND);
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (col_ok && pre && (epi.flags & PLNLP_EPI_BIAS)) bias4 = *reinterpret_cast<const float4*>(epi.bias + col);
+        float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (ROWDOT) { if (col_ok) rw4 = *reinterpret_cast<const float4*>(epi.rowdot_w + col); }
         constexpr int RB = NB >= 7 ? 4 : 8;                    // rows per batch (the wide tiles have few registers to spare)
 #pragma unroll
         for (int i0 = 0; i0 < 8; i0 += RB) {
@@ -339,15 +346,37 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
                     if (pre) y = epi_apply4_pre(epi, y, orow, col, g.n, bias4, g4[i], p4[i]);
                     else y = epi_apply4(epi, y, orow, col, g.n, op);
                     *reinterpret_cast<float4*>(op + col) = y;
+                    if constexpr (ROWDOT) rd[i0 + i] += y.x * rw4.x + y.y * rw4.y + y.z * rw4.z + y.w * rw4.w;
                 }
             }
         }
     });
+    if constexpr (ROWDOT) {
+        // the 16 lanes that share a row (lane & 15 = their 16-byte column group) fold their shares in a fixed tree; the
+        // tile's partial goes to row nt of rowdot_out (plnlp_rowdot_finish_f32 adds the tiles in order)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = rd[i];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            const int64_t orow = row_w + i * 4 + (lane >> 4);
+            if ((lane & 15) == 0 && orow < g.m) epi.rowdot_out[(int64_t)nt * epi.rowdot_ld + orow] = v;
+        }
+    }
 }
 
 template <int NB>
 static int launch_nb(const Args& a, const Epi& e, bool ragged, hipStream_t s) {
     dim3 grid((unsigned)(a.gm * a.gn));
+    if (e.flags & PLNLP_EPI_ROWDOT) {
+        if constexpr (NB == 4 || NB == 8) {
+            if (e.rowdot_ld < a.m) return PLNLP_E_SHAPE;
+            if (ragged) hipLaunchKernelGGL((gemm_x3s_kernel<NB, true, true>), grid, dim3(256), 0, s, a, e);
+            else        hipLaunchKernelGGL((gemm_x3s_kernel<NB, false, true>), grid, dim3(256), 0, s, a, e);
+            return launch_status();
+        } else {
+            return PLNLP_E_UNSUPPORTED;
+        }
+    }
     if (ragged) hipLaunchKernelGGL((gemm_x3s_kernel<NB, true>), grid, dim3(256), 0, s, a, e);
     else        hipLaunchKernelGGL((gemm_x3s_kernel<NB, false>), grid, dim3(256), 0, s, a, e);
     return launch_status();

@@ -503,6 +503,18 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_kernel(const float* __restri
     }
 }
 
+// the tail of PLNLP_EPI_ROWDOT: out[r] = bias + sum of the column tiles' partial dot products, tiles in order
+__global__ __launch_bounds__(256) void rowdot_finish_kernel(const float* __restrict__ partial, int64_t ld, int tiles,
+                                                            int64_t n_rows, const float* __restrict__ bias,
+                                                            float* __restrict__ out) {
+    const float b = bias ? bias[0] : 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
+        float acc = partial[r];
+        for (int t = 1; t < tiles; ++t) acc += partial[(int64_t)t * ld + r];
+        out[r] = acc + b;
+    }
+}
+
 static inline unsigned ew_grid(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (unsigned)(b < 2048 ? (b > 0 ? b : 1) : 2048);
@@ -718,6 +730,17 @@ extern "C" int plnlp_mlp_head_backward_f32(const float* a, int64_t lda, const fl
     const int64_t cols = 2 * feat;              // [dw | dbp]: one reduction over the blocks for both
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, s, workspace, blocks, (int)cols,
                        1.0f, sums);
+    return launch_status();
+}
+
+extern "C" int plnlp_rowdot_finish_f32(const float* partial, int64_t ld, int tiles, int64_t n_rows, const float* bias,
+                                       float* out, void* stream) {
+    using namespace plnlp;
+    if (n_rows < 0 || tiles < 1 || ld < n_rows) return PLNLP_E_SHAPE;
+    if (n_rows == 0) return 0;
+    if (!partial || !out) return PLNLP_E_NULL;
+    hipLaunchKernelGGL(rowdot_finish_kernel, dim3(ew_grid(n_rows)), dim3(256), 0, (hipStream_t)stream, partial, ld, tiles,
+                       n_rows, bias, out);
     return launch_status();
 }
 

@@ -462,11 +462,14 @@ def _gemm_math() -> int:
     raise ValueError(f"GEMM_MATH mode {mode!r}: 'f32' or 'bf16x3'")
 
 
+FUSE_HEAD_FORWARD = {"enabled": True}
+
+
 def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_trans: bool,
          out: Optional[torch.Tensor] = None, epilogue: Optional[L.Epilogue] = None,
          split_k: Optional[int] = None, b_index: Optional[torch.Tensor] = None,
          a_index: Optional[Sequence[Optional[torch.Tensor]]] = None, a_index2: Optional[torch.Tensor] = None,
-         b_index2: Optional[torch.Tensor] = None) -> torch.Tensor:
+         b_index2: Optional[torch.Tensor] = None, rowdot: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None):
     """C = EPI(sum_s op(A_s) op(B_s))  (plnlp_gemm_f32).  A_s: [M,K] or [K,M] if
     a_trans; B_s: [N,K] if b_trans (nn.Linear weight layout) else [K,N].
     b_index (int32 [K], one segment, a_trans and not b_trans): B's row for reduction index j
@@ -475,7 +478,10 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     a_index[s][i] -- A_s is gathered in the loader (a layer evaluated at some rows only).
     a_index2 / b_index2 (int32, with a_index[0] / b_index, one segment, bf16x3 only): the gathered row is the
     elementwise PRODUCT of rows index[i] and index2[i] -- the Hadamard of an edge's endpoint rows formed in
-    the loader (MLPPredictor's first linear and its weight gradient)."""
+    the loader (MLPPredictor's first linear and its weight gradient).
+    rowdot = (w [n] or [1, n], bias [1] or None): also evaluate the 1-output linear  s[r] = <C[r, :], w> + bias  on the stored
+    result in the launch's epilogue (PLNLP_EPI_ROWDOT: the stationary-weights kernel only) -- returns (C, s [m, 1]), or
+    (C, None) when the launch does not take that form and the caller has to make its own pass over C."""
     lib = L.load()
     ops = (L.GemmOperand * len(segs))()
     ops[0].math = _gemm_math()
@@ -518,10 +524,28 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     if keep[-1] is not None:
         split_k = 1              # (the form never cuts K: few row panels get narrower column tiles instead)
     ws = torch.empty(split_k * m * n, dtype=torch.float32, device=out.device) if split_k > 1 else None
+    partial = None
+    if rowdot is not None:
+        tiles = lib.plnlp_gemm_rowdot_tiles(m, n) if (keep[-1] is not None and FUSE_HEAD_FORWARD["enabled"]) else 0
+        rw = _f32c(rowdot[0].reshape(-1))
+        if tiles > 0 and rw.data_ptr() % 16 == 0 and rw.numel() == n:
+            if epilogue is None:
+                epilogue = L.Epilogue()
+            partial = torch.empty(tiles, m, dtype=torch.float32, device=out.device)
+            epilogue.flags |= L.EPI_ROWDOT
+            epilogue.rowdot_w, epilogue.rowdot_out, epilogue.rowdot_ld = rw.data_ptr(), partial.data_ptr(), m
+            keep.append(rw)
     rc = lib.plnlp_gemm_f32(ops, len(segs), int(a_trans), int(b_trans), out.data_ptr(), _ld(out), m, n,
                             C.byref(epilogue) if epilogue is not None else None, split_k,
                             L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr())
     L.check(rc, "plnlp_gemm_f32")
+    if rowdot is not None:
+        if partial is None:
+            return out, None
+        s_out = torch.empty(m, 1, dtype=torch.float32, device=out.device)
+        L.check(lib.plnlp_rowdot_finish_f32(partial.data_ptr(), m, partial.shape[0], m, L.ptr(rowdot[1]), s_out.data_ptr(),
+                                            L.stream_ptr()), "plnlp_rowdot_finish_f32")
+        return out, s_out
     return out
 
 
@@ -1942,17 +1966,22 @@ class MLPStackFn(torch.autograd.Function):
     def forward(ctx, x, dropout_p: float, training: bool, *params):
         x = _f32c(x)
         n_layers = len(params) // 2
-        xs, acts = [x], []
+        xs, acts, head = [x], [], None
         for i in range(n_layers):
             w, b = params[2 * i], params[2 * i + 1]
             last = i == n_layers - 1
             act = _Act(not last, 0.0 if last else dropout_p, training)
             acts.append(act)
             if last and w.shape[0] == 1:
-                y = matvec(xs[-1], w, b).reshape(-1, 1)
+                y = head if head is not None else matvec(xs[-1], w, b).reshape(-1, 1)
             else:
-                y = gemm([(xs[-1], w)], False, True,
-                         epilogue=L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr))
+                epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr)
+                if i == n_layers - 2 and params[2 * i + 2].shape[0] == 1:
+                    # the hidden layer under a 1-output head: the head rides in this product's epilogue where the launch
+                    # takes the stationary-weights form (else head stays None and the last layer is its own pass)
+                    y, head = gemm([(xs[-1], w)], False, True, epilogue=epi, rowdot=(params[2 * i + 2], params[2 * i + 3]))
+                else:
+                    y = gemm([(xs[-1], w)], False, True, epilogue=epi)
             xs.append(y)
         ctx.acts, ctx.n_layers = acts, n_layers
         ctx.save_for_backward(*xs[:-1], *params)

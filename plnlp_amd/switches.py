@@ -63,6 +63,9 @@ MODULE = [
      "`False`: the first GCN layer transforms `[emb ‖ x]` first, as GCNConv does, instead of aggregating first"),
     ("ops.FUSE_EDGE_MLP['enabled']", "False",
      "`True`: MLPPredictor's Hadamard formed inside the GEMM loaders (measured slower)"),
+    ("ops.FUSE_HEAD_FORWARD['enabled']", "True",
+     "`False`: MLPPredictor's 1-output head as its own pass over the hidden activation (`plnlp_matvec_f32`) instead of in the "
+     "hidden product's epilogue (`PLNLP_EPI_ROWDOT`)"),
     ("ops.FUSE_HEAD_BACKWARD['enabled']", "True",
      "`False`: the backward of MLPPredictor's 1-output head as four passes over the hidden activation (outer product, three "
      "column sums) instead of one (`plnlp_mlp_head_backward_f32`)"),

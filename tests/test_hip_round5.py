@@ -145,6 +145,56 @@ def test_fused_head_backward_is_the_four_separate_passes(P, rows, feat, p):
             assert torch.equal(u, v), i_
 
 
+@pytest.mark.parametrize("rows,feat,p", [(20000, 512, 0.3), (40000, 256, 0.0), (262144, 512, 0.3), (17000, 384, 0.2)])
+def test_head_in_the_hidden_products_epilogue(P, rows, feat, p):
+    """PLNLP_EPI_ROWDOT: MLPPredictor's 1-output head (layer.py:86) evaluated in the epilogue of the hidden layer's product on
+    the stationary-weights kernel -- the hidden activation is the bits of the plain launch; the scores equal the separate
+    pass (plnlp_matvec_f32 over the stored activation) to fp32 round-off of a `feat`-term dot product and float64 at 1e-5;
+    the launch counters show no matvec-sized second product; through MLPStackFn the output and every gradient agree with
+    the fusion off (the backward never sees the difference: it reads the stored activation)."""
+    ops = P.ops
+    gen = torch.Generator().manual_seed(rows + feat)
+    x = torch.randn(rows, feat, generator=gen).cuda()
+    w1 = (torch.randn(feat, feat, generator=gen) / feat ** 0.5).cuda()
+    b1 = (torch.randn(feat, generator=gen) * 0.1).cuda()
+    w2 = (torch.randn(1, feat, generator=gen) / feat ** 0.5).cuda()
+    b2 = torch.tensor([0.25]).cuda()
+    from plnlp_amd import _lib
+    epi = lambda: _lib.make_epilogue(bias=b1, relu=True, dropout_p=p, dropout_seed=77)
+    c0 = ops.launch_counts()
+    hid, score = ops.gemm([(x, w1)], False, True, epilogue=epi(), rowdot=(w2, b2))
+    d = _delta(P, c0)
+    assert score is not None and d["gemm_x3s"] == 1 and sum(d.values()) == 1, d
+    plain = ops.gemm([(x, w1)], False, True, epilogue=epi())
+    assert torch.equal(hid, plain)
+    want = ops.matvec(plain, w2, b2)
+    ref64 = plain.double().cpu() @ w2.double().cpu().reshape(-1) + 0.25
+    mag = (plain.double().cpu().abs() @ w2.double().cpu().abs().reshape(-1)) + 0.25
+    assert float(((score.reshape(-1).double().cpu() - ref64).abs() / mag).max()) <= 2e-6
+    assert float(((score.reshape(-1) - want).abs().double().cpu() / mag).max()) <= 2e-6
+    if rows <= 40000:
+        g = torch.randn(rows, 1, generator=gen).cuda()
+        outs = {}
+        for on in (True, False):
+            ops.FUSE_HEAD_FORWARD["enabled"] = on
+            try:
+                leaves = [t.detach().clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+                ops.manual_seed(5)
+                c0 = ops.launch_counts()
+                out = ops.MLPStackFn.apply(leaves[0], p, True, *leaves[1:])
+                out.backward(g)
+                outs[on] = (out.detach(), [t.grad.clone() for t in leaves])
+            finally:
+                ops.FUSE_HEAD_FORWARD["enabled"] = True
+        close(outs[True][0], outs[False][0], rtol=1e-5, atol=2e-6 * float(mag.max()))
+        for u, v in zip(outs[True][1], outs[False][1]):
+            assert torch.equal(u, v)          # the backward reads g and the stored activation: identical either way
+    # a shape the form does not cover (too few rows for the stationary kernel): (C, None), the caller makes its own pass
+    small, none = ops.gemm([(x[:2000], w1)], False, True, epilogue=epi(), rowdot=(w2, b2))
+    assert none is None
+    close(small, plain[:2000], rtol=1e-5)         # (the tile kernel cuts K here: another association of the same sums)
+
+
 # ------------------------------------------------------------------ create_input_feat (ADVICE r4) ----
 def test_public_create_input_feat_is_the_real_matrix_with_its_gradient(P):
     """BaseModel.create_input_feat mirrors model.py:98-105: a caller gets torch.cat([emb.weight, data.x], -1) -- current
