@@ -12,7 +12,8 @@
  *     allocates, frees or synchronises;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
  *     default stream) and is stream-ordered; entry points are re-entrant and
- *     keep no global state (safe for one-process-per-GPU data parallelism);
+ *     keep no global state that affects results (safe for one-process-per-GPU data parallelism) -- the two
+ *     exceptions are measurement aids: the launch counters (plnlp_launch_counts) and plnlp_gemm_stationary_tuning;
  *   - return value: 0 = enqueued; PLNLP_E_* (negative) = argument rejected,
  *     nothing enqueued; positive = hipError_t reported by the launch;
  *   - matrices are row-major fp32 with an explicit leading dimension (elements);
