@@ -1836,8 +1836,7 @@ class GCNInputConvFn(torch.autograd.Function):
         dz = _act_backward(gy.contiguous(), y, act)
         need = ctx.needs_input_grad
         gemb = gw = gb = None
-        if need[2]:
-            gb = colsum(dz)
+        bias_sum = SideColsum(dz) if need[2] else None          # beside the products and the transposed aggregation below
         if need[1]:
             gwa = gemm([(dz, ax)], True, False)                                       # [out, ep + fp]
             gw = torch.cat([gwa[:, :e], gwa[:, ep:ep + f]], dim=1)
@@ -1848,6 +1847,8 @@ class GCNInputConvFn(torch.autograd.Function):
                 ctx.direct_grad_to.grad = full[:, :e]                                   # a view: no copy
             else:
                 gemb = full[:, :e].contiguous()
+        if bias_sum is not None:
+            gb = bias_sum.join()
         return gemb, gw, gb, None, None, None, None
 
 
@@ -1908,8 +1909,7 @@ class GCNConvFn(torch.autograd.Function):
         dz = sg.values if sg is not None else _act_backward(gy.contiguous(), y, act)
         need = ctx.needs_input_grad
         gx = gw = gb = None
-        if need[2]:
-            gb = colsum(dz)
+        bias_sum = SideColsum(dz) if need[2] else None          # beside the transposed aggregation and the two products below
         if need[0] or need[1]:
             gxw = csr_aggregate(graph.t(), dz, "sum", use_values=True,
                                 src_map=sg.node_map if sg is not None else None)
@@ -1924,6 +1924,8 @@ class GCNConvFn(torch.autograd.Function):
                           epilogue=L.make_epilogue(gate=x, gate_scale=ia.scale) if ia is not None else None)
                 if gx.shape[1] != kin:
                     gx = gx[:, :kin]
+        if bias_sum is not None:
+            gb = bias_sum.join()
         return gx, gw, gb, None, None, None, None, None
 
 

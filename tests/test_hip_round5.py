@@ -392,18 +392,20 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
     """the trained-regime harness of round 4 runs at h = 64 on 2-3 000 nodes -- every GEMM below the 16 384
     rows from which the stationary-weights kernel (the default of all three workloads) is used, every aggregation below
     the F = 256 forms.  These legs train the recipes AT THEIR WIDTHS (README.md:35 h = 256, README.md:24 h = 512), same
-    initial weights / walks / negatives / permutations as the oracle's float32 and float64 runs (fixture g12, 8 seeds):
+    initial weights / walks / negatives / permutations as the oracle's float32 and float64 runs (fixture g12, 16 / 8 seeds):
       collab_wide  40 000-node soft geometric graph with 24 hub nodes (~1 500 neighbours: rows beyond the long-row
                    threshold), SAGE x1 + DOT, WeightedHingeAUC on one-hop walk pairs, batches of 32 768 (+ as many negatives):
                    ~96 % of the nodes touched, inside the row-sparse window, so the last conv runs at ~38 000 touched rows;
-      ddi_wide     ddi's own size and density (4 267 nodes, ~450 neighbours each), SAGE x2 + MLP at h = 512, 8 192 x (1 + 3)
-                   = 32 768 scorer rows per step.
+      ddi_wide     ddi's own size and density (4 267 nodes, eight communities of 500: ~450 neighbours each), SAGE x2 + MLP at
+                   h = 512, 8 192 x (1 + 3) = 32 768 scorer rows per step, 30 epochs of 12 steps: long enough for every
+                   converged run to sit on the 90 % Hits@20 plateau the 10 % unrankable positives leave (README.md:8's metric).
     Asserted: (a) by the launch counters, that the runs went through gemm_x3s and the fused / slab aggregation forms;
     (b) epoch-1 loss of every seed vs the float32 oracle within twice the oracle's own float32-float64 gap there (+ 1e-4),
     every epoch's loss within 4 x that gap (+ 0.2 %) -- the lottery the teacher-forced test pins down;
-    (c) the final level of the recipe's metric (collab: Hits@50; ddi: AUC -- after the 36 steps the CPU oracle can afford
-    this recipe is still near chance at Hits@20, recorded, not asserted) within 0.3 points + 2 s.e. of the float32 oracle's
-    over the 8 seeds, on valid and test."""
+    (c) the final level of the recipe's own metric (collab: Hits@50, mean over 16 seeds; ddi: Hits@20, median over 8) within
+    0.3 points + 2 s.e. of the float32 oracle's, on valid and test; the epochs each seed needs to reach the level (collab: 90 %
+    of the float64 oracle's final level; ddi: 88 %) distributed like the float32 oracle's (Mann-Whitney, two-sided,
+    p > 0.05 / 4) and reached by the same share of seeds."""
     import trained_parity as T
     ref32, ref64, loss32, loss64 = _wide_fixture(golden, T, recipe)
     n = ref32.shape[0]
@@ -433,7 +435,9 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
     c = T.compare(hip, ref32, ref64, recipe)
     text += "\n" + T.describe(f"{recipe}, HIP {P.ops.GEMM_MATH['mode']}", c)
     ki = T.metrics_of(recipe).index("Hits@20")
-    text += f"\n    Hits@20 valid, last epoch, mean over seeds: HIP {hip[:, -1, ki, 0].mean():.2f}  oracle f32 {ref32[:, -1, ki, 0].mean():.2f}"
+    ka = T.metrics_of(recipe).index("AUC")
+    text += (f"\n    last epoch, mean over seeds: Hits@20 valid HIP {hip[:, -1, ki, 0].mean():.2f}  oracle f32 {ref32[:, -1, ki, 0].mean():.2f};"
+             f"  AUC valid HIP {hip[:, -1, ka, 0].mean():.2f}  oracle f32 {ref32[:, -1, ka, 0].mean():.2f}")
     print(text)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
@@ -441,7 +445,9 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
             f.write(text + "\n")
         np.savez_compressed(os.path.join(out_dir, f"trained_curves_{recipe}.npz"), hits=hip.astype(np.float32), losses=losses)
     assert (np.abs(c["diff_f32"]) <= 0.3 + 2.0 * c["diff_f32_se"]).all(), text
+    assert c["mw_p"] > 0.05 / 4, text
+    assert abs(c["reached_hip"] - c["reached_f32"]) <= 0.26, text                      # (8 / 16 seeds: steps of 0.125 / 0.06)
     if recipe == "collab_wide":
         assert 70.0 < c["final_f32"].min() and c["final_f32"].max() < 99.0, text      # trained, not saturated
     else:
-        assert c["final_f32"].min() > 60.0, text                                       # AUC well off chance
+        assert c["final_f32"].min() > 85.0, text                                       # the plateau was reached

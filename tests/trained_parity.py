@@ -63,12 +63,14 @@ RECIPES = {
     # row-sparse window (ops.SPARSE_BACKWARD), so the last conv runs at the ~38 000 touched rows, as on the real graph
     "collab_wide": dict(problem="geometric_wide", h=256, layers=1, predictor="DOT", loss="WeightedHingeAUC", k=1, lr=0.01,
                         clip=1.0, epochs=8, batch=32768, walk_length=1, decay=True, metric="Hits@50", level=None,
-                        center="mean", seeds=8),
+                        center="mean", seeds=16),
     # README.md:24 at h = 512: 8 192 positives + 3 x 8 192 negatives = 32 768 scorer rows per step; an epoch is the first
-    # `train_edges` training edges (the encoder still aggregates over the whole graph every step)
-    "ddi_wide": dict(problem="sbm_dense", h=512, layers=2, predictor="MLP", loss="AUC", k=3, lr=0.005, clip=2.0,
-                     epochs=6, batch=8192, walk_length=0, decay=False, metric="AUC", level=None, center="mean",
-                     seeds=8, train_edges=49152),
+    # `train_edges` training edges = 12 steps (the encoder still aggregates over the whole graph every step).  30 epochs = 360
+    # steps: a GPU pilot (scripts/pilot_wide_legs.py) put the run on its 90 % Hits@20 plateau after 11-19 epochs at this
+    # learning rate and left it there (at 0.005 it arrives earlier and then decays slowly, at 0.01 it oscillates)
+    "ddi_wide": dict(problem="sbm_dense", h=512, layers=2, predictor="MLP", loss="AUC", k=3, lr=0.002, clip=2.0,
+                     epochs=30, batch=8192, walk_length=0, decay=False, metric="Hits@20", level=88.0, center="median",
+                     seeds=8, train_edges=98304),
 }
 
 
