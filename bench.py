@@ -991,7 +991,11 @@ def main():
         # rank-0-only measurements further down (roofline, control model) find the choice made: the op itself never
         # communicates (ops.tune_aggregation / ops._agg_tune)
         P.ops.tune_aggregation(g["adj_t"], [cfg["hidden"], cfg.get("emb", cfg["hidden"])], group=pg)
+    counts0 = P.ops.launch_counts()
     dt, final_loss = timed_steps(model, dp_mode, n_ranks, B * world, rank)
+    counts1 = P.ops.launch_counts()
+    # which kernel families the measured steps went through (plnlp_launch_counts), per step, warm-up included
+    launches_per_step = {kk: round((counts1[kk] - counts0[kk]) / float(K + W), 2) for kk in counts1 if counts1[kk] != counts0[kk]}
     host_ms_per_step = host_enqueue_s[-1] / K * 1e3          # (of THIS call: a process group's first calls are the cost model's)
     host_busy_ms_per_step = host_busy_s[-1] / K * 1e3
     if pg is not None:
@@ -1173,6 +1177,7 @@ def main():
                                           "backward runs on those rows); bit-identical loss / gradients / update to the "
                                           "full-matrix step, which is timed as ms_per_step_full_forward"},
         "final_loss": final_loss, "negative_sampling_s": sampler_s,
+        "kernel_families_per_step": launches_per_step,
         "negative_sampler": "%s (plnlp_amd.negative_sample, %d negatives in one call)" % (sampler, need * k),
         "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 1,
     }
