@@ -27,6 +27,7 @@
 // kernel adds them in slice order -- deterministic, no atomics.
 #include "common.hip.h"
 #include "gemm_x3s.hip.h"     // the stationary-weights form (its own translation unit, gemm_x3s.hip)
+#include "gemm_wgw.hip.h"     // the one-workgroup-per-result weight gradient of a 129 .. 224 wide layer (gemm_wgw.hip)
 #include <utility>
 
 namespace plnlp {
@@ -970,6 +971,19 @@ static int stationary_form(const plnlp_gemm_operand* segs, int n_seg, int a_tran
     return x3s::pick_nb(m, n);
 }
 
+// K slices of the wide weight-gradient form (gemm_wgw.hip) for this launch, 0 where it does not apply: one K-segment,
+// A^T B with both operands as stored (no gathered rows, no second B buffer, no split result), split-bf16 math, and
+// wgw::slices_for's shape rule.  The launch takes the form exactly when the caller cuts K into this many slices.
+static int wide_wgrad_slices(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, int64_t m, int64_t n) {
+    if (!segs || n_seg != 1 || !a_trans || b_trans || segs[0].math != PLNLP_GEMM_MATH_BF16X3) return 0;
+    const plnlp_gemm_operand& o = segs[0];
+    if (o.a_index || o.b_index || o.a_index2 || o.b_index2 || !o.a || !o.b) return 0;
+    return plnlp::wgw::slices_for(m, n, o.k, o.a, o.lda, o.b, o.ldb);
+}
+extern "C" int plnlp_gemm_wide_wgrad_slices(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans,
+                                            int64_t m, int64_t n) {
+    return wide_wgrad_slices(segs, n_seg, a_trans, b_trans, m, n);
+}
 extern "C" int plnlp_gemm_stationary_applies(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans,
                                              const float* c, int64_t ldc, int64_t m, int64_t n, const float* c2,
                                              int64_t ldc2, int64_t n_split) {
@@ -1149,6 +1163,21 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     }
     if (e.flags & PLNLP_EPI_ROWDOT) return PLNLP_E_UNSUPPORTED;      // the row-dot epilogue lives in the stationary kernel only
     const int reduce_slices = split_k;
+    // ---- the wide weight gradient (gemm_wgw.hip): the whole result in one workgroup per K slice; taken when the caller cut K
+    // into exactly the slices plnlp_gemm_wide_wgrad_slices names for this launch (its workspace is then the right size)
+    if (!b2 && !c2 && split_k > 1 && split_k == wide_wgrad_slices(segs, n_seg, a_trans, b_trans, m, n)) {
+        wgw::Args w{};
+        w.a = g.seg[0].a; w.lda = g.seg[0].lda; w.b = g.seg[0].b; w.ldb = g.seg[0].ldb;
+        w.m = (int)m; w.n = (int)n; w.k = g.seg[0].k; w.slices = split_k; w.ws = workspace;
+        count_launch(LK_GEMM_WGRAD_WIDE);
+        if (int rc = wgw::launch(w, s)) return rc;
+        count_launch(LK_GEMM_SPLITK_REDUCE);
+        if (((uintptr_t)c % 16 == 0) && (ldc % 4 == 0) && ((uintptr_t)workspace % 16 == 0)) return wgw::reduce(w, c, ldc, e, s);
+        int64_t blocks = (m * n / 4 + 255) / 256;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, reduce_slices,
+                           g.ws_stride, c, ldc, m, (int)n, e, c2, ldc2, (int)n_split, (int64_t)0);
+        return launch_status();
+    }
     g.mt0 = 0; g.nt0 = 0; g.gm = gm; g.gn = (int)gn; g.z0 = 0;
     auto launch_grid = [&](const GemmArgs& ga, int md, dim3 grid) -> int {
         if (math == PLNLP_GEMM_MATH_BF16X3) return x16::launch_kernels(ga, md, grid, a_trans, b_trans, s, e);

@@ -1,0 +1,365 @@
+// K4w -- the split-bf16 weight gradient of a layer 129 .. 224 wide:  C[m, n] = A^T B,  A [k, m], B [k, n],  m, n <= 224,
+// k = the rows of the graph (10^5 .. 10^7).  gfx950.
+//
+// Why a kernel of its own: on the 128 x 128 kernels (gemm_f32.hip) a 200 x 200 result is four tiles of which 39 % is
+// padding, every operand panel is fetched by two workgroups, and each loaded element -- split into its three bf16 terms
+// on the way into LDS, 11 VALU instructions per pair -- feeds 16 MFMA blocks per 256 loaded elements.  Here ONE workgroup
+// holds the whole result: 448 threads = 7 waves, wave w owns the 32-row strip w of C and walks its seven 32 x 32 column
+// blocks (112 accumulator registers); a K-step loads 16 rows of A and of B once (224 columns each), splits them
+// once, and feeds 49 MFMA blocks per 448 loaded elements -- 1.75 x the MFMA work per split.  The reduction over k
+// is cut into `slices` contiguous ranges, one workgroup each (one per CU: the two LDS buffers are 84 KB), whose raw
+// partials the split-K reduce kernel of gemm_f32.hip adds in slice order: deterministic, no atomics.
+//
+// Same arithmetic as the tile kernels (same split x = hi + mid + lo, round-to-nearest each; the same six products per
+// 32 x 32 x 16 block, small terms first); the slices differ, so the f32 sums associate differently -- inside the
+// contract every split-K launch already has (tests: against float64, bound 2^-22 sum |a||b|).
+//
+// LDS image of one operand K-step (16 x 224), in 16-byte units: [term 3][k-group 2][position 224], one unit = the 8 bf16
+// k 8g .. 8g+7 of one column = exactly one lane's MFMA fragment: ONE ds_read_b128 (256 B/clk; the first version of this
+// kernel kept the tile kernels' row-contiguous image -- a fragment = four ds_read_b32 at 128 B/clk -- and was bound by
+// those reads, 172 KB per K-step).  To write whole units a staging thread owns 8 consecutive k of TWO adjacent columns
+// (eight 8-byte loads, lanes side by side: a wave reads 512 contiguous bytes of a row); the two columns go to positions
+// cp and w/2 + cp (w = the operand's width), so that both of a wave's stores cover consecutive units (conflict-free) and
+// the live positions are 0 .. w-1.  Position p therefore holds column 2p (p < w/2) or 2 (p - w/2) + 1: the MFMAs work on
+// positions, the write-back maps them to rows / columns of C.  Threads whose column pair lies past the width re-read the
+// last pair and park it at the dead positions w .. 223 (products nobody stores).
+#include "gemm_wgw.hip.h"
+#include <utility>
+
+namespace plnlp {
+namespace wgw {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int NT = 448;                 // threads: 2 operands x 2 k-groups x 112 column pairs
+constexpr int CP = W / 2;               // 112
+constexpr int KT = 16;                  // k per step
+constexpr int TERMU = 2 * W;            // 16-byte units per term
+constexpr int OPERU = 3 * TERMU;        // units per operand
+constexpr int BUFU = 2 * OPERU;         // units per buffer (A then B)
+constexpr int LDS_BYTES = 2 * BUFU * 16;  // 86 016
+
+__device__ __forceinline__ unsigned pk(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+
+// one staging thread's share of a K-step: 8 consecutive k x 2 adjacent columns of one operand
+struct Raw { f32x2 x[8]; };
+
+// where a staging thread reads and writes (fixed for the whole launch)
+struct Role {
+    const float* src;     // its operand at (row 8 kg of step 0, its column pair)
+    int64_t ld;
+    int unit0, unit1;     // LDS units (within a buffer, term 0) of its two columns
+    int row8;             // its first row within a K-step (0 or 8)
+};
+
+// the split of one staging thread's share (8 k x 2 columns) in 18 stages of ~5 VALU instructions that ride between MFMAs:
+// per column, stage 0-3 = hi term of k-pair q (and the residual), 4-7 = mid term, 8 = lo terms; a term's 16-byte unit is
+// stored as soon as its four dwords exist (stages 3, 7, 8), so a wave's six stores are spread over the step -- three
+// back-to-back ds_write_b128 from all 7 waves at once filled the LDS store queue and stalled the waves at issue
+struct Split {
+    f32x2 r[4];
+    unsigned t[4];        // the term being assembled
+    template <int I>
+    __device__ __forceinline__ void stage(const Raw& w, u32x4* __restrict__ buf, const Role& ro) {
+#pragma clang fp contract(off)
+        constexpr int C = I / 9, K = I % 9;
+        u32x4* dst = buf + (C ? ro.unit1 : ro.unit0);
+        if constexpr (K < 4) {
+            f32x2 v = {w.x[2 * K][C], w.x[2 * K + 1][C]};
+            t[K] = pk(v);
+            r[K].x = v.x - __uint_as_float(t[K] << 16);
+            r[K].y = v.y - __uint_as_float(t[K] & 0xffff0000u);
+        } else if constexpr (K < 8) {
+            constexpr int Q = K - 4;
+            t[Q] = pk(r[Q]);
+            r[Q].x -= __uint_as_float(t[Q] << 16);
+            r[Q].y -= __uint_as_float(t[Q] & 0xffff0000u);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = pk(r[q]);
+        }
+        if constexpr (K == 3 || K == 7 || K == 8) {
+            const u32x4 v = {t[0], t[1], t[2], t[3]};
+            dst[(K == 3 ? 0 : K == 7 ? 1 : 2) * TERMU] = v;
+        }
+    }
+};
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// the whole split of one thread's share, not interleaved with anything (prologue, the partial last step)
+__device__ __forceinline__ void split_store(u32x4* __restrict__ buf, const Role& ro, const Raw& w) {
+    Split sp;
+    static_for<18>([&](auto ic) { sp.template stage<decltype(ic)::value>(w, buf, ro); });
+}
+
+// a FULL K-step (no row past the end): plain 8-byte loads
+template <int I0 = 0, int I1 = 8>
+__device__ __forceinline__ void load_full(const Role& ro, Raw& w, int64_t step) {
+    const float* p = ro.src + step * KT * ro.ld;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) w.x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + i * ro.ld));
+}
+
+// one lane's fragment of term s: k 8h .. 8h+7 of position `pos`
+__device__ __forceinline__ bf16x8 frag(const u32x4* __restrict__ oper, int s, int pos, int h) {
+    return __builtin_bit_cast(bf16x8, oper[s * TERMU + h * W + pos]);
+}
+
+constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};    // the six products, small terms first
+
+// the MFMAs of one K-step from buffer `buf`, nothing else (the reduction's partial last step)
+template <int NBLK>
+__device__ __forceinline__ void mma_plain(f32x16 (&acc)[NBLK], const u32x4* __restrict__ buf, int wave, int l31, int h) {
+    bf16x8 a[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a[s] = frag(buf, s, 32 * wave + l31, h);
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) b[s] = frag(buf + OPERU, s, 32 * j + l31, h);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[u]], b[TB[u]], acc[j], 0, 0, 0);
+    }
+}
+
+// One pipelined K-step.  The workgroup is alone on its CU and its 7 waves meet at a barrier every step, so everything that is
+// not an MFMA must ride BEHIND MFMAs inside each wave -- a step is one basic block of 6 NBLK slots (slot = one MFMA + what is
+// pinned behind it with sched_barrier; nothing crosses a slot):
+//   * buffer D holds this step's terms (tile t); the B fragments of column block j + 1 are fetched behind the first MFMA of
+//     block j;
+//   * the step's ONE barrier sits at slot BS = 6 NBLK - 10: after this wave's last read of buffer D and its last store into
+//     buffer D^1, with 10 MFMAs still to issue.  Behind those, the next step's A fragments and first B fragments are
+//     fetched from buffer D^1 (complete as of the barrier): the next step starts on its MFMAs at once.  (With the barrier at
+//     the end of the step, store drain + barrier + fragment latency left the matrix pipe idle 30 % of the time.)
+//   * the split of a tile runs from one barrier to the next: stages 0-4 of tile t + 2 (register set D, into buffer D --
+//     free once barrier(t) has passed) behind the last slots of this step, stages 5-17 of tile t + 1 (register set D^1,
+//     into buffer D^1) spread over the slots before BS - 7 -- one stage every other slot, each store in a slot of its own;
+//     then set D^1 is refilled with tile t + 3 (its loads have a step to land).
+// Hazards: every read of buffer D lies before barrier(t); writes of buffer D (tile t + 2) come after it.  Buffer D^1 is
+// written before barrier(t) and read after it; its previous reads (step t - 1) lie before barrier(t - 1).
+// P: which of the two B fragment sets this step's block 0 uses (it alternates per step when NBLK is odd).
+template <int HEAD>
+constexpr int head_stage_at(int q) {            // the split stage (5 .. 17) pinned behind slot q of the head, -1: none
+    for (int i = 5; i < 18; ++i)
+        if (((i - 5) * HEAD) / 13 == q) return i;
+    return -1;
+}
+template <int NBLK, int D, int P>
+__device__ __forceinline__ void step_pipelined(f32x16 (&acc)[NBLK], u32x4* __restrict__ lds, Raw (&raw)[2], Split (&S)[2],
+                                               const Role& ro, int64_t next, bf16x8 (&A)[2][3], bf16x8 (&B)[2][3], int wave,
+                                               int l31, int h) {
+    u32x4* cbuf = lds + D * BUFU;
+    const u32x4* bt = cbuf + OPERU;
+    u32x4* nbuf = lds + (D ^ 1) * BUFU;
+    constexpr int SLOTS = 6 * NBLK, BS = SLOTS - 10, HEAD = BS - 7, LD = BS - 6;
+    static_assert(HEAD >= 13 && BS == 6 * (NBLK - 2) + 2, "slot plan");
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<SLOTS>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int j = q / 6, u = q % 6;
+        if constexpr (q == BS) __syncthreads();
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[D][TA[u]], B[(P + j) & 1][TB[u]], acc[j], 0, 0, 0);
+        if constexpr (u == 0 && j + 1 < NBLK) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) B[(P + j + 1) & 1][s] = frag(bt, s, 32 * (j + 1) + l31, h);
+        }
+        if constexpr (q == BS) {                     // the next step's A fragments (the other set: this step still multiplies A[D])
+#pragma unroll
+            for (int s = 0; s < 3; ++s) A[D ^ 1][s] = frag(nbuf, s, 32 * wave + l31, h);
+        }
+        if constexpr (q == BS + 4) {                 // ... and its first B fragments, into the set block NBLK - 2 has just left
+#pragma unroll
+            for (int s = 0; s < 3; ++s) B[(P + NBLK) & 1][s] = frag(nbuf + OPERU, s, l31, h);
+        }
+        if constexpr (q < HEAD) {
+            constexpr int st = head_stage_at<HEAD>(q);
+            if constexpr (st >= 0) S[D ^ 1].template stage<st>(raw[D ^ 1], nbuf, ro);
+        }
+        if constexpr (q == LD)     load_full<0, 4>(ro, raw[D ^ 1], next);
+        if constexpr (q == LD + 1) load_full<4, 8>(ro, raw[D ^ 1], next);
+        if constexpr (q > BS && ((q - BS) & 1)) S[D].template stage<(q - BS) / 2>(raw[D], cbuf, ro);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// position -> column of an operand `width` wide (see the header)
+__device__ __forceinline__ int column_of(int pos, int width) {
+    const int half = width >> 1;
+    return pos < half ? 2 * pos : 2 * (pos - half) + 1;
+}
+
+// NBLK: 32-position blocks of B with a live position (5 .. 7) -- compile-time, so that a K-step is ONE basic block
+template <int NBLK>
+__global__ __launch_bounds__(NT, 1) void wgrad_wide_kernel(Args g) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    Role ro;
+    {
+        const int o = t >= 2 * CP, u = t - 2 * CP * o, kg = u >= CP, cp = u - CP * kg;
+        const int width = o ? g.n : g.m, half = width >> 1;
+        const bool live = cp < half;
+        const int col = live ? 2 * cp : width - 2;
+        const int p0 = live ? cp : width + 2 * (cp - half);
+        const int p1 = live ? half + cp : p0 + 1;
+        ro.ld = o ? g.ldb : g.lda;
+        ro.row8 = 8 * kg;
+        ro.src = (o ? g.b : g.a) + (int64_t)(8 * kg) * ro.ld + col;
+        ro.unit0 = o * OPERU + kg * W + p0;
+        ro.unit1 = o * OPERU + kg * W + p1;
+    }
+
+    // K-steps of this slice: [sb, sf) full ones, then (last slice only) the reduction's partial last step
+    const int64_t steps = (g.k + KT - 1) / KT, full = g.k / KT;
+    const int64_t per = (steps + g.slices - 1) / g.slices;
+    const int64_t sb = (int64_t)blockIdx.x * per;
+    const int64_t se = sb + per < steps ? sb + per : steps;
+    const int64_t sf = se < full ? se : full;
+
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+    if (sb < sf) {
+        const int64_t last = sf - 1;
+        Raw raw[2];
+        Split S[2];
+        bf16x8 A[2][3], B[2][3];
+        load_full(ro, raw[0], sb);
+        load_full(ro, raw[1], sb + 1 < last ? sb + 1 : last);
+        split_store(lds, ro, raw[0]);
+        load_full(ro, raw[0], sb + 2 < last ? sb + 2 : last);
+        static_for<5>([&](auto ic) { S[1].template stage<decltype(ic)::value>(raw[1], lds + BUFU, ro); });
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            A[0][s] = frag(lds, s, 32 * wave + l31, h);
+            B[0][s] = frag(lds + OPERU, s, l31, h);
+        }
+        int64_t i = sb;
+        // (look-ahead loads past the slice's last full step re-read that step: what they stage is never multiplied)
+        for (; i + 2 <= sf; i += 2) {
+            step_pipelined<NBLK, 0, 0>(acc, lds, raw, S, ro, i + 3 < last ? i + 3 : last, A, B, wave, l31, h);
+            step_pipelined<NBLK, 1, NBLK & 1>(acc, lds, raw, S, ro, i + 4 < last ? i + 4 : last, A, B, wave, l31, h);
+        }
+        if (i < sf) step_pipelined<NBLK, 0, 0>(acc, lds, raw, S, ro, last, A, B, wave, l31, h);
+        __syncthreads();              // (the last step's look-ahead reads are behind us before anything re-uses the buffers)
+    }
+    if (se > sf && sb <= sf) {        // the reduction's partial last step: rows past the end are zeros
+        Raw w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = sf * KT + ro.row8 + i, rc = r < g.k ? r : g.k - 1;
+            const f32x2 v = *reinterpret_cast<const f32x2*>(ro.src + (rc - ro.row8) * ro.ld);
+            const f32x2 z = {0.f, 0.f};
+            w.x[i] = r < g.k ? v : z;
+        }
+        split_store(lds, ro, w);
+        __syncthreads();
+        mma_plain<NBLK>(acc, lds, wave, l31, h);
+    }
+
+    // raw partial of this slice.  MFMA C/D map: position of B = lane & 31, position of A = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+    // within the block; once per workgroup (a few hundred K-steps), so plain 4-byte stores
+    float* out = g.ws + (int64_t)blockIdx.x * g.m * g.n;
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+        const int pb = 32 * j + l31;
+        if (pb >= g.n) continue;
+        const int col = column_of(pb, g.n);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int pa = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (pa < g.m) out[(int64_t)column_of(pa, g.m) * g.n + col] = acc[j][q];
+        }
+    }
+}
+
+int slices_for(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb) {
+    // wider than one 128-tile in BOTH directions (else the tile kernels waste nothing worth a second kernel), whole
+    // 16-byte column groups, a reduction long enough to give every CU a slice of a few dozen K-steps
+    if (m <= 128 || n <= 128 || m > W || n > W || (m % 4) || (n % 4) || k < MIN_K) return 0;
+    if (((uintptr_t)a % 16) || ((uintptr_t)b % 16) || (lda % 4) || (ldb % 4) || lda < m || ldb < n) return 0;
+    return 256;                   // one workgroup per CU
+}
+
+// the slices' sum: 8 threads per 16-byte group of the result, thread g adds slices [g S/8, (g+1) S/8) in order (all its loads
+// in flight at once), the 8 partial sums are added in order of g.  The generic reduce of gemm_f32.hip walks ALL slices per
+// thread: 256 slices = 32 dependent rounds of 8 loads on 40 workgroups, 0.1 ms for a 200 x 200 result.
+constexpr int RG = 8, RE = 32;          // slice groups x result groups per workgroup (256 threads)
+__global__ __launch_bounds__(RG * RE) void wide_reduce_kernel(const float* __restrict__ ws, int slices, int64_t stride,
+                                                              float* __restrict__ c, int64_t ldc, int64_t m, int n, Epi epi) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ f32x4 part[RG][RE];
+    const int e = threadIdx.x % RE, gidx = threadIdx.x / RE;
+    const int64_t i4 = (int64_t)blockIdx.x * RE + e, total4 = (m * n) >> 2;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (i4 < total4) {
+        const int per = (slices + RG - 1) / RG;
+        const int z0 = gidx * per, z1 = z0 + per < slices ? z0 + per : slices;
+        const float* p = ws + i4 * 4;
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(z + u) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; z < z1; ++z) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)z * stride);
+    }
+    part[gidx][e] = acc;
+    __syncthreads();
+    if (gidx != 0 || i4 >= total4) return;
+#pragma unroll
+    for (int g2 = 1; g2 < RG; ++g2) acc += part[g2][e];
+    const int64_t i = i4 * 4, row = i / n;
+    const int col = (int)(i - row * n);
+    float4 y = make_float4(acc.x, acc.y, acc.z, acc.w);
+    y = epi_apply4(epi, y, row, col, n, c + row * ldc);
+    *reinterpret_cast<float4*>(c + row * ldc + col) = y;
+}
+
+int launch(const Args& g, hipStream_t s) {
+    const int nblk = (g.n + 31) / 32;
+    auto run = [&](auto kernel) -> int {
+        // (per launch: the attribute belongs to the device's copy of the function, and a process may hold several devices)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess)
+            return PLNLP_E_UNSUPPORTED;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)g.slices), dim3(NT), LDS_BYTES, s, g);
+        return launch_status();
+    };
+    switch (nblk) {
+        case 5: return run(wgrad_wide_kernel<5>);
+        case 6: return run(wgrad_wide_kernel<6>);
+        case 7: return run(wgrad_wide_kernel<7>);
+    }
+    return PLNLP_E_SHAPE;
+}
+
+// c[m, n] (leading dimension ldc, 16-byte aligned, ldc % 4 == 0) = epilogue(sum of the slices)
+int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, hipStream_t s) {
+    const int64_t total4 = ((int64_t)g.m * g.n) >> 2;
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)((total4 + RE - 1) / RE)), dim3(RG * RE), 0, s, g.ws, g.slices,
+                       (int64_t)g.m * g.n, c, ldc, (int64_t)g.m, g.n, e);
+    return launch_status();
+}
+
+}  // namespace wgw
+}  // namespace plnlp

@@ -1,0 +1,28 @@
+// The interface between gemm_f32.hip (gemm_impl decides which kernel a launch runs) and gemm_wgw.hip (the split-bf16
+// weight gradient whose WHOLE result, up to 224 x 224, is one workgroup's tile).
+#pragma once
+#include "common.hip.h"
+
+namespace plnlp {
+namespace wgw {
+
+constexpr int W = 224;            // result rows / columns one workgroup holds
+constexpr int MIN_K = 32768;      // reduction lengths below this stay on the 128 x 128 kernels
+
+struct Args {
+    const float* a; int64_t lda;  // [k, m]: the reduction index is the row (dz in  dW = dz^T x)
+    const float* b; int64_t ldb;  // [k, n]
+    int m, n;
+    int64_t k;
+    int slices;                   // K slices = workgroups; slice z writes its raw partial to ws + z m n (leading dimension n)
+    float* ws;
+};
+
+// K slices the form wants for this product, 0 where it does not apply (the rule, in one place)
+int slices_for(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb);
+int launch(const Args& g, hipStream_t s);
+// c = epilogue(sum of the slices' partials, in a fixed order); c 16-byte aligned, ldc % 4 == 0 (else use splitk_reduce_kernel)
+int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, hipStream_t s);
+
+}  // namespace wgw
+}  // namespace plnlp

@@ -424,6 +424,11 @@ GEMM_STATIONARY_B = {"enabled": os.environ.get("PLNLP_GEMM_STATIONARY_B", "1") !
                      "min_rows": 16384}     # (informational: the rule itself lives in the library, plnlp_gemm_stationary_applies)
 
 
+# the weight gradient of a 129 .. 224 wide layer with the whole result held by one workgroup per K slice (csrc/gemm_wgw.hip;
+# the rule lives in the library, plnlp_gemm_wide_wgrad_slices).  off = the 128 x 128 kernels (A/B runs, tests of both)
+GEMM_WIDE_WGRAD = {"enabled": os.environ.get("PLNLP_GEMM_WIDE_WGRAD", "1") != "0"}
+
+
 def _lend_b_terms(ops, n_seg: int, a_trans: bool, b_trans: bool, out: torch.Tensor, m: int, n: int,
                   out2: Optional[torch.Tensor] = None, n_split: Optional[int] = None):
     """lend the launch a scratch buffer for B's pre-split image (plnlp_gemm_operand.b_terms) exactly where the library will
@@ -518,7 +523,10 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=keep[0].device)
     if split_k is None:
-        split_k = _pick_split_k(m, n, ktiles)
+        # (the wide weight-gradient form -- the whole <= 224 x 224 result per workgroup -- is taken by the launch exactly
+        # when K is cut into the slices the library names for it)
+        split_k = (lib.plnlp_gemm_wide_wgrad_slices(ops, len(segs), int(a_trans), int(b_trans), m, n)
+                   if GEMM_WIDE_WGRAD["enabled"] else 0) or _pick_split_k(m, n, ktiles)
     split_k = max(1, min(split_k, ktiles))
     keep.append(_lend_b_terms(ops, len(segs), a_trans, b_trans, out, m, n))
     if keep[-1] is not None:

@@ -23,6 +23,10 @@ SHAPES = {
     "cit_in_fwd_k180": (2927963, 200, [180], False, True, "bias_relu"),
     "cit_in_fwd_k192": (2927963, 200, [192], False, True, "bias_relu"),
     "cit_l2_fwd_k200": (2927963, 200, [200], False, True, False),
+    # its two weight gradients: dz^T [A emb | A x] (200 x 180) and (A^T dz)^T h (200 x 200) over all 2.9 M rows
+    "cit_in_wgrad": (200, 180, [2927963], True, False, False),
+    "cit_l2_wgrad": (200, 200, [2927963], True, False, False),
+    "wgrad_224": (224, 224, [2927963], True, False, False),
     # tail quantisation probes: 3584 tiles = exactly 7 rounds of the 512 workgroup slots, vs 7.2 rounds above
     "collab_fwd_7rounds": (229376, 256, [256, 256], False, True, True),
     "collab_fwd_plain_7rounds": (229376, 256, [256, 256], False, True, False),
@@ -41,7 +45,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--min-rows", type=int, default=0, help="nb mode: rows of A from which the stationary-weights form applies (0: the default 16384)")
     ap.add_argument("--repeats", type=int, default=3, help="timed blocks per shape; the median is reported")
-    ap.add_argument("--math", default="env", choices=["env", "f32", "bf16x3", "ab", "st", "nb"],
+    ap.add_argument("--math", default="env", choices=["env", "f32", "bf16x3", "ab", "st", "nb", "wide"],
                     help="how the products are formed (ops.GEMM_MATH); ab = measure both, interleaved")
     ap.add_argument("--error", action="store_true",
                     help="also report max |C - C_fp64| / sum_k |a||b| over 64 sampled result rows (no epilogue)")
@@ -74,18 +78,22 @@ def main():
             a_index = [None, rows]
         out = torch.empty(m, n, device=dev)
         flop = 2.0 * m * n * sum(ks)
-        maths = {"env": [None], "f32": ["f32"], "bf16x3": ["bf16x3"], "ab": ["f32", "bf16x3"], "st": [], "nb": []}[args.math]
+        maths = {"env": [None], "f32": ["f32"], "bf16x3": ["bf16x3"], "ab": ["f32", "bf16x3"], "st": [], "nb": [], "wide": []}[args.math]
         modes = [(mt, None) for mt in maths]
         if args.math == "st":         # split-bf16 products: the 128 x 128 kernels vs the stationary-weights kernel
             modes = [("bf16x3", False), ("bf16x3", True)]
         if args.math == "nb":         # the stationary-weights kernel by column-tile width, tail launch on / off, vs the tile kernel
             modes = [("bf16x3", False)] + [("bf16x3", (nb, args.min_rows)) for nb in (0, 8, 4, 2, 1)]
+        if args.math == "wide":       # weight gradients 129 .. 224 wide: the 128 x 128 kernels vs one workgroup per result
+            modes = [("bf16x3", "tile"), ("bf16x3", "wide")]
         ts = {md: [] for md in modes}
 
         def arm(md):
             if md[0] is not None:
                 P.ops.GEMM_MATH["mode"] = md[0]
-            if md[1] is not None:
+            if md[1] in ("tile", "wide"):
+                P.ops.GEMM_WIDE_WGRAD["enabled"] = md[1] == "wide"
+            elif md[1] is not None:
                 P.ops.GEMM_STATIONARY_B["enabled"] = bool(md[1])
                 nb, tail = md[1] if isinstance(md[1], tuple) else (0, 1)
                 _lib.load().plnlp_gemm_stationary_tuning(nb, tail)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# the wide weight-gradient kernel (csrc/gemm_wgw.hip): where the wave cycles go (separate --pmc passes)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+SH=${SH:-cit_l2_wgrad}
+OUT=${OUT:-gpurun_out/r05w/pmc_gemm_wide.json}
+mkdir -p $(dirname $OUT)
+rm -rf gpurun_out/pmc_gw
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT -f csv -d gpurun_out/pmc_gw/a -o g -- python3 scripts/bench_gemm.py --math wide --shapes $SH --iters 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES -f csv -d gpurun_out/pmc_gw/b -o g -- python3 scripts/bench_gemm.py --math wide --shapes $SH --iters 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY -f csv -d gpurun_out/pmc_gw/c -o g -- python3 scripts/bench_gemm.py --math wide --shapes $SH --iters 3 > gpurun_out/pmc_gw_c.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA -f csv -d gpurun_out/pmc_gw/d -o g -- python3 scripts/bench_gemm.py --math wide --shapes $SH --iters 3 > gpurun_out/pmc_gw_d.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INST_CYCLES_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA -f csv -d gpurun_out/pmc_gw/e -o g -- python3 scripts/bench_gemm.py --math wide --shapes $SH --iters 3 > gpurun_out/pmc_gw_e.log 2>&1
+python3 scripts/pmc_collect.py wgrad_wide_kernel $OUT "gpurun_out/pmc_gw/**/*counter_collection.csv" > /dev/null
+tail -3 gpurun_out/pmc_gw_c.log gpurun_out/pmc_gw_d.log gpurun_out/pmc_gw_e.log
+rm -rf gpurun_out/pmc_gw
+python3 - <<PY
+import json
+d=json.load(open("$OUT"))
+for k,v in d.items():
+    print(k[:90]); print("   ", {a:(round(b,3) if isinstance(b,float) else b) for a,b in v.items()})
+PY

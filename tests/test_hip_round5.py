@@ -451,3 +451,69 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
         assert 70.0 < c["final_f32"].min() and c["final_f32"].max() < 99.0, text      # trained, not saturated
     else:
         assert c["final_f32"].min() > 85.0, text                                       # the plateau was reached
+
+
+# ------------------------------------------------ the wide weight gradient (csrc/gemm_wgw.hip) ----
+@pytest.mark.parametrize("m,n,k,pad", [(200, 200, 300_001, 0), (200, 180, 65_536, 0), (224, 224, 40_000, 0), (132, 132, 50_007, 0),
+                                       (200, 200, 32_768, 24), (196, 160, 33_333, 8), (204, 192, 100_000, 0)])
+def test_wide_weight_gradient_is_fp32_grade_and_deterministic(P, m, n, k, pad):
+    """C[m, n] = A^T B over k rows with the whole result held by one workgroup per K slice (layers 129 .. 224 wide, citation2's
+    h = 200): asserted by the launch counter to be the kernel that ran; against float64 inside the per-product bound of every
+    split-bf16 launch (2^-22 of sum |a||b|) and the f32 summation bound; the same bits twice; and the 128 x 128 kernels'
+    result (the form switched off: another summation order) within f32 round-off of it.  k odd / not a multiple of 16 (the
+    partial last K-step), widths that leave 1 .. 3 column blocks partly empty, operands that are column slices of wider
+    buffers (pad > 0: leading dimension > width)."""
+    ops = P.ops
+    old = ops.GEMM_MATH["mode"]
+    ops.GEMM_MATH["mode"] = "bf16x3"
+    try:
+        gen = torch.Generator(device="cuda").manual_seed(m * 7 + n * 3 + k)
+        a_buf = torch.randn(k, m + pad, device="cuda", generator=gen) * 0.05
+        b_buf = torch.randn(k, n + pad, device="cuda", generator=gen)
+        a, b = a_buf[:, :m], b_buf[:, pad:pad + n] if pad % 4 == 0 else b_buf[:, :n]
+        c0 = ops.launch_counts()
+        got = ops.gemm([(a, b)], True, False)
+        d = _delta(P, c0)
+        assert d["gemm_wgrad_wide"] == 1 and d["gemm_splitk_reduce"] == 1 and d["gemm_tile_x3"] == 0, d
+        assert torch.equal(got, ops.gemm([(a, b)], True, False))
+        a64, b64 = a.double(), b.double()
+        want = a64.t() @ b64
+        mag = a64.abs().t() @ b64.abs()
+        err = float(((got.double() - want).abs() / mag).max())
+        ops.GEMM_WIDE_WGRAD["enabled"] = False
+        c0 = ops.launch_counts()
+        tile = ops.gemm([(a, b)], True, False)
+        d = _delta(P, c0)
+        assert d["gemm_wgrad_wide"] == 0 and d["gemm_tile_x3"] == 1, d
+        err_tile = float(((tile.double() - want).abs() / mag).max())
+        print(f"{m}x{n} over {k}: wide {err:.2e}  tile {err_tile:.2e} of sum |a||b|")
+        assert err <= 2.0 ** -22 and err <= 1.5 * err_tile + 2e-8
+    finally:
+        ops.GEMM_MATH["mode"] = old
+        ops.GEMM_WIDE_WGRAD["enabled"] = True
+
+
+def test_wide_weight_gradient_rule(P):
+    """where the form applies (plnlp_gemm_wide_wgrad_slices) and that everything else keeps the 128 x 128 kernels: a gathered
+    operand, a width <= 128 or > 224 or not a multiple of 4, a short reduction, the f32 math, an operand off 16-byte alignment"""
+    ops = P.ops
+    old = ops.GEMM_MATH["mode"]
+    ops.GEMM_MATH["mode"] = "bf16x3"
+    try:
+        def ran(a, b, **kw):
+            c0 = ops.launch_counts()
+            ops.gemm([(a, b)], True, False, **kw)
+            return _delta(P, c0)["gemm_wgrad_wide"]
+        k = 40_000
+        x = torch.randn(k, 232, device="cuda")
+        assert ran(x[:, :200], x[:, :200]) == 1
+        assert ran(x[:, :128], x[:, :200]) == 0 and ran(x[:, :200], x[:, :128]) == 0
+        assert ran(x[:, :228], x[:, :200]) == 0 and ran(x[:, :202], x[:, :200]) == 0
+        assert ran(x[:, 2:202], x[:, :200]) == 0                      # 8 bytes off
+        assert ran(x[:30_000, :200], x[:30_000, :200]) == 0
+        rows = torch.arange(k, device="cuda", dtype=torch.int32)
+        assert ran(x[:, :200], x[:, :200], b_index=rows) == 0
+        ops.GEMM_MATH["mode"] = "f32"
+        assert ran(x[:, :200], x[:, :200]) == 0
+    finally:
+        ops.GEMM_MATH["mode"] = old
