@@ -338,10 +338,17 @@ __global__ __launch_bounds__(RG * RE) void wide_reduce_kernel(const float* __res
 int launch(const Args& g, hipStream_t s) {
     const int nblk = (g.n + 31) / 32;
     auto run = [&](auto kernel) -> int {
-        // (per launch: the attribute belongs to the device's copy of the function, and a process may hold several devices)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess)
-            return PLNLP_E_UNSUPPORTED;
+        // (once per device and instantiation: the attribute belongs to the device's copy of the function, and a process may
+        // hold several devices)
+        static bool armed[8][64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return PLNLP_E_UNSUPPORTED;
+        if (dev < 0 || dev >= 64 || !armed[nblk][dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    LDS_BYTES) != hipSuccess)
+                return PLNLP_E_UNSUPPORTED;
+            if (dev >= 0 && dev < 64) armed[nblk][dev] = true;
+        }
         hipLaunchKernelGGL(kernel, dim3((unsigned)g.slices), dim3(NT), LDS_BYTES, s, g);
         return launch_status();
     };
