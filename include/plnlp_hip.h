@@ -39,7 +39,7 @@ extern "C" {
  *              split-K), plnlp_launch_counts / plnlp_launch_kind_name (which kernel families have been launched),
  *              plnlp_mlp_head_backward_f32 (the 1-output head's backward in one pass over the hidden activation),
  *              PLNLP_EPI_ROWDOT + plnlp_gemm_rowdot_tiles / plnlp_rowdot_finish_f32 (its forward in the hidden GEMM's epilogue).
- * 11 (round 5): plnlp_gemm_wide_wgrad_slices (the weight gradient of a 129 .. 224 wide layer with the whole result held by one
+ * 11 (round 5): plnlp_gemm_wide_wgrad_slices (the weight gradient with whole 224- / 256-wide blocks of the result held by one
  *              workgroup per K slice: the host asks how many slices that form wants and cuts K accordingly). */
 #define PLNLP_ABI_VERSION 11
 
@@ -270,13 +270,18 @@ int64_t plnlp_gemm_b_terms_bytes(int64_t m, int64_t n, int64_t k0, int64_t k1);
  * host-side mirror of it that `F.linear`'s callers kept, plnlp/layer.py:83,86).  No launch, no device access. */
 int plnlp_gemm_stationary_applies(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, const float* c,
                                   int64_t ldc, int64_t m, int64_t n, const float* c2, int64_t ldc2, int64_t n_split);
-/* K slices the WIDE weight-gradient form wants for C[m, n] = A^T B (a_trans = 1, b_trans = 0, one segment, operands as stored,
- * BF16X3 math, 128 < m, n <= 224 both multiples of 4, 16-byte aligned operands, k >= 32 768): one workgroup per slice holds the
- * whole result -- every operand row is read once and split once, instead of once per 128-wide tile (csrc/gemm_wgw.hip); 0 where
- * the form does not apply.  A plnlp_gemm_f32 launch takes the form exactly when its split_k equals this number (and its workspace
+/* K slices the WIDE weight-gradient form wants for C[m, n] = A^T B (a_trans = 1, b_trans = 0, one segment, A as stored, BF16X3
+ * math, 16-byte aligned operands, k >= 32 768), 0 where the form does not apply.  Whole blocks of the result per workgroup and
+ * K slice -- every operand row is read once and split once per block instead of once per 128-wide tile (csrc/gemm_wgw.hip):
+ *   128 < m, n <= 224, both multiples of 4: ONE block (7 waves); B one buffer, not gathered;
+ *   m and n multiples of 256, at most 8 blocks of 256 x 256 (8 waves): B may be two buffers side by side along n (b2 / ldb2 /
+ *     nb_split as in plnlp_gemm_pair_f32, nb_split a multiple of 256; b2 = NULL: one buffer) and its rows may be gathered
+ *     (seg->b_index, 16-byte aligned; b_index_on as in plnlp_gemm_pair_f32, 3 for one buffer).
+ * A plnlp_gemm_f32 / plnlp_gemm_pair_f32 launch takes the form exactly when its split_k equals this number (and its workspace
  * holds split_k * m * n floats, as for every split-K launch); any other split_k runs the 128 x 128 kernels.  Replaces nothing in
  * the reference (`F.linear`'s weight gradient is one cuBLAS call, plnlp/layer.py:83,86).  No launch, no device access. */
-int plnlp_gemm_wide_wgrad_slices(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, int64_t m, int64_t n);
+int plnlp_gemm_wide_wgrad_slices(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, int64_t m, int64_t n,
+                                 const float* b2, int64_t ldb2, int64_t nb_split, int b_index_on);
 /* column tiles of the stationary-weights kernel's result for an [m, n] product = rows of plnlp_epilogue.rowdot_out that a
  * PLNLP_EPI_ROWDOT launch writes; 0 when the row-dot epilogue is not available for this shape (tile widths 128 / 256 only) */
 int plnlp_gemm_rowdot_tiles(int64_t m, int64_t n);

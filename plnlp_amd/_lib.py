@@ -108,7 +108,8 @@ SIGNATURES = {
     "plnlp_rowdot_finish_f32": (C.c_int, [C.c_void_p, c_i64, C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plnlp_gemm_stationary_applies": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
                                                 c_i64, C.c_void_p, c_i64, c_i64]),
-    "plnlp_gemm_wide_wgrad_slices": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, c_i64, c_i64]),
+    "plnlp_gemm_wide_wgrad_slices": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, c_i64, c_i64, C.c_void_p,
+                                               c_i64, c_i64, C.c_int]),
     "plnlp_mlp_head_backward_workspace_floats": (c_i64, [c_i64, c_i64]),
     "plnlp_mlp_head_backward_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_float, c_i64, c_i64, C.c_void_p,
                                               c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_void_p]),

@@ -971,18 +971,27 @@ static int stationary_form(const plnlp_gemm_operand* segs, int n_seg, int a_tran
     return x3s::pick_nb(m, n);
 }
 
-// K slices of the wide weight-gradient form (gemm_wgw.hip) for this launch, 0 where it does not apply: one K-segment,
-// A^T B with both operands as stored (no gathered rows, no second B buffer, no split result), split-bf16 math, and
-// wgw::slices_for's shape rule.  The launch takes the form exactly when the caller cuts K into this many slices.
-static int wide_wgrad_slices(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, int64_t m, int64_t n) {
+// The wide weight-gradient form (gemm_wgw.hip) for this launch: its arguments (everything but slices / ws), and the K slices it
+// wants -- 0 where it does not apply: one K-segment, A^T B with A as stored, split-bf16 math, and wgw::slices_for's shape
+// rule (B in one or two buffers, its rows gathered or not).  The launch takes the form exactly when the caller cuts K into
+// this many slices.
+static int wide_wgrad_slices(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, int64_t m, int64_t n,
+                             const float* b2, int64_t ldb2, int64_t nb_split, int bidx_mask, plnlp::wgw::Args* out) {
     if (!segs || n_seg != 1 || !a_trans || b_trans || segs[0].math != PLNLP_GEMM_MATH_BF16X3) return 0;
     const plnlp_gemm_operand& o = segs[0];
-    if (o.a_index || o.b_index || o.a_index2 || o.b_index2 || !o.a || !o.b) return 0;
-    return plnlp::wgw::slices_for(m, n, o.k, o.a, o.lda, o.b, o.ldb);
+    if (o.a_index || o.a_index2 || o.b_index2 || !o.a || !o.b || m > 0x7FFFFFFF || n > 0x7FFFFFFF) return 0;
+    plnlp::wgw::Args w{};
+    w.a = o.a; w.lda = o.lda; w.b = o.b; w.ldb = o.ldb; w.m = (int)m; w.n = (int)n; w.k = o.k;
+    w.b2 = b2; w.ldb2 = ldb2; w.nb_split = b2 ? (int)nb_split : (int)n;
+    w.b_index = o.b_index; w.bidx_mask = o.b_index ? bidx_mask & (b2 ? 3 : 1) : 0;
+    if (w.b_index && !w.bidx_mask) w.b_index = nullptr;
+    if (out) *out = w;
+    return plnlp::wgw::slices_for(w);
 }
 extern "C" int plnlp_gemm_wide_wgrad_slices(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans,
-                                            int64_t m, int64_t n) {
-    return wide_wgrad_slices(segs, n_seg, a_trans, b_trans, m, n);
+                                            int64_t m, int64_t n, const float* b2, int64_t ldb2, int64_t nb_split,
+                                            int b_index_on) {
+    return wide_wgrad_slices(segs, n_seg, a_trans, b_trans, m, n, b2, ldb2, nb_split, b_index_on, nullptr);
 }
 extern "C" int plnlp_gemm_stationary_applies(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans,
                                              const float* c, int64_t ldc, int64_t m, int64_t n, const float* c2,
@@ -1163,17 +1172,18 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     }
     if (e.flags & PLNLP_EPI_ROWDOT) return PLNLP_E_UNSUPPORTED;      // the row-dot epilogue lives in the stationary kernel only
     const int reduce_slices = split_k;
-    // ---- the wide weight gradient (gemm_wgw.hip): the whole result in one workgroup per K slice; taken when the caller cut K
-    // into exactly the slices plnlp_gemm_wide_wgrad_slices names for this launch (its workspace is then the right size)
-    if (!b2 && !c2 && split_k > 1 && split_k == wide_wgrad_slices(segs, n_seg, a_trans, b_trans, m, n)) {
-        wgw::Args w{};
-        w.a = g.seg[0].a; w.lda = g.seg[0].lda; w.b = g.seg[0].b; w.ldb = g.seg[0].ldb;
-        w.m = (int)m; w.n = (int)n; w.k = g.seg[0].k; w.slices = split_k; w.ws = workspace;
+    // ---- the wide weight gradient (gemm_wgw.hip): whole 224- / 256-wide blocks of the result per workgroup and K slice; taken
+    // when the caller cut K into exactly the slices plnlp_gemm_wide_wgrad_slices names for this launch (its workspace is then
+    // the right size)
+    wgw::Args w{};
+    if (split_k > 1 && split_k == wide_wgrad_slices(segs, n_seg, a_trans, b_trans, m, n, b2, ldb2, nb_split, bidx_mask, &w)) {
+        w.slices = split_k; w.ws = workspace;
         count_launch(LK_GEMM_WGRAD_WIDE);
         if (int rc = wgw::launch(w, s)) return rc;
         count_launch(LK_GEMM_SPLITK_REDUCE);
-        if (((uintptr_t)c % 16 == 0) && (ldc % 4 == 0) && ((uintptr_t)workspace % 16 == 0)) return wgw::reduce(w, c, ldc, e, s);
+        if (!c2 && ((uintptr_t)c % 16 == 0) && (ldc % 4 == 0) && ((uintptr_t)workspace % 16 == 0)) return wgw::reduce(w, c, ldc, e, s);
         int64_t blocks = (m * n / 4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, reduce_slices,
                            g.ws_stride, c, ldc, m, (int)n, e, c2, ldc2, (int)n_split, (int64_t)0);
         return launch_status();

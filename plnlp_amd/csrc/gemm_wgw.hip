@@ -1,5 +1,9 @@
-// K4w -- the split-bf16 weight gradient of a layer 129 .. 224 wide:  C[m, n] = A^T B,  A [k, m], B [k, n],  m, n <= 224,
-// k = the rows of the graph (10^5 .. 10^7).  gfx950.
+// K4w -- the split-bf16 weight gradient with a whole W x W block of the result per workgroup:  C[m, n] = A^T B,  A [k, m],
+// B [k, n], k = the rows of the graph or of the batch (10^5 .. 10^7).  gfx950.  Two geometries:
+//   W = 224 (7 waves): a layer 129 .. 224 wide in ONE block (citation2's h = 200);
+//   W = 256 (8 waves): m and n multiples of 256 (collab 256 x 512, ddi 512 x 512), the result cut into 256 x 256 blocks;
+//       B may be two buffers side by side along n ([agg | x], plnlp_gemm_pair_f32) and its rows may be gathered (b_index).
+// The text below describes W = 224; the other geometry differs only in the constants.
 //
 // Why a kernel of its own: on the 128 x 128 kernels (gemm_f32.hip) a 200 x 200 result is four tiles of which 39 % is
 // padding, every operand panel is fetched by two workgroups, and each loaded element -- split into its three bf16 terms
@@ -32,16 +36,21 @@ namespace wgw {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int NT = 448;                 // threads: 2 operands x 2 k-groups x 112 column pairs
-constexpr int CP = W / 2;               // 112
 constexpr int KT = 16;                  // k per step
-constexpr int TERMU = 2 * W;            // 16-byte units per term
-constexpr int OPERU = 3 * TERMU;        // units per operand
-constexpr int BUFU = 2 * OPERU;         // units per buffer (A then B)
-constexpr int LDS_BYTES = 2 * BUFU * 16;  // 86 016
+template <int NW>
+struct Geo {                            // NW waves = NW 32-row strips of the block
+    static constexpr int W = 32 * NW;           // rows / columns of the block
+    static constexpr int CP = W / 2;            // column pairs per operand row
+    static constexpr int NT = 64 * NW;          // threads: 2 operands x 2 k-groups x CP column pairs
+    static constexpr int TERMU = 2 * W;         // 16-byte units per term
+    static constexpr int OPERU = 3 * TERMU;     // units per operand
+    static constexpr int BUFU = 2 * OPERU;      // units per buffer (A then B)
+    static constexpr int LDS_BYTES = 2 * BUFU * 16;     // 86 016 / 98 304
+};
 
 __device__ __forceinline__ unsigned pk(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
 
@@ -50,20 +59,21 @@ struct Raw { f32x2 x[8]; };
 
 // where a staging thread reads and writes (fixed for the whole launch)
 struct Role {
-    const float* src;     // its operand at (row 8 kg of step 0, its column pair)
+    const float* src;     // its operand at (row 0, its column pair)
     int64_t ld;
     int unit0, unit1;     // LDS units (within a buffer, term 0) of its two columns
     int row8;             // its first row within a K-step (0 or 8)
+    const int32_t* index; // GATHER: row j of the reduction is row index[j] of the operand (nullptr: row j itself)
 };
 
 // the split of one staging thread's share (8 k x 2 columns) in 18 stages of ~5 VALU instructions that ride between MFMAs:
 // per column, stage 0-3 = hi term of k-pair q (and the residual), 4-7 = mid term, 8 = lo terms; a term's 16-byte unit is
 // stored as soon as its four dwords exist (stages 3, 7, 8), so a wave's six stores are spread over the step -- three
-// back-to-back ds_write_b128 from all 7 waves at once filled the LDS store queue and stalled the waves at issue
+// back-to-back ds_write_b128 from all the waves at once filled the LDS store queue and stalled the waves at issue
 struct Split {
     f32x2 r[4];
     unsigned t[4];        // the term being assembled
-    template <int I>
+    template <int I, int TERMU>
     __device__ __forceinline__ void stage(const Raw& w, u32x4* __restrict__ buf, const Role& ro) {
 #pragma clang fp contract(off)
         constexpr int C = I / 9, K = I % 9;
@@ -98,37 +108,52 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // the whole split of one thread's share, not interleaved with anything (prologue, the partial last step)
+template <int TERMU>
 __device__ __forceinline__ void split_store(u32x4* __restrict__ buf, const Role& ro, const Raw& w) {
     Split sp;
-    static_for<18>([&](auto ic) { sp.template stage<decltype(ic)::value>(w, buf, ro); });
+    static_for<18>([&](auto ic) { sp.template stage<decltype(ic)::value, TERMU>(w, buf, ro); });
 }
 
-// a FULL K-step (no row past the end): plain 8-byte loads
-template <int I0 = 0, int I1 = 8>
-__device__ __forceinline__ void load_full(const Role& ro, Raw& w, int64_t step) {
-    const float* p = ro.src + step * KT * ro.ld;
+// GATHER: the operand rows of the 8 reduction indices a thread stages in one K-step (wave-uniform addresses: broadcast loads)
+struct Rows { i32x4 lo, hi; };
+__device__ __forceinline__ void load_rows(const Role& ro, Rows& ix, int64_t step) {
+    const int32_t* p = ro.index + step * KT + ro.row8;
+    ix.lo = *reinterpret_cast<const i32x4*>(p);
+    ix.hi = *reinterpret_cast<const i32x4*>(p + 4);
+}
+
+// a FULL K-step (no reduction index past the end): plain 8-byte loads, rows I0 .. I1-1 of the thread's 8.  GATHER: the rows
+// come from `ix` (loaded a step earlier) where the thread's operand is gathered
+template <bool GATHER, int I0 = 0, int I1 = 8>
+__device__ __forceinline__ void load_full(const Role& ro, Raw& w, int64_t step, const Rows& ix) {
+    const int64_t r0 = step * KT + ro.row8;
 #pragma unroll
-    for (int i = I0; i < I1; ++i) w.x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + i * ro.ld));
+    for (int i = I0; i < I1; ++i) {
+        int64_t r = r0 + i;
+        if constexpr (GATHER) r = ro.index ? (int64_t)(i < 4 ? ix.lo[i & 3] : ix.hi[i & 3]) : r;
+        w.x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(ro.src + r * ro.ld));
+    }
 }
 
 // one lane's fragment of term s: k 8h .. 8h+7 of position `pos`
+template <int NW>
 __device__ __forceinline__ bf16x8 frag(const u32x4* __restrict__ oper, int s, int pos, int h) {
-    return __builtin_bit_cast(bf16x8, oper[s * TERMU + h * W + pos]);
+    return __builtin_bit_cast(bf16x8, oper[s * Geo<NW>::TERMU + h * Geo<NW>::W + pos]);
 }
 
 constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};    // the six products, small terms first
 
 // the MFMAs of one K-step from buffer `buf`, nothing else (the reduction's partial last step)
-template <int NBLK>
+template <int NW, int NBLK>
 __device__ __forceinline__ void mma_plain(f32x16 (&acc)[NBLK], const u32x4* __restrict__ buf, int wave, int l31, int h) {
     bf16x8 a[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) a[s] = frag(buf, s, 32 * wave + l31, h);
+    for (int s = 0; s < 3; ++s) a[s] = frag<NW>(buf, s, 32 * wave + l31, h);
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) {
         bf16x8 b[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) b[s] = frag(buf + OPERU, s, 32 * j + l31, h);
+        for (int s = 0; s < 3; ++s) b[s] = frag<NW>(buf + Geo<NW>::OPERU, s, 32 * j + l31, h);
 #pragma unroll
         for (int u = 0; u < 6; ++u) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[u]], b[TB[u]], acc[j], 0, 0, 0);
     }
@@ -156,13 +181,14 @@ constexpr int head_stage_at(int q) {            // the split stage (5 .. 17) pin
         if (((i - 5) * HEAD) / 13 == q) return i;
     return -1;
 }
-template <int NBLK, int D, int P>
+template <int NW, int NBLK, int D, int P, bool GATHER>
 __device__ __forceinline__ void step_pipelined(f32x16 (&acc)[NBLK], u32x4* __restrict__ lds, Raw (&raw)[2], Split (&S)[2],
-                                               const Role& ro, int64_t next, bf16x8 (&A)[2][3], bf16x8 (&B)[2][3], int wave,
-                                               int l31, int h) {
-    u32x4* cbuf = lds + D * BUFU;
-    const u32x4* bt = cbuf + OPERU;
-    u32x4* nbuf = lds + (D ^ 1) * BUFU;
+                                               const Role& ro, int64_t next, int64_t next_rows, Rows& ix, bf16x8 (&A)[2][3],
+                                               bf16x8 (&B)[2][3], int wave, int l31, int h) {
+    typedef Geo<NW> G;
+    u32x4* cbuf = lds + D * G::BUFU;
+    const u32x4* bt = cbuf + G::OPERU;
+    u32x4* nbuf = lds + (D ^ 1) * G::BUFU;
     constexpr int SLOTS = 6 * NBLK, BS = SLOTS - 10, HEAD = BS - 7, LD = BS - 6;
     static_assert(HEAD >= 13 && BS == 6 * (NBLK - 2) + 2, "slot plan");
     __builtin_amdgcn_sched_barrier(0);
@@ -173,59 +199,79 @@ __device__ __forceinline__ void step_pipelined(f32x16 (&acc)[NBLK], u32x4* __res
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[D][TA[u]], B[(P + j) & 1][TB[u]], acc[j], 0, 0, 0);
         if constexpr (u == 0 && j + 1 < NBLK) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) B[(P + j + 1) & 1][s] = frag(bt, s, 32 * (j + 1) + l31, h);
+            for (int s = 0; s < 3; ++s) B[(P + j + 1) & 1][s] = frag<NW>(bt, s, 32 * (j + 1) + l31, h);
         }
         if constexpr (q == BS) {                     // the next step's A fragments (the other set: this step still multiplies A[D])
 #pragma unroll
-            for (int s = 0; s < 3; ++s) A[D ^ 1][s] = frag(nbuf, s, 32 * wave + l31, h);
+            for (int s = 0; s < 3; ++s) A[D ^ 1][s] = frag<NW>(nbuf, s, 32 * wave + l31, h);
         }
         if constexpr (q == BS + 4) {                 // ... and its first B fragments, into the set block NBLK - 2 has just left
 #pragma unroll
-            for (int s = 0; s < 3; ++s) B[(P + NBLK) & 1][s] = frag(nbuf + OPERU, s, l31, h);
+            for (int s = 0; s < 3; ++s) B[(P + NBLK) & 1][s] = frag<NW>(nbuf + G::OPERU, s, l31, h);
         }
         if constexpr (q < HEAD) {
             constexpr int st = head_stage_at<HEAD>(q);
-            if constexpr (st >= 0) S[D ^ 1].template stage<st>(raw[D ^ 1], nbuf, ro);
+            if constexpr (st >= 0) S[D ^ 1].template stage<st, G::TERMU>(raw[D ^ 1], nbuf, ro);
         }
-        if constexpr (q == LD)     load_full<0, 4>(ro, raw[D ^ 1], next);
-        if constexpr (q == LD + 1) load_full<4, 8>(ro, raw[D ^ 1], next);
-        if constexpr (q > BS && ((q - BS) & 1)) S[D].template stage<(q - BS) / 2>(raw[D], cbuf, ro);
+        if constexpr (q == LD)     load_full<GATHER, 0, 4>(ro, raw[D ^ 1], next, ix);
+        if constexpr (q == LD + 1) {
+            load_full<GATHER, 4, 8>(ro, raw[D ^ 1], next, ix);
+            if constexpr (GATHER) { if (ro.index) load_rows(ro, ix, next_rows); }     // (the rows of the NEXT step's refill)
+        }
+        if constexpr (q > BS && ((q - BS) & 1)) S[D].template stage<(q - BS) / 2, G::TERMU>(raw[D], cbuf, ro);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
 
-// position -> column of an operand `width` wide (see the header)
+// position -> column of an operand block `width` wide (see the header)
 __device__ __forceinline__ int column_of(int pos, int width) {
     const int half = width >> 1;
     return pos < half ? 2 * pos : 2 * (pos - half) + 1;
 }
 
-// NBLK: 32-position blocks of B with a live position (5 .. 7) -- compile-time, so that a K-step is ONE basic block
-template <int NBLK>
-__global__ __launch_bounds__(NT, 1) void wgrad_wide_kernel(Args g) {
+// NBLK: 32-position blocks of B with a live position -- compile-time, so that a K-step is ONE basic block
+template <int NW, int NBLK, bool GATHER>
+__global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
+    typedef Geo<NW> G;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
+    // workgroup -> (K slice z, result block (mt, nt)): the blocks of one slice sit on ONE XCD (workgroups are dealt to the
+    // XCDs round-robin), so the A rows they share come out of that XCD's L2 the second time
+    int64_t z; int mt, nt;
+    {
+        const int tiles = g.tiles_m * g.tiles_n;
+        const int64_t id = blockIdx.x, q = id >> 3;
+        z = (q / tiles) * 8 + (id & 7);
+        const int tile = (int)(q % tiles);
+        mt = tile / g.tiles_n; nt = tile % g.tiles_n;
+    }
+    const int wa = g.m - mt * G::W < G::W ? g.m - mt * G::W : G::W;        // live rows / columns of this block
+    const int wb = g.n - nt * G::W < G::W ? g.n - nt * G::W : G::W;
     Role ro;
     {
-        const int o = t >= 2 * CP, u = t - 2 * CP * o, kg = u >= CP, cp = u - CP * kg;
-        const int width = o ? g.n : g.m, half = width >> 1;
+        const int o = t >= 2 * G::CP, u = t - 2 * G::CP * o, kg = u >= G::CP, cp = u - G::CP * kg;
+        const int width = o ? wb : wa, half = width >> 1;
         const bool live = cp < half;
         const int col = live ? 2 * cp : width - 2;
         const int p0 = live ? cp : width + 2 * (cp - half);
         const int p1 = live ? half + cp : p0 + 1;
-        ro.ld = o ? g.ldb : g.lda;
+        // B's columns from nb_split on live in the second buffer (the pair form: [agg | x])
+        const bool second = o && g.b2 && nt * G::W >= g.nb_split;
+        const float* base = !o ? g.a + mt * G::W : (second ? g.b2 + (nt * G::W - g.nb_split) : g.b + nt * G::W);
+        ro.ld = !o ? g.lda : (second ? g.ldb2 : g.ldb);
         ro.row8 = 8 * kg;
-        ro.src = (o ? g.b : g.a) + (int64_t)(8 * kg) * ro.ld + col;
-        ro.unit0 = o * OPERU + kg * W + p0;
-        ro.unit1 = o * OPERU + kg * W + p1;
+        ro.src = base + col;
+        ro.unit0 = o * G::OPERU + kg * G::W + p0;
+        ro.unit1 = o * G::OPERU + kg * G::W + p1;
+        ro.index = (GATHER && o && (g.bidx_mask & (second ? 2 : 1))) ? g.b_index : nullptr;
     }
 
     // K-steps of this slice: [sb, sf) full ones, then (last slice only) the reduction's partial last step
     const int64_t steps = (g.k + KT - 1) / KT, full = g.k / KT;
     const int64_t per = (steps + g.slices - 1) / g.slices;
-    const int64_t sb = (int64_t)blockIdx.x * per;
+    const int64_t sb = z * per;
     const int64_t se = sb + per < steps ? sb + per : steps;
     const int64_t sf = se < full ? se : full;
 
@@ -237,64 +283,83 @@ __global__ __launch_bounds__(NT, 1) void wgrad_wide_kernel(Args g) {
 
     if (sb < sf) {
         const int64_t last = sf - 1;
+        auto at = [&](int64_t step) { return step < last ? step : last; };
         Raw raw[2];
         Split S[2];
+        Rows ix{};
         bf16x8 A[2][3], B[2][3];
-        load_full(ro, raw[0], sb);
-        load_full(ro, raw[1], sb + 1 < last ? sb + 1 : last);
-        split_store(lds, ro, raw[0]);
-        load_full(ro, raw[0], sb + 2 < last ? sb + 2 : last);
-        static_for<5>([&](auto ic) { S[1].template stage<decltype(ic)::value>(raw[1], lds + BUFU, ro); });
+        auto fetch = [&](Raw& w, int64_t step) {          // (prologue: the rows, then the data that depends on them)
+            if constexpr (GATHER) { if (ro.index) load_rows(ro, ix, step); }
+            load_full<GATHER>(ro, w, step, ix);
+        };
+        fetch(raw[0], sb);
+        fetch(raw[1], at(sb + 1));
+        split_store<G::TERMU>(lds, ro, raw[0]);
+        fetch(raw[0], at(sb + 2));
+        if constexpr (GATHER) { if (ro.index) load_rows(ro, ix, at(sb + 3)); }     // for the first step's refill
+        static_for<5>([&](auto ic) { S[1].template stage<decltype(ic)::value, G::TERMU>(raw[1], lds + G::BUFU, ro); });
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            A[0][s] = frag(lds, s, 32 * wave + l31, h);
-            B[0][s] = frag(lds + OPERU, s, l31, h);
+            A[0][s] = frag<NW>(lds, s, 32 * wave + l31, h);
+            B[0][s] = frag<NW>(lds + G::OPERU, s, l31, h);
         }
         int64_t i = sb;
         // (look-ahead loads past the slice's last full step re-read that step: what they stage is never multiplied)
         for (; i + 2 <= sf; i += 2) {
-            step_pipelined<NBLK, 0, 0>(acc, lds, raw, S, ro, i + 3 < last ? i + 3 : last, A, B, wave, l31, h);
-            step_pipelined<NBLK, 1, NBLK & 1>(acc, lds, raw, S, ro, i + 4 < last ? i + 4 : last, A, B, wave, l31, h);
+            step_pipelined<NW, NBLK, 0, 0, GATHER>(acc, lds, raw, S, ro, at(i + 3), at(i + 4), ix, A, B, wave, l31, h);
+            step_pipelined<NW, NBLK, 1, NBLK & 1, GATHER>(acc, lds, raw, S, ro, at(i + 4), at(i + 5), ix, A, B, wave, l31, h);
         }
-        if (i < sf) step_pipelined<NBLK, 0, 0>(acc, lds, raw, S, ro, last, A, B, wave, l31, h);
+        if (i < sf) step_pipelined<NW, NBLK, 0, 0, GATHER>(acc, lds, raw, S, ro, last, last, ix, A, B, wave, l31, h);
         __syncthreads();              // (the last step's look-ahead reads are behind us before anything re-uses the buffers)
     }
-    if (se > sf && sb <= sf) {        // the reduction's partial last step: rows past the end are zeros
+    if (se > sf && sb <= sf) {        // the reduction's partial last step: indices past the end contribute zeros
         Raw w;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t r = sf * KT + ro.row8 + i, rc = r < g.k ? r : g.k - 1;
-            const f32x2 v = *reinterpret_cast<const f32x2*>(ro.src + (rc - ro.row8) * ro.ld);
-            const f32x2 z = {0.f, 0.f};
-            w.x[i] = r < g.k ? v : z;
+            int64_t row = rc;
+            if constexpr (GATHER) { if (ro.index) row = ro.index[rc]; }
+            const f32x2 v = *reinterpret_cast<const f32x2*>(ro.src + row * ro.ld);
+            const f32x2 zero = {0.f, 0.f};
+            w.x[i] = r < g.k ? v : zero;
         }
-        split_store(lds, ro, w);
+        split_store<G::TERMU>(lds, ro, w);
         __syncthreads();
-        mma_plain<NBLK>(acc, lds, wave, l31, h);
+        mma_plain<NW, NBLK>(acc, lds, wave, l31, h);
     }
 
     // raw partial of this slice.  MFMA C/D map: position of B = lane & 31, position of A = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
-    // within the block; once per workgroup (a few hundred K-steps), so plain 4-byte stores
-    float* out = g.ws + (int64_t)blockIdx.x * g.m * g.n;
+    // within the block; once per workgroup (tens to hundreds of K-steps), so plain 4-byte stores
+    float* out = g.ws + z * (int64_t)g.m * g.n + (int64_t)mt * G::W * g.n + nt * G::W;
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) {
         const int pb = 32 * j + l31;
-        if (pb >= g.n) continue;
-        const int col = column_of(pb, g.n);
+        if (pb >= wb) continue;
+        const int col = column_of(pb, wb);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int pa = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (pa < g.m) out[(int64_t)column_of(pa, g.m) * g.n + col] = acc[j][q];
+            if (pa < wa) out[(int64_t)column_of(pa, wa) * g.n + col] = acc[j][q];
         }
     }
 }
 
-int slices_for(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb) {
-    // wider than one 128-tile in BOTH directions (else the tile kernels waste nothing worth a second kernel), whole
-    // 16-byte column groups, a reduction long enough to give every CU a slice of a few dozen K-steps
-    if (m <= 128 || n <= 128 || m > W || n > W || (m % 4) || (n % 4) || k < MIN_K) return 0;
-    if (((uintptr_t)a % 16) || ((uintptr_t)b % 16) || (lda % 4) || (ldb % 4) || lda < m || ldb < n) return 0;
+// The rule, in one place.  One block (W = 224): wider than one 128-tile in BOTH directions (else the tile kernels waste nothing
+// worth a second kernel).  Blocks of 256 x 256: both extents whole blocks, at most 8 of them.  Whole 16-byte column groups,
+// aligned operands, a reduction long enough to give every CU a slice of a few dozen K-steps.
+int slices_for(const Args& g) {
+    if (g.k < MIN_K || !g.a || !g.b) return 0;
+    if (((uintptr_t)g.a % 16) || ((uintptr_t)g.b % 16) || (g.lda % 4) || (g.ldb % 4) || g.lda < g.m) return 0;
+    if (g.b2 && (((uintptr_t)g.b2 % 16) || (g.ldb2 % 4) || g.nb_split <= 0 || g.nb_split >= g.n)) return 0;
+    if (g.b_index && ((uintptr_t)g.b_index % 16)) return 0;
+    if (g.m % 256 == 0 && g.n % 256 == 0 && (!g.b2 || g.nb_split % 256 == 0)) {
+        const int tiles = (g.m / 256) * (g.n / 256);
+        if (tiles > 8 || (!g.b2 && g.ldb < g.n) || (g.b2 && (g.ldb < g.nb_split || g.ldb2 < g.n - g.nb_split))) return 0;
+        return tiles <= 2 ? 256 / tiles : (tiles <= 4 ? 64 : 32);          // (a multiple of 8: the slices are dealt over the XCDs)
+    }
+    if (g.b2 || g.b_index) return 0;
+    if (g.m <= 128 || g.n <= 128 || g.m > W || g.n > W || (g.m % 4) || (g.n % 4) || g.ldb < g.n) return 0;
     return 256;                   // one workgroup per CU
 }
 
@@ -335,27 +400,36 @@ __global__ __launch_bounds__(RG * RE) void wide_reduce_kernel(const float* __res
     *reinterpret_cast<float4*>(c + row * ldc + col) = y;
 }
 
-int launch(const Args& g, hipStream_t s) {
-    const int nblk = (g.n + 31) / 32;
-    auto run = [&](auto kernel) -> int {
-        // (once per device and instantiation: the attribute belongs to the device's copy of the function, and a process may
-        // hold several devices)
-        static bool armed[8][64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return PLNLP_E_UNSUPPORTED;
-        if (dev < 0 || dev >= 64 || !armed[nblk][dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    LDS_BYTES) != hipSuccess)
-                return PLNLP_E_UNSUPPORTED;
-            if (dev >= 0 && dev < 64) armed[nblk][dev] = true;
-        }
-        hipLaunchKernelGGL(kernel, dim3((unsigned)g.slices), dim3(NT), LDS_BYTES, s, g);
-        return launch_status();
-    };
-    switch (nblk) {
-        case 5: return run(wgrad_wide_kernel<5>);
-        case 6: return run(wgrad_wide_kernel<6>);
-        case 7: return run(wgrad_wide_kernel<7>);
+template <int NW, int NBLK, bool GATHER>
+static int launch_as(const Args& g, hipStream_t s) {
+    auto kernel = wgrad_wide_kernel<NW, NBLK, GATHER>;
+    // (once per device and instantiation: the attribute belongs to the device's copy of the function, and a process may
+    // hold several devices)
+    static bool armed[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PLNLP_E_UNSUPPORTED;
+    if (dev < 0 || dev >= 64 || !armed[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Geo<NW>::LDS_BYTES) != hipSuccess)
+            return PLNLP_E_UNSUPPORTED;
+        if (dev >= 0 && dev < 64) armed[dev] = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(g.slices * g.tiles_m * g.tiles_n)), dim3(Geo<NW>::NT), Geo<NW>::LDS_BYTES, s, g);
+    return launch_status();
+}
+
+int launch(const Args& g_in, hipStream_t s) {
+    Args g = g_in;
+    if (g.slices % 8) return PLNLP_E_SHAPE;
+    if (g.m % 256 == 0 && g.n % 256 == 0) {
+        g.tiles_m = g.m / 256; g.tiles_n = g.n / 256;
+        return (g.b_index && g.bidx_mask) ? launch_as<8, 8, true>(g, s) : launch_as<8, 8, false>(g, s);
+    }
+    g.tiles_m = g.tiles_n = 1;
+    switch ((g.n + 31) / 32) {
+        case 5: return launch_as<7, 5, false>(g, s);
+        case 6: return launch_as<7, 6, false>(g, s);
+        case 7: return launch_as<7, 7, false>(g, s);
     }
     return PLNLP_E_SHAPE;
 }

@@ -6,20 +6,24 @@
 namespace plnlp {
 namespace wgw {
 
-constexpr int W = 224;            // result rows / columns one workgroup holds
+constexpr int W = 224;            // result rows / columns the one-block geometry holds
 constexpr int MIN_K = 32768;      // reduction lengths below this stay on the 128 x 128 kernels
 
 struct Args {
     const float* a; int64_t lda;  // [k, m]: the reduction index is the row (dz in  dW = dz^T x)
-    const float* b; int64_t ldb;  // [k, n]
+    const float* b; int64_t ldb;  // [k, n] -- or its first nb_split columns, the rest in b2 (the pair form [agg | x])
+    const float* b2; int64_t ldb2; int nb_split;
+    const int32_t* b_index;       // nullable: reduction index j reads row b_index[j] of B; bidx_mask bit 0 = b, bit 1 = b2
+    int bidx_mask;
     int m, n;
     int64_t k;
-    int slices;                   // K slices = workgroups; slice z writes its raw partial to ws + z m n (leading dimension n)
+    int slices;                   // K slices; slice z writes its raw partial to ws + z m n (leading dimension n)
     float* ws;
+    int tiles_m, tiles_n;         // (filled in by launch) result blocks per slice
 };
 
-// K slices the form wants for this product, 0 where it does not apply (the rule, in one place)
-int slices_for(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb);
+// K slices the form wants for this product (everything but slices / ws / tiles filled in), 0 where it does not apply
+int slices_for(const Args& g);
 int launch(const Args& g, hipStream_t s);
 // c = epilogue(sum of the slices' partials, in a fixed order); c 16-byte aligned, ldc % 4 == 0 (else use splitk_reduce_kernel)
 int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, hipStream_t s);

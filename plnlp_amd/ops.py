@@ -525,7 +525,7 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     if split_k is None:
         # (the wide weight-gradient form -- the whole <= 224 x 224 result per workgroup -- is taken by the launch exactly
         # when K is cut into the slices the library names for it)
-        split_k = (lib.plnlp_gemm_wide_wgrad_slices(ops, len(segs), int(a_trans), int(b_trans), m, n)
+        split_k = (lib.plnlp_gemm_wide_wgrad_slices(ops, len(segs), int(a_trans), int(b_trans), m, n, None, 0, n, 3)
                    if GEMM_WIDE_WGRAD["enabled"] else 0) or _pick_split_k(m, n, ktiles)
     split_k = max(1, min(split_k, ktiles))
     keep.append(_lend_b_terms(ops, len(segs), a_trans, b_trans, out, m, n))
@@ -609,6 +609,8 @@ def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool
         assert b1.shape[0] == k
     ktiles = (k + 31) // 32
     split_k = max(1, min(_pick_split_k(m, n, ktiles), ktiles)) if a_trans else 1
+    if a_trans and GEMM_WIDE_WGRAD["enabled"]:      # (the wide form is taken by the launch exactly when K is cut its way)
+        split_k = lib.plnlp_gemm_wide_wgrad_slices(ops, 1, 1, 0, m, n, b2.data_ptr(), _ld(b2), n1, int(rows_on)) or split_k
     c1 = out1 if out1 is not None else torch.empty(m, n1, dtype=torch.float32, device=a.device)
     assert c1.shape == (m, n1) and c1.is_contiguous()
     c2 = torch.empty(m, n2, dtype=torch.float32, device=a.device)

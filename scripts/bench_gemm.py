@@ -27,6 +27,10 @@ SHAPES = {
     "cit_in_wgrad": (200, 180, [2927963], True, False, False),
     "cit_l2_wgrad": (200, 200, [2927963], True, False, False),
     "wgrad_224": (224, 224, [2927963], True, False, False),
+    "collab_wgrad_256x512": (256, 512, [132224], True, False, False),
+    # the same product with A's rows gathered from a 65 536-row table (50 MB: cache-resident) -- what the launch costs when
+    # the activation matrix does not come from HBM
+    "cit_l2_fwd_k200_cached": (2927963, 200, [200], False, True, "gather0"),
     # tail quantisation probes: 3584 tiles = exactly 7 rounds of the 512 workgroup slots, vs 7.2 rounds above
     "collab_fwd_7rounds": (229376, 256, [256, 256], False, True, True),
     "collab_fwd_plain_7rounds": (229376, 256, [256, 256], False, True, False),
@@ -68,9 +72,15 @@ def main():
         e = None
         if epi == "bias_relu":
             e = _lib.make_epilogue(bias=bias, relu=True)
-        elif epi:
+        elif epi and epi != "gather0":
             e = _lib.make_epilogue(bias=bias, relu=True, dropout_p=0.3, dropout_seed=1)
         a_index = None
+        if epi == "gather0":
+            table = torch.randn(65536, ks[0], device=dev)
+            rows = (torch.arange(m, device=dev) % 65536).to(torch.int32)
+            segs[0] = (table, segs[0][1])
+            a_index = [rows]
+            e = None
         if epi == "gather":           # the second segment's A rows gathered from a larger table
             table = torch.randn(235868, ks[1], device=dev)
             rows = torch.randperm(235868, device=dev)[:m].sort().values.to(torch.int32)

@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA -f csv -d gpurun_out/pmc_gw/d -o g -- python3 scripts/bench_gemm.py --math wide --shapes $SH --iters 3 > gpurun_out/pmc_gw_d.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INST_CYCLES_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA -f csv -d gpurun_out/pmc_gw/e -o g -- python3 scripts/bench_gemm.py --math wide --shapes $SH --iters 3 > gpurun_out/pmc_gw_e.log 2>&1
 python3 scripts/pmc_collect.py wgrad_wide_kernel $OUT "gpurun_out/pmc_gw/**/*counter_collection.csv" > /dev/null
-tail -3 gpurun_out/pmc_gw_c.log gpurun_out/pmc_gw_d.log gpurun_out/pmc_gw_e.log
+tail -n 3 gpurun_out/pmc_gw_c.log gpurun_out/pmc_gw_d.log gpurun_out/pmc_gw_e.log
 rm -rf gpurun_out/pmc_gw
 python3 - <<PY
 import json

@@ -512,8 +512,62 @@ def test_wide_weight_gradient_rule(P):
         assert ran(x[:, 2:202], x[:, :200]) == 0                      # 8 bytes off
         assert ran(x[:30_000, :200], x[:30_000, :200]) == 0
         rows = torch.arange(k, device="cuda", dtype=torch.int32)
-        assert ran(x[:, :200], x[:, :200], b_index=rows) == 0
+        assert ran(x[:, :200], x[:, :200], b_index=rows) == 0                  # (gathered rows: the 256-block geometry only)
         ops.GEMM_MATH["mode"] = "f32"
         assert ran(x[:, :200], x[:, :200]) == 0
     finally:
         ops.GEMM_MATH["mode"] = old
+
+
+@pytest.mark.parametrize("m,n,k,form", [(256, 256, 40_000, "plain"), (256, 512, 132_224, "plain"), (512, 512, 65_536, "plain"),
+                                        (256, 512, 50_007, "gathered"), (256, 512, 132_224, "pair"),
+                                        (256, 512, 40_001, "pair_gathered"), (256, 512, 132_224, "pair_compact")])
+def test_wide_weight_gradient_in_256_blocks(P, m, n, k, form):
+    """the same kernel with 8 waves and 256 x 256 blocks of the result (collab's 256 x 512, ddi's 512 x 512): B in one buffer or
+    as the pair [x1 | x2] of two (ops.wgrad_pair), its rows as stored, gathered through `rows`, or gathered in x2 only
+    (x1 compact -- the collab step's launch).  Asserted by the launch counter; against float64 at the split-bf16 bound and
+    against the 128 x 128 kernels' own error; the same bits twice."""
+    ops = P.ops
+    old = ops.GEMM_MATH["mode"]
+    ops.GEMM_MATH["mode"] = "bf16x3"
+    try:
+        gen = torch.Generator(device="cuda").manual_seed(m + n + k)
+        dz = torch.randn(k, m, device="cuda", generator=gen) * 0.05
+        n_src = k if form in ("plain", "pair") else 3 * k // 2
+        rows = None
+        if form not in ("plain", "pair"):
+            rows = torch.randperm(n_src, device="cuda", generator=gen)[:k].sort().values.to(torch.int32)
+        if form.startswith("pair"):
+            n1 = n // 2
+            x1 = torch.randn(k if form == "pair_compact" else n_src, n1, device="cuda", generator=gen)
+            x2 = torch.randn(n_src, n - n1, device="cuda", generator=gen)
+
+            def run():
+                return torch.cat(ops.wgrad_pair(dz, x1, x2, rows=rows, x1_compact=form == "pair_compact"), dim=1)
+            b1 = x1 if (rows is None or form == "pair_compact") else x1[rows.long()]
+            b_eff = torch.cat([b1, x2 if rows is None else x2[rows.long()]], dim=1)
+        else:
+            x = torch.randn(n_src, n, device="cuda", generator=gen)
+
+            def run():
+                return ops.gemm([(dz, x)], True, False, b_index=rows)
+            b_eff = x if rows is None else x[rows.long()]
+        c0 = ops.launch_counts()
+        got = run()
+        d = _delta(P, c0)
+        assert d["gemm_wgrad_wide"] == 1 and d["gemm_splitk_reduce"] == 1 and d["gemm_tile_x3"] == 0, d
+        assert torch.equal(got, run())
+        want = dz.double().t() @ b_eff.double()
+        mag = dz.double().abs().t() @ b_eff.double().abs()
+        err = float(((got.double() - want).abs() / mag).max())
+        ops.GEMM_WIDE_WGRAD["enabled"] = False
+        c0 = ops.launch_counts()
+        tile = run()
+        d = _delta(P, c0)
+        assert d["gemm_wgrad_wide"] == 0 and d["gemm_tile_x3"] >= 1, d
+        err_tile = float(((tile.double() - want).abs() / mag).max())
+        print(f"{form} {m}x{n} over {k}: wide {err:.2e}  tile {err_tile:.2e} of sum |a||b|")
+        assert err <= 2.0 ** -22 and err <= 1.5 * err_tile + 2e-8
+    finally:
+        ops.GEMM_MATH["mode"] = old
+        ops.GEMM_WIDE_WGRAD["enabled"] = True
