@@ -1181,7 +1181,9 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
         count_launch(LK_GEMM_WGRAD_WIDE);
         if (int rc = wgw::launch(w, s)) return rc;
         count_launch(LK_GEMM_SPLITK_REDUCE);
-        if (!c2 && ((uintptr_t)c % 16 == 0) && (ldc % 4 == 0) && ((uintptr_t)workspace % 16 == 0)) return wgw::reduce(w, c, ldc, e, s);
+        if (((uintptr_t)c % 16 == 0) && (ldc % 4 == 0) && ((uintptr_t)workspace % 16 == 0) &&
+            (!c2 || (((uintptr_t)c2 % 16 == 0) && (ldc2 % 4 == 0) && (n_split % 4 == 0))))
+            return wgw::reduce(w, c, ldc, e, c2, ldc2, (int)n_split, s);
         int64_t blocks = (m * n / 4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, reduce_slices,

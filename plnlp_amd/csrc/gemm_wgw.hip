@@ -63,7 +63,8 @@ struct Role {
     int64_t ld;
     int unit0, unit1;     // LDS units (within a buffer, term 0) of its two columns
     int row8;             // its first row within a K-step (0 or 8)
-    const int32_t* index; // GATHER: row j of the reduction is row index[j] of the operand (nullptr: row j itself)
+    const int32_t* index; // GATHER kernels: the launch's row list (always readable) ...
+    bool gathered;        // ... and whether THIS thread's operand reads row index[j] for reduction index j, or row j itself
 };
 
 // the split of one staging thread's share (8 k x 2 columns) in 18 stages of ~5 VALU instructions that ride between MFMAs:
@@ -130,7 +131,7 @@ __device__ __forceinline__ void load_full(const Role& ro, Raw& w, int64_t step, 
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
         int64_t r = r0 + i;
-        if constexpr (GATHER) r = ro.index ? (int64_t)(i < 4 ? ix.lo[i & 3] : ix.hi[i & 3]) : r;
+        if constexpr (GATHER) r = ro.gathered ? (int64_t)(i < 4 ? ix.lo[i & 3] : ix.hi[i & 3]) : r;
         w.x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(ro.src + r * ro.ld));
     }
 }
@@ -216,7 +217,7 @@ __device__ __forceinline__ void step_pipelined(f32x16 (&acc)[NBLK], u32x4* __res
         if constexpr (q == LD)     load_full<GATHER, 0, 4>(ro, raw[D ^ 1], next, ix);
         if constexpr (q == LD + 1) {
             load_full<GATHER, 4, 8>(ro, raw[D ^ 1], next, ix);
-            if constexpr (GATHER) { if (ro.index) load_rows(ro, ix, next_rows); }     // (the rows of the NEXT step's refill)
+            if constexpr (GATHER) load_rows(ro, ix, next_rows);      // (the rows of the NEXT step's refill; every thread: no branch)
         }
         if constexpr (q > BS && ((q - BS) & 1)) S[D].template stage<(q - BS) / 2, G::TERMU>(raw[D], cbuf, ro);
         __builtin_amdgcn_sched_barrier(0);
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
         ro.src = base + col;
         ro.unit0 = o * G::OPERU + kg * G::W + p0;
         ro.unit1 = o * G::OPERU + kg * G::W + p1;
-        ro.index = (GATHER && o && (g.bidx_mask & (second ? 2 : 1))) ? g.b_index : nullptr;
+        ro.index = g.b_index;
+        ro.gathered = GATHER && o && (g.bidx_mask & (second ? 2 : 1));
     }
 
     // K-steps of this slice: [sb, sf) full ones, then (last slice only) the reduction's partial last step
@@ -289,14 +291,14 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
         Rows ix{};
         bf16x8 A[2][3], B[2][3];
         auto fetch = [&](Raw& w, int64_t step) {          // (prologue: the rows, then the data that depends on them)
-            if constexpr (GATHER) { if (ro.index) load_rows(ro, ix, step); }
+            if constexpr (GATHER) load_rows(ro, ix, step);
             load_full<GATHER>(ro, w, step, ix);
         };
         fetch(raw[0], sb);
         fetch(raw[1], at(sb + 1));
         split_store<G::TERMU>(lds, ro, raw[0]);
         fetch(raw[0], at(sb + 2));
-        if constexpr (GATHER) { if (ro.index) load_rows(ro, ix, at(sb + 3)); }     // for the first step's refill
+        if constexpr (GATHER) load_rows(ro, ix, at(sb + 3));       // for the first step's refill
         static_for<5>([&](auto ic) { S[1].template stage<decltype(ic)::value, G::TERMU>(raw[1], lds + G::BUFU, ro); });
         __syncthreads();
 #pragma unroll
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
         for (int i = 0; i < 8; ++i) {
             const int64_t r = sf * KT + ro.row8 + i, rc = r < g.k ? r : g.k - 1;
             int64_t row = rc;
-            if constexpr (GATHER) { if (ro.index) row = ro.index[rc]; }
+            if constexpr (GATHER) { if (ro.gathered) row = ro.index[rc]; }
             const f32x2 v = *reinterpret_cast<const f32x2*>(ro.src + row * ro.ld);
             const f32x2 zero = {0.f, 0.f};
             w.x[i] = r < g.k ? v : zero;
@@ -368,7 +370,8 @@ int slices_for(const Args& g) {
 // thread: 256 slices = 32 dependent rounds of 8 loads on 40 workgroups, 0.1 ms for a 200 x 200 result.
 constexpr int RG = 8, RE = 32;          // slice groups x result groups per workgroup (256 threads)
 __global__ __launch_bounds__(RG * RE) void wide_reduce_kernel(const float* __restrict__ ws, int slices, int64_t stride,
-                                                              float* __restrict__ c, int64_t ldc, int64_t m, int n, Epi epi) {
+                                                              float* __restrict__ c, int64_t ldc, int64_t m, int n, Epi epi,
+                                                              float* __restrict__ c2, int64_t ldc2, int n_split) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ f32x4 part[RG][RE];
     const int e = threadIdx.x % RE, gidx = threadIdx.x / RE;
@@ -396,6 +399,10 @@ __global__ __launch_bounds__(RG * RE) void wide_reduce_kernel(const float* __res
     const int64_t i = i4 * 4, row = i / n;
     const int col = (int)(i - row * n);
     float4 y = make_float4(acc.x, acc.y, acc.z, acc.w);
+    if (c2 && col >= n_split) {                   // the pair form's second result (no epilogue there)
+        *reinterpret_cast<float4*>(c2 + row * ldc2 + (col - n_split)) = y;
+        return;
+    }
     y = epi_apply4(epi, y, row, col, n, c + row * ldc);
     *reinterpret_cast<float4*>(c + row * ldc + col) = y;
 }
@@ -434,11 +441,12 @@ int launch(const Args& g_in, hipStream_t s) {
     return PLNLP_E_SHAPE;
 }
 
-// c[m, n] (leading dimension ldc, 16-byte aligned, ldc % 4 == 0) = epilogue(sum of the slices)
-int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, hipStream_t s) {
+// c[m, n] (leading dimension ldc) = epilogue(sum of the slices); c2 != nullptr: columns from n_split on go to c2[:, col - n_split]
+// (the pair form).  Everything 16-byte aligned, leading dimensions and n_split multiples of 4 (the caller checks).
+int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, float* c2, int64_t ldc2, int n_split, hipStream_t s) {
     const int64_t total4 = ((int64_t)g.m * g.n) >> 2;
     hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)((total4 + RE - 1) / RE)), dim3(RG * RE), 0, s, g.ws, g.slices,
-                       (int64_t)g.m * g.n, c, ldc, (int64_t)g.m, g.n, e);
+                       (int64_t)g.m * g.n, c, ldc, (int64_t)g.m, g.n, e, c2, ldc2, n_split);
     return launch_status();
 }
 

@@ -25,8 +25,9 @@ struct Args {
 // K slices the form wants for this product (everything but slices / ws / tiles filled in), 0 where it does not apply
 int slices_for(const Args& g);
 int launch(const Args& g, hipStream_t s);
-// c = epilogue(sum of the slices' partials, in a fixed order); c 16-byte aligned, ldc % 4 == 0 (else use splitk_reduce_kernel)
-int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, hipStream_t s);
+// c = epilogue(sum of the slices' partials, in a fixed order); columns from n_split on to c2 when given (the pair form).
+// Pointers 16-byte aligned, ldc / ldc2 / n_split multiples of 4 (else use splitk_reduce_kernel)
+int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, float* c2, int64_t ldc2, int n_split, hipStream_t s);
 
 }  // namespace wgw
 }  // namespace plnlp

@@ -424,7 +424,7 @@ GEMM_STATIONARY_B = {"enabled": os.environ.get("PLNLP_GEMM_STATIONARY_B", "1") !
                      "min_rows": 16384}     # (informational: the rule itself lives in the library, plnlp_gemm_stationary_applies)
 
 
-# the weight gradient of a 129 .. 224 wide layer with the whole result held by one workgroup per K slice (csrc/gemm_wgw.hip;
+# the weight gradients with whole 224- / 256-wide blocks of the result held by one workgroup per K slice (csrc/gemm_wgw.hip;
 # the rule lives in the library, plnlp_gemm_wide_wgrad_slices).  off = the 128 x 128 kernels (A/B runs, tests of both)
 GEMM_WIDE_WGRAD = {"enabled": os.environ.get("PLNLP_GEMM_WIDE_WGRAD", "1") != "0"}
 

@@ -14,8 +14,9 @@ ENV = [
      "`0`: every split-bf16 product on the 128x128 tile kernel (no stationary pre-split weights, `csrc/gemm_x3s.hip`); "
      "same bits"),
     ("PLNLP_GEMM_WIDE_WGRAD", "ops.GEMM_WIDE_WGRAD['enabled']", "1",
-     "`0`: the weight gradient of a 129..224 wide layer over >= 32 768 rows (citation2's h = 200) on the 128x128 tile kernel "
-     "instead of the one-workgroup-per-result kernel (`csrc/gemm_wgw.hip`); same arithmetic, another summation order"),
+     "`0`: every weight gradient on the 128x128 tile kernel instead of the whole-block kernel (`csrc/gemm_wgw.hip`: one 224-wide "
+     "block for a 129..224 wide layer -- citation2's h = 200 --, 256x256 blocks for collab's 256x512 pair and ddi's 512x512; "
+     "reductions of >= 32 768 rows); same arithmetic, another summation order"),
     ("PLNLP_SPARSE_FORWARD", "ops.SPARSE_FORWARD['enabled']", "1",
      "`0`: the last conv of a training step is evaluated at every node instead of the rows the batch touches"),
     ("PLNLP_AGG_AUTOTUNE", "ops.AGG_AUTOTUNE['enabled']", "1",
