@@ -290,15 +290,15 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
         Split S[2];
         Rows ix{};
         bf16x8 A[2][3], B[2][3];
-        auto fetch = [&](Raw& w, int64_t step) {          // (prologue: the rows, then the data that depends on them)
-            if constexpr (GATHER) load_rows(ro, ix, step);
-            load_full<GATHER>(ro, w, step, ix);
-        };
-        fetch(raw[0], sb);
-        fetch(raw[1], at(sb + 1));
-        split_store<G::TERMU>(lds, ro, raw[0]);
-        fetch(raw[0], at(sb + 2));
-        if constexpr (GATHER) load_rows(ro, ix, at(sb + 3));       // for the first step's refill
+        {   // (GATHER: the row lists of the first three steps in ONE round trip, then the data that depends on them)
+            Rows i0{}, i1{}, i2{};
+            if constexpr (GATHER) { load_rows(ro, i0, sb); load_rows(ro, i1, at(sb + 1)); load_rows(ro, i2, at(sb + 2)); }
+            load_full<GATHER>(ro, raw[0], sb, i0);
+            load_full<GATHER>(ro, raw[1], at(sb + 1), i1);
+            if constexpr (GATHER) load_rows(ro, ix, at(sb + 3));       // for the first step's refill
+            split_store<G::TERMU>(lds, ro, raw[0]);
+            load_full<GATHER>(ro, raw[0], at(sb + 2), i2);
+        }
         static_for<5>([&](auto ic) { S[1].template stage<decltype(ic)::value, G::TERMU>(raw[1], lds + G::BUFU, ro); });
         __syncthreads();
 #pragma unroll
