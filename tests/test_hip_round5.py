@@ -39,7 +39,8 @@ def _delta(P, before):
 # ------------------------------------------------------------------------- launch counters ----
 def test_launch_counters_name_the_kernel_family_that_ran(P):
     """plnlp_launch_counts: a 20 000-row split-bf16 product with K-contiguous A runs the stationary-weights kernel, 2 000
-    rows the tile kernel, the f32 form the f32 tile kernel, a weight gradient cuts K and reduces the slices; a graph with
+    rows the tile kernel, the f32 form the f32 tile kernel, a weight gradient cuts K and reduces the slices (the tile kernel below
+    32 768 rows, the whole-block kernel from there on); a graph with
     a hub row runs the fused main + chunk pass, one without runs the plain one-wave-per-row launch.  And the host's
     question (plnlp_gemm_stationary_applies) has the launch's answer."""
     ops = P.ops
@@ -56,10 +57,12 @@ def test_launch_counters_name_the_kernel_family_that_ran(P):
             assert d[want] == 1 and sum(v for k, v in d.items() if k != "gemm_splitk_reduce") == 1, (rows, math, d)
         ops.GEMM_MATH["mode"] = "bf16x3"
         a = torch.randn(40000, 256, device="cuda")
-        c0 = ops.launch_counts()
-        ops.gemm([(a, a)], True, False)                       # [256, 256] = a^T a over 40 000 rows: split-K
-        d = _delta(P, c0)
-        assert d["gemm_tile_x3"] == 1 and d["gemm_splitk_reduce"] == 1 and d["gemm_x3s"] == 0, d
+        for rows, want in ((20000, "gemm_tile_x3"), (40000, "gemm_wgrad_wide")):
+            c0 = ops.launch_counts()
+            ops.gemm([(a[:rows], a[:rows])], True, False)    # [256, 256] = a^T a: split-K; from 32 768 rows on the whole-block kernel
+            d = _delta(P, c0)
+            assert d[want] == 1 and d["gemm_splitk_reduce"] == 1 and d["gemm_x3s"] == 0, (rows, d)
+            assert d["gemm_tile_x3"] + d["gemm_wgrad_wide"] == 1, (rows, d)
         # an unaligned result (leading dimension 257) declines the stationary form -- and keeps its split-K
         out = torch.empty(20000, 257, device="cuda")[:, :256]
         c0 = ops.launch_counts()
