@@ -12,7 +12,7 @@
 // blocks (112 accumulator registers); a K-step loads 16 rows of A and of B once (224 columns each), splits them
 // once, and feeds 49 MFMA blocks per 448 loaded elements -- 1.75 x the MFMA work per split.  The reduction over k
 // is cut into `slices` contiguous ranges, one workgroup each (one per CU: the two LDS buffers are 84 KB), whose raw
-// partials the split-K reduce kernel of gemm_f32.hip adds in slice order: deterministic, no atomics.
+// partials wide_reduce_kernel (below) adds in a fixed order: deterministic, no atomics.
 //
 // Same arithmetic as the tile kernels (same split x = hi + mid + lo, round-to-nearest each; the same six products per
 // 32 x 32 x 16 block, small terms first); the slices differ, so the f32 sums associate differently -- inside the
@@ -20,8 +20,8 @@
 //
 // LDS image of one operand K-step (16 x 224), in 16-byte units: [term 3][k-group 2][position 224], one unit = the 8 bf16
 // k 8g .. 8g+7 of one column = exactly one lane's MFMA fragment: ONE ds_read_b128 (256 B/clk; the first version of this
-// kernel kept the tile kernels' row-contiguous image -- a fragment = four ds_read_b32 at 128 B/clk -- and was bound by
-// those reads, 172 KB per K-step).  To write whole units a staging thread owns 8 consecutive k of TWO adjacent columns
+// kernel kept the tile kernels' row-contiguous image -- a fragment = four ds_read_b32 at 128 B/clk, 172 KB of reads per
+// K-step: 5 % slower).  To write whole units a staging thread owns 8 consecutive k of TWO adjacent columns
 // (eight 8-byte loads, lanes side by side: a wave reads 512 contiguous bytes of a row); the two columns go to positions
 // cp and w/2 + cp (w = the operand's width), so that both of a wave's stores cover consecutive units (conflict-free) and
 // the live positions are 0 .. w-1.  Position p therefore holds column 2p (p < w/2) or 2 (p - w/2) + 1: the MFMAs work on
