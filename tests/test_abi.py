@@ -56,6 +56,33 @@ def test_argument_validation_without_launch(lib):
     assert lib.plnlp_sqnorm_partials(0) == 0 and lib.plnlp_sqnorm_partials(1) == 1
 
 
+def test_wide_weight_gradient_rule_without_a_device(lib):
+    """plnlp_gemm_wide_wgrad_slices is host arithmetic on the launch's arguments (no launch, no device access): which weight
+    gradients take the whole-block kernel (csrc/gemm_wgw.hip) and into how many K slices -- the number the host then passes
+    as split_k.  Pointers here are made-up aligned addresses; nothing is dereferenced."""
+    from plnlp_amd import _lib
+
+    def slices(m, n, k, a=0x10000, b=0x20000, lda=None, ldb=None, math=None, b2=None, ldb2=0, nb_split=None, index=0, on=3,
+               a_trans=1, b_trans=0):
+        ops = (_lib.GemmOperand * 1)()
+        ops[0].a, ops[0].lda, ops[0].b, ops[0].ldb, ops[0].k = a, lda or m, b, ldb or (nb_split or n), k
+        ops[0].math = _lib.GEMM_MATH_BF16X3 if math is None else math
+        ops[0].b_index = index
+        return lib.plnlp_gemm_wide_wgrad_slices(ops, 1, a_trans, b_trans, m, n, b2, ldb2, n if nb_split is None else nb_split, on)
+
+    assert slices(200, 200, 2_927_963) == 256 and slices(200, 180, 40_000) == 256 and slices(224, 132, 32_768) == 256
+    assert slices(256, 256, 40_000) == 256 and slices(256, 512, 132_224) == 128 and slices(512, 512, 262_144) == 64
+    assert slices(512, 1024, 262_144) == 32 and slices(1024, 1024, 262_144) == 0                    # at most 8 blocks
+    assert slices(256, 512, 132_224, b2=0x30000, ldb2=256, nb_split=256, index=0x40000, on=2) == 128    # the collab step's pair
+    assert slices(256, 512, 132_224, b2=0x30000, ldb2=256, nb_split=128) == 0                        # seam inside a block
+    assert slices(200, 200, 40_000, index=0x40000) == 0                                             # gathered rows: 256-blocks only
+    assert slices(256, 256, 40_000, index=0x40004) == 0                                             # row list off 16 bytes
+    assert slices(200, 200, 32_767) == 0 and slices(128, 200, 40_000) == 0 and slices(228, 200, 40_000) == 0
+    assert slices(202, 200, 40_000) == 0 and slices(200, 200, 40_000, a=0x10008) == 0 and slices(200, 200, 40_000, lda=202) == 0
+    assert slices(200, 200, 40_000, math=_lib.GEMM_MATH_F32) == 0
+    assert slices(200, 200, 40_000, a_trans=0) == 0 and slices(200, 200, 40_000, b_trans=1) == 0
+
+
 def test_product_ops_refuse_cpu_tensors():
     import plnlp_amd
     from plnlp_amd._lib import PlnlpHipError
