@@ -458,7 +458,8 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
 
 # ------------------------------------------------ the wide weight gradient (csrc/gemm_wgw.hip) ----
 @pytest.mark.parametrize("m,n,k,pad", [(200, 200, 300_001, 0), (200, 180, 65_536, 0), (224, 224, 40_000, 0), (132, 132, 50_007, 0),
-                                       (200, 200, 32_768, 24), (196, 160, 33_333, 8), (204, 192, 100_000, 0)])
+                                       (200, 200, 32_768, 24), (196, 160, 33_333, 8), (204, 192, 100_000, 0),
+                                       (200, 200, 32_790, 0)])        # 2 050 K-steps in 256 slices of 9: the last 28 slices are empty
 def test_wide_weight_gradient_is_fp32_grade_and_deterministic(P, m, n, k, pad):
     """C[m, n] = A^T B over k rows with the whole result held by one workgroup per K slice (layers 129 .. 224 wide, citation2's
     h = 200): asserted by the launch counter to be the kernel that ran; against float64 inside the per-product bound of every
@@ -523,6 +524,8 @@ def test_wide_weight_gradient_rule(P):
 
 
 @pytest.mark.parametrize("m,n,k,form", [(256, 256, 40_000, "plain"), (256, 512, 132_224, "plain"), (512, 512, 65_536, "plain"),
+                                        (512, 512, 32_790, "plain"),   # 2 050 K-steps in 64 slices of 33: the last slice is partial, one is empty
+                                        (256, 512, 32_769, "pair_compact"),
                                         (256, 512, 50_007, "gathered"), (256, 512, 132_224, "pair"),
                                         (256, 512, 40_001, "pair_gathered"), (256, 512, 132_224, "pair_compact")])
 def test_wide_weight_gradient_in_256_blocks(P, m, n, k, form):
