@@ -121,7 +121,7 @@ class BaseModel(object):
                 and isinstance(self.encoder.convs[0], GCNConv) and self.emb.weight.shape[1] % 4 != 0
                 and self.emb.weight.requires_grad and dp_exchange != "shard"):
             w = self.emb.weight
-            buf = torch.zeros(w.shape[0], ops._pad4(w.shape[1]), dtype=w.dtype, device=w.device)
+            buf = torch.zeros(w.shape[0], ops._pad_emb(w.shape[1]), dtype=w.dtype, device=w.device)
             buf[:, :w.shape[1]].copy_(w.detach())
             w.data = buf[:, :w.shape[1]]
 

@@ -1710,13 +1710,25 @@ def padded_base(t: torch.Tensor) -> Optional[torch.Tensor]:
         return None
     n, e = t.shape
     ep = t.stride(0)
-    if ep != _pad4(e) or t.untyped_storage().nbytes() < n * ep * t.element_size():
+    if ep != _pad_emb(e) or t.untyped_storage().nbytes() < n * ep * t.element_size():
         return None
     return torch.as_strided(t, (n, ep), (ep, 1))
 
 
 def _pad4(n: int) -> int:
     return (n + 3) // 4 * 4
+
+
+# row width (in floats) an embedding table of an unaligned width is padded to: a multiple of this.  4 = whole 16-byte groups
+# (the minimum the vector kernels need); 16 = whole 64-byte sectors: citation2's 50 columns become 64 instead of 52 -- every
+# gathered row is then exactly two 128-byte lines instead of 2.6 on average, and [A emb | A x] is 64 + 128 = 192 columns with
+# no pad block; same box, interleaved x 3: 23.47 -> 23.22 ms per step (profiles/r05_emb_pad_ab.txt)
+EMB_PAD = {"floats": int(os.environ.get("PLNLP_EMB_PAD", "16"))}
+
+
+def _pad_emb(e: int) -> int:
+    g = EMB_PAD["floats"]
+    return (e + g - 1) // g * g
 
 
 class ConcatFeatFn(torch.autograd.Function):
@@ -1802,7 +1814,7 @@ class GCNInputConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb_weight, w, b, graph: Graph, act: _Act, feats, cache: dict):
         n, e, f = emb_weight.shape[0], emb_weight.shape[1], feats.shape[1]
-        ep, fp = _pad4(e), _pad4(f)
+        ep, fp = _pad_emb(e), _pad4(f)
         key = ("gcn_input", feats.data_ptr(), feats._version, n, e, f)
         st = cache.get("gcn_input")
         # the entry holds the graph and the feature tensor themselves (compared by identity): an id() or a

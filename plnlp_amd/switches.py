@@ -17,6 +17,9 @@ ENV = [
      "`0`: every weight gradient on the 128x128 tile kernel instead of the whole-block kernel (`csrc/gemm_wgw.hip`: one 224-wide "
      "block for a 129..224 wide layer -- citation2's h = 200 --, 256x256 blocks for collab's 256x512 pair and ddi's 512x512; "
      "reductions of >= 32 768 rows); same arithmetic, another summation order"),
+    ("PLNLP_EMB_PAD", "ops.EMB_PAD['floats']", "16",
+     "row granule (floats) an embedding table of an unaligned width is padded to when it is kept padded "
+     "(`model.PAD_EMBEDDING_TABLE`): `4` = 16-byte rows (citation2: 52 columns), `16` = whole 64-byte sectors (64 columns)"),
     ("PLNLP_SPARSE_FORWARD", "ops.SPARSE_FORWARD['enabled']", "1",
      "`0`: the last conv of a training step is evaluated at every node instead of the rows the batch touches"),
     ("PLNLP_AGG_AUTOTUNE", "ops.AGG_AUTOTUNE['enabled']", "1",
@@ -52,7 +55,7 @@ MODULE = [
      "`False`: the sharded step (`dp_exchange='shard'`) runs its last layer over the whole row block"),
     ("model.PAD_EMBEDDING_TABLE['enabled']", "True",
      "`False`: an embedding table of an unaligned width under a first GCN layer (citation2: 50) is a plain contiguous tensor, "
-     "padded for the aggregation and un-padded for Adam by a copy each step, instead of living padded to 16-byte rows"),
+     "padded for the aggregation and un-padded for Adam by a copy each step, instead of living padded (`PLNLP_EMB_PAD`)"),
     ("ops.STEP_THROTTLE['depth']", "2",
      "steps the host may run ahead of the GPU; `0`: unbounded, side-stream tensors handed over with `record_stream`"),
     ("ops.PROLOGUE_OVERLAP['enabled']", "True",

@@ -234,7 +234,7 @@ def test_public_create_input_feat_is_the_real_matrix_with_its_gradient(P):
 
 def test_unaligned_embedding_table_is_kept_padded_and_trains_to_the_same_bits(P):
     """citation2's recipe (README.md:40) trains a 50-wide table next to 128 features under a GCN: BaseModel keeps such a
-    table padded to 16-byte rows (emb.weight = the [:, :50] view of a zero-padded [N, 52] buffer), the 52-wide
+    table padded (ops.EMB_PAD: emb.weight = the [:, :50] view of a zero-padded [N, 64] buffer), the 64-wide
     aggregation gathers from it directly, the gradient arrives and Adam steps in that layout -- and nothing changes:
     five steps end on the bits of the model whose table is a plain contiguous [N, 50] tensor (which pays the padded copy
     and the strided -> contiguous gradient copy every step).  state_dict holds the [N, 50] parameter either way."""
