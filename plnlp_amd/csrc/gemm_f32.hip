@@ -27,7 +27,7 @@
 // kernel adds them in slice order -- deterministic, no atomics.
 #include "common.hip.h"
 #include "gemm_x3s.hip.h"     // the stationary-weights form (its own translation unit, gemm_x3s.hip)
-#include "gemm_wgw.hip.h"     // the one-workgroup-per-result weight gradient of a 129 .. 224 wide layer (gemm_wgw.hip)
+#include "gemm_wgw.hip.h"     // the weight gradients with whole 224- / 256-wide blocks of the result per workgroup (gemm_wgw.hip)
 #include <utility>
 
 namespace plnlp {

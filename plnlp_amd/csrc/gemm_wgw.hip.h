@@ -1,5 +1,5 @@
 // The interface between gemm_f32.hip (gemm_impl decides which kernel a launch runs) and gemm_wgw.hip (the split-bf16
-// weight gradient whose WHOLE result, up to 224 x 224, is one workgroup's tile).
+// weight gradient with whole blocks of the result per workgroup: one block of up to 224 x 224, or 256 x 256 blocks).
 #pragma once
 #include "common.hip.h"
 
