@@ -13,7 +13,7 @@
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
  *     default stream) and is stream-ordered; entry points are re-entrant and
  *     keep no global state that affects results (safe for one-process-per-GPU data parallelism) -- the two
- *     exceptions are measurement aids: the launch counters (plnlp_launch_counts) and plnlp_gemm_stationary_tuning;
+ *     exceptions are measurement aids: the launch counters (plnlp_launch_counts) and plnlp_gemm_stationary_tuning / _block_tuning;
  *   - return value: 0 = enqueued; PLNLP_E_* (negative) = argument rejected,
  *     nothing enqueued; positive = hipError_t reported by the launch;
  *   - matrices are row-major fp32 with an explicit leading dimension (elements);
@@ -40,8 +40,10 @@ extern "C" {
  *              plnlp_mlp_head_backward_f32 (the 1-output head's backward in one pass over the hidden activation),
  *              PLNLP_EPI_ROWDOT + plnlp_gemm_rowdot_tiles / plnlp_rowdot_finish_f32 (its forward in the hidden GEMM's epilogue).
  * 11 (round 5): plnlp_gemm_wide_wgrad_slices (the weight gradient with whole 224- / 256-wide blocks of the result held by one
- *              workgroup per K slice: the host asks how many slices that form wants and cuts K accordingly). */
-#define PLNLP_ABI_VERSION 11
+ *              workgroup per K slice: the host asks how many slices that form wants and cuts K accordingly).
+ * 12 (round 6): plnlp_gemm_block_tuning (the stationary-weights product with a whole 256-row block per workgroup, gemm_x3b.hip);
+ *              launch kind "gemm_x3b". */
+#define PLNLP_ABI_VERSION 12
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
 #define PLNLP_E_SHAPE     (-2)   /* negative / inconsistent size            */
@@ -292,6 +294,12 @@ int plnlp_rowdot_finish_f32(const float* partial, int64_t ld, int tiles, int64_t
  * nb = 1 / 2 / 4 / 7 / 8 forces the column-tile width (x 32 columns), 0 = automatic; min_rows > 0 changes the number of
  * rows of A from which the form is used at all (default 16 384; the caller must lend b_terms for such launches too) */
 void plnlp_gemm_stationary_tuning(int nb, int min_rows);
+/* measurement knob of the stationary-weights form's whole-block kernel (csrc/gemm_x3b.hip: one 256-row x 224 / 256-column block
+ * of the result per workgroup, 8 waves on ONE weight-image stream per CU, plain loads only; taken by the launches of >= 32 768 rows
+ * whose column tiles are 224 / 256 wide -- same bits as the 128-row kernel).  Process-global, A/B runs only:
+ * 0 = the rule, 1 = never (csrc/gemm_x3s.hip everywhere), 2 = the rule without 128-row half blocks in the last round.  Replaces
+ * nothing in the reference (`F.linear` is one cuBLAS call, plnlp/layer.py:83,86). */
+void plnlp_gemm_block_tuning(int mode);
 
 /* how the products are formed.  Both take and return fp32 and accumulate in fp32:
  *   F32    -- v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain over k (157 TFLOP/s peak)

@@ -104,6 +104,7 @@ SIGNATURES = {
                                  c_i64, C.POINTER(Epilogue), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
     "plnlp_gemm_b_terms_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "plnlp_gemm_stationary_tuning": (None, [C.c_int, C.c_int]),
+    "plnlp_gemm_block_tuning": (None, [C.c_int]),
     "plnlp_gemm_rowdot_tiles": (C.c_int, [c_i64, c_i64]),
     "plnlp_rowdot_finish_f32": (C.c_int, [C.c_void_p, c_i64, C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plnlp_gemm_stationary_applies": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,
@@ -186,7 +187,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.plnlp_abi_version() != 11:
+    if lib.plnlp_abi_version() != 12:
         raise PlnlpHipError("libplnlp_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -967,7 +967,8 @@ static int stationary_form(const plnlp_gemm_operand* segs, int n_seg, int a_tran
     // (the first layer's padded 192): the tile kernel 1.85 ms against 2.17 (its aligned loaders are at their best,
     // the 224-column tile wastes 11 % of its MFMAs); ragged K (200): the tile kernel's select-zeroed loaders 2.22 ms
     // against 1.94 here, where the padding lives in the weight image
-    if (n > 192 && n <= 224 && !ragged_k) return 0;
+    // -- unless the launch is large enough for the whole-block kernel (gemm_x3b.hip), which takes both
+    if (n > 192 && n <= 224 && !ragged_k && !x3b::applies(m, 7)) return 0;
     return x3s::pick_nb(m, n);
 }
 
@@ -1040,6 +1041,7 @@ extern "C" int plnlp_gemm_f32(const plnlp_gemm_operand* segs, int n_seg, int a_t
 }
 
 extern "C" void plnlp_gemm_stationary_tuning(int nb, int min_rows) { plnlp::x3s::set_tuning(nb, min_rows); }
+extern "C" void plnlp_gemm_block_tuning(int mode) { plnlp::x3b::set_mode(mode); }
 
 extern "C" int plnlp_gemm_rowdot_tiles(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 0;
@@ -1166,7 +1168,10 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
             xa.nseg = n_seg; xa.ks0 = sp.ks0; xa.ks_total = sp.ks_total; xa.image = segs[0].b_terms;
             xa.c = c; xa.ldc = ldc; xa.c2 = c2; xa.ldc2 = ldc2; xa.n_split = c2 ? (int)n_split : (int)n;
             xa.m = m; xa.n = (int)n;
-            count_launch(LK_GEMM_X3S);
+            bool ragged_k = false;
+            int k_steps = 0;
+            for (int si = 0; si < n_seg; ++si) { ragged_k |= (ks[si] % 16) != 0; k_steps += (int)((ks[si] + 15) / 16); }
+            count_launch(x3b::takes(m, n, nb, ragged_k, k_steps, e) ? LK_GEMM_X3B : LK_GEMM_X3S);      // (x3s::launch asks the same question)
             return x3s::launch(sp, xa, nb, e, s);
         }
     }

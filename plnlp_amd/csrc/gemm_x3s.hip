@@ -400,7 +400,9 @@ int pick_nb(int64_t m, int64_t n) {
     if (n <= 32) return 1;
     if (n <= 64) return 2;
     if (n <= 128) return 4;
-    if (n > 192 && n <= 224) return 7;        // h = 200 in one tile (gemm_impl sends only ragged K here, see there)
+    if (n > 192 && n <= 224) return 7;        // h = 200 in one tile (without the whole-block kernel gemm_impl sends only ragged K here)
+    // whole 256-column tiles and enough rows: the whole-block kernel (gemm_x3b.hip), whose last round goes out in half blocks
+    if (n % 256 == 0 && x3b::applies(m, 8)) return 8;
     const int64_t panels = (m + 127) / 128;
     auto rounds = [&](int nb) {
         const int64_t blocks = panels * ((n + 32 * nb - 1) / (32 * nb)), slots = slots_of(nb);
@@ -442,6 +444,7 @@ int launch(const SplitArgs& sp_in, const Args& a_in, int nb, const Epi& e, hipSt
     a.gm = (a.m + 127) / 128;
     a.row_lo = 0;
     a.image = sp.image;
+    if (x3b::takes(a.m, a.n, nb, ragged, a.ks_total, e)) return x3b::launch(a, nb, ragged, e, s);
     return launch_kernel(a, nb, ragged, e, s);
 }
 

@@ -15,6 +15,7 @@ struct Args {
     int64_t m; int n;
     int64_t gm; int gn;           // row panels (128 rows) x n-tiles of THIS launch
     int64_t row_lo;               // its first row (a launch covers the row panels [row_lo / 128, row_lo / 128 + gm))
+    int lead_half;                // gemm_x3b only: odd workgroups start their walk with a 128-row half block
 };
 
 struct SplitArgs {                // what the image is made from
@@ -32,4 +33,12 @@ int64_t image_bytes(int64_t n, const int64_t* k, int nseg, int nb);
 int launch(const SplitArgs& sp, const Args& a, int nb, const Epi& e, hipStream_t s);
 
 }  // namespace x3s
+
+// gemm_x3b.hip: the same product with a whole 256-row block per workgroup (8 waves, one image stream per CU, plain loads)
+namespace x3b {
+bool applies(int64_t m, int nb);          // could a launch of m rows at tile width nb (x3s::pick_nb) take it?
+bool takes(int64_t m, int64_t n, int nb, bool ragged, int k_steps, const Epi& e);     // ... and does it, with this epilogue?
+void set_mode(int mode);                  // measurement knob: 0 the rule, 1 never, 2 no half blocks
+int launch(const x3s::Args& a, int nb, bool ragged, const Epi& e, hipStream_t s);    // (the image is already queued)
+}  // namespace x3b
 }  // namespace plnlp

@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--min-rows", type=int, default=0, help="nb mode: rows of A from which the stationary-weights form applies (0: the default 16384)")
     ap.add_argument("--repeats", type=int, default=3, help="timed blocks per shape; the median is reported")
-    ap.add_argument("--math", default="env", choices=["env", "f32", "bf16x3", "ab", "st", "nb", "wide"],
+    ap.add_argument("--math", default="env", choices=["env", "f32", "bf16x3", "ab", "st", "nb", "wide", "blk"],
                     help="how the products are formed (ops.GEMM_MATH); ab = measure both, interleaved")
     ap.add_argument("--error", action="store_true",
                     help="also report max |C - C_fp64| / sum_k |a||b| over 64 sampled result rows (no epilogue)")
@@ -88,7 +88,7 @@ def main():
             a_index = [None, rows]
         out = torch.empty(m, n, device=dev)
         flop = 2.0 * m * n * sum(ks)
-        maths = {"env": [None], "f32": ["f32"], "bf16x3": ["bf16x3"], "ab": ["f32", "bf16x3"], "st": [], "nb": [], "wide": []}[args.math]
+        maths = {"env": [None], "f32": ["f32"], "bf16x3": ["bf16x3"], "ab": ["f32", "bf16x3"], "st": [], "nb": [], "wide": [], "blk": []}[args.math]
         modes = [(mt, None) for mt in maths]
         if args.math == "st":         # split-bf16 products: the 128 x 128 kernels vs the stationary-weights kernel
             modes = [("bf16x3", False), ("bf16x3", True)]
@@ -96,6 +96,8 @@ def main():
             modes = [("bf16x3", False)] + [("bf16x3", (nb, args.min_rows)) for nb in (0, 8, 4, 2, 1)]
         if args.math == "wide":       # weight gradients 129 .. 224 wide: the 128 x 128 kernels vs one workgroup per result
             modes = [("bf16x3", "tile"), ("bf16x3", "wide")]
+        if args.math == "blk":        # the stationary-weights product: 128-row kernel (x3s) vs whole 256-row blocks (x3b), +- half blocks
+            modes = [("bf16x3", "x3s"), ("bf16x3", "x3b"), ("bf16x3", "x3b_nohalf")]
         ts = {md: [] for md in modes}
 
         def arm(md):
@@ -103,6 +105,8 @@ def main():
                 P.ops.GEMM_MATH["mode"] = md[0]
             if md[1] in ("tile", "wide"):
                 P.ops.GEMM_WIDE_WGRAD["enabled"] = md[1] == "wide"
+            elif md[1] in ("x3s", "x3b", "x3b_nohalf"):
+                _lib.load().plnlp_gemm_block_tuning({"x3s": 1, "x3b": 0, "x3b_nohalf": 2}[md[1]])
             elif md[1] is not None:
                 P.ops.GEMM_STATIONARY_B["enabled"] = bool(md[1])
                 nb, tail = md[1] if isinstance(md[1], tuple) else (0, 1)
@@ -113,6 +117,16 @@ def main():
             for md in modes:
                 arm(md)
                 ts[md].append(time_kernel(lambda: P.ops.gemm(segs, at, bt, out=out, epilogue=e, a_index=a_index), iters=args.iters))
+        if args.math == "blk":        # same bits, whichever kernel ran
+            outs = []
+            for md in modes:
+                arm(md)
+                outs.append(P.ops.gemm(segs, at, bt, epilogue=e, a_index=a_index).clone())
+            torch.cuda.synchronize()
+            same = [bool(torch.equal(outs[0], o)) for o in outs[1:]]
+            print(json.dumps({"shape": name, "bits_equal_x3s": same,
+                              "max_abs_diff": [float((outs[0] - o).abs().max()) for o in outs[1:]]}), flush=True)
+            del outs
         for md in modes:
             t = sorted(ts[md])[len(ts[md]) // 2]
             rec = {"shape": name, "M": m, "N": n, "K": ks, "ms": round(t * 1e3, 4),
