@@ -179,6 +179,56 @@ def launch_ranks(n_ranks, deadline_s=None):
     return 0 if line is not None else 1
 
 
+def comm_info(pg):
+    """{"backend", "rccl_ranks"}: rccl_ranks counts the ranks of an RCCL ("nccl") process group ONLY -- 0 under gloo (the
+    --share-gpu runs and the CPU dry run), so that "did RCCL see N ranks?" cannot be answered yes by a gloo job"""
+    if pg is None:
+        return {"backend": "none", "rccl_ranks": 1}
+    backend = str(torch.distributed.get_backend(pg))
+    return {"backend": backend, "rccl_ranks": torch.distributed.get_world_size(pg) if backend == "nccl" else 0}
+
+
+def xgmi_topology():
+    """the link matrix `rocm-smi --showtopo` prints (link type and hops between every GPU pair), parsed, or "unavailable".
+    Run as a CHILD process with a timeout (a process that has initialised the GPU must not exec another program)."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return "unavailable"
+    try:
+        out = subprocess.run([exe, "--showtopo"], capture_output=True, text=True, timeout=20).stdout
+    except Exception:
+        return "unavailable"
+    tables, name, rows = {}, None, []
+    for ln in out.splitlines():
+        t = ln.strip()
+        if t.startswith("=") and "Link Type" in t:
+            name = "link_type"
+        elif t.startswith("=") and "Hops" in t:
+            name = "hops"
+        elif t.startswith("=") and "Weight" in t:
+            name = "weight"
+        elif t.startswith("="):
+            name = None
+        elif name and t.startswith("GPU") and len(t.split()) > 1 and not t.split()[1].startswith("GPU"):
+            tables.setdefault(name, []).append(t.split()[1:])
+    return tables if tables else "unavailable"
+
+
+def rank_devices(pg, rank, local_rank, device):
+    """what every rank runs on, gathered into the line: device index, name, the visible-device lists of its environment"""
+    props = torch.cuda.get_device_properties(device)
+    mine = {"rank": rank, "local_rank": local_rank, "device": str(device), "name": props.name,
+            "total_memory_GiB": round(props.total_memory / 2 ** 30, 1), "devices_visible": torch.cuda.device_count(),
+            "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES")}
+    if pg is None or torch.distributed.get_world_size(pg) == 1:
+        return [mine]
+    out = [None] * torch.distributed.get_world_size(pg)
+    torch.distributed.all_gather_object(out, mine, group=pg)
+    return out
+
+
 def dry_run_cpu(world, rank, fail_rank=-1):
     """the launcher path without GPUs (gloo): proves that N ranks start, meet and pass the start-up collective
     self-test the real run performs (plnlp_amd.shard.collective_self_test).  fail_rank: that rank exits with an
@@ -192,7 +242,7 @@ def dry_run_cpu(world, rank, fail_rank=-1):
     print("rank %d: collective self-test ok: %s" % (rank, ", ".join(sorted(passed))), file=sys.stderr, flush=True)
     torch.distributed.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "backend": "gloo", "rccl_ranks": ranks, "n_gpus": world,
+        print(json.dumps({"dry_run": True, "backend": "gloo", "rccl_ranks": 0, "ranks": ranks, "n_gpus": world,
                           "all_reduce_ok": True, "collective_self_test": sorted(passed),
                           "note": "launcher check only; no kernel ran, not a measurement"}),
               flush=True)
@@ -275,8 +325,8 @@ def run_rmat_stress(args, P, world, rank, device, pg):
                              "this kernel is the uniform graph of the default workload's `roofline`; measured HBM bytes "
                              "of this launch: scripts/pmc_agg.sh -> profiles/"},
         "graph_build_s": t_graph, "output_checksum": checksum,
-        "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 1,
     }
+    result.update(comm_info(pg))
     if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -927,14 +977,21 @@ def main():
     last_pipe = []
     capture_flag = [None]          # None = the product default (plnlp_amd/capture.py: CAPTURE["enabled"])
     phases = None
+    probe_info = None
     if pg is not None:
         # ---- the cost model's inputs, MEASURED by this run on this rank's GPU: the plain one-process step, the table's
         # Adam, and every exchange form's step through a ONE-rank process group (its whole host / plan / separate-
         # optimiser overhead, every collective degenerate).  plnlp_amd/shard.py::cost_model returns these at world = 1.
         from plnlp_amd import shard as _shard
         Km, Wm = 8, 4
+        # The phase is BOUNDED: a quarter of the launcher's deadline (PLNLP_BENCH_DEADLINE_S, at most 300 s).  A form whose probe
+        # -- priced at 1.5 x what the solo probe took, model construction included -- would not fit the rest of the budget is
+        # not measured (the cost model then chooses among the measured ones); the ranks decide that together (MAX over ranks).
+        probe_budget_s = min(300.0, 0.25 * float(os.environ.get("PLNLP_BENCH_DEADLINE_S", "1500")))
+        t_probe = time.perf_counter()
         solo = make_model(None, "auto")
         dt0, _ = timed_steps(solo, "none", 1, B, 0, collective=False, K=Km, W=Wm)
+        solo_probe_s = time.perf_counter() - t_probe
         step_1gpu = dt0 / Km * 1e3
         emb = solo.emb.weight
         if P.ops.padded_base(emb.detach()) is not None:      # (a table kept padded is stepped as its whole buffer)
@@ -946,13 +1003,23 @@ def main():
         if world > 1:                   # (every rank creates every group: new_group is collective)
             mine = [torch.distributed.new_group([r]) for r in range(world)][rank]
         forms = ["grads"] + (["scores"] if cfg["predictor"] == "DOT" else []) + (["shard"] if cfg["encoder"] == "SAGE" or feats else [])
-        step_1rank = {}
+        step_1rank, skipped = {}, []
         for form in forms:
+            over = torch.tensor([time.perf_counter() - t_probe + 1.5 * solo_probe_s], dtype=torch.float64, device=device)
+            if world > 1:
+                torch.distributed.all_reduce(over, op=torch.distributed.ReduceOp.MAX, group=pg)
+            if float(over.item()) > probe_budget_s and step_1rank:         # (the first form is always measured)
+                skipped.append(form)
+                continue
             m1 = make_model(mine, form)
             dtf, _ = timed_steps(m1, m1.dp_mode(), 1, B, 0, collective=False, K=Km, W=Wm)
             step_1rank[m1.dp_mode()] = dtf / Km * 1e3
             del m1
         torch.cuda.empty_cache()
+        probe_info = {"seconds": round(time.perf_counter() - t_probe, 2), "budget_s": probe_budget_s,
+                      "steps_per_probe": Km + Wm, "forms_measured": sorted(step_1rank), "forms_skipped_for_time": skipped,
+                      "note": "solo step + one probe per exchange form through a one-rank group; budget = min(300 s, a quarter of "
+                              "PLNLP_BENCH_DEADLINE_S)"}
         last_pipe.clear()               # (the solo / one-rank models of this phase are gone: no capture_info about them)
         if world > 1:
             # every rank must reach the SAME choice: each measured on its own GPU with its own noise, and on a near-tie two
@@ -1179,9 +1246,13 @@ def main():
         "final_loss": final_loss, "negative_sampling_s": sampler_s,
         "kernel_families_per_step": launches_per_step,
         "negative_sampler": "%s (plnlp_amd.negative_sample, %d negatives in one call)" % (sampler, need * k),
-        "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 1,
     }
+    result.update(comm_info(pg))
     if pg is not None:
+        result["rank_devices"] = rank_devices(pg, rank, local_rank, device)
+        if rank == 0:
+            result["xgmi_topology"] = xgmi_topology()
+        result["probe_phase"] = probe_info
         result["collective_self_test"] = selftest
         result["dp_prediction"] = prediction
         result["dp_phases"] = phases

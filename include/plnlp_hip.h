@@ -42,7 +42,8 @@ extern "C" {
  * 11 (round 5): plnlp_gemm_wide_wgrad_slices (the weight gradient with whole 224- / 256-wide blocks of the result held by one
  *              workgroup per K slice: the host asks how many slices that form wants and cuts K accordingly).
  * 12 (round 6): plnlp_gemm_block_tuning (the stationary-weights product with a whole 256-row block per workgroup, gemm_x3b.hip);
- *              launch kind "gemm_x3b". */
+ *              launch kind "gemm_x3b"; plnlp_gemm_operand.reserved -> flags (PLNLP_GEMM_FLAG_WIDE_WGRAD: the wide weight-gradient
+ *              form is asked for explicitly, no longer implied by the slice count). */
 #define PLNLP_ABI_VERSION 12
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
@@ -236,6 +237,10 @@ int plnlp_csr_aggregate_max_bwd_f32(const int64_t* rowptr_t, const int32_t* col_
  * in fixed order by a second kernel (deterministic); the epilogue runs in that
  * second kernel.
  */
+#define PLNLP_GEMM_FLAG_WIDE_WGRAD 1   /* the caller asks for the whole-block weight-gradient form (csrc/gemm_wgw.hip) and has cut K
+                                         into plnlp_gemm_wide_wgrad_slices(...) slices: the launch takes the form when BOTH hold.
+                                         Without the flag a split_k that merely happens to equal that number runs the 128 x 128
+                                         kernels (the choice used to be implicit in the slice count)                 */
 typedef struct plnlp_gemm_operand {
     const float* a; int64_t lda;
     const float* b; int64_t ldb;
@@ -247,7 +252,7 @@ typedef struct plnlp_gemm_operand {
                                  a_index[i] (a layer evaluated only at the rows an edge batch reads: the
                                  root operand x is gathered in the loader)                              */
     int32_t math;             /* PLNLP_GEMM_MATH_* of the launch (read from segs[0])                     */
-    int32_t reserved;         /* 0 */
+    int32_t flags;            /* PLNLP_GEMM_FLAG_* (read from segs[0]); 0 = none */
     const int32_t* a_index2;  /* nullable, with a_index (one segment, BF16X3 only): A's row for result row i is the
                                  ELEMENTWISE PRODUCT a[a_index[i], :] * a[a_index2[i], :] -- the Hadamard of the two
                                  endpoint rows of edge i (plnlp/model.py:155-156 + layer.py:81) formed in the loader
@@ -279,7 +284,8 @@ int plnlp_gemm_stationary_applies(const plnlp_gemm_operand* segs, int n_seg, int
  *   m and n multiples of 256, at most 8 blocks of 256 x 256 (8 waves): B may be two buffers side by side along n (b2 / ldb2 /
  *     nb_split as in plnlp_gemm_pair_f32, nb_split a multiple of 256; b2 = NULL: one buffer) and its rows may be gathered
  *     (seg->b_index, 16-byte aligned; b_index_on as in plnlp_gemm_pair_f32, 3 for one buffer).
- * A plnlp_gemm_f32 / plnlp_gemm_pair_f32 launch takes the form exactly when its split_k equals this number (and its workspace
+ * A plnlp_gemm_f32 / plnlp_gemm_pair_f32 launch takes the form exactly when segs[0].flags carries PLNLP_GEMM_FLAG_WIDE_WGRAD and its
+ * split_k equals this number (and its workspace
  * holds split_k * m * n floats, as for every split-K launch); any other split_k runs the 128 x 128 kernels.  Replaces nothing in
  * the reference (`F.linear`'s weight gradient is one cuBLAS call, plnlp/layer.py:83,86).  No launch, no device access. */
 int plnlp_gemm_wide_wgrad_slices(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int b_trans, int64_t m, int64_t n,
@@ -294,11 +300,12 @@ int plnlp_rowdot_finish_f32(const float* partial, int64_t ld, int tiles, int64_t
  * nb = 1 / 2 / 4 / 7 / 8 forces the column-tile width (x 32 columns), 0 = automatic; min_rows > 0 changes the number of
  * rows of A from which the form is used at all (default 16 384; the caller must lend b_terms for such launches too) */
 void plnlp_gemm_stationary_tuning(int nb, int min_rows);
-/* measurement knob of the stationary-weights form's whole-block kernel (csrc/gemm_x3b.hip: one 256-row x 224 / 256-column block
- * of the result per workgroup, 8 waves on ONE weight-image stream per CU, plain loads only; taken by the launches of >= 32 768 rows
- * whose column tiles are 224 / 256 wide -- same bits as the 128-row kernel).  Process-global, A/B runs only:
- * 0 = the rule, 1 = never (csrc/gemm_x3s.hip everywhere), 2 = the rule without 128-row half blocks in the last round.  Replaces
- * nothing in the reference (`F.linear` is one cuBLAS call, plnlp/layer.py:83,86). */
+/* measurement knob of the stationary-weights form's whole-block kernel (csrc/gemm_x3b.hip: one 256-row x 224-column block of the
+ * result per workgroup, 8 waves on ONE weight-image stream per CU, plain loads only, one persistent workgroup per CU walking its
+ * share of the rows with the K loop pipelined across blocks; taken by the launches of >= 32 768 rows whose column tile is 224 wide
+ * -- a layer 193 .. 224 wide: citation2's h = 200 -- same bits as the 128-row kernel).  Process-global, A/B runs only; bits:
+ * 1 = never (csrc/gemm_x3s.hip / the tile kernels everywhere), 2 = no leading half blocks, 4 = also the 256-column tiles.
+ * Replaces nothing in the reference (`F.linear` is one cuBLAS call, plnlp/layer.py:83,86). */
 void plnlp_gemm_block_tuning(int mode);
 
 /* how the products are formed.  Both take and return fp32 and accumulate in fp32:

@@ -44,7 +44,7 @@ class GemmOperand(C.Structure):
     """mirror of plnlp_gemm_operand"""
     _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64),
                 ("k", C.c_int64), ("b_index", C.c_void_p), ("a_index", C.c_void_p),
-                ("math", C.c_int32), ("reserved", C.c_int32), ("a_index2", C.c_void_p), ("b_index2", C.c_void_p),
+                ("math", C.c_int32), ("flags", C.c_int32), ("a_index2", C.c_void_p), ("b_index2", C.c_void_p),
                 ("b_terms", C.c_void_p), ("b_terms_bytes", C.c_int64)]
 
 
@@ -57,6 +57,7 @@ class AdamTensor(C.Structure):
 
 MULTI_MAX = 16
 GEMM_MATH_F32, GEMM_MATH_BF16X3 = 0, 1
+GEMM_FLAG_WIDE_WGRAD = 1          # plnlp_gemm_operand.flags
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_ACCUM, EPI_GATE, EPI_ADDEND, EPI_ADAM, EPI_ROWDOT = 1, 2, 4, 8, 16, 32, 64, 128
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 AGG_LDS_STAGE = 2

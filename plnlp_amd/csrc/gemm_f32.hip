@@ -1178,10 +1178,11 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     if (e.flags & PLNLP_EPI_ROWDOT) return PLNLP_E_UNSUPPORTED;      // the row-dot epilogue lives in the stationary kernel only
     const int reduce_slices = split_k;
     // ---- the wide weight gradient (gemm_wgw.hip): whole 224- / 256-wide blocks of the result per workgroup and K slice; taken
-    // when the caller cut K into exactly the slices plnlp_gemm_wide_wgrad_slices names for this launch (its workspace is then
-    // the right size)
+    // when the caller ASKS for it (PLNLP_GEMM_FLAG_WIDE_WGRAD) and cut K into exactly the slices plnlp_gemm_wide_wgrad_slices
+    // names for this launch (its workspace is then the right size)
     wgw::Args w{};
-    if (split_k > 1 && split_k == wide_wgrad_slices(segs, n_seg, a_trans, b_trans, m, n, b2, ldb2, nb_split, bidx_mask, &w)) {
+    if ((segs[0].flags & PLNLP_GEMM_FLAG_WIDE_WGRAD) && split_k > 1 &&
+        split_k == wide_wgrad_slices(segs, n_seg, a_trans, b_trans, m, n, b2, ldb2, nb_split, bidx_mask, &w)) {
         w.slices = split_k; w.ws = workspace;
         count_launch(LK_GEMM_WGRAD_WIDE);
         if (int rc = wgw::launch(w, s)) return rc;

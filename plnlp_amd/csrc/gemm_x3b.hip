@@ -4,21 +4,29 @@
 //
 //   C[M,N] = EPI( sum_s A_s[M,K_s] * B_s[K_s,N] )       A_s K-contiguous (rows optionally gathered), up to 2 K-segments
 //
-//   * 512 threads = 8 waves, ONE workgroup per CU; wave w owns rows 32 w .. 32 w + 31 of the block and all its columns
-//     (16 NB accumulator registers).  Its A fragment never touches LDS: lane (row l31, k-half h) loads the 8 consecutive k of
-//     its row straight into registers TWO K-steps ahead and splits them there, one 5-instruction stage behind an MFMA at a time;
-//   * the weight image of a K-step (split_b_kernel's [term 3][k-half 2][column] x 16 bytes, 24 KB at NB = 8) is fetched ONCE per
-//     256 rows -- gemm_x3s streams it once per 128 rows through global_load_lds, and with an LDS-DMA in flight the compiler ends
-//     every step in s_waitcnt vmcnt(0), so that every load had one step to land and none was hidden (profiles/
-//     r05_gemm_x3s_ablation.txt: image stream 14-23 % of the launch, A loads 11-20 %).  Here every load of the K loop is a PLAIN
-//     global load into registers (the image: three 16-byte units per thread, stored to LDS with ds_write_b128 two steps later);
-//     the compiler's own counted s_waitcnt vmcnt(n) is all the waiting there is;
+//   * 512 threads = 8 waves, ONE persistent workgroup per CU that walks its share of the rows (struct Walk); wave w owns rows
+//     32 w .. 32 w + 31 of a block and all its columns (16 NB accumulator registers).  Its A fragment never touches LDS: lane
+//     (row l31, k-half h) loads the 8 consecutive k of its row straight into registers TWO K-steps ahead and splits them there,
+//     one 5-instruction stage behind an MFMA at a time;
+//   * the weight image of a K-step (split_b_kernel's [term 3][k-half 2][column] x 16 bytes, 21 / 24 KB) is fetched ONCE per 256
+//     rows -- gemm_x3s streams it once per 128 rows through global_load_lds, and with an LDS-DMA in flight the compiler ends every
+//     step in s_waitcnt vmcnt(0), so that every load had one step to land and none was hidden (profiles/
+//     r05_gemm_x3s_ablation.txt).  Here every load of the K loop is a PLAIN global load into registers (the image: three 16-byte
+//     units per thread, stored to LDS with ds_write_b128 two steps later); the compiler's own counted s_waitcnt vmcnt(n) is all
+//     the waiting there is;
 //   * the step is one basic block of 6 NB slots (slot = one MFMA + what is pinned behind it with sched_barrier); its ONE barrier
 //     sits 10 MFMAs before its end, after this wave's last read of the current image buffer and its last store into the other --
 //     behind those 10 MFMAs the next step's first B fragments are fetched, so the next step starts on its MFMAs at once;
-//   * rows are handed out in blocks of 256 and, for the launch's last partial round of workgroups, of 128 (half blocks: waves
-//     4 .. 7 only help with the image -- a SIMD then carries one MFMA wave instead of two and the block takes half the time), so
-//     that e.g. 517 row blocks on 256 CUs cost 2 + 2 + 1 time units instead of 2 + 2 + 2.
+//   * the pipeline runs THROUGH the block boundaries: the last three steps of a block request (and its last step splits and
+//     stores) the first three steps of the next one, so that a block's write-back is the only time the matrix pipe waits --
+//     and no load sits behind the write-back's stores (the memory counter is in order: a load issued after a store is not
+//     back before the memory side has acknowledged the store);
+//   * the rows are dealt in half blocks of 128 (waves 4 .. 7 then only stage operands: a SIMD carries one MFMA wave instead of
+//     two and the block takes half the time), every CU the same share to half a block, and odd workgroups start with a half
+//     block so that only half of the CUs write back at any time (struct Walk).
+// Measured (profiles/r06_gemm_x3b.txt): at 224-column tiles (h = 200) 21 % faster than the 128 x 128 tile kernel that used to run
+// K = 192, equal to gemm_x3s at K = 200; at 256-column tiles equal to gemm_x3s to a few per cent either way -- both hold the matrix
+// pipe 67 % busy at the 1.85 GHz the power limit leaves -- so those stay on gemm_x3s unless plnlp_gemm_block_tuning says otherwise.
 #include "gemm_x3s.hip.h"
 #include <utility>
 
@@ -130,14 +138,6 @@ __device__ __forceinline__ void store_image(u32x4* __restrict__ buf, int t, cons
     else buf[third_unit<NB>(t)] = ib[2];
 }
 
-#ifdef PLNLP_X3B_TRACE
-__device__ unsigned long long g_trace[8 * 65536];
-#define TRACE(slot) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_trace[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define TRACEW(slot) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_trace[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
-#else
-#define TRACE(slot)
-#define TRACEW(slot)
-#endif
 constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};    // hi lo, lo hi, mid mid, hi mid, mid hi, hi hi
 
 constexpr int stage_slot(int i, int slots) { return 6 + (i * (slots - 10)) / 9; }      // the slot behind which stage i of the A split rides
@@ -291,7 +291,7 @@ __device__ __forceinline__ void write_back(const f32x16 (&acc)[NB], float* __res
                         }
                     }
                     *reinterpret_cast<float4*>(base + (i0 + i) * stride) = y;
-                    if constexpr (ROWDOT) rd[i0 + i] += y.x * rw4.x + y.y * rw4.y + y.z * rw4.z + y.w * rw4.w;
+                    if constexpr (ROWDOT) rd[i0 + i] = x3s::rowdot_acc(rd[i0 + i], y, rw4);
                 }
             }
         }
@@ -356,11 +356,6 @@ __device__ __forceinline__ Block block_of(const Args& g, const Walk& w, int wave
     return b;
 }
 
-#ifdef PLNLP_X3B_TRACE
-#undef TRACE
-#define TRACE(slot) do { if (threadIdx.x == 0 && item < 4) g_trace[(blockIdx.x * 4 + item) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#endif
-
 template <typename T>
 __device__ __forceinline__ void swap_regs(T& a, T& b) { const T c = a; a = b; b = c; }
 
@@ -415,9 +410,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_x3b_kernel(Args g, Epi epi) {
     load_a<RAGGED>(g, blk.p0, blk.p1, 2, h, ra[0][0], ra[0][1]);
     load_image<NB>(blk.img, 2, t, ib[0]);
     __syncthreads();
-    int item = 0;
     while (true) {
-        TRACE(0);
         Walk nxt = cur;
         nxt.advance();
         const bool more = !nxt.done();
@@ -454,7 +447,6 @@ __global__ __launch_bounds__(NT, 1) void gemm_x3b_kernel(Args g, Epi epi) {
             }
             if (ks < KS) step_idle<NB, 0, RAGGED>(b1, g, target(ks + 3), at, ra, ib, sp, t, h);
         }
-        TRACE(2);
         if (KS & 1) {             // an odd number of steps: the two register sets and the two buffers have traded roles
 #pragma unroll
             for (int s = 0; s < 3; ++s) { at[0][s] = at[1][s]; swap_regs(ib[0][s], ib[1][s]); }
@@ -463,23 +455,22 @@ __global__ __launch_bounds__(NT, 1) void gemm_x3b_kernel(Args g, Epi epi) {
             swap_regs(b0, b1);
         }
         if (blk.active) write_back<NB, ROWDOT, ROWOPS>(acc, cw, stash, g, epi, seed_lo, seed_hi, blk.row_w, blk.nt, lane, l31, h);
-        TRACE(4);
         if (!more) break;
         cur = nxt;
         blk = nb_;
-        ++item;
     }
 }
 
-// measurement knob (plnlp_gemm_block_tuning): 0 = the rule below, 1 = never (gemm_x3s everywhere), 2 = no leading half blocks
+// measurement knob (plnlp_gemm_block_tuning), bits: 1 = never (gemm_x3s / the tile kernels everywhere), 2 = no leading half
+// blocks, 4 = also the 256-column tiles (measured: same time as gemm_x3s to -2 .. +5 %, profiles/r06_gemm_x3b.txt -- both run at the
+// power limit there; the default is the 224-column tile, where this kernel is 21 % faster than what ran before)
 static int g_mode = 0;
 void set_mode(int mode) { g_mode = mode; }
 
-// Does a launch of `m` rows at tile width nb (x3s::pick_nb) take this kernel?  The wide tiles only (the accumulators of a
-// 256-row block are what makes one image stream per CU enough), and enough rows to give every CU a half block.
+// Could a launch of `m` rows at tile width nb (x3s::pick_nb) take this kernel?  Enough rows to give every CU a half block.
 bool applies(int64_t m, int nb) {
-    if (g_mode == 1) return false;
-    return (nb == 7 || nb == 8) && m >= 32768;
+    if ((g_mode & 1) || m < 32768) return false;
+    return nb == 7 || (nb == 8 && (g_mode & 4));
 }
 // ... and this epilogue?  Bias / gate rows must load 16 bytes at a time (they do wherever the operands are aligned), no indexed
 // addend (no GEMM of the path carries one), the row-dot head on 256-wide tiles with whole K-steps only.
@@ -540,7 +531,7 @@ int launch(const Args& a_in, int nb, bool ragged, const Epi& e, hipStream_t s) {
     const int64_t halves = (a.m + BR / 2 - 1) / (BR / 2);
     const int cus = cu_count();
     const unsigned grid = (unsigned)(halves < cus ? halves : cus);
-    a.lead_half = g_mode == 2 ? 0 : 1;
+    a.lead_half = (g_mode & 2) ? 0 : 1;
     a.row_lo = 0;
     switch (nb) {
         case 8: return launch_nb<8>(a, e, ragged, grid, s);
@@ -551,13 +542,3 @@ int launch(const Args& a_in, int nb, bool ragged, const Epi& e, hipStream_t s) {
 
 }  // namespace x3b
 }  // namespace plnlp
-#ifdef PLNLP_X3B_TRACE
-extern "C" int plnlp_debug_trace_read(void* dst, int64_t bytes) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(plnlp::x3b::g_trace), bytes, 0, hipMemcpyDeviceToHost);
-}
-extern "C" int plnlp_debug_trace_clear(void) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(plnlp::x3b::g_trace)) != hipSuccess) return -1;
-    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 8 * 65536);
-}
-#endif

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
                     if (pre) y = epi_apply4_pre(epi, y, orow, col, g.n, bias4, g4[i], p4[i]);
                     else y = epi_apply4(epi, y, orow, col, g.n, op);
                     *reinterpret_cast<float4*>(op + col) = y;
-                    if constexpr (ROWDOT) rd[i0 + i] += y.x * rw4.x + y.y * rw4.y + y.z * rw4.z + y.w * rw4.w;
+                    if constexpr (ROWDOT) rd[i0 + i] = rowdot_acc(rd[i0 + i], y, rw4);
                 }
             }
         }

@@ -26,6 +26,12 @@ struct SplitArgs {                // what the image is made from
     void* image;
 };
 
+// PLNLP_EPI_ROWDOT: one lane's share of a row's dot product, one 16-byte column group at a time -- an explicit fma chain, so that
+// both kernels that carry the epilogue (gemm_x3s.hip, gemm_x3b.hip) form the same bits whatever the compiler would contract
+__device__ __forceinline__ float rowdot_acc(float acc, const float4& y, const float4& w) {
+    return fmaf(y.w, w.w, fmaf(y.z, w.z, fmaf(y.y, w.y, fmaf(y.x, w.x, acc))));
+}
+
 int pick_nb(int64_t m, int64_t n);
 void set_tuning(int nb, int min_rows);
 int min_rows();
@@ -38,7 +44,7 @@ int launch(const SplitArgs& sp, const Args& a, int nb, const Epi& e, hipStream_t
 namespace x3b {
 bool applies(int64_t m, int nb);          // could a launch of m rows at tile width nb (x3s::pick_nb) take it?
 bool takes(int64_t m, int64_t n, int nb, bool ragged, int k_steps, const Epi& e);     // ... and does it, with this epilogue?
-void set_mode(int mode);                  // measurement knob: 0 the rule, 1 never, 2 no half blocks
+void set_mode(int mode);                  // measurement knob (bits): 1 never, 2 no leading half blocks, 4 also 256-column tiles
 int launch(const x3s::Args& a, int nb, bool ragged, const Epi& e, hipStream_t s);    // (the image is already queued)
 }  // namespace x3b
 }  // namespace plnlp

@@ -536,6 +536,10 @@ class BaseModel(object):
         """everything train_step enqueues, without the host-side pacing: (detached loss, the step's EdgeBatch).
         This is also what plnlp_amd/capture.py captures in a hipGraph (nothing in here may touch the host once the
         model is warm: no read-back, no event wait)."""
+        with ops.direct_table_grad():          # (a padded table takes its gradient in the padded layout: FusedAdam steps it there)
+            return self._train_step_body(data, pos_edge, neg_edge, num_neg, weight_margin, edges_ready, global_count, prepared)
+
+    def _train_step_body(self, data, pos_edge, neg_edge, num_neg, weight_margin, edges_ready, global_count, prepared):
         self._tune_graph(data.adj_t)
         self.optimizer.zero_grad(set_to_none=True)
         local = pos_edge.size(0)

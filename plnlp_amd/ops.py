@@ -429,6 +429,20 @@ GEMM_STATIONARY_B = {"enabled": os.environ.get("PLNLP_GEMM_STATIONARY_B", "1") !
 GEMM_WIDE_WGRAD = {"enabled": os.environ.get("PLNLP_GEMM_WIDE_WGRAD", "1") != "0"}
 
 
+# the stationary-weights product with a whole 256-row block of the result per workgroup (csrc/gemm_x3b.hip; the rule lives in the
+# library): 'auto' = the 224-column tiles (a layer 193 .. 224 wide) from 32 768 rows on, 'off' = never, 'all' = the 256-column
+# tiles too (measured equal to gemm_x3s within -2 .. +5 %), 'nolead' / 'all-nolead' = without the leading half blocks.  Same bits.
+GEMM_BLOCK = {"mode": os.environ.get("PLNLP_GEMM_BLOCK", "auto"), "applied": None}
+_GEMM_BLOCK_BITS = {"auto": 0, "off": 1, "nolead": 2, "all": 4, "all-nolead": 6}
+
+
+def _apply_gemm_block() -> None:
+    mode = GEMM_BLOCK["mode"]
+    if mode != GEMM_BLOCK["applied"]:
+        L.load().plnlp_gemm_block_tuning(_GEMM_BLOCK_BITS[mode])
+        GEMM_BLOCK["applied"] = mode
+
+
 def _lend_b_terms(ops, n_seg: int, a_trans: bool, b_trans: bool, out: torch.Tensor, m: int, n: int,
                   out2: Optional[torch.Tensor] = None, n_split: Optional[int] = None):
     """lend the launch a scratch buffer for B's pre-split image (plnlp_gemm_operand.b_terms) exactly where the library will
@@ -438,6 +452,7 @@ def _lend_b_terms(ops, n_seg: int, a_trans: bool, b_trans: bool, out: torch.Tens
     if not GEMM_STATIONARY_B["enabled"] or ops[0].math != L.GEMM_MATH_BF16X3:
         return None
     lib = L.load()
+    _apply_gemm_block()
     if not lib.plnlp_gemm_stationary_applies(ops, n_seg, int(a_trans), int(b_trans), out.data_ptr(), _ld(out), m, n,
                                              L.ptr(out2), 0 if out2 is None else _ld(out2), n if n_split is None else n_split):
         return None
@@ -525,8 +540,11 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     if split_k is None:
         # (the wide weight-gradient form -- the whole <= 224 x 224 result per workgroup -- is taken by the launch exactly
         # when K is cut into the slices the library names for it)
-        split_k = (lib.plnlp_gemm_wide_wgrad_slices(ops, len(segs), int(a_trans), int(b_trans), m, n, None, 0, n, 3)
-                   if GEMM_WIDE_WGRAD["enabled"] else 0) or _pick_split_k(m, n, ktiles)
+        wide = (lib.plnlp_gemm_wide_wgrad_slices(ops, len(segs), int(a_trans), int(b_trans), m, n, None, 0, n, 3)
+                if GEMM_WIDE_WGRAD["enabled"] else 0)
+        if wide:
+            ops[0].flags |= L.GEMM_FLAG_WIDE_WGRAD
+        split_k = wide or _pick_split_k(m, n, ktiles)
     split_k = max(1, min(split_k, ktiles))
     keep.append(_lend_b_terms(ops, len(segs), a_trans, b_trans, out, m, n))
     if keep[-1] is not None:
@@ -610,7 +628,10 @@ def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool
     ktiles = (k + 31) // 32
     split_k = max(1, min(_pick_split_k(m, n, ktiles), ktiles)) if a_trans else 1
     if a_trans and GEMM_WIDE_WGRAD["enabled"]:      # (the wide form is taken by the launch exactly when K is cut its way)
-        split_k = lib.plnlp_gemm_wide_wgrad_slices(ops, 1, 1, 0, m, n, b2.data_ptr(), _ld(b2), n1, int(rows_on)) or split_k
+        wide = lib.plnlp_gemm_wide_wgrad_slices(ops, 1, 1, 0, m, n, b2.data_ptr(), _ld(b2), n1, int(rows_on))
+        if wide:
+            ops[0].flags |= L.GEMM_FLAG_WIDE_WGRAD
+            split_k = wide
     c1 = out1 if out1 is not None else torch.empty(m, n1, dtype=torch.float32, device=a.device)
     assert c1.shape == (m, n1) and c1.is_contiguous()
     c2 = torch.empty(m, n2, dtype=torch.float32, device=a.device)
@@ -1723,7 +1744,31 @@ def _pad4(n: int) -> int:
 # (the minimum the vector kernels need); 16 = whole 64-byte sectors: citation2's 50 columns become 64 instead of 52 -- every
 # gathered row is then exactly two 128-byte lines instead of 2.6 on average, and [A emb | A x] is 64 + 128 = 192 columns with
 # no pad block; same box, interleaved x 3: 23.47 -> 23.22 ms per step (profiles/r05_emb_pad_ab.txt)
-EMB_PAD = {"floats": int(os.environ.get("PLNLP_EMB_PAD", "16"))}
+def _emb_pad_floats(value: str) -> int:
+    """PLNLP_EMB_PAD: whole 16-byte groups, at least one (the vector kernels and the GEMM loaders read rows 16 bytes at a time)"""
+    g = int(value)
+    if g < 4 or g % 4 != 0:
+        raise ValueError(f"PLNLP_EMB_PAD={value!r}: the row granule of a padded embedding table is a multiple of 4 floats, >= 4")
+    return g
+
+
+EMB_PAD = {"floats": _emb_pad_floats(os.environ.get("PLNLP_EMB_PAD", "16"))}
+
+# A padded table's gradient set on the parameter directly, in the padded layout (GCNInputConvFn.backward).  Only inside the
+# trainer's own step (BaseModel._train_step_core opts in): there the optimiser is FusedAdam, which steps the padded buffer, and
+# nothing else looks at the gradient.  Anywhere else the function returns the [N, e] gradient and autograd accumulates it --
+# torch.autograd.grad, tensor hooks and foreign optimisers see what they expect (ADVICE r5).
+_DIRECT_TABLE_GRAD = {"depth": 0}
+
+
+class direct_table_grad:
+    def __enter__(self):
+        _DIRECT_TABLE_GRAD["depth"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _DIRECT_TABLE_GRAD["depth"] -= 1
+        return False
 
 
 def _pad_emb(e: int) -> int:
@@ -1826,7 +1871,7 @@ class GCNInputConvFn(torch.autograd.Function):
             fpad[:, :f].copy_(feats)
             csr_aggregate(graph, fpad, "sum", use_values=True, out=ax[:, ep:ep + fp])  # A_hat x, once
             st = {"key": key, "graph": graph, "feats": feats, "ax": ax,
-                  "emb_pad": torch.zeros(n, ep, dtype=torch.float32, device=ax.device),
+                  "emb_pad": None,      # (allocated below, only for a table that is NOT kept padded: 0.75 GB on citation2)
                   # W in the aggregated operand's layout; the pad columns stay zero, the two blocks are
                   # refreshed per step (two copies instead of a fresh zero-filled matrix)
                   "wa": torch.zeros(w.shape[0], kp, dtype=torch.float32, device=w.device)}
@@ -1834,6 +1879,8 @@ class GCNInputConvFn(torch.autograd.Function):
         ax = st["ax"]
         emb_pad = padded_base(emb_weight.detach())       # the table itself when it is kept padded (BaseModel): no copy
         if emb_pad is None:
+            if st["emb_pad"] is None:
+                st["emb_pad"] = torch.zeros(n, ep, dtype=torch.float32, device=ax.device)
             emb_pad = st["emb_pad"]
             emb_pad[:, :e].copy_(emb_weight.detach())
         csr_aggregate(graph, emb_pad, "sum", use_values=True, out=ax[:, :ep])          # A_hat emb, every step
@@ -1846,7 +1893,8 @@ class GCNInputConvFn(torch.autograd.Function):
         ctx.ax = ax            # persistent buffer: this step's backward runs before the next forward rewrites it
         # a padded table takes its gradient in the padded layout too, set on the parameter directly (autograd would copy a
         # strided gradient into a contiguous one: the 0.18 ms this avoids on citation2)
-        ctx.direct_grad_to = emb_weight if (padded_base(emb_weight.detach()) is not None and emb_weight.is_leaf) else None
+        ctx.direct_grad_to = emb_weight if (_DIRECT_TABLE_GRAD["depth"] > 0 and padded_base(emb_weight.detach()) is not None
+                                            and emb_weight.is_leaf) else None
         ctx.save_for_backward(wa, y if act.active else None)
         return y
 

@@ -13,6 +13,11 @@ ENV = [
     ("PLNLP_GEMM_STATIONARY_B", "ops.GEMM_STATIONARY_B['enabled']", "1",
      "`0`: every split-bf16 product on the 128x128 tile kernel (no stationary pre-split weights, `csrc/gemm_x3s.hip`); "
      "same bits"),
+    ("PLNLP_GEMM_BLOCK", "ops.GEMM_BLOCK['mode']", "auto",
+     "the stationary-weights product with a whole 256-row block of the result per workgroup (`csrc/gemm_x3b.hip`, one persistent "
+     "workgroup per CU): `auto` = launches of >= 32 768 rows at 224-column tiles (a layer 193..224 wide: citation2's h = 200), "
+     "`off` = never, `all` = the 256-column tiles too (measured equal to `gemm_x3s` within -2..+5 %: both run at the power limit), "
+     "`nolead` / `all-nolead` = without the leading half blocks of odd workgroups; same bits"),
     ("PLNLP_GEMM_WIDE_WGRAD", "ops.GEMM_WIDE_WGRAD['enabled']", "1",
      "`0`: every weight gradient on the 128x128 tile kernel instead of the whole-block kernel (`csrc/gemm_wgw.hip`: one 224-wide "
      "block for a 129..224 wide layer -- citation2's h = 200 --, 256x256 blocks for collab's 256x512 pair and ddi's 512x512; "

@@ -106,7 +106,7 @@ def main():
             if md[1] in ("tile", "wide"):
                 P.ops.GEMM_WIDE_WGRAD["enabled"] = md[1] == "wide"
             elif md[1] in ("x3s", "x3b", "x3b_nohalf"):
-                _lib.load().plnlp_gemm_block_tuning({"x3s": 1, "x3b": 0, "x3b_nohalf": 2}[md[1]])
+                P.ops.GEMM_BLOCK["mode"] = {"x3s": "off", "x3b": "all", "x3b_nohalf": "all-nolead"}[md[1]]
             elif md[1] is not None:
                 P.ops.GEMM_STATIONARY_B["enabled"] = bool(md[1])
                 nb, tail = md[1] if isinstance(md[1], tuple) else (0, 1)

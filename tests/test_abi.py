@@ -37,7 +37,7 @@ def test_header_symbols_exported(lib):
 
 def test_abi_version_and_error_strings(lib):
     header = open(os.path.join(ROOT, "include", "plnlp_hip.h")).read()
-    assert lib.plnlp_abi_version() == int(re.search(r"#define PLNLP_ABI_VERSION (\d+)", header).group(1)) == 11
+    assert lib.plnlp_abi_version() == int(re.search(r"#define PLNLP_ABI_VERSION (\d+)", header).group(1)) == 12
     assert lib.plnlp_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5):
         assert lib.plnlp_error_string(code).startswith(b"plnlp:")

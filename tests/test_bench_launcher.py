@@ -23,7 +23,8 @@ def test_bench_starts_its_own_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["rccl_ranks"] == 2 and out["n_gpus"] == 2 and out["all_reduce_ok"] and out["dry_run"]
+    assert out["backend"] == "gloo" and out["rccl_ranks"] == 0 and out["ranks"] == 2      # (RCCL ranks are counted under nccl only)
+    assert out["n_gpus"] == 2 and out["all_reduce_ok"] and out["dry_run"]
     # the start-up self-test ran every collective the data-parallel forms use
     assert {"all_reduce_sum", "broadcast", "all_gather_into_tensor", "reduce_scatter_tensor",
             "all_to_all_single_uneven", "barrier"} <= set(out["collective_self_test"])
@@ -37,7 +38,8 @@ def test_bench_eight_ranks_dry_run():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["rccl_ranks"] == 8 and out["n_gpus"] == 8 and out["all_reduce_ok"] and out["dry_run"]
+    assert out["backend"] == "gloo" and out["rccl_ranks"] == 0 and out["ranks"] == 8
+    assert out["n_gpus"] == 8 and out["all_reduce_ok"] and out["dry_run"]
 
 
 def test_a_failing_rank_stops_its_siblings():

@@ -357,6 +357,7 @@ def test_bench_runs_two_ranks_on_one_gpu():
     line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["shared_gpu"] is True and line["scaling_measured"] is False
     assert line["value"] > 0 and line["config"]["parallelism"].startswith("dp2")
-    assert line["rccl_ranks"] == 2
+    assert line["backend"] == "gloo" and line["rccl_ranks"] == 0          # two gloo ranks on one GPU are not RCCL ranks
+    assert [d["rank"] for d in line["rank_devices"]] == [0, 1] and line["probe_phase"]["seconds"] <= line["probe_phase"]["budget_s"]
     pred = line.get("dp_prediction") or {}
     assert pred.get("choice") in ("grads", "scores", "shard"), pred

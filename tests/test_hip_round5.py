@@ -43,8 +43,7 @@ def _stationary(d):
 
 # ------------------------------------------------------------------------- launch counters ----
 def test_launch_counters_name_the_kernel_family_that_ran(P):
-    """plnlp_launch_counts: a 20 000-row split-bf16 product with K-contiguous A runs the stationary-weights kernel (40 000 rows
-    at whole 256-column tiles: its whole-block form), 2 000
+    """plnlp_launch_counts: a 20 000-row split-bf16 product with K-contiguous A runs the stationary-weights kernel, 2 000
     rows the tile kernel, the f32 form the f32 tile kernel, a weight gradient cuts K and reduces the slices (the tile kernel below
     32 768 rows, the whole-block kernel from there on); a graph with
     a hub row runs the fused main + chunk pass, one without runs the plain one-wave-per-row launch.  And the host's
@@ -53,8 +52,7 @@ def test_launch_counters_name_the_kernel_family_that_ran(P):
     old = ops.GEMM_MATH["mode"]
     try:
         w = torch.randn(256, 256, device="cuda")
-        for rows, math, want in ((20000, "bf16x3", "gemm_x3s"), (40000, "bf16x3", "gemm_x3b"), (2000, "bf16x3", "gemm_tile_x3"),
-                                 (20000, "f32", "gemm_tile_f32")):
+        for rows, math, want in ((20000, "bf16x3", "gemm_x3s"), (2000, "bf16x3", "gemm_tile_x3"), (20000, "f32", "gemm_tile_f32")):
             ops.GEMM_MATH["mode"] = math
             a = torch.randn(rows, 256, device="cuda")
             c0 = ops.launch_counts()
@@ -410,12 +408,11 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
                    h = 512, 8 192 x (1 + 3) = 32 768 scorer rows per step, 30 epochs of 12 steps: long enough for every
                    converged run to sit on the 90 % Hits@20 plateau the 10 % unrankable positives leave (README.md:8's metric).
     Asserted: (a) by the launch counters, that the runs went through gemm_x3s and the fused / slab aggregation forms;
-    (b) epoch-1 loss of every seed vs the float32 oracle within twice the oracle's own float32-float64 gap there (+ 1e-4),
-    every epoch's loss within 4 x that gap (+ 0.2 %) -- the lottery the teacher-forced test pins down;
-    (c) the final level of the recipe's own metric (collab: Hits@50, mean over 16 seeds; ddi: Hits@20, median over 8) within
-    0.3 points + 2 s.e. of the float32 oracle's, on valid and test; the epochs each seed needs to reach the level (collab: 90 %
-    of the float64 oracle's final level; ddi: 88 %) distributed like the float32 oracle's (Mann-Whitney, two-sided,
-    p > 0.05 / 4) and reached by the same share of seeds."""
+    (b) epoch-1 loss, paired per seed: mean deviation from the float32 oracle no larger than the oracle's own float64 run's
+    (+ 1e-4); every later epoch's mean deviation within twice that gap (+ 0.2 %) -- the lottery the teacher-forced tests pin down;
+    (c) collab: the final Hits@50, mean over 16 seeds, within 0.3 points + 2 s.e. (0.2) of the float32 oracle's on valid and test,
+    epochs-to-level distributed like the oracle's (Mann-Whitney, two-sided, p > 0.05 / 4), reached by the same share of seeds;
+    ddi: seed by seed -- see the comments at the assertions (round 6: the +-6.5-point band is gone)."""
     import trained_parity as T
     ref32, ref64, loss32, loss64 = _wide_fixture(golden, T, recipe)
     n = ref32.shape[0]
@@ -436,11 +433,15 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
     text = (f"{recipe}: {n} seeds x {losses.shape[1]} epochs; epoch-1 loss vs oracle f32: median {np.median(rel1):.2e} max {rel1.max():.2e}; "
             f"all epochs: HIP vs f32 median {np.median(rel):.2e} max {rel.max():.2e}; oracle f32 vs f64 median {np.median(gap):.2e} "
             f"max {gap.max():.2e}; launches {({k: v for k, v in d.items() if v})}")
-    # (the oracle's own float32 and float64 runs part by 2.6e-4 (collab_wide) / 4.5e-2 (ddi_wide) in the FIRST epoch and by up
-    # to 1.5e-2 / 0.3 later -- ddi at h = 512 crosses its steep phase at a different epoch per seed and arithmetic; the HIP
-    # run is held to twice / four times that spread.  The sharp statement is the teacher-forced test above.)
-    assert rel1.max() <= 2.0 * gap[:, 0].max() + 1e-4, text
-    assert rel.max() <= 4.0 * gap.max() + 2e-3, text
+    # epoch 1, paired per seed: no further from the float32 oracle than its own float64 run is, on average (the mutation leg of
+    # tests/test_hip_round6.py holds single-term bf16 products against the same check: red)
+    ok1, t1 = T.first_epoch_check(losses[:, 0], loss32[:, 0], loss64[:, 0])
+    text += "\n    " + t1
+    assert ok1, text
+    # every later epoch: the mean deviation over the seeds within twice the oracles' own mean gap at that epoch (+ 0.2 %) -- ddi at
+    # h = 512 crosses its steep phase at a different epoch per seed and arithmetic (mean gap up to 0.28 around epoch 11), which
+    # is the lottery the teacher-forced tests pin down step by step
+    assert (rel.mean(0) <= 2.0 * gap.mean(0) + 2e-3).all(), text + f"\n    per epoch HIP {np.round(rel.mean(0), 4)} oracle gap {np.round(gap.mean(0), 4)}"
     # (c) level
     c = T.compare(hip, ref32, ref64, recipe)
     text += "\n" + T.describe(f"{recipe}, HIP {P.ops.GEMM_MATH['mode']}", c)
@@ -454,13 +455,33 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
         with open(os.path.join(out_dir, "trained_parity_wide_r05.txt"), "a") as f:
             f.write(text + "\n")
         np.savez_compressed(os.path.join(out_dir, f"trained_curves_{recipe}.npz"), hits=hip.astype(np.float32), losses=losses)
-    assert (np.abs(c["diff_f32"]) <= 0.3 + 2.0 * c["diff_f32_se"]).all(), text
-    assert c["mw_p"] > 0.05 / 4, text
-    assert abs(c["reached_hip"] - c["reached_f32"]) <= 0.26, text                      # (8 / 16 seeds: steps of 0.125 / 0.06)
     if recipe == "collab_wide":
-        assert 70.0 < c["final_f32"].min() and c["final_f32"].max() < 99.0, text      # trained, not saturated
-    else:
-        assert c["final_f32"].min() > 85.0, text                                       # the plateau was reached
+        assert (np.abs(c["diff_f32"]) <= 0.3 + 2.0 * c["diff_f32_se"]).all(), text       # (s.e. 0.2: a band of +-0.7)
+        assert c["mw_p"] > 0.05 / 4, text
+        assert abs(c["reached_hip"] - c["reached_f32"]) <= 0.26, text                      # (16 seeds: steps of 0.06)
+        assert 70.0 < c["final_f32"].min() and c["final_f32"].max() < 99.0, text          # trained, not saturated
+        return
+    # ddi_wide.  The centre of 8 seeds carries a standard error of 3 points here (one float32-oracle seed is still short of the
+    # plateau after 30 epochs), which made "0.3 + 2 s.e." a band of +-6.5.  Held instead, seed by seed:
+    #   * every seed whose float32-oracle run sits on the plateau: HIP's final level within 0.3 of it, outright;
+    #   * HIP reaches the plateau on at least as many seeds as the float32 oracle, less one;
+    #   * BEFORE the steep phase (epochs 1-6, AUC 55 -> 79 %), paired per seed: the mean |AUC - oracle f32| over the seeds within
+    #     twice the oracle's own float64 gap at that epoch (+ 0.05 points) -- a product with a bias in its gradients leaves
+    #     this band in the first epochs, long before the plateau hides it (scripts/calibrate_wide_parity.py has the table);
+    #   * epochs to 88 % distributed like the float32 oracle's (Mann-Whitney).
+    fh, f32 = T.final_level(hip, recipe), T.final_level(ref32, recipe)
+    on32 = (f32 >= 88.0).all(1)
+    assert on32.sum() >= 6, text
+    assert (np.abs(fh[on32] - f32[on32]) <= 0.3).all(), text + f"\n    per seed HIP {np.round(fh, 2).tolist()} f32 {np.round(f32, 2).tolist()}"
+    assert (fh >= 88.0).all(1).sum() >= on32.sum() - 1, text
+    pre = slice(0, 6)
+    d_hip = np.abs(hip[:, pre, ka, 0] - ref32[:, pre, ka, 0]).mean(0)
+    d_orc = np.abs(ref64[:, pre, ka, 0] - ref32[:, pre, ka, 0]).mean(0)
+    text += f"\n    AUC valid, epochs 1-6, mean |x - oracle f32| over seeds: HIP {np.round(d_hip, 3).tolist()}  oracle f64 {np.round(d_orc, 3).tolist()}"
+    print(text.splitlines()[-1])
+    assert (d_hip <= 2.0 * d_orc + 0.05).all(), text
+    assert c["mw_p"] > 0.05 / 4, text
+    assert c["final_f32"].min() > 85.0, text                                               # the plateau was reached
 
 
 # ------------------------------------------------ the wide weight gradient (csrc/gemm_wgw.hip) ----

@@ -622,3 +622,15 @@ def test_data_path_reads_ogbs_raw_layout(tmp_path, name, ext):
         sym = torch.zeros(n, n, dtype=torch.bool)
         sym[r2, c2] = True
         assert torch.equal(sym, sym.t())
+
+
+def test_emb_pad_granule_is_validated():
+    """PLNLP_EMB_PAD: 0 used to divide by zero in every optimiser step, 6 built a 'padded' table whose rows are not
+    16-byte aligned and handed it to the vector kernels"""
+    from plnlp_amd import ops
+    assert ops._emb_pad_floats("4") == 4 and ops._emb_pad_floats("16") == 16 and ops._emb_pad_floats("64") == 64
+    for bad in ("0", "1", "2", "6", "-4", "18"):
+        with pytest.raises(ValueError):
+            ops._emb_pad_floats(bad)
+    with pytest.raises(ValueError):
+        ops._emb_pad_floats("four")
