@@ -14,6 +14,21 @@ cfg = bench.WORKLOADS["collab"]
 torch.manual_seed(1234); P.manual_seed(1234)
 g = synthetic.make_graph("collab", seed=2, device=dev, weighted=True)
 n, B, k = g["num_nodes"], cfg["batch"], 1
+if os.environ.get("PLNLP_PROBE_RELABEL") == "degree":
+    # VERDICT r5 #6, one locality experiment: nodes renumbered by descending degree, so that the hub source rows -- the rows the
+    # aggregation gathers most often -- are the FIRST rows of the table / gradient (contiguous, a few MiB) instead of scattered
+    # over its 241 MB.  Same graph up to the names of its nodes; everything below is built from the renumbered one.
+    from plnlp_amd.graph import Graph
+    deg = g["adj_t"].degree()
+    new_id = torch.empty(n, dtype=torch.int64, device=dev)
+    new_id[torch.argsort(deg, descending=True, stable=True)] = torch.arange(n, device=dev)
+    r_, c_, v_ = g["adj_t"].coo()
+    adj = Graph.from_coo(new_id[r_.long()], new_id[c_.long()], v_, n, n)
+    g["adj_t"] = adj
+    g["edges"] = new_id[g["edges"]]
+    g["data"].adj_t = adj
+    rr, cc, _ = adj.coo()
+    g["data"].edge_index = torch.stack([cc, rr]).cpu()
 pairs, weights = P.ops.random_walk_pairs(g["adj_t"], g["edges"].reshape(-1), 10, 777)
 sel = torch.randperm(pairs.size(0), device=dev)[:4 * B]
 pos_all, w_all = pairs[sel], weights[sel]
