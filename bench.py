@@ -506,11 +506,119 @@ def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
                       "no-reuse HBM fraction -- that one is taken on the uniform graph (default workload's `roofline`)"))}
 
 
-def _x3_kernel_name(P, m):
-    """which split-bf16 kernel a launch with K-contiguous A and m rows runs (csrc/gemm_f32.hip::gemm_impl)"""
+def _x3_kernel_name(P, m, n=256):
+    """which split-bf16 kernel a launch with K-contiguous A, m rows and n columns runs (csrc/gemm_f32.hip::gemm_impl)"""
     if P.ops.GEMM_STATIONARY_B["enabled"] and m >= 16384:
+        if m >= 32768 and (192 < n <= 224 or (n % 256 == 0 and P.ops.GEMM_BLOCK["mode"].startswith("all"))) and P.ops.GEMM_BLOCK["mode"] != "off":
+            return "x3b::gemm_x3b_kernel (stationary pre-split weights, a whole 256-row block per workgroup, one persistent workgroup per CU)"
         return "x3s::gemm_x3s_kernel (stationary pre-split weights; tile kernel x16::gemm_f32_kernel where the form does not apply)"
     return "x16::gemm_f32_kernel"
+
+
+def _gemm_forms(P, flop, kname, m, n, launch):
+    """time `launch` with the dense products formed both ways; -> the roofline_mfma object of the path's own form"""
+    mode0 = P.ops.GEMM_MATH["mode"]
+    times = {}
+    try:
+        for mode in ("f32", "bf16x3"):
+            P.ops.GEMM_MATH["mode"] = mode
+            times[mode] = time_kernel(launch)
+    finally:
+        P.ops.GEMM_MATH["mode"] = mode0
+    f32_form = {"math": "f32", "kernel": "g16::gemm_f32_kernel (%s)" % kname, "achieved": flop / times["f32"] / 1e12,
+                "peak": 157.3, "unit": "TFLOP/s", "frac": flop / times["f32"] / 157.3e12, "kernel_ms": times["f32"] * 1e3}
+    tx = times["bf16x3"]
+    x3_form = {"math": "bf16x3", "kernel": "%s (%s)" % (_x3_kernel_name(P, m, n), kname), "achieved": 6 * flop / tx / 1e12,
+               "peak": 2500.0, "unit": "TFLOP/s", "frac": 6 * flop / tx / 2.5e15, "kernel_ms": tx * 1e3,
+               "f32_equivalent_TFLOPs": flop / tx / 1e12,
+               "note": "fp32 in / fp32 out; operands split into three bf16 terms, six bf16 MFMAs per block (executed flops = "
+                       "6 x algorithmic) against the dense bf16 peak"}
+    mine, other = (x3_form, f32_form) if mode0 == "bf16x3" else (f32_form, x3_form)
+    return dict({"bound": "mfma", "traffic": None, "flops": flop}, **mine, other_form=other)
+
+
+def measure_step_launches_ddi(P, model, data, cfg, device, rows_scored):
+    """The ddi step's dominant launches AS THE STEP MAKES THEM (SAGE x2 + MLP, the batch touches every node, so the step is dense):
+      aggregation   csr_aggregate(adj, table, mean) over all 4 267 rows, F = 512 -- four such launches per step (two layers,
+                    forward and transposed); the 8.7 MB source is cache-resident: `bound: cache`, frac on the COMPULSORY bytes
+      scorer GEMM   relu(x W1^T + b1) with dropout and the 1-output head in the epilogue (PLNLP_EPI_ROWDOT), M = B (1 + k) rows
+    each timed live with device events on the launch stream."""
+    from plnlp_amd import _lib
+    ops = P.ops
+    adj = data.adj_t
+    x = model.emb.weight.detach()
+    n, F = x.shape
+    out = torch.empty(n, F, device=device)
+    t = time_kernel(lambda: ops.csr_aggregate(adj, x, "mean", False, out=out))
+    by = agg_bytes(adj.nnz, n, F, False)
+    by_min = agg_bytes_compulsory(adj.nnz, n, n, F, False)
+    res = {"roofline_workload_agg": {
+        "bound": "cache", "subject": "the step's own aggregation launch (all %d rows, F = %d: the batch touches every node)" % (n, F),
+        "kernel": "csr_agg_vec_kernel / csr_agg_chunk_kernel (mean, F=%d)" % F,
+        "kernel_form": ops.describe_form(getattr(adj, "_agg_tune", {}).get(F, 0)),
+        "achieved": by_min / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by_min / t / 8.0e12, "traffic": None,
+        "algorithmic_bytes": by_min, "bytes_model": "compulsory", "gather_model_bytes": by, "effective_GBps": by / t / 1e9,
+        "kernel_ms": t * 1e3, "source_MiB": n * F * 4 / 2 ** 20,
+        "note": "the %.1f MiB source is L2 / Infinity-Cache resident: the launch is bound by the caches (effective_GBps = the "
+                "gather-model rate out of L2, ~34 TB/s aggregate), frac = compulsory bytes over the HBM peak" % (n * F * 4 / 2 ** 20)}}
+    h = cfg["hidden"]
+    lin0, lin1 = model.predictor.lins[0], model.predictor.lins[1]
+    xs = torch.randn(rows_scored, h, device=device)
+    hid = torch.empty(rows_scored, h, device=device)
+
+    def launch():
+        epi = _lib.make_epilogue(bias=lin0.bias, relu=True, dropout_p=cfg["dropout"], dropout_seed=1)
+        ops.gemm([(xs, lin0.weight)], False, True, out=hid, epilogue=epi, rowdot=(lin1.weight, lin1.bias))
+    kname = "M=%d (scored pairs), N=%d, K=%d, bias+relu+dropout + the 1-output head (ROWDOT) in the epilogue" % (rows_scored, h, h)
+    res["roofline_mfma"] = dict(_gemm_forms(P, 2.0 * rows_scored * h * h, kname, rows_scored, h, launch),
+                                subject="the step's own scorer product (MLPPredictor's hidden layer, layer.py:83-86)")
+    return res
+
+
+def measure_step_launches_citation2(P, model, data, cfg, device):
+    """The citation2 step's dominant launches AS THE STEP MAKES THEM (GCN x2 over [table | features], MLP scorer):
+      aggregation   the first layer aggregates FIRST (ops.GCNInputConvFn): A_hat applied to the table itself, kept padded to
+                    64 columns -- csr_aggregate(adj, table64, weighted sum) over all 2.93 M rows, forward and transposed: the two
+                    longest aggregation launches of the step.  The 750 MB source is far beyond the caches: `bound: hbm`; the graph
+                    is skewed (hub rows come back out of the caches), so frac is taken on the COMPULSORY bytes, the gather-model
+                    rate is `effective_GBps`
+      GEMM          the second layer's data gradient  dz1 = (A_hat^T dz2) W2 with the first layer's relu / dropout gate in the
+                    epilogue: M = 2.93 M rows, N = K = 200 (one 224-column tile)."""
+    from plnlp_amd import _lib
+    ops = P.ops
+    adj = data.adj_t
+    table = ops.padded_base(model.emb.weight.detach())
+    if table is None:
+        e = model.emb.weight.shape[1]
+        table = torch.zeros(model.emb.weight.shape[0], (e + 15) // 16 * 16, device=device)
+        table[:, :e].copy_(model.emb.weight.detach())
+    n, F = table.shape
+    out = torch.empty(n, F, device=device)
+    t = time_kernel(lambda: ops.csr_aggregate(adj, table, "sum", True, out=out))
+    by = agg_bytes(adj.nnz, n, F, True)
+    by_min = agg_bytes_compulsory(adj.nnz, n, n, F, True)
+    res = {"roofline_workload_agg": {
+        "bound": "hbm", "subject": "the step's own first-layer aggregation launch (A_hat x padded table, all %d rows, F = %d)" % (n, F),
+        "kernel": "csr_agg_vec_kernel<weighted, 16 lanes per row> + csr_agg_chunk_kernel (F=%d)" % F,
+        "achieved": by_min / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by_min / t / 8.0e12, "traffic": None,
+        "algorithmic_bytes": by_min, "bytes_model": "compulsory (index + value lists, every source row once, the result once)",
+        "gather_model_bytes": by, "effective_GBps": by / t / 1e9, "kernel_ms": t * 1e3, "source_MiB": n * F * 4 / 2 ** 20,
+        "note": "skewed graph: the gather model (%.1f GB) over-counts what crosses the HBM pins -- hub rows are re-read from the "
+                "caches -- so the fraction is taken on the compulsory bytes; a 256-byte row is two 128-byte lines per gathered "
+                "neighbour, the launch is bound by requests in flight (rows per wave), not by bytes" % (by / 1e9)}}
+    h = cfg["hidden"]
+    w2 = model.encoder.convs[1].lin.weight
+    gxw = torch.randn(n, h, device=device)
+    gate = torch.randn(n, h, device=device)
+    dz1 = torch.empty(n, h, device=device)
+
+    def launch():
+        epi = _lib.make_epilogue(gate=gate, gate_scale=1.0 / (1.0 - cfg["dropout"]) if cfg["dropout"] > 0 else 1.0)
+        ops.gemm([(gxw, w2)], False, False, out=dz1, epilogue=epi)
+    kname = "M=%d, N=%d, K=%d, gate epilogue (the first layer's relu / dropout derivative)" % (n, h, h)
+    res["roofline_mfma"] = dict(_gemm_forms(P, 2.0 * n * h * h, kname, n, h, launch),
+                                subject="the step's own largest product: the second GCN layer's data gradient")
+    return res
 
 
 def measure_gemm_roofline(P, n_rows, k_in, hidden, device, sage=True):
@@ -699,100 +807,41 @@ def cpu_baseline(cfg, g, pos, neg, w, steps):
                       (steps, B, cfg["num_neg"], cfg["shape"], torch.__version__, cores, os.cpu_count(), cores, dt)}
 
 
-def hits_parity(P, device, epochs=12, recipe="collab", with_f64=False, seed=0):
-    """Hits@K parity (BASELINE.json metric): train the SAME small problem on the GPU path and on the CPU
-    oracle -- same initial weights, same negatives, same batch permutations, dropout 0 so both are
-    deterministic -- and compare Hits@K on held-out edges after every epoch.
-    recipe 'collab': SAGE x1 + DOT, WeightedHingeAUC, k=1, Hits@50 (the bench workload's recipe);
-    recipe 'ddi'   : SAGE x2 + MLP predictor, AUC loss, k=3, Hits@20 (BASELINE config 2's recipe).
-    seed: another initialisation and another stream of negatives / batch permutations (same graph and
-    held-out edges) -- the reference reports mean +- std over 10 such runs (main.py:43)."""
-    import oracle as O
-    from plnlp_amd import synthetic
-    from plnlp_amd.utils import Evaluator, evaluate_hits
-    ddi = recipe == "ddi"
-    g = synthetic.make_graph("collab", seed=11, device="cpu", num_nodes=3000, num_edges=24000, weighted=True)
-    n, h, B, k = g["num_nodes"], 64, 4096, (3 if ddi else 1)
-    layers, pred_name, loss_name, hk = (2, "MLP", "AUC", "Hits@20") if ddi else (1, "DOT", "WeightedHingeAUC", "Hits@50")
-    edges, w = g["edges"], g["weight"] / 5.0
-    gen = torch.Generator().manual_seed(5)
-    perm = torch.randperm(edges.size(0), generator=gen)
-    held, train = edges[perm[:2000]], edges[perm[2000:]]
-    wtrain = w[perm[2000:]]
-    negs = torch.randint(0, n, (20000, 2), generator=gen)
-    adj = P.Graph.from_coo(torch.cat([train[:, 0], train[:, 1]]), torch.cat([train[:, 1], train[:, 0]]), None, n, n)
-    model = P.BaseModel(lr=0.01, dropout=0.0, grad_clip_norm=1.0, gnn_num_layers=layers, mlp_num_layers=2,
-                        emb_hidden_channels=h, gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n,
-                        num_node_feats=0, gnn_encoder_name="SAGE", predictor_name=pred_name,
-                        loss_func=loss_name, optimizer_name="Adam", device=device,
-                        use_node_feats=False, train_node_emb=True)
-    torch.manual_seed(21 + 7919 * seed)
-    model.param_init()
-    enc = O.GNNRef("SAGE", h, h, h, layers, 0.0)
-    enc.load_state_dict({k_: v.cpu() for k_, v in model.encoder.state_dict().items()})
-    if ddi:
-        pred = O.MLPPredictorRef(h, h, 1, 2, 0.0)
-        pred.load_state_dict({k_: v.cpu() for k_, v in model.predictor.state_dict().items()})
-    else:
-        pred = O.DotPredictorRef()
-    emb = torch.nn.Embedding(n, h)
-    emb.weight.data.copy_(model.emb.weight.detach().cpu())
-    csr = O.CSR(adj.rowptr, adj.col.to(torch.int64), None, n)
-    ref = O.TrainerRef(enc, pred, emb, csr, loss_name=loss_name, lr=0.01, clip_norm=1.0)
-    ref64 = None
-    if with_f64:        # the same oracle in float64: |fp32 - fp64| of the REFERENCE arithmetic is the yardstick
-        import copy
-        ref64 = O.TrainerRef(copy.deepcopy(enc).double(), copy.deepcopy(pred).double(), copy.deepcopy(emb).double(),
-                             O.CSR(adj.rowptr, adj.col.to(torch.int64), None, n), loss_name=loss_name, lr=0.01,
-                             clip_norm=1.0)
-
-    class D:
-        pass
-    data = D()
-    data.adj_t = adj.to(device)
-    data.edge_index = torch.stack([adj.coo()[1], adj.coo()[0]])
-    tr_split = {"edge": train} if ddi else {"edge": train, "weight": wtrain}
-    split = {"train": tr_split,
-             "valid": {"edge": held[:1000], "edge_neg": negs[:10000]},
-             "test": {"edge": held[1000:], "edge_neg": negs[10000:]}}
-    ev = Evaluator("ogbl-ddi" if ddi else "ogbl-collab")
-    rows = []
-    losses = {"gpu": [], "cpu": [], "cpu64": []}
-    for epoch in range(epochs):
-        torch.manual_seed(1000 + epoch + 100003 * seed)
-        losses["gpu"].append(float(model.train(data, split, B, "local", k)))
-        torch.manual_seed(1000 + epoch + 100003 * seed)
-        _, neg = O.pos_neg_edges_ref("train", {"train": {"edge": train}}, num_nodes=n, neg_sampler_name="local",
-                                     num_neg=k)
-        losses["cpu"].append(float(ref.train_epoch(train, neg, B, k, None if ddi else wtrain)))
-        res = model.test(data, split, B, ev, "hits")[hk]
-
-        def oracle_hits(t):
-            hh = t.embed_for_eval()
-            pv = [t.score(hh, split[s_]["edge"], B) for s_ in ("valid", "test")]
-            nv = [t.score(hh, split[s_]["edge_neg"], B) for s_ in ("valid", "test")]
-            return O.evaluate_hits_ref(pv[0], nv[0], pv[1], nv[1])[hk]
-        rres = oracle_hits(ref)
-        row = [100 * res[0], 100 * res[1], 100 * rres[0], 100 * rres[1]]
-        if ref64 is not None:
-            torch.manual_seed(1000 + epoch + 100003 * seed)          # same negatives, same permutation stream
-            O.pos_neg_edges_ref("train", {"train": {"edge": train}}, num_nodes=n, neg_sampler_name="local", num_neg=k)
-            losses["cpu64"].append(float(ref64.train_epoch(train, neg, B, k, None if ddi else wtrain.double())))
-            r64 = oracle_hits(ref64)
-            row += [100 * r64[0], 100 * r64[1]]
-        rows.append(tuple(row))
-    last = rows[-1]
-    extra = {}
-    if ref64 is not None:
-        extra = {"cpu64_valid": last[4], "cpu64_test": last[5], "epoch_losses": losses,
-                 "gpu_vs_f64_points": max(max(abs(r[0] - r[4]), abs(r[1] - r[5])) for r in rows),
-                 "cpu32_vs_f64_points": max(max(abs(r[2] - r[4]), abs(r[3] - r[5])) for r in rows)}
-    return {"epochs": epochs, "metric": hk, "gpu_valid": last[0], "gpu_test": last[1], "cpu_valid": last[2],
-            "cpu_test": last[3], **extra,
-            "max_abs_diff_points": max(max(abs(r[0] - r[2]), abs(r[1] - r[3])) for r in rows),
-            "note": "%s (percent) on 1000+1000 held-out edges vs 10000 negatives each, small collab-shaped "
-                    "graph (N=3000), SAGE x%d h=64 + %s, same seeds on the HIP path and the CPU oracle"
-                    % (hk, layers, pred_name)}
+def hits_parity(P, device, seed=0):
+    """Hits@50 parity (BASELINE.json metric) THROUGH THE KERNELS THE TIMED STEPS RUN: the collab recipe at its own width
+    (README.md:35 at h = 256: SAGE x1 + DOT, WeightedHingeAUC on walk pairs, lr decay -- tests/trained_parity.py::RECIPES[
+    "collab_wide"], a 40 000-node soft geometric graph with hub rows) trained for its 8 epochs on the HIP path from the run's fixed
+    initial weights / walks / negatives / permutations, against the float32 and float64 CPU-oracle runs of the SAME seed, which
+    are data: tests/golden/g12_trained_curves_wide.npz (written by tests/golden/make_trained_curves.py; 79 CPU-minutes for all
+    seeds).  One seed is a smoke-level statement; the statistical one (16 seeds, +-0.3) is tests/test_hip_round5.py."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import trained_parity as T
+    recipe = "collab_wide"
+    g12 = np.load(os.path.join(ROOT, "tests", "golden", "g12_trained_curves_wide.npz"))
+    ref32, ref64 = g12[recipe + "_f32"][seed].astype(float), g12[recipe + "_f64"][seed].astype(float)
+    t0 = time.perf_counter()
+    c0 = P.ops.launch_counts()
+    hits, losses = T.run_hip(P, recipe, seed, P.ops.GEMM_MATH["mode"])
+    c1 = P.ops.launch_counts()
+    ki = T.metrics_of(recipe).index("Hits@50")
+    r = T.RECIPES[recipe]
+    return {"metric": "Hits@50", "recipe": "collab_wide: README.md:35 at h = %d on a %d-node geometric graph, %d epochs, batch %d"
+                                           % (r["h"], T.PROBLEMS[r["problem"]]["num_nodes"], r["epochs"], r["batch"]),
+            "seed": seed, "epochs": int(hits.shape[0]),
+            "gpu_valid": float(hits[-1, ki, 0]), "gpu_test": float(hits[-1, ki, 1]),
+            "cpu_valid": float(ref32[-1, ki, 0]), "cpu_test": float(ref32[-1, ki, 1]),
+            "cpu64_valid": float(ref64[-1, ki, 0]), "cpu64_test": float(ref64[-1, ki, 1]),
+            "per_epoch_valid": {"gpu": [round(float(v), 2) for v in hits[:, ki, 0]], "cpu": [round(float(v), 2) for v in ref32[:, ki, 0]],
+                                "cpu64": [round(float(v), 2) for v in ref64[:, ki, 0]]},
+            "max_abs_diff_points": float(np.abs(hits[:, ki, :] - ref32[:, ki, :]).max()),
+            "cpu32_vs_f64_points": float(np.abs(ref32[:, ki, :] - ref64[:, ki, :]).max()),
+            "epoch1_loss": {"gpu": float(losses[0]), "cpu": float(g12[recipe + "_f32_loss"][seed, 0]),
+                            "cpu64": float(g12[recipe + "_f64_loss"][seed, 0])},
+            "kernel_families": {k_: c1[k_] - c0[k_] for k_ in c1 if c1[k_] != c0[k_]},
+            "seconds": time.perf_counter() - t0,
+            "note": "percent, held-out edges vs 10 000 negatives; `cpu` / `cpu64` = the CPU oracle's float32 / float64 run of the same "
+                    "seed (fixture); max_abs_diff_points is over all 8 epochs, valid and test, beside the two oracles' own distance"}
 
 
 def main():
@@ -1270,6 +1319,10 @@ def main():
             launches = measure_step_launches(P, model, data, pos_all[:B], neg_all[:B], cfg, device)
             result["config"]["touched_fraction"] = launches.pop("touched_fraction")
             result.update(launches)
+        elif not args.no_roofline and world == 1 and cfg["shape"] == "ddi":
+            result.update(measure_step_launches_ddi(P, model, data, cfg, device, B * (1 + k)))
+        elif not args.no_roofline and world == 1 and cfg["shape"] == "citation2" and feats:
+            result.update(measure_step_launches_citation2(P, model, data, cfg, device))
         elif not args.no_roofline:
             # the workload's own aggregation launch over all rows; `bound` says whether HBM or the caches limit it
             result["roofline_workload_agg"] = measure_roofline(P, g["adj_t"], cfg["hidden"], device,

@@ -43,7 +43,8 @@ extern "C" {
  *              workgroup per K slice: the host asks how many slices that form wants and cuts K accordingly).
  * 12 (round 6): plnlp_gemm_block_tuning (the stationary-weights product with a whole 256-row block per workgroup, gemm_x3b.hip);
  *              launch kind "gemm_x3b"; plnlp_gemm_operand.reserved -> flags (PLNLP_GEMM_FLAG_WIDE_WGRAD: the wide weight-gradient
- *              form is asked for explicitly, no longer implied by the slice count). */
+ *              form is asked for explicitly, no longer implied by the slice count); plnlp_gemm_operand.a_colsum (the bias gradient
+ *              out of the wide weight-gradient kernel). */
 #define PLNLP_ABI_VERSION 12
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
@@ -266,6 +267,12 @@ typedef struct plnlp_gemm_operand {
                                  stationary-weights kernel (csrc/gemm_x3s.hip).  Same result bits either way; launches
                                  the form does not cover (gathered B rows, unaligned operands, m < 16384) ignore it.   */
     int64_t b_terms_bytes;
+    float* a_colsum;          /* nullable (read from segs[0]); only with PLNLP_GEMM_FLAG_WIDE_WGRAD on a launch that takes that form
+                                 (else PLNLP_E_UNSUPPORTED): the launch also writes a_colsum[0 .. m) = sum over the reduction
+                                 index of A[:, i] -- for dW = dz^T x that is the bias gradient sum_rows dz (the column sums
+                                 autograd computes for F.linear's bias, plnlp/layer.py:83; PyG's conv bias) -- from the rows of dz
+                                 the kernel stages anyway instead of a second pass over dz.  16-byte aligned; the workspace then
+                                 holds split_k * (m * n + m) floats.  Fixed summation order: same bits every launch.          */
 } plnlp_gemm_operand;
 
 /* bytes of scratch plnlp_gemm_operand.b_terms needs for an [m, n] result over K-segments k0 (+ k1, 0 = one segment) */

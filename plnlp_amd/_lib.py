@@ -45,7 +45,7 @@ class GemmOperand(C.Structure):
     _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64),
                 ("k", C.c_int64), ("b_index", C.c_void_p), ("a_index", C.c_void_p),
                 ("math", C.c_int32), ("flags", C.c_int32), ("a_index2", C.c_void_p), ("b_index2", C.c_void_p),
-                ("b_terms", C.c_void_p), ("b_terms_bytes", C.c_int64)]
+                ("b_terms", C.c_void_p), ("b_terms_bytes", C.c_int64), ("a_colsum", C.c_void_p)]
 
 
 class AdamTensor(C.Structure):

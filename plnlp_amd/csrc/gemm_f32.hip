@@ -1184,18 +1184,25 @@ static int gemm_impl(const plnlp_gemm_operand* segs, int n_seg, int a_trans, int
     if ((segs[0].flags & PLNLP_GEMM_FLAG_WIDE_WGRAD) && split_k > 1 &&
         split_k == wide_wgrad_slices(segs, n_seg, a_trans, b_trans, m, n, b2, ldb2, nb_split, bidx_mask, &w)) {
         w.slices = split_k; w.ws = workspace;
+        float* colsum = segs[0].a_colsum;
+        const bool vec = ((uintptr_t)c % 16 == 0) && (ldc % 4 == 0) && ((uintptr_t)workspace % 16 == 0) &&
+                         (!c2 || (((uintptr_t)c2 % 16 == 0) && (ldc2 % 4 == 0) && (n_split % 4 == 0)));
+        if (colsum) {             // the bias gradient rides along: each slice's column sums of A behind the partial products
+            if (!vec || ((uintptr_t)colsum % 16) || (m % 4)) return PLNLP_E_ALIGN;
+            if (workspace_floats < (int64_t)split_k * (m * n + m)) return PLNLP_E_WORKSPACE;
+            w.colsum_ws = workspace + (int64_t)split_k * m * n;
+        }
         count_launch(LK_GEMM_WGRAD_WIDE);
         if (int rc = wgw::launch(w, s)) return rc;
         count_launch(LK_GEMM_SPLITK_REDUCE);
-        if (((uintptr_t)c % 16 == 0) && (ldc % 4 == 0) && ((uintptr_t)workspace % 16 == 0) &&
-            (!c2 || (((uintptr_t)c2 % 16 == 0) && (ldc2 % 4 == 0) && (n_split % 4 == 0))))
-            return wgw::reduce(w, c, ldc, e, c2, ldc2, (int)n_split, s);
+        if (vec) return wgw::reduce(w, c, ldc, e, c2, ldc2, (int)n_split, colsum, s);
         int64_t blocks = (m * n / 4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, reduce_slices,
                            g.ws_stride, c, ldc, m, (int)n, e, c2, ldc2, (int)n_split, (int64_t)0);
         return launch_status();
     }
+    if (segs[0].a_colsum) return PLNLP_E_UNSUPPORTED;     // (column sums of A come out of the wide weight-gradient kernel only)
     g.mt0 = 0; g.nt0 = 0; g.gm = gm; g.gn = (int)gn; g.z0 = 0;
     auto launch_grid = [&](const GemmArgs& ga, int md, dim3 grid) -> int {
         if (math == PLNLP_GEMM_MATH_BF16X3) return x16::launch_kernels(ga, md, grid, a_trans, b_trans, s, e);

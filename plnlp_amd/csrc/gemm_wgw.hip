@@ -71,16 +71,23 @@ struct Role {
 // per column, stage 0-3 = hi term of k-pair q (and the residual), 4-7 = mid term, 8 = lo terms; a term's 16-byte unit is
 // stored as soon as its four dwords exist (stages 3, 7, 8), so a wave's six stores are spread over the step -- three
 // back-to-back ds_write_b128 from all the waves at once filled the LDS store queue and stalled the waves at issue
+// COLSUM: the thread also keeps the running sums of the raw values of its two columns (`cs`, in program order; `live` = 1.f
+// for a real tile, 0.f for the look-ahead tiles past the slice's end, which re-read its last tile) -- the column sums of A = dz are
+// the layer's bias gradient, which used to be a second pass over dz beside this kernel (colsum_partial_vec_kernel)
 struct Split {
     f32x2 r[4];
     unsigned t[4];        // the term being assembled
-    template <int I, int TERMU>
-    __device__ __forceinline__ void stage(const Raw& w, u32x4* __restrict__ buf, const Role& ro) {
+    template <int I, int TERMU, bool COLSUM>
+    __device__ __forceinline__ void stage(const Raw& w, u32x4* __restrict__ buf, const Role& ro, float live, f32x2& cs) {
 #pragma clang fp contract(off)
         constexpr int C = I / 9, K = I % 9;
         u32x4* dst = buf + (C ? ro.unit1 : ro.unit0);
         if constexpr (K < 4) {
             f32x2 v = {w.x[2 * K][C], w.x[2 * K + 1][C]};
+            if constexpr (COLSUM) {
+                cs[C] = __builtin_fmaf(v.x, live, cs[C]);
+                cs[C] = __builtin_fmaf(v.y, live, cs[C]);
+            }
             t[K] = pk(v);
             r[K].x = v.x - __uint_as_float(t[K] << 16);
             r[K].y = v.y - __uint_as_float(t[K] & 0xffff0000u);
@@ -109,10 +116,10 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // the whole split of one thread's share, not interleaved with anything (prologue, the partial last step)
-template <int TERMU>
-__device__ __forceinline__ void split_store(u32x4* __restrict__ buf, const Role& ro, const Raw& w) {
+template <int TERMU, bool COLSUM>
+__device__ __forceinline__ void split_store(u32x4* __restrict__ buf, const Role& ro, const Raw& w, f32x2& cs) {
     Split sp;
-    static_for<18>([&](auto ic) { sp.template stage<decltype(ic)::value, TERMU>(w, buf, ro); });
+    static_for<18>([&](auto ic) { sp.template stage<decltype(ic)::value, TERMU, COLSUM>(w, buf, ro, 1.f, cs); });
 }
 
 // GATHER: the operand rows of the 8 reduction indices a thread stages in one K-step (wave-uniform addresses: broadcast loads)
@@ -182,10 +189,12 @@ constexpr int head_stage_at(int q) {            // the split stage (5 .. 17) pin
         if (((i - 5) * HEAD) / 13 == q) return i;
     return -1;
 }
-template <int NW, int NBLK, int D, int P, bool GATHER>
+// live1 / live2 (COLSUM): 1.f when the tile whose split rides in this step -- tile + 1 (stages 5 .. 17) / tile + 2 (stages 0 .. 4) --
+// is a real tile of the slice
+template <int NW, int NBLK, int D, int P, bool GATHER, bool COLSUM>
 __device__ __forceinline__ void step_pipelined(f32x16 (&acc)[NBLK], u32x4* __restrict__ lds, Raw (&raw)[2], Split (&S)[2],
                                                const Role& ro, int64_t next, int64_t next_rows, Rows& ix, bf16x8 (&A)[2][3],
-                                               bf16x8 (&B)[2][3], int wave, int l31, int h) {
+                                               bf16x8 (&B)[2][3], int wave, int l31, int h, float live1, float live2, f32x2& cs) {
     typedef Geo<NW> G;
     u32x4* cbuf = lds + D * G::BUFU;
     const u32x4* bt = cbuf + G::OPERU;
@@ -212,14 +221,14 @@ __device__ __forceinline__ void step_pipelined(f32x16 (&acc)[NBLK], u32x4* __res
         }
         if constexpr (q < HEAD) {
             constexpr int st = head_stage_at<HEAD>(q);
-            if constexpr (st >= 0) S[D ^ 1].template stage<st, G::TERMU>(raw[D ^ 1], nbuf, ro);
+            if constexpr (st >= 0) S[D ^ 1].template stage<st, G::TERMU, COLSUM>(raw[D ^ 1], nbuf, ro, live1, cs);
         }
         if constexpr (q == LD)     load_full<GATHER, 0, 4>(ro, raw[D ^ 1], next, ix);
         if constexpr (q == LD + 1) {
             load_full<GATHER, 4, 8>(ro, raw[D ^ 1], next, ix);
             if constexpr (GATHER) load_rows(ro, ix, next_rows);      // (the rows of the NEXT step's refill; every thread: no branch)
         }
-        if constexpr (q > BS && ((q - BS) & 1)) S[D].template stage<(q - BS) / 2, G::TERMU>(raw[D], cbuf, ro);
+        if constexpr (q > BS && ((q - BS) & 1)) S[D].template stage<(q - BS) / 2, G::TERMU, COLSUM>(raw[D], cbuf, ro, live2, cs);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
@@ -231,7 +240,7 @@ __device__ __forceinline__ int column_of(int pos, int width) {
 }
 
 // NBLK: 32-position blocks of B with a live position -- compile-time, so that a K-step is ONE basic block
-template <int NW, int NBLK, bool GATHER>
+template <int NW, int NBLK, bool GATHER, bool COLSUM>
 __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
     typedef Geo<NW> G;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
@@ -251,8 +260,8 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
     const int wa = g.m - mt * G::W < G::W ? g.m - mt * G::W : G::W;        // live rows / columns of this block
     const int wb = g.n - nt * G::W < G::W ? g.n - nt * G::W : G::W;
     Role ro;
+    const int o = t >= 2 * G::CP, kg = (t - 2 * G::CP * o) >= G::CP, cp = t - 2 * G::CP * o - G::CP * kg;    // operand, k-group, column pair
     {
-        const int o = t >= 2 * G::CP, u = t - 2 * G::CP * o, kg = u >= G::CP, cp = u - G::CP * kg;
         const int width = o ? wb : wa, half = width >> 1;
         const bool live = cp < half;
         const int col = live ? 2 * cp : width - 2;
@@ -282,6 +291,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
     for (int j = 0; j < NBLK; ++j)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    f32x2 cs = {0.f, 0.f};            // COLSUM: this thread's running column sums (two columns of its operand)
 
     if (sb < sf) {
         const int64_t last = sf - 1;
@@ -296,10 +306,13 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
             load_full<GATHER>(ro, raw[0], sb, i0);
             load_full<GATHER>(ro, raw[1], at(sb + 1), i1);
             if constexpr (GATHER) load_rows(ro, ix, at(sb + 3));       // for the first step's refill
-            split_store<G::TERMU>(lds, ro, raw[0]);
+            split_store<G::TERMU, COLSUM>(lds, ro, raw[0], cs);
             load_full<GATHER>(ro, raw[0], at(sb + 2), i2);
         }
-        static_for<5>([&](auto ic) { S[1].template stage<decltype(ic)::value, G::TERMU>(raw[1], lds + G::BUFU, ro); });
+        {
+            const float live1 = sb + 1 <= last ? 1.f : 0.f;
+            static_for<5>([&](auto ic) { S[1].template stage<decltype(ic)::value, G::TERMU, COLSUM>(raw[1], lds + G::BUFU, ro, live1, cs); });
+        }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -308,11 +321,12 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
         }
         int64_t i = sb;
         // (look-ahead loads past the slice's last full step re-read that step: what they stage is never multiplied)
+        auto real = [&](int64_t tile) { return tile <= last ? 1.f : 0.f; };
         for (; i + 2 <= sf; i += 2) {
-            step_pipelined<NW, NBLK, 0, 0, GATHER>(acc, lds, raw, S, ro, at(i + 3), at(i + 4), ix, A, B, wave, l31, h);
-            step_pipelined<NW, NBLK, 1, NBLK & 1, GATHER>(acc, lds, raw, S, ro, at(i + 4), at(i + 5), ix, A, B, wave, l31, h);
+            step_pipelined<NW, NBLK, 0, 0, GATHER, COLSUM>(acc, lds, raw, S, ro, at(i + 3), at(i + 4), ix, A, B, wave, l31, h, real(i + 1), real(i + 2), cs);
+            step_pipelined<NW, NBLK, 1, NBLK & 1, GATHER, COLSUM>(acc, lds, raw, S, ro, at(i + 4), at(i + 5), ix, A, B, wave, l31, h, real(i + 2), real(i + 3), cs);
         }
-        if (i < sf) step_pipelined<NW, NBLK, 0, 0, GATHER>(acc, lds, raw, S, ro, last, last, ix, A, B, wave, l31, h);
+        if (i < sf) step_pipelined<NW, NBLK, 0, 0, GATHER, COLSUM>(acc, lds, raw, S, ro, last, last, ix, A, B, wave, l31, h, 0.f, 0.f, cs);
         __syncthreads();              // (the last step's look-ahead reads are behind us before anything re-uses the buffers)
     }
     if (se > sf && sb <= sf) {        // the reduction's partial last step: indices past the end contribute zeros
@@ -326,9 +340,22 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_wide_kernel(Args g) {
             const f32x2 zero = {0.f, 0.f};
             w.x[i] = r < g.k ? v : zero;
         }
-        split_store<G::TERMU>(lds, ro, w);
+        split_store<G::TERMU, COLSUM>(lds, ro, w, cs);
         __syncthreads();
         mma_plain<NW, NBLK>(acc, lds, wave, l31, h);
+    }
+    if constexpr (COLSUM) {
+        // this slice's column sums of A: the two k-groups of a column pair meet in LDS, the first n-tile's workgroup writes them
+        float* cl = reinterpret_cast<float*>(lds);
+        __syncthreads();
+        const f32x2 tot = cs;
+        const bool mine = !o && cp < (wa >> 1);
+        if (mine) *reinterpret_cast<f32x2*>(cl + kg * G::W + 2 * cp) = tot;
+        __syncthreads();
+        if (mine && !kg && nt == 0 && g.colsum_ws) {
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(cl + 2 * cp), hi = *reinterpret_cast<const f32x2*>(cl + G::W + 2 * cp);
+            *reinterpret_cast<f32x2*>(g.colsum_ws + z * (int64_t)g.m + mt * G::W + 2 * cp) = lo + hi;
+        }
     }
 
     // raw partial of this slice.  MFMA C/D map: position of B = lane & 31, position of A = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
@@ -371,11 +398,16 @@ int slices_for(const Args& g) {
 constexpr int RG = 8, RE = 32;          // slice groups x result groups per workgroup (256 threads)
 __global__ __launch_bounds__(RG * RE) void wide_reduce_kernel(const float* __restrict__ ws, int slices, int64_t stride,
                                                               float* __restrict__ c, int64_t ldc, int64_t m, int n, Epi epi,
-                                                              float* __restrict__ c2, int64_t ldc2, int n_split) {
+                                                              float* __restrict__ c2, int64_t ldc2, int n_split,
+                                                              const float* __restrict__ colsum_ws, float* __restrict__ colsum,
+                                                              unsigned first_colsum_block) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ f32x4 part[RG][RE];
     const int e = threadIdx.x % RE, gidx = threadIdx.x / RE;
-    const int64_t i4 = (int64_t)blockIdx.x * RE + e, total4 = (m * n) >> 2;
+    // the launch's last blocks add the slices' column sums of A (m floats per slice) the same way
+    const bool cs = blockIdx.x >= first_colsum_block;
+    if (cs) { ws = colsum_ws; stride = m; }
+    const int64_t i4 = (int64_t)(cs ? blockIdx.x - first_colsum_block : blockIdx.x) * RE + e, total4 = cs ? m >> 2 : (m * n) >> 2;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (i4 < total4) {
         const int per = (slices + RG - 1) / RG;
@@ -396,6 +428,10 @@ __global__ __launch_bounds__(RG * RE) void wide_reduce_kernel(const float* __res
     if (gidx != 0 || i4 >= total4) return;
 #pragma unroll
     for (int g2 = 1; g2 < RG; ++g2) acc += part[g2][e];
+    if (cs) {
+        *reinterpret_cast<f32x4*>(colsum + i4 * 4) = acc;
+        return;
+    }
     const int64_t i = i4 * 4, row = i / n;
     const int col = (int)(i - row * n);
     float4 y = make_float4(acc.x, acc.y, acc.z, acc.w);
@@ -407,9 +443,9 @@ __global__ __launch_bounds__(RG * RE) void wide_reduce_kernel(const float* __res
     *reinterpret_cast<float4*>(c + row * ldc + col) = y;
 }
 
-template <int NW, int NBLK, bool GATHER>
-static int launch_as(const Args& g, hipStream_t s) {
-    auto kernel = wgrad_wide_kernel<NW, NBLK, GATHER>;
+template <int NW, int NBLK, bool GATHER, bool COLSUM>
+static int launch_as2(const Args& g, hipStream_t s) {
+    auto kernel = wgrad_wide_kernel<NW, NBLK, GATHER, COLSUM>;
     // (once per device and instantiation: the attribute belongs to the device's copy of the function, and a process may
     // hold several devices)
     static bool armed[64] = {};
@@ -423,6 +459,11 @@ static int launch_as(const Args& g, hipStream_t s) {
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)(g.slices * g.tiles_m * g.tiles_n)), dim3(Geo<NW>::NT), Geo<NW>::LDS_BYTES, s, g);
     return launch_status();
+}
+
+template <int NW, int NBLK, bool GATHER>
+static int launch_as(const Args& g, hipStream_t s) {
+    return g.colsum_ws ? launch_as2<NW, NBLK, GATHER, true>(g, s) : launch_as2<NW, NBLK, GATHER, false>(g, s);
 }
 
 int launch(const Args& g_in, hipStream_t s) {
@@ -443,10 +484,12 @@ int launch(const Args& g_in, hipStream_t s) {
 
 // c[m, n] (leading dimension ldc) = epilogue(sum of the slices); c2 != nullptr: columns from n_split on go to c2[:, col - n_split]
 // (the pair form).  Everything 16-byte aligned, leading dimensions and n_split multiples of 4 (the caller checks).
-int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, float* c2, int64_t ldc2, int n_split, hipStream_t s) {
+int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, float* c2, int64_t ldc2, int n_split, float* colsum, hipStream_t s) {
     const int64_t total4 = ((int64_t)g.m * g.n) >> 2;
-    hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)((total4 + RE - 1) / RE)), dim3(RG * RE), 0, s, g.ws, g.slices,
-                       (int64_t)g.m * g.n, c, ldc, (int64_t)g.m, g.n, e, c2, ldc2, n_split);
+    const unsigned blocks = (unsigned)((total4 + RE - 1) / RE);
+    const unsigned cs_blocks = (colsum && g.colsum_ws) ? (unsigned)(((g.m >> 2) + RE - 1) / RE) : 0u;
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3(blocks + cs_blocks), dim3(RG * RE), 0, s, g.ws, g.slices,
+                       (int64_t)g.m * g.n, c, ldc, (int64_t)g.m, g.n, e, c2, ldc2, n_split, g.colsum_ws, colsum, blocks);
     return launch_status();
 }
 

@@ -19,6 +19,8 @@ struct Args {
     int64_t k;
     int slices;                   // K slices; slice z writes its raw partial to ws + z m n (leading dimension n)
     float* ws;
+    float* colsum_ws;             // nullable: slice z also writes the column sums of ITS rows of A (m floats) to colsum_ws + z m --
+                                  // the bias gradient of the layer whose weight gradient this is (dz is read once for both)
     int tiles_m, tiles_n;         // (filled in by launch) result blocks per slice
 };
 
@@ -27,7 +29,8 @@ int slices_for(const Args& g);
 int launch(const Args& g, hipStream_t s);
 // c = epilogue(sum of the slices' partials, in a fixed order); columns from n_split on to c2 when given (the pair form).
 // Pointers 16-byte aligned, ldc / ldc2 / n_split multiples of 4 (else use splitk_reduce_kernel)
-int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, float* c2, int64_t ldc2, int n_split, hipStream_t s);
+// colsum != nullptr (with g.colsum_ws): also colsum[0 .. m) = the slices' column sums of A, added in the same fixed order
+int reduce(const Args& g, float* c, int64_t ldc, const Epi& e, float* c2, int64_t ldc2, int n_split, float* colsum, hipStream_t s);
 
 }  // namespace wgw
 }  // namespace plnlp

@@ -489,7 +489,8 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
          out: Optional[torch.Tensor] = None, epilogue: Optional[L.Epilogue] = None,
          split_k: Optional[int] = None, b_index: Optional[torch.Tensor] = None,
          a_index: Optional[Sequence[Optional[torch.Tensor]]] = None, a_index2: Optional[torch.Tensor] = None,
-         b_index2: Optional[torch.Tensor] = None, rowdot: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None):
+         b_index2: Optional[torch.Tensor] = None, rowdot: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None,
+         a_colsum: Optional[list] = None):
     """C = EPI(sum_s op(A_s) op(B_s))  (plnlp_gemm_f32).  A_s: [M,K] or [K,M] if
     a_trans; B_s: [N,K] if b_trans (nn.Linear weight layout) else [K,N].
     b_index (int32 [K], one segment, a_trans and not b_trans): B's row for reduction index j
@@ -501,7 +502,10 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     the loader (MLPPredictor's first linear and its weight gradient).
     rowdot = (w [n] or [1, n], bias [1] or None): also evaluate the 1-output linear  s[r] = <C[r, :], w> + bias  on the stored
     result in the launch's epilogue (PLNLP_EPI_ROWDOT: the stationary-weights kernel only) -- returns (C, s [m, 1]), or
-    (C, None) when the launch does not take that form and the caller has to make its own pass over C."""
+    (C, None) when the launch does not take that form and the caller has to make its own pass over C.
+    a_colsum (a list; a_trans weight gradients): when the launch takes the whole-block weight-gradient kernel, the column sums of
+    A over the reduction index -- the bias gradient next to dW = dz^T x -- come out of the same launch and are appended to
+    the list; the list stays empty when the launch runs another kernel (the caller then sums dz itself)."""
     lib = L.load()
     ops = (L.GemmOperand * len(segs))()
     ops[0].math = _gemm_math()
@@ -549,7 +553,13 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
     keep.append(_lend_b_terms(ops, len(segs), a_trans, b_trans, out, m, n))
     if keep[-1] is not None:
         split_k = 1              # (the form never cuts K: few row panels get narrower column tiles instead)
-    ws = torch.empty(split_k * m * n, dtype=torch.float32, device=out.device) if split_k > 1 else None
+    cs = None
+    if a_colsum is not None and split_k > 1 and (ops[0].flags & L.GEMM_FLAG_WIDE_WGRAD) and COLSUM_IN_WGRAD["enabled"] and m % 4 == 0:
+        cs = torch.empty(m, dtype=torch.float32, device=out.device)
+        ops[0].a_colsum = cs.data_ptr()
+        a_colsum.append(cs)
+    ws = (torch.empty(split_k * (m * n + (m if cs is not None else 0)), dtype=torch.float32, device=out.device)
+          if split_k > 1 else None)
     partial = None
     if rowdot is not None:
         tiles = lib.plnlp_gemm_rowdot_tiles(m, n) if (keep[-1] is not None and FUSE_HEAD_FORWARD["enabled"]) else 0
@@ -576,16 +586,23 @@ def gemm(segs: Sequence[Tuple[torch.Tensor, torch.Tensor]], a_trans: bool, b_tra
 
 
 def wgrad_pair(dz: torch.Tensor, x1: torch.Tensor, x2: torch.Tensor, rows: Optional[torch.Tensor] = None,
-               x1_compact: bool = False):
+               x1_compact: bool = False, a_colsum: Optional[list] = None):
     """(dW1, dW2) = dz^T x1, dz^T x2 in one split-K GEMM that reads dz once (gemm_pair); two products when
     the seam would cut a 128-column tile.
     rows (int32 [K]): dz holds only those rows of a row-sparse gradient; x1 / x2 are read at
-    rows[j] (gathered inside the GEMM's loader); x1_compact: x1 already holds just those rows."""
-    out = gemm_pair(dz, x1, x2, True, rows=rows, rows_on=2 if (x1_compact and rows is not None) else 3)
+    rows[j] (gathered inside the GEMM's loader); x1_compact: x1 already holds just those rows.
+    a_colsum: see gemm."""
+    out = gemm_pair(dz, x1, x2, True, rows=rows, rows_on=2 if (x1_compact and rows is not None) else 3, a_colsum=a_colsum)
     if out is None:
-        return (gemm([(dz, x1)], True, False, b_index=None if x1_compact else rows),
+        return (gemm([(dz, x1)], True, False, b_index=None if x1_compact else rows, a_colsum=a_colsum),
                 gemm([(dz, x2)], True, False, b_index=rows))
     return out
+
+
+# the bias gradient (column sums of dz) out of the whole-block weight-gradient kernel, which stages every row of dz anyway
+# (csrc/gemm_wgw.hip, plnlp_gemm_operand.a_colsum), instead of a second pass over dz on the side stream (SideColsum).
+# off = that pass everywhere (A/B runs; another summation order, both deterministic)
+COLSUM_IN_WGRAD = {"enabled": True}
 
 
 def dgrad_pair(dz: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, out1: Optional[torch.Tensor] = None):
@@ -598,7 +615,7 @@ def dgrad_pair(dz: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, out1: Optio
 
 
 def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool, out1: Optional[torch.Tensor] = None,
-              rows: Optional[torch.Tensor] = None, rows_on: int = 3):
+              rows: Optional[torch.Tensor] = None, rows_on: int = 3, a_colsum: Optional[list] = None):
     """(c1, c2) = op(a) @ b1, op(a) @ b2 in ONE launch (plnlp_gemm_pair_f32): `a` is read once, B comes
     from the two buffers as they are (no concatenated copy) and the two results are two contiguous
     tensors (no strided halves to copy out).  b1 / b2: [K, n1] / [K, n2] (row-contiguous).
@@ -636,7 +653,13 @@ def gemm_pair(a: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, a_trans: bool
     assert c1.shape == (m, n1) and c1.is_contiguous()
     c2 = torch.empty(m, n2, dtype=torch.float32, device=a.device)
     lent = _lend_b_terms(ops, 1, a_trans, False, c1, m, n, out2=c2, n_split=n1)
-    ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device) if split_k > 1 else None
+    cs = None
+    if a_colsum is not None and split_k > 1 and (ops[0].flags & L.GEMM_FLAG_WIDE_WGRAD) and COLSUM_IN_WGRAD["enabled"] and m % 4 == 0:
+        cs = torch.empty(m, dtype=torch.float32, device=a.device)          # (see gemm: the bias gradient out of the same launch)
+        ops[0].a_colsum = cs.data_ptr()
+        a_colsum.append(cs)
+    ws = (torch.empty(split_k * (m * n + (m if cs is not None else 0)), dtype=torch.float32, device=a.device)
+          if split_k > 1 else None)
     L.check(lib.plnlp_gemm_pair_f32(ops, b2.data_ptr(), _ld(b2), n1, int(rows_on), int(a_trans), 0, c1.data_ptr(), _ld(c1),
                                     c2.data_ptr(), _ld(c2), n1, m, n, split_k, L.ptr(ws),
                                     0 if ws is None else ws.numel(), L.stream_ptr()), "plnlp_gemm_pair_f32")
@@ -1575,14 +1598,17 @@ class SAGEConvFn(torch.autograd.Function):
                 # the input is the embedding table and nothing but Adam consumes its gradient: update it in the
                 # epilogue of the aggregation that finishes that gradient (no 242 MB gradient written and read
                 # back).  The weight gradients read the OLD table, so they go first.
-                bias_sum = SideColsum(dz) if need[2] else None      # beside the weight gradients and the aggregation below
+                # the bias gradient (column sums of dz) comes out of the weight-gradient launch where that is the whole-block
+                # kernel (`cs` non-empty), else from its own pass beside the aggregation below
+                cs = [] if need[2] else None
                 if need[1] and need[3]:
-                    gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows, x1_compact=compact_fwd)
+                    gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows, x1_compact=compact_fwd, a_colsum=cs)
                 else:
                     if need[1]:
-                        gwl = gemm([(dz, agg)], True, False, b_index=None if compact_fwd else sg.rows)
+                        gwl = gemm([(dz, agg)], True, False, b_index=None if compact_fwd else sg.rows, a_colsum=cs)
                     if need[3]:
-                        gwr = gemm([(dz, x)], True, False, b_index=sg.rows)
+                        gwr = gemm([(dz, x)], True, False, b_index=sg.rows, a_colsum=cs if not need[1] else None)
+                bias_sum = SideColsum(dz) if (need[2] and not cs) else None
                 ad = sink.adam
                 sc = _step_scalars["active"]
                 epi = L.make_epilogue(addend=gx_c, addend_index=sg.node_map,
@@ -1592,8 +1618,8 @@ class SAGEConvFn(torch.autograd.Function):
                 csr_aggregate(graph.t_mean(), gagg_c, "sum", use_values=True, src_map=sg.node_map, out=x.data,
                               epilogue=epi)
                 sink.adam_applied = True
-                if bias_sum is not None:
-                    gbl = bias_sum.join()
+                if need[2]:
+                    gbl = cs[0] if cs else bias_sum.join()
                 return None, gwl, gbl, gwr, None, None, None, None, None, None
             out = sink.buffer if sink is not None else torch.empty(x.shape[0], cin, dtype=torch.float32,
                                                                    device=x.device)
@@ -1603,15 +1629,16 @@ class SAGEConvFn(torch.autograd.Function):
                 sink.on_ready()
             if sink is None:
                 gx = out
+        cs = [] if need[2] else None
         if need[1] and need[3]:
-            gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows, x1_compact=compact_fwd)
+            gwl, gwr = wgrad_pair(dz, agg, x, rows=sg.rows, x1_compact=compact_fwd, a_colsum=cs)
         else:
             if need[1]:
-                gwl = gemm([(dz, agg)], True, False, b_index=None if compact_fwd else sg.rows)
+                gwl = gemm([(dz, agg)], True, False, b_index=None if compact_fwd else sg.rows, a_colsum=cs)
             if need[3]:
-                gwr = gemm([(dz, x)], True, False, b_index=sg.rows)
+                gwr = gemm([(dz, x)], True, False, b_index=sg.rows, a_colsum=cs if not need[1] else None)
         if need[2]:
-            gbl = colsum(dz)
+            gbl = cs[0] if cs else colsum(dz)
         return gx, gwl, gbl, gwr, None, None, None, None, None, None
 
 
@@ -1906,10 +1933,11 @@ class GCNInputConvFn(torch.autograd.Function):
         dz = _act_backward(gy.contiguous(), y, act)
         need = ctx.needs_input_grad
         gemb = gw = gb = None
-        bias_sum = SideColsum(dz) if need[2] else None          # beside the products and the transposed aggregation below
+        cs = [] if need[2] else None        # (the bias gradient out of the weight-gradient launch where that is the whole-block kernel)
         if need[1]:
-            gwa = gemm([(dz, ax)], True, False)                                       # [out, ep + fp]
+            gwa = gemm([(dz, ax)], True, False, a_colsum=cs)                          # [out, ep + fp]
             gw = torch.cat([gwa[:, :e], gwa[:, ep:ep + f]], dim=1)
+        bias_sum = SideColsum(dz) if (need[2] and not cs) else None       # else: beside the products and the transposed aggregation below
         if need[0]:
             g_aemb = gemm([(dz, wa[:, :ep].contiguous())], False, False)              # [N, ep]: embedding columns only
             full = csr_aggregate(graph.t(), g_aemb, "sum", use_values=True)           # (its pad columns are exact zeros)
@@ -1917,8 +1945,8 @@ class GCNInputConvFn(torch.autograd.Function):
                 ctx.direct_grad_to.grad = full[:, :e]                                   # a view: no copy
             else:
                 gemb = full[:, :e].contiguous()
-        if bias_sum is not None:
-            gb = bias_sum.join()
+        if need[2]:
+            gb = cs[0] if cs else bias_sum.join()
         return gemb, gw, gb, None, None, None, None
 
 

@@ -81,6 +81,9 @@ MODULE = [
     ("ops.FUSE_HEAD_BACKWARD['enabled']", "True",
      "`False`: the backward of MLPPredictor's 1-output head as four passes over the hidden activation (outer product, three "
      "column sums) instead of one (`plnlp_mlp_head_backward_f32`)"),
+    ("ops.COLSUM_IN_WGRAD['enabled']", "True",
+     "`False`: a conv's bias gradient always as its own pass over dz (`plnlp_colsum_f32`) instead of out of the whole-block "
+     "weight-gradient kernel, which stages every row of dz anyway (`plnlp_gemm_operand.a_colsum`); another summation order"),
     ("ops.COLSUM_SIDE_STREAM['enabled']", "True",
      "`False`: a conv's bias gradient (column sums of dz) in line on the main stream instead of on the second side stream "
      "beside the weight-gradient GEMM (-1.0 % on the collab step)"),

@@ -851,8 +851,8 @@ def test_random_walk_bit_exact_and_valid(P):
 def test_hits50_training_parity_gpu_vs_oracle(P, math):
     """BASELINE.json: 'Hits@K within +-0.3 of reference'.  Same seeds on both sides, a dozen epochs of
     training: Hits@50 of the HIP path tracks the CPU oracle within 0.3 points at every epoch."""
-    import bench
-    r = bench.hits_parity(P, torch.device("cuda"), epochs=8)
+    import small_hits_parity
+    r = small_hits_parity.hits_parity(P, torch.device("cuda"), epochs=8)
     assert r["max_abs_diff_points"] <= 0.3, r
     assert r["gpu_test"] > 0.0
 
@@ -864,8 +864,8 @@ def test_hits20_training_parity_ddi_recipe(P, math):
     point (and weights by lr per step where a gradient is zero up to round-off) between fp32 and fp64,
     and the first step's loss is identical on all three -- so the GPU path is held to the reference's
     own fp32-vs-fp64 drift, not to +-0.3 of one fp32 realisation (the DOT recipe above does meet +-0.3)."""
-    import bench
-    r = bench.hits_parity(P, torch.device("cuda"), epochs=6, recipe="ddi", with_f64=True)
+    import small_hits_parity
+    r = small_hits_parity.hits_parity(P, torch.device("cuda"), epochs=6, recipe="ddi", with_f64=True)
     assert r["metric"] == "Hits@20"
     lo = r["epoch_losses"]
     g, c, d = (np.array(lo[k_]) for k_ in ("gpu", "cpu", "cpu64"))

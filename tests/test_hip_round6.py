@@ -469,3 +469,66 @@ def test_padded_table_gradient_reaches_autograd_outside_the_trainers_step(P):
         out = m.encoder(m._input_feat(data), data.adj_t)
         out.square().sum().backward()
     assert torch.equal(m.emb.weight.grad, g) and P.ops.padded_base(m.emb.weight.grad) is not None
+
+
+@pytest.mark.parametrize("m,n,k", [(200, 200, 300_001), (200, 180, 65_536), (224, 224, 40_000), (256, 256, 40_007), (512, 512, 70_000),
+                                   (200, 200, 32_790)])
+def test_bias_gradient_out_of_the_wide_weight_gradient_kernel(P, m, n, k):
+    """the whole-block weight-gradient kernel (csrc/gemm_wgw.hip) stages every row of dz anyway -- the column sums of
+    dz, the layer's bias gradient (the sums autograd forms for F.linear's bias, plnlp/layer.py:83, and PyG's conv bias), now
+    come out of the same launch (plnlp_gemm_operand.a_colsum) instead of a second pass over dz.  Against float64 at 1e-5 of
+    sum |dz|, the same bits twice, the weight gradient's bits untouched, the separate colsum kernel not launched."""
+    ops = P.ops
+    old = ops.GEMM_MATH["mode"]
+    ops.GEMM_MATH["mode"] = "bf16x3"
+    try:
+        gen = torch.Generator(device="cuda").manual_seed(m + n + k)
+        dz = torch.randn(k, m, device="cuda", generator=gen) * (1.0 + torch.arange(m, device="cuda") % 7)
+        x = torch.randn(k, n, device="cuda", generator=gen)
+        plain = ops.gemm([(dz, x)], True, False)
+        outs = []
+        for _ in range(2):
+            cs = []
+            c0 = ops.launch_counts()
+            gw = ops.gemm([(dz, x)], True, False, a_colsum=cs)
+            d = _delta(P, c0)
+            assert d["gemm_wgrad_wide"] == 1 and len(cs) == 1 and cs[0].shape == (m,), d
+            assert torch.equal(gw, plain)
+            outs.append(cs[0].clone())
+        assert torch.equal(outs[0], outs[1])
+        want = dz.double().sum(0)
+        bound = dz.double().abs().sum(0)
+        assert float(((outs[0].double() - want).abs() / bound).max()) <= 1e-5
+        close(outs[0], ops.colsum(dz), rtol=1e-5, atol=1e-5 * float(bound.max()))
+        ops.COLSUM_IN_WGRAD["enabled"] = False
+        cs = []
+        assert torch.equal(ops.gemm([(dz, x)], True, False, a_colsum=cs), plain) and cs == []
+    finally:
+        ops.GEMM_MATH["mode"] = old
+        ops.COLSUM_IN_WGRAD["enabled"] = True
+
+
+def test_bias_gradient_rides_with_the_gathered_pair(P):
+    """the collab step's weight gradients [dWl | dWr] = dz^T [agg | x[rows]] (two B buffers, gathered rows, 256 x 512) with the
+    bias gradient of lin_l out of the same launch; and through SAGEConvFn: every gradient equals the run with the separate pass"""
+    ops = P.ops
+    old = ops.GEMM_MATH["mode"]
+    ops.GEMM_MATH["mode"] = "bf16x3"
+    try:
+        gen = torch.Generator(device="cuda").manual_seed(8)
+        t_rows, n_src, h = 40_032, 70_000, 256
+        dz = torch.randn(t_rows, h, device="cuda", generator=gen)
+        agg = torch.randn(t_rows, h, device="cuda", generator=gen)
+        x = torch.randn(n_src, h, device="cuda", generator=gen)
+        rows = torch.randperm(n_src, device="cuda", generator=gen)[:t_rows].sort().values.to(torch.int32)
+        cs = []
+        c0 = ops.launch_counts()
+        gwl, gwr = ops.wgrad_pair(dz, agg, x, rows=rows, x1_compact=True, a_colsum=cs)
+        d = _delta(P, c0)
+        assert d["gemm_wgrad_wide"] == 1 and len(cs) == 1, d
+        ref_l, ref_r = ops.wgrad_pair(dz, agg, x, rows=rows, x1_compact=True)
+        assert torch.equal(gwl, ref_l) and torch.equal(gwr, ref_r)
+        want = dz.double().sum(0)
+        assert float(((cs[0].double() - want).abs() / dz.double().abs().sum(0)).max()) <= 1e-5
+    finally:
+        ops.GEMM_MATH["mode"] = old
