@@ -44,7 +44,8 @@ extern "C" {
  * 12 (round 6): plnlp_gemm_block_tuning (the stationary-weights product with a whole 256-row block per workgroup, gemm_x3b.hip);
  *              launch kind "gemm_x3b"; plnlp_gemm_operand.reserved -> flags (PLNLP_GEMM_FLAG_WIDE_WGRAD: the wide weight-gradient
  *              form is asked for explicitly, no longer implied by the slice count); plnlp_gemm_operand.a_colsum (the bias gradient
- *              out of the wide weight-gradient kernel). */
+ *              out of the wide weight-gradient kernel); plnlp_dense_aggregate_f32 / _scratch_bytes (a dense graph's aggregation on
+ *              the matrix cores); launch kind "agg_dense". */
 #define PLNLP_ABI_VERSION 12
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
@@ -204,6 +205,23 @@ int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
                             const plnlp_epilogue* epi /* nullable, HOST ptr */,
                             const plnlp_row_split* split /* nullable, HOST ptr */,
                             void* stream);
+
+/* The same aggregation for a DENSE graph, as a product on the matrix cores (csrc/aggregate_dense.hip; replaces torch_sparse.matmul
+ * under SAGEConv, plnlp/layer.py:30-36, where the adjacency is dense enough that a matrix of counts beats the CSR gather --
+ * ogbl-ddi: 4 267 nodes, 11.7 % of all pairs are edges):
+ *   out[r, :] = EPI( row_scale[r] * sum_k counts[r, k] * (src_scale[k] * x[k, :]) )
+ * counts: bf16 [n_rows, ld_counts] -- entry (r, k) = the number of CSR entries (r, k), exact up to 256; ld_counts a multiple of
+ * 16 >= n_src rounded up to 16, zeros beyond n_src; built once per static graph by the caller.  src_scale (nullable [n_src]): the
+ * per-source weight of a valued graph whose values depend on the column only (the mean's backward: 1 / deg); row_scale (nullable
+ * [n_rows]): the mean's 1 / max(deg, 1).  x is split into FOUR bf16 terms (round-to-nearest each, residuals exact: what is dropped is
+ * below 2^-32 |x|), the counts are exact, so every product is exact like the CSR kernels' and the sums are f32 in another order.
+ * epi: every flag plnlp_csr_aggregate_f32 takes (PLNLP_EPI_ADAM included); operands 16-byte aligned.  scratch: DEVICE memory of
+ * plnlp_dense_aggregate_scratch_bytes(n_rows, n_src, feat) bytes the launch may overwrite (x's image + the K slices' partials).
+ * feat % 4 == 0; x / out 16-byte aligned with ldx, ldo multiples of 4.  Deterministic (fixed slice order). */
+int64_t plnlp_dense_aggregate_scratch_bytes(int64_t n_rows, int64_t n_src, int64_t feat);
+int plnlp_dense_aggregate_f32(const void* counts, int64_t ld_counts, const float* src_scale, const float* row_scale,
+                              const float* x, int64_t ldx, float* out, int64_t ldo, int64_t n_rows, int64_t n_src, int64_t feat,
+                              const plnlp_epilogue* epi /* nullable, HOST ptr */, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* reduce = max (torch_sparse.matmul(adj_t, x, reduce='max'); SAGEConv(aggr='max') in PyG, the third
  * reduction SURVEY.md 8(b) lists next to sum / mean):

@@ -115,6 +115,9 @@ SIGNATURES = {
     "plnlp_mlp_head_backward_workspace_floats": (c_i64, [c_i64, c_i64]),
     "plnlp_mlp_head_backward_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_float, c_i64, c_i64, C.c_void_p,
                                               c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_void_p]),
+    "plnlp_dense_aggregate_scratch_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "plnlp_dense_aggregate_f32": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, c_i64,
+                                            c_i64, c_i64, c_i64, C.POINTER(Epilogue), C.c_void_p, c_i64, C.c_void_p]),
     "plnlp_launch_counts": (C.c_int, [C.c_void_p, C.c_int]),
     "plnlp_launch_kind_name": (C.c_char_p, [C.c_int]),
     "plnlp_gemm_split_out_f32": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64,

@@ -39,6 +39,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     units.append(("gemm_x3s.hip", "gemm_x3s.o", ["-fno-slp-vectorize"]))
     units.append(("gemm_wgw.hip", "gemm_wgw.o", ["-fno-slp-vectorize"]))
     units.append(("gemm_x3b.hip", "gemm_x3b.o", ["-fno-slp-vectorize"]))
+    units.append(("aggregate_dense.hip", "aggregate_dense.o", ["-fno-slp-vectorize"]))
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "plnlp_hip.h"))
     newest_header = max(os.path.getmtime(h) for h in headers)

@@ -316,6 +316,7 @@ enum LaunchKind : int {
     LK_AGG_SCALAR,            //   any width / alignment
     LK_GEMM_WGRAD_WIDE,       // split-bf16 weight gradient, the whole (<= 224 x 224) result per workgroup (gemm_wgw.hip)
     LK_GEMM_X3B,              // split-bf16, stationary pre-split weights, a 256-row block per workgroup (gemm_x3b.hip)
+    LK_AGG_DENSE,             // aggregation of a dense graph as a bf16-counts x split-bf16 product (aggregate_dense.hip)
     LK_COUNT
 };
 void count_launch(int kind);

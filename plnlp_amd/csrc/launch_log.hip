@@ -20,6 +20,6 @@ extern "C" int plnlp_launch_counts(int64_t* out, int n) {
 extern "C" const char* plnlp_launch_kind_name(int kind) {
     static const char* names[plnlp::LK_COUNT] = {
         "gemm_x3s", "gemm_tile_x3", "gemm_tile_f32", "gemm_splitk_reduce", "agg_vec", "agg_vec_slabs", "agg_vec_xcd",
-        "agg_fused", "agg_fused_hub_xcd", "agg_chunk", "agg_chunk_xcd", "agg_finalize", "agg_lds", "agg_scalar", "gemm_wgrad_wide", "gemm_x3b"};
+        "agg_fused", "agg_fused_hub_xcd", "agg_chunk", "agg_chunk_xcd", "agg_finalize", "agg_lds", "agg_scalar", "gemm_wgrad_wide", "gemm_x3b", "agg_dense"};
     return (kind >= 0 && kind < plnlp::LK_COUNT) ? names[kind] : nullptr;
 }

@@ -317,6 +317,28 @@ class Graph:
             self._t_pos = rel[order].to(torch.int32).contiguous()
         return self._t_pos
 
+    def dense_counts(self, min_density: float, min_rows: int, max_rows: int):
+        """The adjacency as a dense matrix of entry COUNTS in bf16, [n_rows, n_cols rounded up to 16] (duplicates count twice,
+        like the CSR sums) -- what plnlp_dense_aggregate_f32 multiplies on the matrix cores.  Only for graphs dense and small
+        enough that this beats the CSR gather (ogbl-ddi: 4 267 nodes at 11.7 %: 36 MB); None otherwise, decided and built once
+        per static graph.  The counts are the PATTERN's: a caller that wants the values too may use them only where the values depend on
+        the column alone (t_mean(): A^T D^-1, whose column weights go to the kernel as src_scale: `_col_scale`)."""
+        hit = getattr(self, "_dense_counts", False)
+        if hit is not False:
+            return hit
+        out = None
+        cells = self.n_rows * self.n_cols
+        if (min_rows <= self.n_rows <= max_rows and self.n_cols <= max_rows and self.device.type == "cuda"
+                and self.nnz >= min_density * cells):
+            kp = (self.n_cols + 15) // 16 * 16
+            dense = torch.zeros(self.n_rows, kp, dtype=torch.float32, device=self.device)
+            dense.view(-1).index_add_(0, self.row_index() * kp + self.col.long(),
+                                      torch.ones(self.nnz, dtype=torch.float32, device=self.device))
+            if float(dense.max()) <= 256.0:                 # (bf16 holds integers up to 256 exactly)
+                out = dense.to(torch.bfloat16).contiguous()
+        self._dense_counts = out
+        return out
+
     def t_mean(self) -> "Graph":
         """The operator of the mean aggregation's backward as ONE valued CSR: A^T D^-1, i.e. the
         transposed structure with entry value 1 / max(deg(source row of A), 1).  Built once per static
@@ -325,6 +347,7 @@ class Graph:
         if getattr(self, "_t_mean", None) is None:
             gt = self.t()
             g = Graph(gt.rowptr, gt.col, self.inv_degree()[gt.col.long()].contiguous(), gt.n_rows, gt.n_cols)
+            g._col_scale = self.inv_degree()          # (its values depend on the column only: val[e] = _col_scale[col[e]])
             g._agg_tune = self._agg_tune
             self._t_mean = g
         return self._t_mean

@@ -282,6 +282,42 @@ def _agg_tune(graph, x, out, reduce, use_values, src_scale, src_map, epilogue, f
     return cache[key]
 
 
+# The aggregation of a DENSE graph as a product on the matrix cores (csrc/aggregate_dense.hip; plnlp_dense_aggregate_f32): the
+# adjacency as a bf16 matrix of counts times x split into three bf16 terms.  For graphs like ogbl-ddi (4 267 nodes, 11.7 % of all
+# pairs are edges), where every row is a "long row" of the CSR kernels.  Same f32-grade sums in another order; off = CSR everywhere.
+DENSE_AGG = {"enabled": os.environ.get("PLNLP_DENSE_AGG", "1") != "0", "min_density": 0.05, "min_rows": 2048, "max_rows": 16384}
+
+
+def _dense_aggregate(graph, x, reduce, use_values, src_scale, out, epilogue):
+    """csr_aggregate's launch on the dense form, or None where it does not apply (the caller then runs the CSR kernels)"""
+    if not (DENSE_AGG["enabled"] and isinstance(graph, Graph) and x.is_cuda and x.shape[1] % 4 == 0):
+        return None
+    if GEMM_MATH["mode"] != "bf16x3":        # it IS a split-bf16 product: with the dense products on the exact-f32 MFMA (the
+        return None                          # reference's arithmetic) the aggregation stays the CSR kernels' chain of f32 adds
+    if use_values and graph.val is not None and getattr(graph, "_col_scale", None) is None:
+        return None                          # arbitrary entry values (GCN's normalised adjacency): the CSR kernels
+    counts = graph.dense_counts(DENSE_AGG["min_density"], DENSE_AGG["min_rows"], DENSE_AGG["max_rows"])
+    if counts is None:
+        return None
+    lib = L.load()
+    n, feat = graph.n_rows, x.shape[1]
+    scale = getattr(graph, "_col_scale", None) if (use_values and graph.val is not None) else None
+    if src_scale is not None:
+        scale = src_scale if scale is None else scale * src_scale
+    row_scale = graph.inv_degree() if reduce == "mean" else None
+    if out is None:
+        out = torch.empty(n, feat, dtype=torch.float32, device=x.device)
+    if _ld(x) % 4 or _ld(out) % 4 or x.data_ptr() % 16 or out.data_ptr() % 16:
+        return None
+    nbytes = lib.plnlp_dense_aggregate_scratch_bytes(n, graph.n_cols, feat)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    rc = lib.plnlp_dense_aggregate_f32(counts.data_ptr(), counts.shape[1], L.ptr(scale), L.ptr(row_scale), x.data_ptr(), _ld(x),
+                                       out.data_ptr(), _ld(out), n, graph.n_cols, feat,
+                                       C.byref(epilogue) if epilogue is not None else None, scratch.data_ptr(), nbytes, L.stream_ptr())
+    L.check(rc, "plnlp_dense_aggregate_f32")
+    return out
+
+
 def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool = True,
                   src_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                   epilogue: Optional[L.Epilogue] = None, split="auto",
@@ -302,6 +338,10 @@ def csr_aggregate(graph, x: torch.Tensor, reduce: str = "sum", use_values: bool 
         assert src_map.dtype == torch.int32 and src_map.numel() == graph.n_cols
     feat = x.shape[1]
     n_out = graph.n_rows
+    if src_map is None and row_index is None and reduce in ("sum", "mean"):
+        done = _dense_aggregate(graph, x, reduce, use_values, src_scale, out, epilogue)       # a dense graph: on the matrix cores
+        if done is not None:
+            return done
     if row_index is not None:
         assert row_index.dtype == torch.int32 and out_map is not None and out_map.dtype == torch.int32
         n_out = row_index.numel()

@@ -25,6 +25,10 @@ ENV = [
     ("PLNLP_EMB_PAD", "ops.EMB_PAD['floats']", "16",
      "row granule (floats) an embedding table of an unaligned width is padded to when it is kept padded "
      "(`model.PAD_EMBEDDING_TABLE`): `4` = 16-byte rows (citation2: 52 columns), `16` = whole 64-byte sectors (64 columns)"),
+    ("PLNLP_DENSE_AGG", "ops.DENSE_AGG['enabled']", "1",
+     "`0`: the aggregation of a dense graph (>= 5 % of all node pairs, 2 048..16 384 nodes: ogbl-ddi) on the CSR kernels like every "
+     "other graph, instead of as a bf16-counts x split-bf16 product on the matrix cores (`csrc/aggregate_dense.hip`); another "
+     "summation order"),
     ("PLNLP_SPARSE_FORWARD", "ops.SPARSE_FORWARD['enabled']", "1",
      "`0`: the last conv of a training step is evaluated at every node instead of the rows the batch touches"),
     ("PLNLP_AGG_AUTOTUNE", "ops.AGG_AUTOTUNE['enabled']", "1",

@@ -376,7 +376,7 @@ def test_teacher_forced_epoch_agrees_step_by_step(P, recipe, math, max_steps):
         assert worst_bulk <= 2e-5
         if recipe in T.WIDE:
             assert _stationary(dlt) >= 2 * len(batches), dlt
-            assert dlt["agg_fused"] + dlt["agg_fused_hub_xcd"] + dlt["agg_vec_slabs"] + dlt["agg_chunk"] >= len(batches), dlt
+            assert dlt["agg_fused"] + dlt["agg_fused_hub_xcd"] + dlt["agg_vec_slabs"] + dlt["agg_chunk"] + dlt["agg_dense"] >= len(batches), dlt
     finally:
         P.ops.GEMM_MATH["mode"] = old
 
@@ -407,7 +407,8 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
       ddi_wide     ddi's own size and density (4 267 nodes, eight communities of 500: ~450 neighbours each), SAGE x2 + MLP at
                    h = 512, 8 192 x (1 + 3) = 32 768 scorer rows per step, 30 epochs of 12 steps: long enough for every
                    converged run to sit on the 90 % Hits@20 plateau the 10 % unrankable positives leave (README.md:8's metric).
-    Asserted: (a) by the launch counters, that the runs went through gemm_x3s and the fused / slab aggregation forms;
+    Asserted: (a) by the launch counters, that the runs went through gemm_x3s and the fused / slab aggregation forms (ddi_wide since
+    round 6: the dense-graph aggregation on the matrix cores, csrc/aggregate_dense.hip);
     (b) epoch-1 loss, paired per seed: mean deviation from the float32 oracle no larger than the oracle's own float64 run's
     (+ 1e-4); every later epoch's mean deviation within twice that gap (+ 0.2 %) -- the lottery the teacher-forced tests pin down;
     (c) collab: the final Hits@50, mean over 16 seeds, within 0.3 points + 2 s.e. (0.2) of the float32 oracle's on valid and test,
@@ -423,7 +424,7 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
     # (a) the forms
     steps = sum(1 for _ in range(n)) * T.RECIPES[recipe]["epochs"]
     assert _stationary(d) >= 2 * steps, d                              # at least forward + data-gradient per step
-    assert d["agg_fused"] + d["agg_fused_hub_xcd"] + d["agg_vec_slabs"] + d["agg_chunk"] > steps, d
+    assert d["agg_fused"] + d["agg_fused_hub_xcd"] + d["agg_vec_slabs"] + d["agg_chunk"] + d["agg_dense"] > steps, d
     if recipe == "collab_wide":
         assert d["agg_fused"] + d["agg_fused_hub_xcd"] > steps, d     # hub rows: the chunk pass inside the main launch
     # (b) losses
@@ -463,17 +464,20 @@ def test_trained_regime_parity_through_the_benchmarks_kernels(P, golden, recipe)
         return
     # ddi_wide.  The centre of 8 seeds carries a standard error of 3 points here (one float32-oracle seed is still short of the
     # plateau after 30 epochs), which made "0.3 + 2 s.e." a band of +-6.5.  Held instead, seed by seed:
-    #   * every seed whose float32-oracle run sits on the plateau: HIP's final level within 0.3 of it, outright;
+    #   * every seed on which both the HIP run and the float32 oracle sit on the plateau: the two final levels within 0.3, outright;
     #   * HIP reaches the plateau on at least as many seeds as the float32 oracle, less one;
     #   * BEFORE the steep phase (epochs 1-6, AUC 55 -> 79 %), paired per seed: the mean |AUC - oracle f32| over the seeds within
     #     twice the oracle's own float64 gap at that epoch (+ 0.05 points) -- a product with a bias in its gradients leaves
     #     this band in the first epochs, long before the plateau hides it (scripts/calibrate_wide_parity.py has the table);
     #   * epochs to 88 % distributed like the float32 oracle's (Mann-Whitney).
     fh, f32 = T.final_level(hip, recipe), T.final_level(ref32, recipe)
-    on32 = (f32 >= 88.0).all(1)
+    on32, onh = (f32 >= 88.0).all(1), (fh >= 88.0).all(1)
+    text += f"\n    per seed final level (valid / test): HIP {np.round(fh, 2).tolist()}  oracle f32 {np.round(f32, 2).tolist()}"
     assert on32.sum() >= 6, text
-    assert (np.abs(fh[on32] - f32[on32]) <= 0.3).all(), text + f"\n    per seed HIP {np.round(fh, 2).tolist()} f32 {np.round(f32, 2).tolist()}"
-    assert (fh >= 88.0).all(1).sum() >= on32.sum() - 1, text
+    # (WHICH seed is the one-in-eight straggler differs between arithmetics -- the float32 and float64 oracles disagree on it too)
+    both = on32 & onh
+    assert both.sum() >= 5 and (np.abs(fh[both] - f32[both]) <= 0.3).all(), text
+    assert onh.sum() >= on32.sum() - 1, text
     pre = slice(0, 6)
     d_hip = np.abs(hip[:, pre, ka, 0] - ref32[:, pre, ka, 0]).mean(0)
     d_orc = np.abs(ref64[:, pre, ka, 0] - ref32[:, pre, ka, 0]).mean(0)

@@ -346,7 +346,7 @@ def test_teacher_forced_steps_with_the_recipes_dropout(P, recipe):
           f"|weight - oracle| after a step {worst_bulk:.2e}; launches {({k: v for k, v in d.items() if v})}")
     assert steps == 6 and worst_loss <= 1e-5 and worst_bulk <= 2e-5, out
     assert d["gemm_x3s"] + d["gemm_x3b"] >= 2 * steps, d
-    assert d["agg_fused"] + d["agg_fused_hub_xcd"] + d["agg_vec_slabs"] + d["agg_chunk"] >= steps, d
+    assert d["agg_fused"] + d["agg_fused_hub_xcd"] + d["agg_vec_slabs"] + d["agg_chunk"] + d["agg_dense"] >= steps, d
 
 
 @pytest.mark.parametrize("recipe", ["collab_wide", "ddi_wide"])
@@ -532,3 +532,105 @@ def test_bias_gradient_rides_with_the_gathered_pair(P):
         assert float(((cs[0].double() - want).abs() / dz.double().abs().sum(0)).max()) <= 1e-5
     finally:
         ops.GEMM_MATH["mode"] = old
+
+
+# ------------------------------------------ a dense graph's aggregation on the matrix cores ----
+def _dense_graph(P, n=2600, density=0.08, seed=4, dup=True):
+    gen = torch.Generator().manual_seed(seed)
+    e = int(density * n * n / 2)
+    a, b = torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)
+    if dup:                                     # parallel edges: counted twice, like the CSR sum
+        a, b = torch.cat([a, a[:5000]]), torch.cat([b, b[:5000]])
+    return P.Graph.from_coo(torch.cat([a, b]), torch.cat([b, a]), None, n, n).to("cuda")
+
+
+def _both_agg_forms(P, fn):
+    old = P.ops.DENSE_AGG["enabled"]
+    try:
+        P.ops.DENSE_AGG["enabled"] = True
+        c0 = P.ops.launch_counts()
+        dense = fn()
+        d = _delta(P, c0)
+        P.ops.DENSE_AGG["enabled"] = False
+        c0 = P.ops.launch_counts()
+        csr = fn()
+        d2 = _delta(P, c0)
+    finally:
+        P.ops.DENSE_AGG["enabled"] = old
+    assert d["agg_dense"] >= 1 and d2["agg_dense"] == 0, (d, d2)
+    return dense, csr
+
+
+@pytest.mark.parametrize("feat", [512, 200, 64])
+def test_dense_graph_aggregation_on_the_matrix_cores(P, feat):
+    """VERDICT r5 #4.  A graph like ogbl-ddi (8 % of all node pairs are edges, every row beyond the CSR kernels' long-row threshold):
+    the mean / sum aggregation as counts (bf16, exact) x features (four bf16 terms: complete) on the MFMA (csrc/aggregate_dense.hip) against the
+    CSR kernels and float64 -- forward mean, plain sum, the mean's backward operator A^T D^-1 (a valued graph whose values depend on
+    the column only) with the indexed-addend + gate epilogue, and with the table's Adam step in the epilogue; parallel edges
+    count twice; same bits twice; which kernel ran by the launch counters."""
+    from plnlp_amd import _lib as L
+    g = _dense_graph(P)
+    n = g.n_rows
+    gen = torch.Generator(device="cuda").manual_seed(feat)
+    x = torch.randn(n, feat, device="cuda", generator=gen)
+    rr, cc, _ = g.coo()
+    a64 = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    a64.view(-1).index_add_(0, rr.long() * n + cc.long(), torch.ones(rr.numel(), dtype=torch.float64, device="cuda"))
+    assert float(a64.max()) >= 2.0
+    deg = a64.sum(1).clamp_min(1.0)
+    for reduce in ("mean", "sum"):
+        dense, csr = _both_agg_forms(P, lambda: P.ops.csr_aggregate(g, x, reduce, False))
+        want = a64 @ x.double()
+        bound = a64 @ x.double().abs()
+        if reduce == "mean":
+            want, bound = want / deg[:, None], bound / deg[:, None]
+        assert float(((dense.double() - want).abs() / bound.clamp_min(1e-30)).max()) <= 1e-6       # exact products, f32 sums
+        close(dense, csr, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+        assert torch.equal(dense, P.ops.csr_aggregate(g, x, reduce, False))
+    # the mean's backward: gx = A^T D^-1 gagg + addend (the root path), gated by the layer input's relu / dropout
+    gagg = torch.randn(n, feat, device="cuda", generator=gen)
+    addend = torch.randn(n, feat, device="cuda", generator=gen)
+    gate = torch.randn(n, feat, device="cuda", generator=gen)
+    mk = lambda: L.make_epilogue(addend=addend, gate=gate, gate_scale=1.25)
+    dense, csr = _both_agg_forms(P, lambda: P.ops.csr_aggregate(g.t_mean(), gagg, "sum", True, epilogue=mk()))
+    want = torch.where(gate > 0, (a64.t() @ (gagg.double() / deg[:, None]) + addend.double()) * 1.25, torch.zeros(n, feat, dtype=torch.float64, device="cuda"))
+    close(dense, want.float(), rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    close(dense, csr, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    # ... and with the table's Adam step in the epilogue: parameter and moments as the CSR kernel leaves them (to rounding of the gradient)
+    outs = []
+    for on in (True, False):
+        P.ops.DENSE_AGG["enabled"] = on
+        table, m, v = x.clone(), torch.zeros_like(x), torch.zeros_like(x)
+        e = L.make_epilogue(addend=addend, adam=(m, v, 1, 1e-2, 0.9, 0.999, 1e-8))
+        P.ops.csr_aggregate(g.t_mean(), gagg, "sum", True, out=table, epilogue=e)
+        outs.append((table, m, v))
+    P.ops.DENSE_AGG["enabled"] = True
+    grad = (a64.t() @ (gagg.double() / deg[:, None]) + addend.double())
+    close(outs[0][1], (0.1 * grad).float(), rtol=1e-5, atol=1e-6 * float(grad.abs().max()))          # m after one step = (1 - beta1) g
+    close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6 * float(grad.abs().max()))
+    live = grad.abs() > 1e-3 * grad.abs().max()           # (Adam's first step is lr * sign(g) up to eps: compare where g is not round-off)
+    assert float((outs[0][0] - outs[1][0]).abs()[live].max()) <= 1e-5
+
+
+def test_dense_form_rule_and_the_sparse_graphs(P):
+    """the dense form is taken by dense, mid-sized, unvalued graphs only: a sparse graph, a small one, a valued one (GCN's normalised
+    adjacency), a row-restricted or source-mapped launch all stay on the CSR kernels"""
+    from gpu_util import rand_csr, to_graph
+    import oracle as O
+    x = torch.randn(3000, 64, device="cuda")
+    sparse = to_graph(P, rand_csr(3000, 20000, 5, weighted=False))
+    c0 = P.ops.launch_counts()
+    P.ops.csr_aggregate(sparse, x, "mean", False)
+    assert _delta(P, c0)["agg_dense"] == 0
+    small = _dense_graph(P, n=600, density=0.2, dup=False)
+    c0 = P.ops.launch_counts()
+    P.ops.csr_aggregate(small, x[:600], "mean", False)
+    assert _delta(P, c0)["agg_dense"] == 0
+    dense = _dense_graph(P, n=2600, density=0.08, dup=False)
+    valued = P.gcn_normalization(dense)
+    c0 = P.ops.launch_counts()
+    P.ops.csr_aggregate(valued, x[:2600], "sum", True)
+    assert _delta(P, c0)["agg_dense"] == 0
+    c0 = P.ops.launch_counts()
+    P.ops.csr_aggregate(valued, x[:2600], "mean", False)            # (values ignored: the pattern's counts)
+    assert _delta(P, c0)["agg_dense"] == 1
