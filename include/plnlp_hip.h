@@ -213,8 +213,9 @@ int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
  * counts: bf16 [n_rows, ld_counts] -- entry (r, k) = the number of CSR entries (r, k), exact up to 256; ld_counts a multiple of
  * 16 >= n_src rounded up to 16, zeros beyond n_src; built once per static graph by the caller.  src_scale (nullable [n_src]): the
  * per-source weight of a valued graph whose values depend on the column only (the mean's backward: 1 / deg); row_scale (nullable
- * [n_rows]): the mean's 1 / max(deg, 1).  x is split into FOUR bf16 terms (round-to-nearest each, residuals exact: what is dropped is
- * below 2^-32 |x|), the counts are exact, so every product is exact like the CSR kernels' and the sums are f32 in another order.
+ * [n_rows]): the mean's 1 / max(deg, 1).  x is split into three bf16 terms (the GEMMs' split: what is dropped is below 2^-24 |x|), the
+ * counts are exact; f32 accumulation in two levels (four K-steps on the matrix pipe, then plain f32 adds): against float64 the rms
+ * error is below the CSR kernels', the sums are the same to f32 round-off in another order.
  * epi: every flag plnlp_csr_aggregate_f32 takes (PLNLP_EPI_ADAM included); operands 16-byte aligned.  scratch: DEVICE memory of
  * plnlp_dense_aggregate_scratch_bytes(n_rows, n_src, feat) bytes the launch may overwrite (x's image + the K slices' partials).
  * feat % 4 == 0; x / out 16-byte aligned with ldx, ldo multiples of 4.  Deterministic (fixed slice order). */

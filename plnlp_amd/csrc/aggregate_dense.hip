@@ -6,11 +6,11 @@
 // all node pairs are edges, a row has ~500 entries, EVERY row is a "long row" of the CSR kernels (csr_aggregate.hip), whose gather
 // then moves 4.4 GB out of L2 per launch to add up what is, as a matrix, 4 267 x 4 267 small integers times an 8.7 MB operand.
 // Here the adjacency is a matrix of COUNTS in bf16 (exact up to 256 parallel edges; built once per static graph by the host,
-// 36 MB) and the feature matrix is split into FOUR bf16 terms (x = t0 + t1 + t2 + t3, round-to-nearest each, every residual exact
-// in f32: what is dropped is below 2^-32 |x|, i.e. nothing of an f32 value's 24 bits -- the GEMMs' three terms drop 2^-24 |x|, the
-// same for every row that gathers x, which the full-size ddi step showed up as 7e-4 of the scale of one bias gradient).  One
-// operand exact, the other complete: a 32 x 32 x 16 block is FOUR MFMAs (smallest term first) with f32 accumulation -- the CSR
-// kernels' sums of exact products in another order (k-block by k-block instead of entry by entry).  north_star keeps the matrix cores for the dense linears "as evidenced by rocprof": the evidence for this exception is
+// 36 MB) and the feature matrix is split into three bf16 terms as in the GEMMs (x = hi + mid + lo, round-to-nearest each, the
+// residuals exact in f32: what is dropped is below 2^-24 |x|).  One operand is exact, so a 32 x 32 x 16 block is THREE MFMAs
+// (counts x lo, x mid, x hi; small terms first) with f32 accumulation -- the CSR kernels' f32 sums in another order (k-block by
+// k-block instead of entry by entry); measured against float64 the rms error is 0.75 x the CSR kernels' (1.14e-7 against 1.52e-7 of the
+// rms value on the ddi graph).  A fourth term was built and measured: same error (the f32 accumulation is what is left), +18 % time.  north_star keeps the matrix cores for the dense linears "as evidenced by rocprof": the evidence for this exception is
 // profiles/r06_ddi_dense_agg.txt (same box, the step's four aggregation launches).
 //
 // Division of labour: 256 threads = 4 waves, a workgroup owns 128 rows x 128 columns of one K slice; wave w owns rows 32 w ..
@@ -31,15 +31,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int NB = 4, WN = 32 * NB;                 // column blocks per wave / columns per workgroup
-constexpr int TERMS = 4;
-constexpr int STAGE_UNITS = 2 * TERMS * WN;         // 16-byte units of one K-step of the image ([term 4][k-half 2][column])
-constexpr int PER = STAGE_UNITS / 256;              // units a thread moves per step (4)
+constexpr int TERMS = 3;
+constexpr int STAGE_UNITS = 2 * TERMS * WN;         // 16-byte units of one K-step of the image ([term][k-half 2][column])
+constexpr int PER = STAGE_UNITS / 256;              // units a thread moves per step (3)
 constexpr int CS = 64 + 4;                          // the write-back's LDS row stride (floats)
 constexpr int LDS_BYTES = 2 * STAGE_UNITS * 16 > 4 * 32 * CS * 4 ? 2 * STAGE_UNITS * 16 : 4 * 32 * CS * 4;
 
 struct Args {
     const uint16_t* counts; int64_t ld_counts;      // bf16 [n_rows, ld_counts], ld_counts a multiple of 16 >= n_src, zero beyond n_src
-    const void* image;                              // x split into its four bf16 terms (split_x_kernel)
+    const void* image;                              // x split into its three bf16 terms (split_x_kernel)
     float* ws;                                      // [slices][n_rows][feat] raw partials
     int64_t n_rows; int feat;
     int ks_total, slices, gn;                       // K-steps of 16 in all, K slices, column tiles
@@ -105,9 +105,10 @@ __global__ __launch_bounds__(256, 2) void dense_agg_kernel(Args g) {
 
     // Two levels of accumulation: the MFMAs add into `acc` for four K-steps, then `acc` is added to `tot` by plain f32 adds
     // (round-to-nearest-even) and cleared.  The matrix pipe's own f32 accumulation carries a small one-sided rounding bias
-    // (measured: +1.6e-9 of the mean |result| per launch against -4e-11 for the CSR kernels' fma chain); keeping its addend
-    // short keeps that bias below what the scorer's nearly cancelling bias gradient can see (tests/test_hip_round4.py: the
-    // full-size ddi step against float64).
+    // and its error grows with the length of the chain: accumulated in one go over a slice's 67 K-steps the full-size ddi step's
+    // scorer-bias gradient -- a sum of 786 432 nearly cancelling terms -- sat 7e-4 of its scale from float64 (tests/test_hip_round4.py:
+    // bound 1e-4; the CSR kernels: inside); with the short chains the aggregation's rms error is below the CSR kernels' and the
+    // step is inside the bound.  Costs 64 registers (two workgroups per CU instead of three: 0.085 -> 0.093 ms per launch).
     f32x16 acc[NB], tot[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j)
@@ -245,7 +246,7 @@ extern "C" int plnlp_dense_aggregate_f32(const void* counts, int64_t ld_counts, 
     if (e.flags && !e.vec4) return PLNLP_E_ALIGN;
     if ((e.flags & PLNLP_EPI_ADAM) && ((uintptr_t)e.adam_m % 16 || (uintptr_t)e.adam_v % 16)) return PLNLP_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    // x -> its four bf16 terms, in the K-step image of the main loop (zeros past n_src and past feat)
+    // x -> its three bf16 terms, in the K-step image of the main loop (zeros past n_src and past feat)
     aggd::SplitArgs sp{};
     sp.x = x; sp.ldx = ldx; sp.k_scale = src_scale; sp.n_src = n_src; sp.feat = (int)feat;
     sp.ks_total = (int)((n_src + 15) / 16); sp.gn = (int)((feat + aggd::WN - 1) / aggd::WN); sp.image = scratch;

@@ -564,7 +564,7 @@ def _both_agg_forms(P, fn):
 @pytest.mark.parametrize("feat", [512, 200, 64])
 def test_dense_graph_aggregation_on_the_matrix_cores(P, feat):
     """VERDICT r5 #4.  A graph like ogbl-ddi (8 % of all node pairs are edges, every row beyond the CSR kernels' long-row threshold):
-    the mean / sum aggregation as counts (bf16, exact) x features (four bf16 terms: complete) on the MFMA (csrc/aggregate_dense.hip) against the
+    the mean / sum aggregation as counts (bf16, exact) x features (three bf16 terms, two-level f32 accumulation) on the MFMA (csrc/aggregate_dense.hip) against the
     CSR kernels and float64 -- forward mean, plain sum, the mean's backward operator A^T D^-1 (a valued graph whose values depend on
     the column only) with the indexed-addend + gate epilogue, and with the table's Adam step in the epilogue; parallel edges
     count twice; same bits twice; which kernel ran by the launch counters."""
@@ -584,7 +584,7 @@ def test_dense_graph_aggregation_on_the_matrix_cores(P, feat):
         bound = a64 @ x.double().abs()
         if reduce == "mean":
             want, bound = want / deg[:, None], bound / deg[:, None]
-        assert float(((dense.double() - want).abs() / bound.clamp_min(1e-30)).max()) <= 1e-6       # exact products, f32 sums
+        assert float(((dense.double() - want).abs() / bound.clamp_min(1e-30)).max()) <= 1e-6       # f32-grade: 2^-24 per term + the f32 sums
         close(dense, csr, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
         assert torch.equal(dense, P.ops.csr_aggregate(g, x, reduce, False))
     # the mean's backward: gx = A^T D^-1 gagg + addend (the root path), gated by the layer input's relu / dropout
