@@ -552,7 +552,32 @@ def measure_step_launches_ddi(P, model, data, cfg, device, rows_scored):
     t = time_kernel(lambda: ops.csr_aggregate(adj, x, "mean", False, out=out))
     by = agg_bytes(adj.nnz, n, F, False)
     by_min = agg_bytes_compulsory(adj.nnz, n, n, F, False)
-    res = {"roofline_workload_agg": {
+    c0 = ops.launch_counts()
+    ops.csr_aggregate(adj, x, "mean", False, out=out)
+    dense = ops.launch_counts()["agg_dense"] > c0["agg_dense"]
+    if dense:
+        # the graph is dense enough for the matrix cores (csrc/aggregate_dense.hip): bf16 counts x three-term split = 3 MFMAs per block
+        ops.DENSE_AGG["enabled"] = False
+        try:
+            t_csr = time_kernel(lambda: ops.csr_aggregate(adj, x, "mean", False, out=out))
+        finally:
+            ops.DENSE_AGG["enabled"] = True
+        kp = (n + 15) // 16 * 16
+        flop = 2.0 * n * kp * F
+        res = {"roofline_workload_agg": {
+            "bound": "mfma", "subject": "the step's own aggregation launch (all %d rows, F = %d: the batch touches every node), as a "
+                                        "product on the matrix cores -- the graph holds %.1f %% of all node pairs" % (n, F, 100.0 * adj.nnz / n / n),
+            "kernel": "aggd::split_x_kernel + aggd::dense_agg_kernel + aggd::dense_reduce_kernel (bf16 counts [%d, %d] x x in three bf16 terms)" % (n, kp),
+            "achieved": 3 * flop / t / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": 3 * flop / t / 2.5e15, "traffic": None,
+            "flops": flop, "executed_flops": 3 * flop, "kernel_ms": t * 1e3, "compulsory_bytes": by_min,
+            "csr_kernels": {"kernel_ms": t_csr * 1e3, "gather_model_bytes": by, "effective_GBps": by / t_csr / 1e9,
+                            "form": ops.describe_form(getattr(adj, "_agg_tune", {}).get(F, 0))},
+            "note": "a SMALL product for the chip (%.0f GFLOP executed = %.0f us of matrix-pipe time at the peak): the launch is bound by its "
+                    "latency chain (K cut into slices, ~2 workgroups per CU), not by the pipe; the CSR kernels gather %.1f GB out of L2 for "
+                    "the same result in %.2f x the time (csr_kernels, measured here)" % (3 * flop / 1e9, 3 * flop / 2.5e15 * 1e6, by / 1e9, t_csr / t)}}
+    else:
+        res = None
+    res = res or {"roofline_workload_agg": {
         "bound": "cache", "subject": "the step's own aggregation launch (all %d rows, F = %d: the batch touches every node)" % (n, F),
         "kernel": "csr_agg_vec_kernel / csr_agg_chunk_kernel (mean, F=%d)" % F,
         "kernel_form": ops.describe_form(getattr(adj, "_agg_tune", {}).get(F, 0)),

@@ -193,7 +193,12 @@ def _time_agg_forms(graph, x, out, reduce, use_values, src_scale, epilogue) -> i
     torch.cuda.synchronize(x.device)
 
     def run(cand):
-        csr_aggregate(graph, x, reduce, use_values, src_scale=src_scale, out=out, epilogue=epilogue, tune=cand)
+        was = DENSE_AGG["enabled"]
+        DENSE_AGG["enabled"] = False          # (the CSR kernels' forms are what is compared here, also on a graph the dense form takes)
+        try:
+            csr_aggregate(graph, x, reduce, use_values, src_scale=src_scale, out=out, epilogue=epilogue, tune=cand)
+        finally:
+            DENSE_AGG["enabled"] = was
     for cand in cands:
         run(cand)
     for cand in cands:

@@ -634,3 +634,28 @@ def test_dense_form_rule_and_the_sparse_graphs(P):
     c0 = P.ops.launch_counts()
     P.ops.csr_aggregate(valued, x[:2600], "mean", False)            # (values ignored: the pattern's counts)
     assert _delta(P, c0)["agg_dense"] == 1
+
+
+def test_one_column_colsum_keeps_its_association(P):
+    """plnlp_colsum_f32 at feat = 1 (the 1-output head's bias gradient, 98 us of the ddi step's main stream until its loads were
+    pipelined eight deep): partial[b] = x[b] + x[b + blocks] + ... in row order, lane l of the final wave adds partial[l], partial[l
+    + 64], ... and the 64 lanes fold in the xor tree 32, 16, .. 1 -- restated here in numpy float32: the kernel's bits."""
+    import numpy as np
+    from plnlp_amd import _lib
+    lib = _lib.load()
+    for rows in (262_144, 100_003, 1_500, 7):
+        x = torch.randn(rows, generator=torch.Generator().manual_seed(rows)) * 3.0
+        got = float(P.ops.colsum(x.cuda().reshape(-1, 1)))
+        blocks = int(lib.plnlp_colsum_workspace_floats(rows, 1))
+        xs = x.numpy().astype(np.float32)
+        partial = np.zeros(blocks, dtype=np.float32)
+        for r0 in range(0, rows, blocks):                      # row order inside every partial sum
+            seg = xs[r0:r0 + blocks]
+            partial[:seg.size] = (partial[:seg.size] + seg).astype(np.float32)
+        lanes = np.zeros(64, dtype=np.float32)
+        for b0 in range(0, blocks, 64):
+            seg = partial[b0:b0 + 64]
+            lanes[:seg.size] = (lanes[:seg.size] + seg).astype(np.float32)
+        for o in (32, 16, 8, 4, 2, 1):
+            lanes = (lanes + lanes[np.arange(64) ^ o]).astype(np.float32)
+        assert got == float(lanes[0]), (rows, got, float(lanes[0]))
