@@ -1046,7 +1046,7 @@ extern "C" void plnlp_gemm_block_tuning(int mode) { plnlp::x3b::set_mode(mode); 
 extern "C" int plnlp_gemm_rowdot_tiles(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 0;
     const int nb = plnlp::x3s::pick_nb(m, n);
-    if (nb != 4 && nb != 8) return 0;
+    if (nb != 4 && nb != 7 && nb != 8) return 0;
     return (int)((n + 32 * nb - 1) / (32 * nb));
 }
 

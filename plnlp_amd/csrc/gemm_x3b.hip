@@ -204,14 +204,14 @@ __device__ __forceinline__ void step_idle(u32x4* __restrict__ nbuf, const Args& 
 
 // ---- the write-back of one block: 64 columns at a time through this wave's private LDS region (the MFMA C/D map -- col =
 // lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5) -- would leave as 4-byte scattered stores), then 16-byte row stores with
-// the epilogue on float4: gemm_x3s.hip's write-back, same bits.  No global load sits between its stores unless the epilogue has
-// row-dependent operands: the memory counter is in order, a load behind a store waits until the memory side has acknowledged
+// the epilogue on float4: gemm_x3s.hip's write-back, same bits.  No global load sits between its stores: the memory counter is in order, a load behind a store waits until the memory side has acknowledged
 // the store -- four such waits per block (the bias of each chunk) cost 38 000 cycles where the whole K loop takes 109 000.  The
-// bias and ROWDOT's weights therefore come from an LDS copy made once per launch (`stash`: [bias n floats | rowdot_w n floats]).
+// bias and ROWDOT's weights therefore come from an LDS copy made once per launch (`stash`: [bias n floats | rowdot_w n floats]), the
+// dropout row map from the pad column of the LDS tile, and epilogues with row-dependent operands (gate / accumulate) are not taken
+// (takes()).
 // ROWDOT (PLNLP_EPI_ROWDOT): also forms, per row, the dot product of this tile's stored values with rowdot_w.
-// ROWOPS: the epilogue has row-dependent operands (PLNLP_EPI_GATE / _ACCUM); the other instantiations hold no registers for them.
 constexpr int STASH_N = 2048;               // widest result whose bias / row-dot weights the stash holds (the launcher checks)
-template <int NB, bool ROWDOT, bool ROWOPS>
+template <int NB, bool ROWDOT>
 __device__ __forceinline__ void write_back(const f32x16 (&acc)[NB], float* __restrict__ cw, const float* __restrict__ stash,
                                            const Args& g, const Epi& epi, uint32_t seed_lo, uint32_t seed_hi, int64_t row_w,
                                            int nt, int lane, int l31, int h) {
@@ -250,24 +250,10 @@ __device__ __forceinline__ void write_back(const f32x16 (&acc)[NB], float* __res
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (col_ok && (epi.flags & PLNLP_EPI_BIAS)) bias4 = *reinterpret_cast<const float4*>(stash + col);
         if constexpr (ROWDOT) { if (col_ok) rw4 = *reinterpret_cast<const float4*>(stash + STASH_N + col); }
-        // the row-dependent operands (gate and accumulate rows) are requested for a batch of rows BEFORE its first store
         constexpr int RB = 2;                                  // rows per batch
 #pragma unroll
         for (int i0 = 0; i0 < 8; i0 += RB) {
-            float4 g4[RB], p4[RB], v4[RB];
-            if constexpr (ROWOPS) {
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    g4[i] = p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int r = (live >> (i0 + i)) & 1 ? i0 + i : 0;       // (clamped: a row the store discards)
-                    if (col_ok && (epi.flags & PLNLP_EPI_GATE)) {
-                        const int64_t orow = row0 + 4 * r;
-                        const int64_t gr = epi.gate_index ? (int64_t)epi.gate_index[orow] : orow;
-                        g4[i] = *reinterpret_cast<const float4*>(epi.gate + gr * epi.ld_gate + col);
-                    }
-                    if (col_ok && (epi.flags & PLNLP_EPI_ACCUM)) p4[i] = *reinterpret_cast<const float4*>(base + r * stride);
-                }
-            }
+            float4 v4[RB];
             int dr[RB];
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
@@ -277,19 +263,12 @@ __device__ __forceinline__ void write_back(const f32x16 (&acc)[NB], float* __res
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 if (col_ok && ((live >> (i0 + i)) & 1)) {
-                    // common.hip.h::epi_apply4_pre's arithmetic in its order (bias, relu, dropout, accumulate, gate)
+                    // common.hip.h::epi_apply4_pre's arithmetic in its order (bias, relu, dropout)
                     float4 y = v4[i];
                     if (epi.flags & PLNLP_EPI_BIAS) { y.x += bias4.x; y.y += bias4.y; y.z += bias4.z; y.w += bias4.w; }
                     if (epi.flags & PLNLP_EPI_RELU) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
                     if (epi.flags & PLNLP_EPI_DROPOUT)
                         y = dropout_apply4(y, (uint64_t)(unsigned)dr[i] * (uint64_t)g.n + (uint64_t)col, seed_lo, seed_hi, epi.thresh, epi.keep_scale);
-                    if constexpr (ROWOPS) {
-                        if (epi.flags & PLNLP_EPI_ACCUM) { y.x += p4[i].x; y.y += p4[i].y; y.z += p4[i].z; y.w += p4[i].w; }
-                        if (epi.flags & PLNLP_EPI_GATE) {
-                            y.x = g4[i].x > 0.f ? y.x * epi.gate_scale : 0.f; y.y = g4[i].y > 0.f ? y.y * epi.gate_scale : 0.f;
-                            y.z = g4[i].z > 0.f ? y.z * epi.gate_scale : 0.f; y.w = g4[i].w > 0.f ? y.w * epi.gate_scale : 0.f;
-                        }
-                    }
                     *reinterpret_cast<float4*>(base + (i0 + i) * stride) = y;
                     if constexpr (ROWDOT) rd[i0 + i] = x3s::rowdot_acc(rd[i0 + i], y, rw4);
                 }
@@ -359,7 +338,7 @@ __device__ __forceinline__ Block block_of(const Args& g, const Walk& w, int wave
 template <typename T>
 __device__ __forceinline__ void swap_regs(T& a, T& b) { const T c = a; a = b; b = c; }
 
-template <int NB, bool RAGGED, bool ROWDOT, bool ROWOPS>
+template <int NB, bool RAGGED, bool ROWDOT>
 __global__ __launch_bounds__(NT, 1) void gemm_x3b_kernel(Args g, Epi epi) {
     typedef Geo<NB> G;
     constexpr int WN = G::WN;
@@ -454,7 +433,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_x3b_kernel(Args g, Epi epi) {
             swap_regs(ra[0][1], ra[1][1]);
             swap_regs(b0, b1);
         }
-        if (blk.active) write_back<NB, ROWDOT, ROWOPS>(acc, cw, stash, g, epi, seed_lo, seed_hi, blk.row_w, blk.nt, lane, l31, h);
+        if (blk.active) write_back<NB, ROWDOT>(acc, cw, stash, g, epi, seed_lo, seed_hi, blk.row_w, blk.nt, lane, l31, h);
         if (!more) break;
         cur = nxt;
         blk = nb_;
@@ -478,7 +457,11 @@ bool takes(int64_t m, int64_t n, int nb, bool ragged, int k_steps, const Epi& e)
     if (!applies(m, nb) || k_steps < 3) return false;
     if ((e.flags & (PLNLP_EPI_BIAS | PLNLP_EPI_ROWDOT)) && n > STASH_N) return false;     // (their LDS copy, see write_back)
     if (e.flags && (!e.vec4 || (e.flags & PLNLP_EPI_ADDEND))) return false;
-    if ((e.flags & PLNLP_EPI_ROWDOT) && (nb != 8 || ragged || (e.flags & (PLNLP_EPI_GATE | PLNLP_EPI_ACCUM)))) return false;
+    // no row-dependent operands (gate / accumulate): their loads sit between the write-back's stores and wait for the stores'
+    // acknowledgements (the memory counter is in order) -- with ONE workgroup per CU nothing covers that; gemm_x3s, two per CU, does
+    // (measured on citation2's gated data gradient: 2.94 ms here against 2.60 there)
+    if (e.flags & (PLNLP_EPI_GATE | PLNLP_EPI_ACCUM)) return false;
+    if ((e.flags & PLNLP_EPI_ROWDOT) && (nb != 8 || ragged)) return false;
     return true;
 }
 
@@ -494,9 +477,9 @@ static int cu_count() {           // (per device; a process may hold several)
     return cus[dev];
 }
 
-template <int NB, bool RAGGED, bool ROWDOT, bool ROWOPS>
+template <int NB, bool RAGGED, bool ROWDOT>
 static int launch_as(const Args& a, const Epi& e, unsigned grid, hipStream_t s) {
-    auto kernel = gemm_x3b_kernel<NB, RAGGED, ROWDOT, ROWOPS>;
+    auto kernel = gemm_x3b_kernel<NB, RAGGED, ROWDOT>;
     constexpr int LDS = 2 * Geo<NB>::STAGE_BYTES + Geo<NB>::C_BYTES + 2 * STASH_N * 4;
     // (once per device and instantiation: the attribute belongs to the device's copy of the function)
     static bool armed[64] = {};
@@ -513,16 +496,14 @@ static int launch_as(const Args& a, const Epi& e, unsigned grid, hipStream_t s) 
 
 template <int NB>
 static int launch_nb(const Args& a, const Epi& e, bool ragged, unsigned grid, hipStream_t s) {
-    const bool rowops = (e.flags & (PLNLP_EPI_GATE | PLNLP_EPI_ACCUM)) != 0;
     if (e.flags & PLNLP_EPI_ROWDOT) {
         if constexpr (NB == 8) {
             if (e.rowdot_ld < a.m) return PLNLP_E_SHAPE;
-            if (!ragged && !rowops) return launch_as<NB, false, true, false>(a, e, grid, s);
+            if (!ragged) return launch_as<NB, false, true>(a, e, grid, s);
         }
         return PLNLP_E_UNSUPPORTED;           // (takes() keeps such launches away)
     }
-    if (ragged) return rowops ? launch_as<NB, true, false, true>(a, e, grid, s) : launch_as<NB, true, false, false>(a, e, grid, s);
-    return rowops ? launch_as<NB, false, false, true>(a, e, grid, s) : launch_as<NB, false, false, false>(a, e, grid, s);
+    return ragged ? launch_as<NB, true, false>(a, e, grid, s) : launch_as<NB, false, false>(a, e, grid, s);
 }
 
 // the main kernel of a launch whose image x3s::launch has just queued (a.image, a.gn, a.m .. filled in): one workgroup per CU

@@ -158,7 +158,7 @@ __device__ __forceinline__ void load_a(const Args& g, const float* p0, const flo
 // (A K loop with TWO steps of load look-ahead was built and measured in round 4 -- three raw A sets through untracked inline-asm
 // loads, three LDS stages, one counted s_waitcnt vmcnt + a bare s_barrier per step, the B fragments read one column block
 // at a time to fit the registers: 2-4 % SLOWER than this one on every shape (profiles/r04_gemm_deep_loop.jsonl), removed.)
-// ROWDOT (PLNLP_EPI_ROWDOT, NB = 4 / 8): the write-back also forms, per row, the dot product of this tile's stored values with
+// ROWDOT (PLNLP_EPI_ROWDOT, NB = 4 / 7 / 8): the write-back also forms, per row, the dot product of this tile's stored values with
 // rowdot_w -- a 1-output linear on top of this layer (MLPPredictor's head) without a second pass over the activation.
 template <int NB, bool RAGGED, bool ROWDOT = false>
 __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s_kernel(Args g, Epi epi) {
@@ -368,7 +368,7 @@ template <int NB>
 static int launch_nb(const Args& a, const Epi& e, bool ragged, hipStream_t s) {
     dim3 grid((unsigned)(a.gm * a.gn));
     if (e.flags & PLNLP_EPI_ROWDOT) {
-        if constexpr (NB == 4 || NB == 8) {
+        if constexpr (NB == 4 || NB == 7 || NB == 8) {
             if (e.rowdot_ld < a.m) return PLNLP_E_SHAPE;
             if (ragged) hipLaunchKernelGGL((gemm_x3s_kernel<NB, true, true>), grid, dim3(256), 0, s, a, e);
             else        hipLaunchKernelGGL((gemm_x3s_kernel<NB, false, true>), grid, dim3(256), 0, s, a, e);

@@ -349,25 +349,27 @@ __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* __
 // feat == 1 (the gradient of a 1-output head's bias: the column sum of a [rows, 1] vector): colsum_partial_kernel leaves
 // 255 of every 256 threads idle (81 us for 262 144 rows).  Same partial sums in the same order -- partial[b] = x[b] +
 // x[b + blocks] + ... sequentially -- with thread = b: consecutive threads read consecutive addresses.
+constexpr int COL1_U = 32;
 __global__ __launch_bounds__(256) void colsum_partial_col1_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows,
                                                                   const float* __restrict__ rw, int64_t n_blocks,
                                                                   float* __restrict__ partial) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= n_blocks) return;
     float acc = 0.f;
-    // (eight loads in flight per thread, added in row order: the chain of dependent round trips -- 256 per thread for the
-    // ddi scorer's 262 144 rows on four workgroups -- was 98 us of the ddi step's main stream)
-    for (int64_t r = b; r < n_rows; r += 8 * n_blocks) {
-        float v[8], w[8];
+    // (COL1_U loads in flight per thread, added in row order: the chain of dependent round trips -- 256 per thread for the ddi
+    // scorer's 262 144 rows on four workgroups, ~3 us each -- was 98 us of the ddi step's main stream; eight in flight left 86)
+    constexpr int U = COL1_U;
+    for (int64_t r = b; r < n_rows; r += U * n_blocks) {
+        float v[U], w[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int64_t rr = r + u * n_blocks;
             const bool ok = rr < n_rows;
             v[u] = ok ? x[rr * ldx] : 0.f;
             w[u] = (ok && rw) ? rw[rr] : 1.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < U; ++u)
             if (r + u * n_blocks < n_rows) acc = rw ? fmaf(w[u], v[u], acc) : acc + v[u];
     }
     partial[b] = acc;

@@ -1946,7 +1946,9 @@ class GCNInputConvFn(torch.autograd.Function):
                   "emb_pad": None,      # (allocated below, only for a table that is NOT kept padded: 0.75 GB on citation2)
                   # W in the aggregated operand's layout; the pad columns stay zero, the two blocks are
                   # refreshed per step (two copies instead of a fresh zero-filled matrix)
-                  "wa": torch.zeros(w.shape[0], kp, dtype=torch.float32, device=w.device)}
+                  "wa": torch.zeros(w.shape[0], kp, dtype=torch.float32, device=w.device),
+                  # W's columns in that layout: one indexed copy per step each way instead of two copies / a concatenation
+                  "wcols": torch.cat([torch.arange(e, device=w.device), ep + torch.arange(f, device=w.device)])}
             cache["gcn_input"] = st
         ax = st["ax"]
         emb_pad = padded_base(emb_weight.detach())       # the table itself when it is kept padded (BaseModel): no copy
@@ -1957,11 +1959,10 @@ class GCNInputConvFn(torch.autograd.Function):
             emb_pad[:, :e].copy_(emb_weight.detach())
         csr_aggregate(graph, emb_pad, "sum", use_values=True, out=ax[:, :ep])          # A_hat emb, every step
         wa = st["wa"]
-        wa[:, :e].copy_(w[:, :e])
-        wa[:, ep:ep + f].copy_(w[:, e:])
+        wa.index_copy_(1, st["wcols"], w.detach())
         epi = L.make_epilogue(bias=b, relu=act.relu, dropout_p=act.p, dropout_seed=act.seed, dropout_seed_ptr=act.seed_ptr)
         y = gemm([(ax, wa)], False, True, epilogue=epi)
-        ctx.graph, ctx.act, ctx.dims = graph, act, (e, f, ep, fp)
+        ctx.graph, ctx.act, ctx.dims, ctx.wcols = graph, act, (e, f, ep, fp), st["wcols"]
         ctx.ax = ax            # persistent buffer: this step's backward runs before the next forward rewrites it
         # a padded table takes its gradient in the padded layout too, set on the parameter directly (autograd would copy a
         # strided gradient into a contiguous one: the 0.18 ms this avoids on citation2)
@@ -1981,10 +1982,10 @@ class GCNInputConvFn(torch.autograd.Function):
         cs = [] if need[2] else None        # (the bias gradient out of the weight-gradient launch where that is the whole-block kernel)
         if need[1]:
             gwa = gemm([(dz, ax)], True, False, a_colsum=cs)                          # [out, ep + fp]
-            gw = torch.cat([gwa[:, :e], gwa[:, ep:ep + f]], dim=1)
+            gw = gwa.index_select(1, ctx.wcols)
         bias_sum = SideColsum(dz) if (need[2] and not cs) else None       # else: beside the products and the transposed aggregation below
         if need[0]:
-            g_aemb = gemm([(dz, wa[:, :ep].contiguous())], False, False)              # [N, ep]: embedding columns only
+            g_aemb = gemm([(dz, wa[:, :ep])], False, False)         # [N, ep]: embedding columns only (a view: ldb = the padded width)
             full = csr_aggregate(graph.t(), g_aemb, "sum", use_values=True)           # (its pad columns are exact zeros)
             if ctx.direct_grad_to is not None and ctx.direct_grad_to.grad is None:
                 ctx.direct_grad_to.grad = full[:, :e]                                   # a view: no copy
