@@ -86,14 +86,16 @@ class GCNConv(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.lin.weight)
         torch.nn.init.zeros_(self.bias)
 
-    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, channel=None, out_rows=None):
+    def forward(self, x, adj_t, act: _Act = None, in_act: _Act = None, channel=None, out_rows=None, input_grad_sink=None):
+        """input_grad_sink: an ops.GradSink with the embedding table's Adam state, honoured on the [emb | features] input path
+        only (ops.GCNInputConvFn); otherwise it stays untouched and the table's gradient goes through autograd"""
         act = act if act is not None else _Act(False, 0.0, False)
         parts = getattr(x, "_plnlp_parts", None)
         if parts is not None and channel is None and in_act is None and ops.GCN_INPUT_FUSION["enabled"]:
             # x = [emb.weight | constant features]: aggregate first, the feature block once (ops.GCNInputConvFn)
             emb_weight, feats, cache = parts
             return ops.GCNInputConvFn.apply(emb_weight, self.lin.weight, self.bias, _require_graph(adj_t), act, feats,
-                                            cache)
+                                            cache, input_grad_sink)
         x = ops.materialize_concat(x)
         return ops.GCNConvFn.apply(x, self.lin.weight, self.bias, _require_graph(adj_t), act, in_act, channel, out_rows)
 
@@ -155,7 +157,8 @@ class BaseGNN(torch.nn.Module):
         """shard: a plnlp_amd.shard.ShardContext -> row-sharded pass (see _forward_sharded).
         output_rows: an ops.CompactIncidence -- the last conv produces only those rows, as a compact
         matrix (ops.SPARSE_FORWARD / "OutputRows"); needs output_grad_channel and native convs.
-        input_grad_sink: an ops.GradSink for the gradient of `x` (first conv must be a SAGEConv).
+        input_grad_sink: an ops.GradSink for the gradient of `x` (first conv: a SAGEConv on the raw table, or a GCNConv on
+        [table | features] -- there only the fused Adam update of the table is taken from it).
         output_grad_channel: an ops.SparseGradChannel through which the (single) consumer of the
         returned h hands back its gradient row-sparse; only honoured by the native convs.
         fuse_output_gate (only meaningful for a 1-layer encoder, whose output IS a
@@ -183,8 +186,10 @@ class BaseGNN(torch.nn.Module):
                 elif i == 0 and input_grad_sink is not None and isinstance(conv, SAGEConv):
                     x = conv(x, adj_t, act, None, input_grad_sink, ch, out_rows=output_rows if i == last else None)
                 else:
+                    extra = ({"input_grad_sink": input_grad_sink}
+                             if (i == 0 and input_grad_sink is not None and isinstance(conv, GCNConv)) else {})
                     x = conv(x, adj_t, act, prev_act if torch.is_grad_enabled() else None, channel=ch,
-                             out_rows=output_rows if (i == last and ch is not None) else None)
+                             out_rows=output_rows if (i == last and ch is not None) else None, **extra)
                 prev_act = act
             else:  # foreign conv module: un-fused reference order
                 x = conv(x, adj_t)

@@ -299,10 +299,22 @@ class BaseModel(object):
     def _embedding_grad_sink(self, x_in, replicated_update=False):
         """Data parallel + SAGE on the raw embedding table: deliver the (large) embedding gradient
         early so its all-reduce overlaps the encoder's weight-gradient GEMMs (ops.GradSink)."""
-        from .layer import SAGEConv
+        from .layer import SAGEConv, GCNConv
         from .ops import GradSink
         self._early_work = None
         self._adam_sink = None
+        parts = getattr(x_in, "_plnlp_parts", None)
+        if (self.emb is not None and parts is not None and parts[0] is self.emb.weight and self.emb.weight.requires_grad
+                and x_in.is_cuda and isinstance(self.encoder.convs[0], GCNConv)):
+            # [table | constant features] into a first GCNConv (ops.GCNInputConvFn): no early all-reduce to start, but the
+            # table's Adam step can ride in the aggregation that finishes its gradient -- same conditions as below
+            if ((self.process_group is None or replicated_update) and self._fused_step and FUSE_EMBEDDING_ADAM["enabled"]
+                    and ops.padded_base(self.emb.weight.data) is not None):
+                adam = fused_adam_state(self.optimizer, self.emb.weight, padded=True)
+                if adam is not None:
+                    self._adam_sink = GradSink(None, None, adam=adam, like=self.emb.weight)
+                    return self._adam_sink
+            return None
         if (self.emb is None or x_in is not self.emb.weight
                 or not self.emb.weight.requires_grad or not x_in.is_cuda
                 or not isinstance(self.encoder.convs[0], SAGEConv) or self.encoder.convs[0].aggr != "mean"):
@@ -361,8 +373,9 @@ class BaseModel(object):
         if sink is not None:
             if sink.adam_applied:       # the table was stepped inside the backward pass; its .grad stays None
                 self.optimizer.state[self.emb.weight]["step"] += 1
-            else:                       # the backward took a path without the fused update: the gradient is in the buffer
+            elif sink.buffer_used:      # the backward took a path without the fused update: the gradient is in the buffer
                 self.emb.weight.grad = sink.buffer
+            # (else: the sink was never asked -- the gradient went through autograd)
             self._adam_sink = None
         if self._fused_step:
             clip = {}

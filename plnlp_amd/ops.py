@@ -1454,6 +1454,11 @@ class GradSink:
             self._buffer = torch.empty_like(self._like)
         return self._buffer
 
+    @property
+    def buffer_used(self) -> bool:
+        """False: no backward asked for the buffer -- the gradient, if any, went through autograd as usual"""
+        return self._buffer is not None
+
 
 class AggregateFn(torch.autograd.Function):
     """torch_sparse.matmul(adj_t, x, reduce) with its autograd (Appendix A.3)."""
@@ -1929,7 +1934,11 @@ class GCNInputConvFn(torch.autograd.Function):
     0.48 -> 0.56 of the MFMA peak on the forward product, profiles/r02_gemm_microbench_v8.jsonl)."""
 
     @staticmethod
-    def forward(ctx, emb_weight, w, b, graph: Graph, act: _Act, feats, cache: dict):
+    def forward(ctx, emb_weight, w, b, graph: Graph, act: _Act, feats, cache: dict, sink: Optional["GradSink"] = None):
+        """sink: a GradSink carrying the table's Adam state (sink.adam, moments in the table's padded layout) -- the backward may
+        then step the table in the epilogue of the aggregation that finishes its gradient (PLNLP_EPI_ADAM), as SAGEConvFn does
+        on the raw table; it sets sink.adam_applied when it did, else the gradient goes the usual way"""
+        ctx.sink = sink
         n, e, f = emb_weight.shape[0], emb_weight.shape[1], feats.shape[1]
         ep, fp = _pad_emb(e), _pad4(f)
         key = ("gcn_input", feats.data_ptr(), feats._version, n, e, f)
@@ -1986,6 +1995,25 @@ class GCNInputConvFn(torch.autograd.Function):
         bias_sum = SideColsum(dz) if (need[2] and not cs) else None       # else: beside the products and the transposed aggregation below
         if need[0]:
             g_aemb = gemm([(dz, wa[:, :ep])], False, False)         # [N, ep]: embedding columns only (a view: ldb = the padded width)
+            sink = ctx.sink
+            table = padded_base(ctx.direct_grad_to.detach()) if ctx.direct_grad_to is not None else None
+            ad = sink.adam if (sink is not None and table is not None) else None
+            if (ad is not None and ad["param"] is ctx.direct_grad_to and ad["exp_avg"].shape == table.shape
+                    and ctx.direct_grad_to.grad is None and _vector_path(g_aemb, table, ep)):
+                # nothing but Adam consumes the table's gradient (the reference clips encoder and predictor, not the embedding;
+                # one process: nothing to reduce): the aggregation that finishes the gradient steps the table -- no [N, ep]
+                # gradient written and read back (0.75 GB each way on citation2).  The weight gradient above read `ax`, the
+                # aggregated table, not the table: nothing queued after this launch reads the old values.  Pad columns: zero
+                # gradient, zero moments, a zero update.
+                sc = _step_scalars["active"]
+                epi = L.make_epilogue(adam=(ad["exp_avg"], ad["exp_avg_sq"], ad["step"], ad["lr"], ad["betas"][0], ad["betas"][1],
+                                            ad["eps"]),
+                                      adam_scalars_ptr=sc.adam_ptr() if sc is not None else 0)
+                csr_aggregate(graph.t(), g_aemb, "sum", use_values=True, out=table, epilogue=epi)
+                sink.adam_applied = True
+                if need[2]:
+                    gb = cs[0] if cs else bias_sum.join()
+                return None, gw, gb, None, None, None, None, None
             full = csr_aggregate(graph.t(), g_aemb, "sum", use_values=True)           # (its pad columns are exact zeros)
             if ctx.direct_grad_to is not None and ctx.direct_grad_to.grad is None:
                 ctx.direct_grad_to.grad = full[:, :e]                                   # a view: no copy
@@ -1993,7 +2021,7 @@ class GCNInputConvFn(torch.autograd.Function):
                 gemb = full[:, :e].contiguous()
         if need[2]:
             gb = cs[0] if cs else bias_sum.join()
-        return gemb, gw, gb, None, None, None, None
+        return gemb, gw, gb, None, None, None, None, None
 
 
 class GCNConvFn(torch.autograd.Function):

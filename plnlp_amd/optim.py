@@ -63,19 +63,26 @@ class FusedAdam(torch.optim.Optimizer):
                 p.data.copy_(pc)
 
 
-def fused_adam_state(opt: "FusedAdam", p: torch.nn.Parameter) -> Optional[dict]:
+def fused_adam_state(opt: "FusedAdam", p: torch.nn.Parameter, padded: bool = False) -> Optional[dict]:
     """Adam state and hyper-parameters of `p` for an update applied OUTSIDE opt.step() (ops.GradSink.adam: the
     PLNLP_EPI_ADAM epilogue).  None when the group's settings are not plain Adam.  The caller advances
-    state['step'] itself once the update has really been applied."""
+    state['step'] itself once the update has really been applied.
+    padded: `p` is a table kept padded (ops.padded_base) and is stepped in that layout -- fresh moments take the padded shape,
+    as FusedAdam.step gives them; None when moments of the unpadded shape already exist."""
     for group in opt.param_groups:
         if any(q is p for q in group["params"]):
             if group["weight_decay"] != 0.0 or group["decoupled"]:
                 return None
             st = opt.state[p]
+            like = ops.padded_base(p.data) if padded else p
+            if like is None:
+                return None
             if not st:
                 st["step"] = 0
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg"] = torch.zeros_like(like, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(like, memory_format=torch.contiguous_format)
+            if st["exp_avg"].shape != like.shape:
+                return None
             return dict(param=p, exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], step=st["step"] + 1,
                         lr=group["lr"], betas=group["betas"], eps=group["eps"])
     return None

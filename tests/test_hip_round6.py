@@ -661,3 +661,52 @@ def test_one_column_colsum_keeps_its_association(P):
         for o in (32, 16, 8, 4, 2, 1):
             lanes = (lanes + lanes[np.arange(64) ^ o]).astype(np.float32)
         assert got == float(lanes[0]), (rows, got, float(lanes[0]))
+
+
+# ------------------------------------ the table's Adam step in the aggregation that finishes its gradient: [table | features] into a GCN ----
+def test_table_adam_in_the_gcn_input_aggregation_gives_the_same_bits(P):
+    """citation2's shape of model -- a padded 50-wide table next to constant features into a first GCNConv (ops.GCNInputConvFn): with
+    model.FUSE_EMBEDDING_ADAM the transposed 64-wide aggregation that finishes the table's gradient applies the table's Adam step in
+    its epilogue (PLNLP_EPI_ADAM; hub rows through the chunk + finalize passes) instead of writing the gradient for the optimiser
+    kernel -- the same arithmetic on the same values: losses, every parameter, both moments (padded layout, pad columns zero) and
+    the step count after 3 epochs are bit-identical, and emb.weight.grad is never materialised."""
+    from plnlp_amd import model as M, synthetic
+    n, B, k, e, f, h = 4000, 2048, 3, 50, 16, 200
+    g = synthetic.make_graph("collab", seed=19, device="cpu", num_nodes=n, num_edges=30000)
+    data = g["data"]
+    data.adj_t = P.gcn_normalization(g["adj_t"].to("cuda"))
+    assert int((data.adj_t.rowptr[1:] - data.adj_t.rowptr[:-1]).max()) > 256       # a hub row: chunk + finalize passes
+    data.x = torch.randn(n, f, generator=torch.Generator().manual_seed(5)).cuda()
+    split = {"train": {"edge": g["edges"]}}
+    res = {}
+    for fused in (True, False):
+        M.FUSE_EMBEDDING_ADAM["enabled"] = fused
+        try:
+            m = P.BaseModel(lr=0.01, dropout=0.3, grad_clip_norm=1.0, gnn_num_layers=2, mlp_num_layers=2, emb_hidden_channels=e,
+                            gnn_hidden_channels=h, mlp_hidden_channels=h, num_nodes=n, num_node_feats=f, gnn_encoder_name="GCN",
+                            predictor_name="MLP", loss_func="AUC", optimizer_name="Adam", device="cuda", use_node_feats=True,
+                            train_node_emb=True)
+            torch.manual_seed(21)
+            P.manual_seed(21)
+            m.param_init()
+            assert P.ops.padded_base(m.emb.weight.detach()) is not None
+            losses = []
+            c0 = P.ops.launch_counts()
+            for ep in range(3):
+                torch.manual_seed(70 + ep)
+                losses.append(m.train(data, split, B, "global", k))
+            torch.cuda.synchronize()
+            st = m.optimizer.state[m.emb.weight]
+            assert st["exp_avg"].shape == (n, 64) and not bool(st["exp_avg"][:, e:].any()) and not bool(st["exp_avg_sq"][:, e:].any())
+            assert not bool(P.ops.padded_base(m.emb.weight.detach())[:, e:].any())
+            if fused:
+                assert m.emb.weight.grad is None
+            res[fused] = (losses, [p.detach().clone() for p in m.para_list], st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                          st["step"])
+        finally:
+            M.FUSE_EMBEDDING_ADAM["enabled"] = True
+    assert res[True][0] == res[False][0]
+    assert res[True][4] == res[False][4] and res[True][4] > 0
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
