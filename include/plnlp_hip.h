@@ -45,7 +45,7 @@ extern "C" {
  *              launch kind "gemm_x3b"; plnlp_gemm_operand.reserved -> flags (PLNLP_GEMM_FLAG_WIDE_WGRAD: the wide weight-gradient
  *              form is asked for explicitly, no longer implied by the slice count); plnlp_gemm_operand.a_colsum (the bias gradient
  *              out of the wide weight-gradient kernel); plnlp_dense_aggregate_f32 / _scratch_bytes (a dense graph's aggregation on
- *              the matrix cores); launch kind "agg_dense". */
+ *              the matrix cores); launch kind "agg_dense"; plnlp_edge_segment_tuning (the segment backward's forms by segment count). */
 #define PLNLP_ABI_VERSION 12
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
@@ -494,7 +494,16 @@ int plnlp_rmat_edges(int scale, int64_t n_nodes, int64_t edge_lo, int64_t n_edge
  * for node slot s (seg_node[s] = node id, or s itself when seg_node is NULL), items
  * [seg_ptr[s], seg_ptr[s+1]) each
  * name an edge id and the OTHER endpoint:
- *   gh[seg_node[s], :] = EPI( sum_items g[edge] (.) h[other, :] )   */
+ *   gh[seg_node[s], :] = EPI( sum_items g[edge] (.) h[other, :] )
+ * Vector rows (feat % 4 == 0, 16-byte aligned): a LONG segment is shared by the waves of a workgroup (one wave per segment
+ * makes the launch as long as the hub's serial chain of items) -- from 8 192 segments on, eight segments per workgroup of
+ * eight waves: a wave sums its own if it has at most 64 items (item order), the longer ones are summed by all eight waves
+ * (contiguous eighths, partial sums added in wave order); below 8 192 segments every segment is shared by the four waves of
+ * its own workgroup (a dense graph: ddi).  Deterministic: the association depends on the segment's length only.
+ * plnlp_edge_segment_tuning(1): one wave per segment whatever its length (the round-5 form; measurement knob, process-global);
+ * 2: groups of four waves / four segments instead of eight / eight; 0 = the rule above. */
+void plnlp_edge_segment_tuning(int form);
+
 int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh,
                                const int64_t* seg_ptr, const int64_t* seg_node, int64_t n_seg,
                                const int32_t* item_edge, const int32_t* item_other,

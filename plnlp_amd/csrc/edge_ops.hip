@@ -203,6 +203,157 @@ __global__ __launch_bounds__(256) void edge_segment_bwd_kernel(
     }
 }
 
+// The vector path again, with the work of a LONG segment shared by the waves of a workgroup.  One wave per segment (above) makes
+// the launch as long as its longest segment: the hub's items are a serial chain of batches of four rows (citation2's step: 263 K
+// touched nodes with two items each -- 0.18 ms when no segment is long -- and one with several hundred: 0.61 ms; ddi: 4 267 nodes,
+// 123 items on average, 250+ at the hubs).
+// A workgroup of W waves takes S consecutive segments (S = W: many segments; S = 1: fewer segments than the chip holds waves):
+//   phase A (S = W): wave w sums segment w alone if it has at most LONG items -- item order, the bits of the kernel above;
+//   phase B: every longer segment of the group, one after the other, by ALL W waves: contiguous W-ths of its items in order,
+//     the partial sums added in wave order through LDS by wave 0 -- a fixed association that depends on
+//     the segment's length only.  S = 1: every segment goes this way.
+template <bool GVEC, int NK, int U>
+__device__ __forceinline__ void segment_sum(float4 (&acc)[NK], int64_t lo, int64_t hi, int s0, int nslots, int lane,
+                                            const float* __restrict__ h, int64_t ldh, const int32_t* __restrict__ item_edge,
+                                            const int32_t* __restrict__ item_other, const float* __restrict__ g, int64_t ldg) {
+    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+        const int n = (int)((hi - i0) < 64 ? (hi - i0) : 64);
+        int ev = 0, ov = 0;
+        float gv = 0.f;
+        if (lane < n) {
+            ev = item_edge[i0 + lane];
+            ov = item_other[i0 + lane];
+            if constexpr (!GVEC) gv = g[ev];
+        }
+        for (int j = 0; j < n; j += U) {
+            float4 x[U][NK], gg[U][NK];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j + u < n) {
+                    const int o = __builtin_amdgcn_readlane(ov, j + u);
+                    const float4* p = reinterpret_cast<const float4*>(h + (int64_t)o * ldh);
+                    if constexpr (GVEC) {
+                        const int ed = __builtin_amdgcn_readlane(ev, j + u);
+                        const float4* q = reinterpret_cast<const float4*>(g + (int64_t)ed * ldg);
+#pragma unroll
+                        for (int c = 0; c < NK; ++c) {
+                            const int sl = s0 + lane + 64 * c;
+                            gg[u][c] = sl < nslots ? q[sl] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    } else {
+                        w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), j + u));
+                    }
+#pragma unroll
+                    for (int c = 0; c < NK; ++c) {
+                        const int sl = s0 + lane + 64 * c;
+                        x[u][c] = sl < nslots ? p[sl] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j + u < n) {
+#pragma unroll
+                    for (int c = 0; c < NK; ++c) {
+                        if constexpr (GVEC) {
+                            acc[c].x = fmaf(gg[u][c].x, x[u][c].x, acc[c].x); acc[c].y = fmaf(gg[u][c].y, x[u][c].y, acc[c].y);
+                            acc[c].z = fmaf(gg[u][c].z, x[u][c].z, acc[c].z); acc[c].w = fmaf(gg[u][c].w, x[u][c].w, acc[c].w);
+                        } else {
+                            acc[c].x = fmaf(w[u], x[u][c].x, acc[c].x); acc[c].y = fmaf(w[u], x[u][c].y, acc[c].y);
+                            acc[c].z = fmaf(w[u], x[u][c].z, acc[c].z); acc[c].w = fmaf(w[u], x[u][c].w, acc[c].w);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NK>
+__device__ __forceinline__ void segment_store(const float4 (&acc)[NK], int64_t node, int s0, int nslots, int lane, int feat,
+                                              float* __restrict__ gh, int64_t ldgh, const Epi& epi) {
+    float* orow = gh + node * ldgh;
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+        const int sl = s0 + lane + 64 * c;
+        if (sl < nslots) {
+            const float4 y = epi_apply4(epi, acc[c], node, (int64_t)sl * 4, feat, orow);
+            reinterpret_cast<float4*>(orow)[sl] = y;
+        }
+    }
+}
+
+constexpr int SEGMENT_LONG = 64;            // items from which a segment is shared by the workgroup (S = W)
+
+template <bool GVEC, int NK, int W, int S>
+__global__ __launch_bounds__(64 * W) void edge_segment_bwd_group_kernel(
+    const float* __restrict__ h, int64_t ldh, const int64_t* __restrict__ seg_ptr,
+    const int64_t* __restrict__ seg_node, int64_t n_seg, const int32_t* __restrict__ item_edge,
+    const int32_t* __restrict__ item_other, int feat, const float* __restrict__ g, int64_t ldg,
+    float* __restrict__ gh, int64_t ldgh, Epi epi) {
+    static_assert(S == 1 || S == W, "one segment per workgroup, or one per wave");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t first = (int64_t)blockIdx.x * S;
+    if (first >= n_seg) return;                                  // (the whole workgroup)
+    const int64_t long_len = S == 1 ? -1 : SEGMENT_LONG;
+    // the group's S + 1 bounds: one load, lane k holds bound k (clamped at the end of the list)
+    const int64_t mine = seg_ptr[first + lane < n_seg ? first + lane : n_seg];
+    auto bound = [&](int k) -> int64_t {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)mine, k);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)mine >> 32), k);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    __shared__ float4 part[(W - 1) * NK * 64];
+    const int nslots = feat >> 2;
+    for (int s0 = 0; s0 < nslots; s0 += 64 * NK) {
+        // t = -1: phase A (this wave's own segment, if short); t = 0 .. S-1: phase B (segment t of the group, if long, by the
+        // whole workgroup).  One loop so that both phases share the registers of one copy of the summation.
+        for (int t = S > 1 ? -1 : 0; t < S; ++t) {
+            const bool coop = t >= 0;
+            const int k = coop ? t : wave;
+            const int64_t beg = bound(k), end = bound(k + 1);
+            const bool is_long = end - beg > long_len;
+            if (first + k >= n_seg || is_long != coop) continue;    // (phase B: uniform over the workgroup)
+            int64_t lo = beg, hi = end;
+            if (coop) {
+                const int64_t q = (end - beg + W - 1) / W;
+                lo = beg + wave * q < end ? beg + wave * q : end;
+                hi = lo + q < end ? lo + q : end;
+            }
+            float4 acc[NK];
+#pragma unroll
+            for (int c = 0; c < NK; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            segment_sum<GVEC, NK, (S == 1 && NK == 1 ? 8 : 4)>(acc, lo, hi, s0, nslots, lane, h, ldh, item_edge, item_other, g, ldg);
+            if (coop) {
+                if (wave > 0) {
+#pragma unroll
+                    for (int c = 0; c < NK; ++c) part[((wave - 1) * NK + c) * 64 + lane] = acc[c];
+                }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int wv = 1; wv < W; ++wv)
+#pragma unroll
+                        for (int c = 0; c < NK; ++c) {
+                            const float4 v = part[((wv - 1) * NK + c) * 64 + lane];
+                            acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+                        }
+                }
+            }
+            if (!coop || wave == 0)
+                segment_store<NK>(acc, seg_node ? seg_node[first + k] : first + k, s0, nslots, lane, feat, gh, ldgh, epi);
+            if (coop) __syncthreads();                              // (the partial sums have been read)
+        }
+    }
+}
+
+// measurement knob (plnlp_edge_segment_tuning): 0 = long segments shared by a workgroup (the rule in plnlp_edge_segment_bwd_f32),
+// 1 = one wave per segment always (the round-5 form), 2 = many segments in groups of four waves / four segments (measured on
+// citation2's step: 273 us against 250 for eight / eight, 613 for one wave per segment)
+static int g_segment_form = 0;
+
 static inline int pick_lpr(int64_t feat, bool vec) {
     const int64_t units = vec ? feat / 4 : feat;
     if (units <= 8) return 8;
@@ -288,6 +439,8 @@ extern "C" int plnlp_edge_scatter_bwd_f32(const float* h, int64_t ldh, const int
     return launch_status();
 }
 
+extern "C" void plnlp_edge_segment_tuning(int form) { plnlp::g_segment_form = form; }
+
 extern "C" int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh, const int64_t* seg_ptr,
                                           const int64_t* seg_node, int64_t n_seg, const int32_t* item_edge,
                                           const int32_t* item_other, int64_t feat, const float* g, int64_t ldg,
@@ -306,6 +459,25 @@ extern "C" int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh, const int
                      (!(e.flags & PLNLP_EPI_GATE) || true);
     dim3 grid((unsigned)((n_seg + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
+    if (vec && g_segment_form != 1) {
+        // fewer segments than the chip holds waves: a workgroup of four waves per segment; many segments: eight per workgroup of
+        // eight waves, its long ones (> SEGMENT_LONG items) shared by the eight
+        const bool few = n_seg < 8192;
+#define V2(GV, NK)                                                                                                            \
+    do {                                                                                                                      \
+        if (few) hipLaunchKernelGGL((edge_segment_bwd_group_kernel<GV, NK, 4, 1>), dim3((unsigned)n_seg), dim3(256), 0, s, h, ldh, \
+                                    seg_ptr, seg_node, n_seg, item_edge, item_other, (int)feat, g, ldg, gh, ldgh, e);         \
+        else if (g_segment_form == 2)                                                                                         \
+            hipLaunchKernelGGL((edge_segment_bwd_group_kernel<GV, NK, 4, 4>), dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, s,  \
+                               h, ldh, seg_ptr, seg_node, n_seg, item_edge, item_other, (int)feat, g, ldg, gh, ldgh, e);      \
+        else hipLaunchKernelGGL((edge_segment_bwd_group_kernel<GV, NK, 8, 8>), dim3((unsigned)((n_seg + 7) / 8)), dim3(512), 0, s, \
+                                h, ldh, seg_ptr, seg_node, n_seg, item_edge, item_other, (int)feat, g, ldg, gh, ldgh, e);     \
+    } while (0)
+        if (g_is_vector) { if (feat <= 256) V2(true, 1); else V2(true, 2); }
+        else             { if (feat <= 256) V2(false, 1); else V2(false, 2); }
+#undef V2
+        return launch_status();
+    }
 #define L(GV, V, NK)                                                                                                  \
     hipLaunchKernelGGL((edge_segment_bwd_kernel<GV, V, NK>), grid, dim3(256), 0, s, h, ldh, seg_ptr, seg_node, n_seg, \
                        item_edge, item_other, (int)feat, g, ldg, gh, ldgh, e)

@@ -1147,6 +1147,19 @@ def random_walk_pairs(graph, start: torch.Tensor, walk_length: int, seed: int):
     return pairs[keep], weights[keep]
 
 
+# the segment backward's long segments shared by the waves of a workgroup (csrc/edge_ops.hip::edge_segment_bwd_group_kernel: eight
+# segments per workgroup of eight waves from 8 192 segments on, one segment per workgroup of four below): 'auto' = that rule,
+# 'wave' = one wave per segment whatever its length (the round-5 form), 'group4' = groups of four instead of eight (A/B runs)
+EDGE_SEGMENT = {"form": os.environ.get("PLNLP_EDGE_SEGMENT", "auto"), "applied": None}
+
+
+def _apply_edge_segment() -> None:
+    form = EDGE_SEGMENT["form"]
+    if form != EDGE_SEGMENT["applied"]:
+        L.load().plnlp_edge_segment_tuning({"auto": 0, "wave": 1, "group4": 2}[form])
+        EDGE_SEGMENT["applied"] = form
+
+
 def edge_segment_bwd(h: torch.Tensor, inc: Incidence, g: torch.Tensor,
                      out: Optional[torch.Tensor] = None,
                      epilogue: Optional[L.Epilogue] = None) -> torch.Tensor:
@@ -1165,6 +1178,7 @@ def edge_segment_bwd(h: torch.Tensor, inc: Incidence, g: torch.Tensor,
             return csr_aggregate(inc, h, "sum", True, out=out, epilogue=epilogue)
         finally:
             inc.val = None
+    _apply_edge_segment()
     L.check(lib.plnlp_edge_segment_bwd_f32(
         h.data_ptr(), _ld(h), inc.seg_ptr.data_ptr(), None, inc.n_rows, inc.item_edge.data_ptr(),
         inc.item_other.data_ptr(), h.shape[1], g.data_ptr(), _ld(g) if is_vec else 0, int(is_vec),

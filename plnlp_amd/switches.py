@@ -18,6 +18,12 @@ ENV = [
      "workgroup per CU): `auto` = launches of >= 32 768 rows at 224-column tiles (a layer 193..224 wide: citation2's h = 200), "
      "`off` = never, `all` = the 256-column tiles too (measured equal to `gemm_x3s` within -2..+5 %: both run at the power limit), "
      "`nolead` / `all-nolead` = without the leading half blocks of odd workgroups; same bits"),
+    ("PLNLP_EDGE_SEGMENT", "ops.EDGE_SEGMENT['form']", "auto",
+     "the fused scorer's deterministic backward over the touched nodes (`edge_segment_bwd_group_kernel`): `auto` = long segments are "
+     "shared by the waves of a workgroup -- from 8 192 segments on, eight segments per workgroup of eight waves, those of more than 64 "
+     "items summed by all eight (citation2: 263 K nodes with two items each and a few hubs with hundreds), below that every segment by "
+     "the four waves of its own workgroup (ddi: 4 267 nodes, 123 items on average); `wave` = one wave per segment whatever its length "
+     "(the round-5 form: the launch lasts as long as the hub's chain); `group4` = groups of four waves / four segments"),
     ("PLNLP_GEMM_WIDE_WGRAD", "ops.GEMM_WIDE_WGRAD['enabled']", "1",
      "`0`: every weight gradient on the 128x128 tile kernel instead of the whole-block kernel (`csrc/gemm_wgw.hip`: one 224-wide "
      "block for a 129..224 wide layer -- citation2's h = 200 --, 256x256 blocks for collab's 256x512 pair and ddi's 512x512; "

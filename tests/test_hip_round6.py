@@ -710,3 +710,75 @@ def test_table_adam_in_the_gcn_input_aggregation_gives_the_same_bits(P):
     for a, b in zip(res[True][1], res[False][1]):
         assert torch.equal(a, b)
     assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+
+
+# ------------------------------------ the fused scorer's deterministic backward: work split by the number of segments ----
+@pytest.mark.parametrize("n,e,feat", [(20_000, 30_000, 200), (20_000, 30_000, 512), (9_000, 200_000, 64), (3_000, 60_000, 512),
+                                      (4_267, 100_000, 200), (50, 9_000, 256)])
+def test_segment_backward_forms(P, n, e, feat):
+    """csrc/edge_ops.hip::edge_segment_bwd_group_kernel: one wave per segment makes the launch as long as its longest segment (the hub's
+    items are one serial chain).  From 8 192 segments on a workgroup of eight waves takes eight consecutive segments: a wave sums
+    its own if it has at most 64 items (item order: the round-5 bits), the longer ones are shared by all eight waves (contiguous
+    eighths in order, partial sums added in wave order: another association, a function of the segment's length only); below 8 192
+    segments (ddi: 4 267 nodes, hundreds of items at the hubs) every segment is shared by the four waves of its own workgroup.
+    Segments without items (nodes the batch does not touch) come out as zeros; the producing layer's gate in the epilogue; launch
+    to launch the same bits; float64-close relative to sum |terms|."""
+    from plnlp_amd import _lib as L
+    gen = torch.Generator(device="cuda").manual_seed(n + e + feat)
+    h = torch.randn(n, feat, device="cuda", generator=gen)
+    src = torch.randint(0, n, (e,), device="cuda", generator=gen)
+    dst = torch.randint(0, n, (e,), device="cuda", generator=gen)
+    src[: e // 20] = 7                                   # a hub
+    dst[e // 20: e // 16] = 7
+    lonely = torch.arange(11, n, 97, device="cuda")    # nodes without items
+    src[torch.isin(src, lonely)] = 3
+    dst[torch.isin(dst, lonely)] = 5
+    go = torch.randn(e, feat, device="cuda", generator=gen)
+    inc = P.ops.Incidence(src, dst, n)
+    old = P.ops.EDGE_SEGMENT["form"]
+    res = {}
+    try:
+        for form in ("wave", "auto"):
+            P.ops.EDGE_SEGMENT["form"] = form
+            plain = P.ops.edge_segment_bwd(h, inc, go)
+            gated = P.ops.edge_segment_bwd(h, inc, go, epilogue=L.make_epilogue(gate=h, gate_scale=1.5))
+            assert torch.equal(plain, P.ops.edge_segment_bwd(h, inc, go))
+            res[form] = (plain, gated)
+    finally:
+        P.ops.EDGE_SEGMENT["form"] = old
+        P.ops._apply_edge_segment()
+    want = torch.zeros(n, feat, dtype=torch.float64, device="cuda")
+    want.index_add_(0, src, go.double() * h[dst].double())
+    want.index_add_(0, dst, go.double() * h[src].double())
+    mag = torch.zeros(n, feat, dtype=torch.float64, device="cuda")
+    mag.index_add_(0, src, (go.double() * h[dst].double()).abs())
+    mag.index_add_(0, dst, (go.double() * h[src].double()).abs())
+    for form in ("wave", "auto"):
+        plain, gated = res[form]
+        assert float(((plain.double() - want).abs() / (mag + 1e-30)).max()) <= 2e-6, form
+        assert torch.equal(gated, torch.where(h > 0, plain * 1.5, torch.zeros_like(plain))), form
+        assert not bool(plain[lonely].any())
+    items = torch.bincount(src, minlength=n) + torch.bincount(dst, minlength=n)
+    assert int(items.max()) > 64
+    if n >= 8192:                  # a wave per short segment, item order kept: the round-5 bits; the long ones by the workgroup
+        short = items <= 64
+        assert torch.equal(res["auto"][0][short], res["wave"][0][short])
+        assert not torch.equal(res["auto"][0][~short], res["wave"][0][~short])
+    else:                          # every segment by the four waves of a workgroup: another association
+        assert not torch.equal(res["auto"][0], res["wave"][0])
+
+
+def test_segment_backward_scalar_rows_keep_the_round5_kernel(P):
+    """rows that are not whole 16-byte groups (feat % 4 != 0) stay on the scalar form under every setting"""
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    n, e, feat = 9000, 20_000, 30
+    h = torch.randn(n, feat, device="cuda", generator=gen)
+    src = torch.randint(0, n, (e,), device="cuda", generator=gen)
+    dst = torch.randint(0, n, (e,), device="cuda", generator=gen)
+    go = torch.randn(e, feat, device="cuda", generator=gen)
+    inc = P.ops.Incidence(src, dst, n)
+    got = P.ops.edge_segment_bwd(h, inc, go)
+    want = torch.zeros(n, feat, dtype=torch.float64, device="cuda")
+    want.index_add_(0, src, go.double() * h[dst].double())
+    want.index_add_(0, dst, go.double() * h[src].double())
+    close(got, want.float(), rtol=1e-5, atol=1e-4)
