@@ -39,4 +39,13 @@ for pass in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIV
 done
 python3 scripts/pmc_collect.py agg $R/ddi_agg_pmc.json "$R/pmc_d/**/*counter_collection.csv" > /dev/null
 rm -rf $R/pmc_d
+# 5. the segment backward alone (one wave per segment | long segments shared by a workgroup) and its counters
+python scripts/probe_segment_bwd.py > $R/segment_backward_times.jsonl 2>/dev/null
+mkdir -p $R/pmc_s
+for pass in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES"; do
+  d=$R/pmc_s/$(echo $pass | tr ' ' '_')
+  PROBE_ITERS=3 rocprofv3 --kernel-trace --pmc $pass -f csv -d $d -o s -- python3 scripts/probe_segment_bwd.py > /dev/null 2>&1
+done
+python3 scripts/pmc_collect.py edge_segment $R/segment_backward_pmc.json "$R/pmc_s/**/*counter_collection.csv" > /dev/null
+rm -rf $R/pmc_s
 ls -la $R
