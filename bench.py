@@ -506,13 +506,26 @@ def measure_roofline(P, graph, feat, device, weighted=False, shape="collab"):
                       "no-reuse HBM fraction -- that one is taken on the uniform graph (default workload's `roofline`)"))}
 
 
-def _x3_kernel_name(P, m, n=256):
-    """which split-bf16 kernel a launch with K-contiguous A, m rows and n columns runs (csrc/gemm_f32.hip::gemm_impl)"""
-    if P.ops.GEMM_STATIONARY_B["enabled"] and m >= 16384:
-        if m >= 32768 and (192 < n <= 224 or (n % 256 == 0 and P.ops.GEMM_BLOCK["mode"].startswith("all"))) and P.ops.GEMM_BLOCK["mode"] != "off":
-            return "x3b::gemm_x3b_kernel (stationary pre-split weights, a whole 256-row block per workgroup, one persistent workgroup per CU)"
-        return "x3s::gemm_x3s_kernel (stationary pre-split weights; tile kernel x16::gemm_f32_kernel where the form does not apply)"
-    return "x16::gemm_f32_kernel"
+_X3_KERNELS = {
+    "gemm_x3b": "x3b::gemm_x3b_kernel (stationary pre-split weights, a whole 256-row block per workgroup, one persistent workgroup per CU)",
+    "gemm_x3s": "x3s::gemm_x3s_kernel (stationary pre-split weights, 128-row panels)",
+    "gemm_tile_x3": "x16::gemm_f32_kernel (128 x 128 tiles, both operands split in the loaders)",
+}
+
+
+def _x3_kernel_name(P, launch):
+    """which split-bf16 kernel `launch` runs: asked of the library's launch counters (plnlp_launch_counts), not re-derived here"""
+    mode0 = P.ops.GEMM_MATH["mode"]
+    try:
+        P.ops.GEMM_MATH["mode"] = "bf16x3"
+        c0 = P.ops.launch_counts()
+        launch()
+        torch.cuda.synchronize()
+        c1 = P.ops.launch_counts()
+    finally:
+        P.ops.GEMM_MATH["mode"] = mode0
+    ran = [k for k in _X3_KERNELS if c1.get(k, 0) > c0.get(k, 0)]
+    return " + ".join(_X3_KERNELS[k] for k in ran) if ran else "x16::gemm_f32_kernel"
 
 
 def _gemm_forms(P, flop, kname, m, n, launch):
@@ -528,7 +541,7 @@ def _gemm_forms(P, flop, kname, m, n, launch):
     f32_form = {"math": "f32", "kernel": "g16::gemm_f32_kernel (%s)" % kname, "achieved": flop / times["f32"] / 1e12,
                 "peak": 157.3, "unit": "TFLOP/s", "frac": flop / times["f32"] / 157.3e12, "kernel_ms": times["f32"] * 1e3}
     tx = times["bf16x3"]
-    x3_form = {"math": "bf16x3", "kernel": "%s (%s)" % (_x3_kernel_name(P, m, n), kname), "achieved": 6 * flop / tx / 1e12,
+    x3_form = {"math": "bf16x3", "kernel": "%s (%s)" % (_x3_kernel_name(P, launch), kname), "achieved": 6 * flop / tx / 1e12,
                "peak": 2500.0, "unit": "TFLOP/s", "frac": 6 * flop / tx / 2.5e15, "kernel_ms": tx * 1e3,
                "f32_equivalent_TFLOPs": flop / tx / 1e12,
                "note": "fp32 in / fp32 out; operands split into three bf16 terms, six bf16 MFMAs per block (executed flops = "
@@ -673,7 +686,7 @@ def measure_gemm_roofline(P, n_rows, k_in, hidden, device, sage=True):
                 "unit": "TFLOP/s", "frac": flop / times["f32"] / 157.3e12, "kernel_ms": times["f32"] * 1e3,
                 "note": "v_mfma_f32_32x32x2_f32 (an fmaf chain; gfx950 has no TF32), peak = 256 CUs x 256 FLOP/clk x 2.4 GHz"}
     t = times["bf16x3"]
-    x3_form = {"kernel": "%s (%s)" % (_x3_kernel_name(P, n_rows), kname), "achieved": 6 * flop / t / 1e12, "peak": 2500.0,
+    x3_form = {"kernel": "%s (%s)" % (_x3_kernel_name(P, lambda: P.ops.gemm(segs, False, True, out=out, epilogue=epi)), kname), "achieved": 6 * flop / t / 1e12, "peak": 2500.0,
                "unit": "TFLOP/s", "frac": 6 * flop / t / 2.5e15, "kernel_ms": t * 1e3,
                "f32_equivalent_TFLOPs": flop / t / 1e12, "f32_equivalent_over_f32_mfma_peak": flop / t / 157.3e12,
                "note": "fp32 in / fp32 out; every operand element split in the loader into three bf16 terms, six "
@@ -745,7 +758,8 @@ def measure_step_launches(P, model, data, pos_b, neg_b, cfg, device):
     f32_form = {"math": "f32", "kernel": "g16::gemm_f32_kernel (%s)" % kname, "achieved": flop / times["f32"] / 1e12,
                 "peak": 157.3, "unit": "TFLOP/s", "frac": flop / times["f32"] / 157.3e12, "kernel_ms": times["f32"] * 1e3}
     tx = times["bf16x3"]
-    x3_form = {"math": "bf16x3", "kernel": "%s (%s)" % (_x3_kernel_name(P, Tp), kname), "achieved": 6 * flop / tx / 1e12,
+    x3_form = {"math": "bf16x3", "kernel": "%s (%s)" % (_x3_kernel_name(P, lambda: ops.gemm([(agg, conv.lin_l.weight), (x, conv.lin_r.weight)], False, True,
+                                                                                           out=y, epilogue=epi, a_index=[None, rows])), kname), "achieved": 6 * flop / tx / 1e12,
                "peak": 2500.0, "unit": "TFLOP/s", "frac": 6 * flop / tx / 2.5e15, "kernel_ms": tx * 1e3,
                "f32_equivalent_TFLOPs": flop / tx / 1e12,
                "note": "fp32 in / fp32 out; operands split into three bf16 terms, six bf16 MFMAs per block (executed flops = "

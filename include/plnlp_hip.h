@@ -501,7 +501,10 @@ int plnlp_rmat_edges(int scale, int64_t n_nodes, int64_t edge_lo, int64_t n_edge
  * (contiguous eighths, partial sums added in wave order); below 8 192 segments every segment is shared by the four waves of
  * its own workgroup (a dense graph: ddi).  Deterministic: the association depends on the segment's length only.
  * plnlp_edge_segment_tuning(1): one wave per segment whatever its length (the round-5 form; measurement knob, process-global);
- * 2: groups of four waves / four segments instead of eight / eight; 0 = the rule above. */
+ * 2: groups of four waves / four segments instead of eight / eight; 3: few segments without the XCD-pinned column slabs (below);
+ * 0 = the rule above.  Few segments (< 8 192), rows of 256 / 512 floats, a table of more than 4 MB (one XCD's L2): eight workgroups
+ * per segment, one eighth of the columns each (workgroup b: slab b % 8 -- consecutive workgroups run on consecutive XCDs, so an
+ * XCD's L2 holds one slab of h), the partial sums of the workgroup's lane groups added in group order. */
 void plnlp_edge_segment_tuning(int form);
 
 int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh,

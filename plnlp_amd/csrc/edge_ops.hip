@@ -349,9 +349,78 @@ __global__ __launch_bounds__(64 * W) void edge_segment_bwd_group_kernel(
     }
 }
 
+// Few segments over a table that does not fit ONE XCD's L2 (ddi: 4 267 rows x 2 KB = 8.7 MB against 4 MB): in the forms above every
+// row of h comes over the fabric like the rows of g -- 1.9 GB per launch where g alone is 1.07 GB, at the fabric's 7 TB/s.  Here the
+// feature columns are cut into EIGHT slabs and workgroup b takes slab b % 8 of segment b / 8: consecutive workgroups go to
+// consecutive XCDs, so every XCD reads one slab of h only (1.1 MB: L2-resident) and its eighth of every g row.  A slab is SL float4
+// slots wide; the 64 / SL lane groups of the workgroup's four waves take contiguous shares of the segment's items in order, and the
+// first SL lanes add the groups' partial sums in group order through LDS (a fixed association).
+template <bool GVEC, int SL>
+__global__ __launch_bounds__(256) void edge_segment_bwd_slab_kernel(
+    const float* __restrict__ h, int64_t ldh, const int64_t* __restrict__ seg_ptr,
+    const int64_t* __restrict__ seg_node, int64_t n_seg, const int32_t* __restrict__ item_edge,
+    const int32_t* __restrict__ item_other, int feat, const float* __restrict__ g, int64_t ldg,
+    float* __restrict__ gh, int64_t ldgh, Epi epi) {
+    constexpr int GPW = 64 / SL;                                 // lane groups per wave
+    constexpr int NG = 4 * GPW;                                  // ... per workgroup
+    constexpr int U = 4;
+    const int slab = blockIdx.x & 7;
+    const int64_t seg = (int64_t)(blockIdx.x >> 3);
+    if (seg >= n_seg) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % SL, grp = wave * GPW + lane / SL;
+    const int64_t beg = seg_ptr[seg], end = seg_ptr[seg + 1];
+    const int64_t q = (end - beg + NG - 1) / NG;
+    const int64_t lo = beg + grp * q < end ? beg + grp * q : end;
+    const int64_t hi = lo + q < end ? lo + q : end;
+    const int col = (slab * SL + sub) * 4;                       // (feat == 32 SL: the launcher checks)
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = lo; i < hi; i += U) {
+        float4 x[U], gg[U];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i + u < hi) {
+                const int ed = item_edge[i + u], o = item_other[i + u];
+                x[u] = *reinterpret_cast<const float4*>(h + (int64_t)o * ldh + col);
+                if constexpr (GVEC) gg[u] = *reinterpret_cast<const float4*>(g + (int64_t)ed * ldg + col);
+                else w[u] = g[ed];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i + u < hi) {
+                if constexpr (GVEC) {
+                    acc.x = fmaf(gg[u].x, x[u].x, acc.x); acc.y = fmaf(gg[u].y, x[u].y, acc.y);
+                    acc.z = fmaf(gg[u].z, x[u].z, acc.z); acc.w = fmaf(gg[u].w, x[u].w, acc.w);
+                } else {
+                    acc.x = fmaf(w[u], x[u].x, acc.x); acc.y = fmaf(w[u], x[u].y, acc.y);
+                    acc.z = fmaf(w[u], x[u].z, acc.z); acc.w = fmaf(w[u], x[u].w, acc.w);
+                }
+            }
+        }
+    }
+    __shared__ float4 part[NG * SL];
+    part[grp * SL + sub] = acc;
+    __syncthreads();
+    if (threadIdx.x < SL) {
+        float4 t = part[sub];
+#pragma unroll
+        for (int k = 1; k < NG; ++k) {
+            const float4 v = part[k * SL + sub];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        const int64_t node = seg_node ? seg_node[seg] : seg;
+        float* orow = gh + node * ldgh;
+        const float4 y = epi_apply4(epi, t, node, (int64_t)col, feat, orow);
+        *reinterpret_cast<float4*>(orow + col) = y;
+    }
+}
+
 // measurement knob (plnlp_edge_segment_tuning): 0 = long segments shared by a workgroup (the rule in plnlp_edge_segment_bwd_f32),
 // 1 = one wave per segment always (the round-5 form), 2 = many segments in groups of four waves / four segments (measured on
-// citation2's step: 273 us against 250 for eight / eight, 613 for one wave per segment)
+// citation2's step: 273 us against 250 for eight / eight, 613 for one wave per segment), 3 = few segments without the XCD-pinned
+// column slabs
 static int g_segment_form = 0;
 
 static inline int pick_lpr(int64_t feat, bool vec) {
@@ -463,6 +532,17 @@ extern "C" int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh, const int
         // fewer segments than the chip holds waves: a workgroup of four waves per segment; many segments: eight per workgroup of
         // eight waves, its long ones (> SEGMENT_LONG items) shared by the eight
         const bool few = n_seg < 8192;
+        // few segments, a table beyond one XCD's L2 (4 MB), rows of 256 / 512 floats: column slabs pinned to the XCDs
+        if (few && g_segment_form != 3 && n_seg * feat * 4 > (4ll << 20) && (feat == 512 || feat == 256)) {
+            const dim3 g3((unsigned)(n_seg * 8));
+#define V3(GV, SL)                                                                                                             \
+    hipLaunchKernelGGL((edge_segment_bwd_slab_kernel<GV, SL>), g3, dim3(256), 0, s, h, ldh, seg_ptr, seg_node, n_seg, item_edge, \
+                       item_other, (int)feat, g, ldg, gh, ldgh, e)
+            if (g_is_vector) { if (feat == 512) V3(true, 16); else V3(true, 8); }
+            else             { if (feat == 512) V3(false, 16); else V3(false, 8); }
+#undef V3
+            return launch_status();
+        }
 #define V2(GV, NK)                                                                                                            \
     do {                                                                                                                      \
         if (few) hipLaunchKernelGGL((edge_segment_bwd_group_kernel<GV, NK, 4, 1>), dim3((unsigned)n_seg), dim3(256), 0, s, h, ldh, \

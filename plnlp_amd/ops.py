@@ -1149,14 +1149,15 @@ def random_walk_pairs(graph, start: torch.Tensor, walk_length: int, seed: int):
 
 # the segment backward's long segments shared by the waves of a workgroup (csrc/edge_ops.hip::edge_segment_bwd_group_kernel: eight
 # segments per workgroup of eight waves from 8 192 segments on, one segment per workgroup of four below): 'auto' = that rule,
-# 'wave' = one wave per segment whatever its length (the round-5 form), 'group4' = groups of four instead of eight (A/B runs)
+# 'wave' = one wave per segment whatever its length (the round-5 form), 'group4' = groups of four instead of eight, 'noslab' = few
+# segments without the XCD-pinned column slabs (A/B runs)
 EDGE_SEGMENT = {"form": os.environ.get("PLNLP_EDGE_SEGMENT", "auto"), "applied": None}
 
 
 def _apply_edge_segment() -> None:
     form = EDGE_SEGMENT["form"]
     if form != EDGE_SEGMENT["applied"]:
-        L.load().plnlp_edge_segment_tuning({"auto": 0, "wave": 1, "group4": 2}[form])
+        L.load().plnlp_edge_segment_tuning({"auto": 0, "wave": 1, "group4": 2, "noslab": 3}[form])
         EDGE_SEGMENT["applied"] = form
 
 

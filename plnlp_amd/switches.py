@@ -23,7 +23,8 @@ ENV = [
      "shared by the waves of a workgroup -- from 8 192 segments on, eight segments per workgroup of eight waves, those of more than 64 "
      "items summed by all eight (citation2: 263 K nodes with two items each and a few hubs with hundreds), below that every segment by "
      "the four waves of its own workgroup (ddi: 4 267 nodes, 123 items on average); `wave` = one wave per segment whatever its length "
-     "(the round-5 form: the launch lasts as long as the hub's chain); `group4` = groups of four waves / four segments"),
+     "(the round-5 form: the launch lasts as long as the hub's chain); `group4` = groups of four waves / four segments; `noslab` = few segments without the XCD-pinned column slabs (ddi: eight "
+     "workgroups per segment, one eighth of the columns each, so that every XCD's L2 holds one slab of the table)"),
     ("PLNLP_GEMM_WIDE_WGRAD", "ops.GEMM_WIDE_WGRAD['enabled']", "1",
      "`0`: every weight gradient on the 128x128 tile kernel instead of the whole-block kernel (`csrc/gemm_wgw.hip`: one 224-wide "
      "block for a 129..224 wide layer -- citation2's h = 200 --, 256x256 blocks for collab's 256x512 pair and ddi's 512x512; "

@@ -714,13 +714,14 @@ def test_table_adam_in_the_gcn_input_aggregation_gives_the_same_bits(P):
 
 # ------------------------------------ the fused scorer's deterministic backward: work split by the number of segments ----
 @pytest.mark.parametrize("n,e,feat", [(20_000, 30_000, 200), (20_000, 30_000, 512), (9_000, 200_000, 64), (3_000, 60_000, 512),
-                                      (4_267, 100_000, 200), (50, 9_000, 256)])
+                                      (4_267, 100_000, 200), (50, 9_000, 256), (5_000, 80_000, 256), (1_000, 40_000, 512)])
 def test_segment_backward_forms(P, n, e, feat):
     """csrc/edge_ops.hip::edge_segment_bwd_group_kernel: one wave per segment makes the launch as long as its longest segment (the hub's
     items are one serial chain).  From 8 192 segments on a workgroup of eight waves takes eight consecutive segments: a wave sums
     its own if it has at most 64 items (item order: the round-5 bits), the longer ones are shared by all eight waves (contiguous
     eighths in order, partial sums added in wave order: another association, a function of the segment's length only); below 8 192
-    segments (ddi: 4 267 nodes, hundreds of items at the hubs) every segment is shared by the four waves of its own workgroup.
+    segments (ddi: 4 267 nodes, hundreds of items at the hubs) every segment is shared by the four waves of its own workgroup -- and
+    when the table is beyond one XCD's L2 (4 MB) at 256 / 512 columns, by eight workgroups that take one XCD-pinned column slab each.
     Segments without items (nodes the batch does not touch) come out as zeros; the producing layer's gate in the epilogue; launch
     to launch the same bits; float64-close relative to sum |terms|."""
     from plnlp_amd import _lib as L
