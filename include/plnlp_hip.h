@@ -424,6 +424,8 @@ int plnlp_mlp_head_backward_f32(const float* a, int64_t lda, const float* g, con
  * MLPPredictor.forward (layer.py:81).  src/dst are int64 like the reference's
  * edge tensors; h has n_rows rows and a negative index i addresses row n_rows + i
  * (the reference appends a mean row so that -1 means "unseen node", model.py:191-194).
+ * plnlp_edge_hadamard_fwd_f32 on a table of 4 .. 24 MB at 256 / 512 columns (beyond one XCD's L2, an eighth of it inside: ogbl-ddi)
+ * runs in eight XCD-pinned column slabs (workgroup b: slab b % 8) -- the same products; plnlp_edge_segment_tuning(3) turns that off.
  */
 int plnlp_edge_dot_fwd_f32(const float* h, int64_t ldh, int64_t n_rows,
                            const int64_t* src, const int64_t* dst, int64_t n_edges,

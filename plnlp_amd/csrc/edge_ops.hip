@@ -76,6 +76,26 @@ __global__ __launch_bounds__(256) void edge_hadamard_fwd_kernel(const float* __r
     }
 }
 
+// A table beyond one XCD's L2 (ddi: 4 267 x 2 KB = 8.7 MB against 4 MB) whose rows every edge gathers: the columns in EIGHT slabs,
+// workgroup b takes slab b % 8 (consecutive workgroups run on consecutive XCDs), so an XCD's L2 holds one slab of the table and the
+// gathers stay in it -- what goes over the fabric is the result.  SL float4 slots per slab (feat == 32 SL); same values.
+template <int SL>
+__global__ __launch_bounds__(256) void edge_hadamard_fwd_slab_kernel(const float* __restrict__ h, int64_t ldh, int64_t n_rows,
+                                                                     const int64_t* __restrict__ src,
+                                                                     const int64_t* __restrict__ dst, int64_t n_edges,
+                                                                     float* __restrict__ out, int64_t ldo) {
+    constexpr int GPB = 256 / SL;
+    const int slab = blockIdx.x & 7;
+    const int64_t wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+    const int sub = threadIdx.x % SL, grp = threadIdx.x / SL;
+    const int col = (slab * SL + sub) * 4;
+    for (int64_t e = wg * GPB + grp; e < n_edges; e += nwg * GPB) {
+        const float4 u = *reinterpret_cast<const float4*>(h + wrap_index(src[e], n_rows) * ldh + col);
+        const float4 v = *reinterpret_cast<const float4*>(h + wrap_index(dst[e], n_rows) * ldh + col);
+        *reinterpret_cast<float4*>(out + e * ldo + col) = make_float4(u.x * v.x, u.y * v.y, u.z * v.z, u.w * v.w);
+    }
+}
+
 // ---------------- backward: atomic scatter -----------------------------------------
 template <int LPR, bool GVEC>
 __global__ __launch_bounds__(256) void edge_scatter_bwd_kernel(const float* __restrict__ h, int64_t ldh,
@@ -477,6 +497,18 @@ extern "C" int plnlp_edge_hadamard_fwd_f32(const float* h, int64_t ldh, int64_t 
     const int lpr = pick_lpr(feat, vec);
     dim3 grid(edge_grid(n_edges, lpr));
     hipStream_t s = (hipStream_t)stream;
+    // the table beyond one XCD's L2 (4 MB) but an eighth of it well inside: XCD-pinned column slabs
+    if (vec && g_segment_form != 3 && (feat == 512 || feat == 256) && n_rows * feat * 4 > (4ll << 20) &&
+        n_rows * feat * 4 <= (24ll << 20) && n_edges >= 4096) {
+        const int gpb = feat == 512 ? 16 : 32;
+        int64_t nwg = (n_edges + gpb - 1) / gpb;
+        nwg = nwg < 2048 ? nwg : 2048;
+        const dim3 g8((unsigned)(nwg * 8));
+        if (feat == 512) hipLaunchKernelGGL((edge_hadamard_fwd_slab_kernel<16>), g8, dim3(256), 0, s, h, ldh, n_rows, src, dst, n_edges,
+                                            out, ldo);
+        else hipLaunchKernelGGL((edge_hadamard_fwd_slab_kernel<8>), g8, dim3(256), 0, s, h, ldh, n_rows, src, dst, n_edges, out, ldo);
+        return launch_status();
+    }
 #define M(L)                                                                                                     \
     if (vec) hipLaunchKernelGGL((edge_hadamard_fwd_kernel<L, true>), grid, dim3(256), 0, s, h, ldh, n_rows, src,  \
                                 dst, n_edges, (int)feat, out, ldo);                                              \

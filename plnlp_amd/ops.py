@@ -881,6 +881,7 @@ def edge_hadamard_fwd(h: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> 
     L.require_device(h, src, dst)
     h, src, dst = _f32c(h), _edge_idx(src), _edge_idx(dst)
     out = torch.empty(src.numel(), h.shape[1], dtype=torch.float32, device=h.device)
+    _apply_edge_segment()            # ('noslab' also turns off this launch's XCD-pinned column slabs)
     L.check(lib.plnlp_edge_hadamard_fwd_f32(h.data_ptr(), _ld(h), h.shape[0], src.data_ptr(), dst.data_ptr(),
                                             src.numel(), h.shape[1], out.data_ptr(), _ld(out), L.stream_ptr()),
             "plnlp_edge_hadamard_fwd_f32")

@@ -783,3 +783,26 @@ def test_segment_backward_scalar_rows_keep_the_round5_kernel(P):
     want.index_add_(0, src, go.double() * h[dst].double())
     want.index_add_(0, dst, go.double() * h[src].double())
     close(got, want.float(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,feat", [(4_267, 512), (6_000, 256), (3_000, 256)])
+def test_hadamard_forward_in_xcd_pinned_column_slabs(P, n, feat):
+    """a table beyond one XCD's L2 (4 MB) whose rows every edge gathers (ddi: 4 267 x 2 KB): the columns in eight slabs, workgroup b
+    on slab b % 8 -- the same products, bit for bit, -1 endpoints (the appended mean row of test()) included; the small table keeps
+    the plain kernel"""
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    h = torch.randn(n, feat, device="cuda", generator=gen)
+    src = torch.randint(0, n, (70_001,), device="cuda", generator=gen)
+    dst = torch.randint(0, n, (70_001,), device="cuda", generator=gen)
+    src[::11] = -1
+    old = P.ops.EDGE_SEGMENT["form"]
+    try:
+        P.ops.EDGE_SEGMENT["form"] = "noslab"
+        plain = P.ops.edge_hadamard_fwd(h, src, dst)
+        P.ops.EDGE_SEGMENT["form"] = "auto"
+        slabs = P.ops.edge_hadamard_fwd(h, src, dst)
+    finally:
+        P.ops.EDGE_SEGMENT["form"] = old
+        P.ops._apply_edge_segment()
+    assert torch.equal(plain, slabs)
+    assert torch.equal(plain, h[src] * h[dst])
