@@ -45,7 +45,7 @@ extern "C" {
  *              launch kind "gemm_x3b"; plnlp_gemm_operand.reserved -> flags (PLNLP_GEMM_FLAG_WIDE_WGRAD: the wide weight-gradient
  *              form is asked for explicitly, no longer implied by the slice count); plnlp_gemm_operand.a_colsum (the bias gradient
  *              out of the wide weight-gradient kernel); plnlp_dense_aggregate_f32 / _scratch_bytes (a dense graph's aggregation on
- *              the matrix cores); launch kind "agg_dense"; plnlp_edge_segment_tuning (the segment backward's forms by segment count). */
+ *              the matrix cores); launch kind "agg_dense"; plnlp_edge_segment_tuning (the segment backward's forms by segment count); plnlp_dense_aggregate_tuning. */
 #define PLNLP_ABI_VERSION 12
 
 #define PLNLP_E_NULL      (-1)   /* required pointer is NULL                */
@@ -218,7 +218,11 @@ int plnlp_csr_aggregate_f32(const int64_t* rowptr, const int32_t* col,
  * error is below the CSR kernels', the sums are the same to f32 round-off in another order.
  * epi: every flag plnlp_csr_aggregate_f32 takes (PLNLP_EPI_ADAM included); operands 16-byte aligned.  scratch: DEVICE memory of
  * plnlp_dense_aggregate_scratch_bytes(n_rows, n_src, feat) bytes the launch may overwrite (x's image + the K slices' partials).
- * feat % 4 == 0; x / out 16-byte aligned with ldx, ldo multiples of 4.  Deterministic (fixed slice order). */
+ * feat % 4 == 0; x / out 16-byte aligned with ldx, ldo multiples of 4.  Deterministic (fixed slice order; the number of K slices
+ * is a function of the shape: whole rounds of the 512 workgroups the chip holds).
+ * plnlp_dense_aggregate_tuning(s): s > 0 forces the slice count (measurement knob, process-global; ask for the scratch size after
+ * setting it), 0 = the rule. */
+void plnlp_dense_aggregate_tuning(int slices);
 int64_t plnlp_dense_aggregate_scratch_bytes(int64_t n_rows, int64_t n_src, int64_t feat);
 int plnlp_dense_aggregate_f32(const void* counts, int64_t ld_counts, const float* src_scale, const float* row_scale,
                               const float* x, int64_t ldx, float* out, int64_t ldo, int64_t n_rows, int64_t n_src, int64_t feat,

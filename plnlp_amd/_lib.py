@@ -107,6 +107,7 @@ SIGNATURES = {
     "plnlp_gemm_stationary_tuning": (None, [C.c_int, C.c_int]),
     "plnlp_gemm_block_tuning": (None, [C.c_int]),
     "plnlp_edge_segment_tuning": (None, [C.c_int]),
+    "plnlp_dense_aggregate_tuning": (None, [C.c_int]),
     "plnlp_gemm_rowdot_tiles": (C.c_int, [c_i64, c_i64]),
     "plnlp_rowdot_finish_f32": (C.c_int, [C.c_void_p, c_i64, C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plnlp_gemm_stationary_applies": (C.c_int, [C.POINTER(GemmOperand), C.c_int, C.c_int, C.c_int, C.c_void_p, c_i64, c_i64,

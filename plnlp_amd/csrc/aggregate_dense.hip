@@ -215,17 +215,31 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(const float* __restri
 
 using namespace plnlp;
 
-// K slices of a launch: ~2 workgroups per CU (the kernel runs 3 per CU), at least 8 K-steps per slice
+// K slices of a launch.  The chip holds 512 workgroups of this kernel at once (two per CU: the two-level accumulation's registers), a
+// launch is ROUNDS of that many, and a workgroup's time is its K-steps plus a fixed part (prologue, the write of its partial tile:
+// ~10 K-steps' worth); the reduce reads every slice (~3 K-steps' worth each).  ddi (34 x 4 tiles, 267 K-steps): four slices -- the
+// first rule, "about two workgroups per CU" -- are 544 workgroups = one full round and a second for 32 of them (77 us); three are
+// one round of 408.  At least 8 K-steps per slice.
+static int g_force_slices = 0;       // measurement knob (plnlp_dense_aggregate_tuning)
 static int dense_slices(int64_t n_rows, int64_t n_src, int64_t feat) {
     const int64_t tiles = ((n_rows + 127) / 128) * ((feat + aggd::WN - 1) / aggd::WN), ks = (n_src + 15) / 16;
-    int64_t s = (512 + tiles - 1) / tiles;
-    if (s > ks / 8) s = ks / 8;
-    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+    int64_t smax = ks / 8;
+    smax = smax < 1 ? 1 : (smax > 64 ? 64 : smax);
+    if (g_force_slices > 0) return (int)(g_force_slices < smax ? g_force_slices : smax);
+    int64_t best = 1, best_cost = -1;
+    for (int64_t s = 1; s <= smax; ++s) {
+        const int64_t rounds = (tiles * s + 511) / 512;
+        const int64_t cost = rounds * ((ks + s - 1) / s + 10) + 3 * s;
+        if (best_cost < 0 || cost < best_cost) { best = s; best_cost = cost; }
+    }
+    return (int)best;
 }
 
 static int64_t dense_image_bytes(int64_t n_src, int64_t feat) {
     return (feat + aggd::WN - 1) / aggd::WN * ((n_src + 15) / 16) * aggd::STAGE_UNITS * 16;
 }
+
+extern "C" void plnlp_dense_aggregate_tuning(int slices) { g_force_slices = slices; }
 
 extern "C" int64_t plnlp_dense_aggregate_scratch_bytes(int64_t n_rows, int64_t n_src, int64_t feat) {
     if (n_rows <= 0 || n_src <= 0 || feat <= 0) return 0;
