@@ -484,6 +484,8 @@ _GEMM_BLOCK_BITS = {"auto": 0, "off": 1, "nolead": 2, "all": 4, "all-nolead": 6}
 def _apply_gemm_block() -> None:
     mode = GEMM_BLOCK["mode"]
     if mode != GEMM_BLOCK["applied"]:
+        if mode not in _GEMM_BLOCK_BITS:
+            raise ValueError("PLNLP_GEMM_BLOCK / ops.GEMM_BLOCK['mode'] = %r: one of %s" % (mode, ", ".join(_GEMM_BLOCK_BITS)))
         L.load().plnlp_gemm_block_tuning(_GEMM_BLOCK_BITS[mode])
         GEMM_BLOCK["applied"] = mode
 
@@ -1155,10 +1157,15 @@ def random_walk_pairs(graph, start: torch.Tensor, walk_length: int, seed: int):
 EDGE_SEGMENT = {"form": os.environ.get("PLNLP_EDGE_SEGMENT", "auto"), "applied": None}
 
 
+_EDGE_SEGMENT_FORMS = {"auto": 0, "wave": 1, "group4": 2, "noslab": 3}
+
+
 def _apply_edge_segment() -> None:
     form = EDGE_SEGMENT["form"]
     if form != EDGE_SEGMENT["applied"]:
-        L.load().plnlp_edge_segment_tuning({"auto": 0, "wave": 1, "group4": 2, "noslab": 3}[form])
+        if form not in _EDGE_SEGMENT_FORMS:
+            raise ValueError("PLNLP_EDGE_SEGMENT / ops.EDGE_SEGMENT['form'] = %r: one of %s" % (form, ", ".join(_EDGE_SEGMENT_FORMS)))
+        L.load().plnlp_edge_segment_tuning(_EDGE_SEGMENT_FORMS[form])
         EDGE_SEGMENT["applied"] = form
 
 

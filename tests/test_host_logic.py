@@ -634,3 +634,16 @@ def test_emb_pad_granule_is_validated():
             ops._emb_pad_floats(bad)
     with pytest.raises(ValueError):
         ops._emb_pad_floats("four")
+
+
+def test_kernel_form_switches_reject_unknown_values():
+    """PLNLP_GEMM_BLOCK / PLNLP_EDGE_SEGMENT: a misspelt value is an error that names the choices, before the library is touched"""
+    from plnlp_amd import ops
+    for table, key, apply in ((ops.GEMM_BLOCK, "mode", ops._apply_gemm_block), (ops.EDGE_SEGMENT, "form", ops._apply_edge_segment)):
+        old = table[key]
+        try:
+            table[key] = "fastest"
+            with pytest.raises(ValueError, match="one of"):
+                apply()
+        finally:
+            table[key] = old
