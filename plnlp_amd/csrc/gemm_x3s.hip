@@ -296,43 +296,55 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
     float rd[8];                                               // ROWDOT: this lane's share of rows i * 4 + (lane >> 4)
 #pragma unroll
     for (int i = 0; i < 8; ++i) rd[i] = 0.f;
-    static_for<NB / 2 + (NB & 1)>([&](auto jc) {
-        constexpr int j0 = 2 * decltype(jc)::value;
-        constexpr int NJ = (j0 + 1 < NB) ? 2 : 1;
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                cw[((q & 3) + 8 * (q >> 2) + 4 * h) * CS + jj * 32 + l31] = acc[j0 + jj][q];
-        // rows i * 4 + (lane >> 4), 16-byte column group lane & 15.  The epilogue's operands (bias once per chunk; gate and
-        // accumulate rows) are requested for all 8 rows BEFORE the first store: a load issued between stores waits for
-        // them (the compiler must assume the result aliases the operand), 8 dependent round trips per chunk.
-        const int c4 = (lane & 15) * 4;
-        const int col = n0 + j0 * 32 + c4;
-        const bool col_ok = c4 < NJ * 32 && col < g.n;
-        const bool second = col >= g.n_split;
+    if constexpr (NB >= 7) {
+        // The wide tiles: the chunks' 4-row batches as ONE sequence, the gate rows of batch t + 1 requested BEFORE the stores of
+        // batch t.  The memory counter is in order: a gate load issued after a batch's stores is back only when the memory side
+        // has acknowledged them -- eight such waits per panel, and a K loop of 13 steps (h = 200) is no longer than they are
+        // (citation2's gated data gradient: 2.5 ms for 1.3 ms of matrix-pipe time).  Same arithmetic, same bits.
+        constexpr int RB = 4, BPC = 8 / RB, NCH = NB / 2 + (NB & 1), NBATCH = NCH * BPC;
         const bool pre = epi.flags && epi.vec4 && !(epi.flags & PLNLP_EPI_ADDEND);
-        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col_ok && pre && (epi.flags & PLNLP_EPI_BIAS)) bias4 = *reinterpret_cast<const float4*>(epi.bias + col);
-        float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (ROWDOT) { if (col_ok) rw4 = *reinterpret_cast<const float4*>(epi.rowdot_w + col); }
-        constexpr int RB = NB >= 7 ? 4 : 8;                    // rows per batch (the wide tiles have few registers to spare)
-#pragma unroll
-        for (int i0 = 0; i0 < 8; i0 += RB) {
-            float4 g4[RB], p4[RB], v4[RB];
-            if (col_ok && pre && (epi.flags & (PLNLP_EPI_GATE | PLNLP_EPI_ACCUM))) {
+        const bool gate_on = pre && (epi.flags & PLNLP_EPI_GATE);
+        const int c4 = (lane & 15) * 4;
+        auto gate_load = [&](auto tt, float4 (&dst)[RB]) {
+            constexpr int t = decltype(tt)::value, j0 = 2 * (t / BPC), i0 = (t % BPC) * RB, NJ = (j0 + 1 < NB) ? 2 : 1;
+            const int col = n0 + j0 * 32 + c4;
+            if (gate_on && c4 < NJ * 32 && col < g.n) {
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     int64_t orow = row_w + (i0 + i) * 4 + (lane >> 4);
                     orow = orow < g.m ? orow : g.m - 1;
-                    if (epi.flags & PLNLP_EPI_GATE) {
-                        const int64_t gr = epi.gate_index ? (int64_t)epi.gate_index[orow] : orow;
-                        g4[i] = *reinterpret_cast<const float4*>(epi.gate + gr * epi.ld_gate + col);
-                    }
-                    if (epi.flags & PLNLP_EPI_ACCUM) {
-                        const float* pp = second ? g.c2 + orow * g.ldc2 - g.n_split : g.c + orow * g.ldc;
-                        p4[i] = *reinterpret_cast<const float4*>(pp + col);
-                    }
+                    const int64_t gr = epi.gate_index ? (int64_t)epi.gate_index[orow] : orow;
+                    dst[i] = *reinterpret_cast<const float4*>(epi.gate + gr * epi.ld_gate + col);
+                }
+            }
+        };
+        float4 gq[2][RB];
+        gate_load(std::integral_constant<int, 0>{}, gq[0]);
+        static_for<NBATCH>([&](auto tt) {
+            constexpr int t = decltype(tt)::value, j0 = 2 * (t / BPC), i0 = (t % BPC) * RB, NJ = (j0 + 1 < NB) ? 2 : 1;
+            if constexpr (i0 == 0) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        cw[((q & 3) + 8 * (q >> 2) + 4 * h) * CS + jj * 32 + l31] = acc[j0 + jj][q];
+            }
+            const int col = n0 + j0 * 32 + c4;
+            const bool col_ok = c4 < NJ * 32 && col < g.n;
+            const bool second = col >= g.n_split;
+            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col_ok && pre && (epi.flags & PLNLP_EPI_BIAS)) bias4 = *reinterpret_cast<const float4*>(epi.bias + col);
+            float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (ROWDOT) { if (col_ok) rw4 = *reinterpret_cast<const float4*>(epi.rowdot_w + col); }
+            if constexpr (t + 1 < NBATCH) gate_load(std::integral_constant<int, t + 1>{}, gq[(t + 1) & 1]);
+            float4 p4[RB], v4[RB];
+            if (col_ok && pre && (epi.flags & PLNLP_EPI_ACCUM)) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    int64_t orow = row_w + (i0 + i) * 4 + (lane >> 4);
+                    orow = orow < g.m ? orow : g.m - 1;
+                    const float* pp = second ? g.c2 + orow * g.ldc2 - g.n_split : g.c + orow * g.ldc;
+                    p4[i] = *reinterpret_cast<const float4*>(pp + col);
                 }
             }
 #pragma unroll
@@ -343,14 +355,70 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
                 if (col_ok && orow < g.m) {
                     float* op = second ? g.c2 + orow * g.ldc2 - g.n_split : g.c + orow * g.ldc;
                     float4 y = v4[i];
-                    if (pre) y = epi_apply4_pre(epi, y, orow, col, g.n, bias4, g4[i], p4[i]);
+                    if (pre) y = epi_apply4_pre(epi, y, orow, col, g.n, bias4, gq[t & 1][i], p4[i]);
                     else y = epi_apply4(epi, y, orow, col, g.n, op);
                     *reinterpret_cast<float4*>(op + col) = y;
                     if constexpr (ROWDOT) rd[i0 + i] = rowdot_acc(rd[i0 + i], y, rw4);
                 }
             }
-        }
-    });
+        });
+    } else {
+        static_for<NB / 2 + (NB & 1)>([&](auto jc) {
+            constexpr int j0 = 2 * decltype(jc)::value;
+            constexpr int NJ = (j0 + 1 < NB) ? 2 : 1;
+    #pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+    #pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    cw[((q & 3) + 8 * (q >> 2) + 4 * h) * CS + jj * 32 + l31] = acc[j0 + jj][q];
+            // rows i * 4 + (lane >> 4), 16-byte column group lane & 15.  The epilogue's operands (bias once per chunk; gate and
+            // accumulate rows) are requested for all 8 rows BEFORE the first store: a load issued between stores waits for
+            // them (the compiler must assume the result aliases the operand), 8 dependent round trips per chunk.
+            const int c4 = (lane & 15) * 4;
+            const int col = n0 + j0 * 32 + c4;
+            const bool col_ok = c4 < NJ * 32 && col < g.n;
+            const bool second = col >= g.n_split;
+            const bool pre = epi.flags && epi.vec4 && !(epi.flags & PLNLP_EPI_ADDEND);
+            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col_ok && pre && (epi.flags & PLNLP_EPI_BIAS)) bias4 = *reinterpret_cast<const float4*>(epi.bias + col);
+            float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (ROWDOT) { if (col_ok) rw4 = *reinterpret_cast<const float4*>(epi.rowdot_w + col); }
+            constexpr int RB = NB >= 7 ? 4 : 8;                    // rows per batch (the wide tiles have few registers to spare)
+    #pragma unroll
+            for (int i0 = 0; i0 < 8; i0 += RB) {
+                float4 g4[RB], p4[RB], v4[RB];
+                if (col_ok && pre && (epi.flags & (PLNLP_EPI_GATE | PLNLP_EPI_ACCUM))) {
+    #pragma unroll
+                    for (int i = 0; i < RB; ++i) {
+                        int64_t orow = row_w + (i0 + i) * 4 + (lane >> 4);
+                        orow = orow < g.m ? orow : g.m - 1;
+                        if (epi.flags & PLNLP_EPI_GATE) {
+                            const int64_t gr = epi.gate_index ? (int64_t)epi.gate_index[orow] : orow;
+                            g4[i] = *reinterpret_cast<const float4*>(epi.gate + gr * epi.ld_gate + col);
+                        }
+                        if (epi.flags & PLNLP_EPI_ACCUM) {
+                            const float* pp = second ? g.c2 + orow * g.ldc2 - g.n_split : g.c + orow * g.ldc;
+                            p4[i] = *reinterpret_cast<const float4*>(pp + col);
+                        }
+                    }
+                }
+    #pragma unroll
+                for (int i = 0; i < RB; ++i) v4[i] = *reinterpret_cast<const float4*>(cw + ((i0 + i) * 4 + (lane >> 4)) * CS + c4);
+    #pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int64_t orow = row_w + (i0 + i) * 4 + (lane >> 4);
+                    if (col_ok && orow < g.m) {
+                        float* op = second ? g.c2 + orow * g.ldc2 - g.n_split : g.c + orow * g.ldc;
+                        float4 y = v4[i];
+                        if (pre) y = epi_apply4_pre(epi, y, orow, col, g.n, bias4, g4[i], p4[i]);
+                        else y = epi_apply4(epi, y, orow, col, g.n, op);
+                        *reinterpret_cast<float4*>(op + col) = y;
+                        if constexpr (ROWDOT) rd[i0 + i] = rowdot_acc(rd[i0 + i], y, rw4);
+                    }
+                }
+            }
+        });
+    }
     if constexpr (ROWDOT) {
         // the 16 lanes that share a row (lane & 15 = their 16-byte column group) fold their shares in a fixed tree; the
         // tile's partial goes to row nt of rowdot_out (plnlp_rowdot_finish_f32 adds the tiles in order)
