@@ -318,24 +318,32 @@ __global__ __launch_bounds__(256, NB >= 7 ? 2 : (NB == 4 ? 3 : 4)) void gemm_x3s
                 }
             }
         };
-        float4 gq[2][RB];
+        // (a chunk's bias and row-dot weights likewise: those of chunk c + 1 are requested before the first store of chunk c)
+        auto chunk_load = [&](auto cc, float4& b4, float4& r4) {
+            constexpr int j0 = 2 * decltype(cc)::value, NJ = (j0 + 1 < NB) ? 2 : 1;
+            const int col = n0 + j0 * 32 + c4;
+            const bool col_ok = c4 < NJ * 32 && col < g.n;
+            b4 = r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col_ok && pre && (epi.flags & PLNLP_EPI_BIAS)) b4 = *reinterpret_cast<const float4*>(epi.bias + col);
+            if constexpr (ROWDOT) { if (col_ok) r4 = *reinterpret_cast<const float4*>(epi.rowdot_w + col); }
+        };
+        float4 gq[2][RB], bq[2], rq[2];
         gate_load(std::integral_constant<int, 0>{}, gq[0]);
+        chunk_load(std::integral_constant<int, 0>{}, bq[0], rq[0]);
         static_for<NBATCH>([&](auto tt) {
-            constexpr int t = decltype(tt)::value, j0 = 2 * (t / BPC), i0 = (t % BPC) * RB, NJ = (j0 + 1 < NB) ? 2 : 1;
+            constexpr int t = decltype(tt)::value, jc = t / BPC, j0 = 2 * jc, i0 = (t % BPC) * RB, NJ = (j0 + 1 < NB) ? 2 : 1;
             if constexpr (i0 == 0) {
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
                         cw[((q & 3) + 8 * (q >> 2) + 4 * h) * CS + jj * 32 + l31] = acc[j0 + jj][q];
+                if constexpr (jc + 1 < NCH) chunk_load(std::integral_constant<int, jc + 1>{}, bq[(jc + 1) & 1], rq[(jc + 1) & 1]);
             }
             const int col = n0 + j0 * 32 + c4;
             const bool col_ok = c4 < NJ * 32 && col < g.n;
             const bool second = col >= g.n_split;
-            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col_ok && pre && (epi.flags & PLNLP_EPI_BIAS)) bias4 = *reinterpret_cast<const float4*>(epi.bias + col);
-            float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (ROWDOT) { if (col_ok) rw4 = *reinterpret_cast<const float4*>(epi.rowdot_w + col); }
+            const float4 bias4 = bq[jc & 1], rw4 = rq[jc & 1];
             if constexpr (t + 1 < NBATCH) gate_load(std::integral_constant<int, t + 1>{}, gq[(t + 1) & 1]);
             float4 p4[RB], v4[RB];
             if (col_ok && pre && (epi.flags & PLNLP_EPI_ACCUM)) {

@@ -363,11 +363,27 @@ def test_full_size_ddi_step_matches_the_oracle(P, math):
     src = torch.cat([pos[:, 0], ne[:, 0]]).cuda()
     dst = torch.cat([pos[:, 1], ne[:, 1]]).cuda()
     out = m._score(hh, src, dst)
+    out.retain_grad()
     B = pos.size(0)
     loss = m.calculate_loss(out[:B], out[B:], k)
     loss.backward()
     g64, g32 = c["grads"]["f64"], c["grads"]["f32"]
     close(loss, g64["loss"], rtol=1e-5)
+    # relu's kink.  Of the scorer's 134 M hidden pre-activations z = <x, W1 row> a handful cancel to within float32 round-off of
+    # their own terms (|z| <= 2^-23 sum_k |x_k W_k|; measured on this problem: 3 elements, one of them at 7e-11 of that sum): which
+    # side of zero such an element lands on is decided by the order of the additions -- any float32 evaluation, the reference's
+    # included, may go either way -- and the side decides whether the element's whole contribution g_r w2_c enters the hidden
+    # layer's bias gradient (a positive pair at initialisation: 6 x |w2_c| ~ 0.25, against a bound of 0.03 on a sum of scale 122).
+    # Those elements are named here, in float64 from the model's own tensors, and their contributions are added to the bound of
+    # the column they sit in; every other column keeps the plain bound.  (profiles/r06_ddi_dense_agg.txt, part 4: how this was found.)
+    with torch.no_grad():
+        l0, l1 = m.predictor.lins[0], m.predictor.lins[1]
+        x64 = (hh[src] * hh[dst]).double()
+        z64 = x64 @ l0.weight.double().t() + l0.bias.double()
+        on_kink = z64.abs() <= 2.0 ** -23 * (x64.abs() @ l0.weight.double().abs().t())
+        kink = (on_kink * (out.grad.double().abs().reshape(-1, 1) * l1.weight.double().abs().reshape(1, -1))).sum(0).cpu()
+        assert int(on_kink.sum()) <= 16, int(on_kink.sum())          # (an exception, not a loophole)
+        del x64, z64, on_kink
     yard = float((g32["pos"] - g64["pos"]).abs().max())
     assert float((out[:B].reshape(-1).cpu().double() - g64["pos"]).abs().max()) <= 4 * yard + 1e-5
     named = [("emb", m.emb.weight.grad)] + [(key, q.grad) for key, q in list(m.encoder.named_parameters()) +
@@ -387,6 +403,11 @@ def test_full_size_ddi_step_matches_the_oracle(P, math):
         # arithmetic what is left is rounding noise of a sum of 786 432 O(1) terms
         rel = 1e-5 if math == "f32" else 1e-4
         floor = 1e-8 * float(2 * c["B"] * (1 + c["k"]))
+        if key == "lins.0.bias":            # per column, with the kink elements' contributions (above)
+            errs = (got.cpu().double() - r64).abs()
+            over = errs > max(rel * scale, 4 * yard) + floor + kink
+            assert not bool(over.any()), (key, over.nonzero().reshape(-1).tolist(), float(errs.max()), yard, scale)
+            continue
         assert err <= max(rel * scale, 4 * yard) + floor, (key, err, yard, scale)
 
 
