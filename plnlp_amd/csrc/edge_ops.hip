@@ -556,8 +556,7 @@ extern "C" int plnlp_edge_segment_bwd_f32(const float* h, int64_t ldh, const int
     Epi e;
     if (int rc = make_epi(epi, &e)) return rc;
     const bool vec = feat % 4 == 0 && ldh % 4 == 0 && ldgh % 4 == 0 && (uintptr_t)h % 16 == 0 &&
-                     (uintptr_t)gh % 16 == 0 && (!g_is_vector || (ldg % 4 == 0 && (uintptr_t)g % 16 == 0)) &&
-                     (!(e.flags & PLNLP_EPI_GATE) || true);
+                     (uintptr_t)gh % 16 == 0 && (!g_is_vector || (ldg % 4 == 0 && (uintptr_t)g % 16 == 0));
     dim3 grid((unsigned)((n_seg + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
     if (vec && g_segment_form != 1) {

@@ -103,3 +103,31 @@ def test_no_oracle_import_in_product():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_dense_aggregation_slices_in_whole_rounds_without_a_device(lib):
+    """plnlp_dense_aggregate_scratch_bytes is host arithmetic: x's three-term image + one partial result per K slice.  The slice
+    count behind it fills whole rounds of the 512 workgroups the chip holds (csrc/aggregate_dense.hip::dense_slices): ogbl-ddi's
+    34 x 4 tiles over 267 K-steps take THREE slices (408 workgroups, one round) -- four, the first rule, were 544: a second round
+    for 32 of them; plnlp_dense_aggregate_tuning forces a count (and the scratch size follows)."""
+    n, f = 4267, 512
+    image = 4 * ((n + 15) // 16) * 768 * 16                    # column tiles x K-steps x (3 terms x 2 x 128 units) x 16 bytes
+
+    def slices():
+        extra = lib.plnlp_dense_aggregate_scratch_bytes(n, n, f) - image
+        assert extra % (n * f * 4) == 0
+        return extra // (n * f * 4)
+    try:
+        assert slices() == 3
+        for forced in (1, 4, 7):
+            lib.plnlp_dense_aggregate_tuning(forced)
+            assert slices() == forced
+        lib.plnlp_dense_aggregate_tuning(1000)                  # at least 8 K-steps per slice: 267 // 8 = 33
+        assert slices() == 33
+    finally:
+        lib.plnlp_dense_aggregate_tuning(0)
+    assert slices() == 3
+    assert lib.plnlp_dense_aggregate_scratch_bytes(0, n, f) == 0 and lib.plnlp_dense_aggregate_scratch_bytes(n, n, 0) == 0
+    # a small dense graph (tests): one tile row, few K-steps -- never more slices than K-steps / 8
+    small = lib.plnlp_dense_aggregate_scratch_bytes(100, 100, 64)
+    assert small == 1 * 7 * 768 * 16 + 1 * 100 * 64 * 4
