@@ -182,8 +182,8 @@ def launch_ranks(n_ranks, deadline_s=None):
 def comm_info(pg):
     """{"backend", "rccl_ranks"}: rccl_ranks counts the ranks of an RCCL ("nccl") process group ONLY -- 0 under gloo (the
     --share-gpu runs and the CPU dry run), so that "did RCCL see N ranks?" cannot be answered yes by a gloo job"""
-    if pg is None:
-        return {"backend": "none", "rccl_ranks": 1}
+    if pg is None:                       # one process, no process group: nothing of RCCL is running
+        return {"backend": "none", "rccl_ranks": 0}
     backend = str(torch.distributed.get_backend(pg))
     return {"backend": backend, "rccl_ranks": torch.distributed.get_world_size(pg) if backend == "nccl" else 0}
 
@@ -416,7 +416,7 @@ def run_rmat_as_rank(args, P, device):
                              "graph lies between frac (compulsory) and fabric-bound; the no-reuse HBM fraction is the default "
                              "workload's `roofline` (uniform graph)"},
         "gemm_layer1_ms": t_gemm * 1e3, "gemm_TFLOPs_f32_equivalent": 2.0 * S * F * 2 * F / t_gemm / 1e12,
-        "graph_build_s": t_graph, "output_checksum": float(y.double().sum().item()), "rccl_ranks": 1,
+        "graph_build_s": t_graph, "output_checksum": float(y.double().sum().item()), "backend": "none", "rccl_ranks": 0,
     }
     print(json.dumps(result), flush=True)
 
